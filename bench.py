@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric: Stereo2Voxel forward throughput (stereo pairs/s), batch 32 per GPU,
+224x224 stereo pair -> 32^3 voxels, fp32, synthetic inputs, random-init weights (BUILD-SPECIFIED
+architecture, arch_spec.py — the reference's model code is not in the mount).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--variant voxel|point]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one forward of the hot path over one resident batch of B pairs per GPU (inputs already in
+HBM).  N>1: one process per GPU, the batch is sharded (weak scaling: B pairs per rank), and each step
+ends with the one exchange the path has — an RCCL all-gather of the (B,32,32,32) predictions for eval
+collation.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (= fp32 vector peak)
+PEAK_HBM_GBS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle (this build's PyTorch-CPU restatement, NOT the reference) timed on the host cores."""
+    import torch
+    import s3r
+    from oracle import s2v_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    m = O.OracleStereo2Voxel().eval()
+    s3r.seed_module(m, 0)
+    B = 2                                           # BASELINE.json configs[0]
+    left, right = s3r.synthetic_pairs(B, seed=0)
+    with torch.no_grad():
+        m(left, right)                              # warm-up (allocations, MKL-DNN primitive cache)
+        times = []
+        t_end = time.perf_counter() + budget_s
+        while time.perf_counter() < t_end and len(times) < 50:
+            t0 = time.perf_counter()
+            m(left, right)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(B / med, 3), "unit": "stereo pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (torch CPU fp32, eval, no_grad) Stereo2Voxel forward, batch {B}, median of "
+                      f"{len(times)} iterations (~{sum(times):.1f} s of CPU work)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="stereo pairs per GPU per step")
+    ap.add_argument("--variant", default="voxel", choices=["voxel", "point"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import s3r
+    spec = s3r.arch_spec
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        log(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}` "
+            f"(WORLD_SIZE={world})")
+        sys.exit(2)
+    dist = None
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B = args.batch
+    model = (s3r.Stereo2Voxel if args.variant == "voxel" else s3r.Stereo2Point)()
+    s3r.seed_module(model, 0)
+    model.to(dev)
+    left, right = s3r.synthetic_pairs(B, seed=1000 + rank)      # random data (never zeros: DVFS, rule 25)
+    left, right = left.to(dev), right.to(dev)
+    gathered = None
+    out_shape = (B, 32, 32, 32) if args.variant == "voxel" else (B, spec.N_POINTS, 3)
+    if world > 1:
+        gathered = torch.empty((world * B,) + out_shape[1:], dtype=torch.float32, device=dev)
+
+    def step():
+        y = model(left, right)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, y)      # eval collation over xGMI (RCCL)
+        return y
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    profiling = not args.no_profile
+    if profiling:
+        s3r.profile_enable(64 * args.steps + 64)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    records = s3r.profile_read(64 * args.steps + 64) if profiling else []
+    if profiling:
+        s3r.profile_enable(0)
+
+    if rank == 0:
+        pairs = world * B * args.steps
+        value = pairs / elapsed
+        ms_per_step = 1e3 * elapsed / args.steps
+        fl = spec.flops_per_pair(args.variant)
+        # ---- roofline of the dominant kernel family: the fp32-MFMA implicit-GEMM convolution
+        roof = None
+        if records:
+            fam = {}
+            for r in records:
+                f = fam.setdefault(r["family"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
+                f["ms"] += r["ms"]; f["flops"] += r["flops"]; f["bytes"] += r["bytes"]; f["n"] += 1
+            per_layer = {}
+            for r in records:
+                if r["family"] == "conv_mfma":
+                    e = per_layer.setdefault(r["tag"], {"ms": 0.0, "flops": 0.0, "n": 0})
+                    e["ms"] += r["ms"]; e["flops"] += r["flops"]; e["n"] += 1
+            names = {100 + i: l.name for i, l in enumerate(spec.ENCODER)}
+            names.update({200 + i: l.name for i, l in enumerate(spec.DECODER)})
+            log("kernel family          launches   ms/step   TFLOP/s    GB/s(algorithmic)")
+            for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+                log(f"  {k:20s} {f['n']:8d} {f['ms'] / args.steps:9.3f} {f['flops'] / f['ms'] / 1e9 if f['ms'] else 0:9.2f} "
+                    f"{f['bytes'] / f['ms'] / 1e6 if f['ms'] else 0:9.1f}")
+            log("conv_mfma per layer:   ms/launch   TFLOP/s   frac of fp32 MFMA peak")
+            for tag, e in sorted(per_layer.items()):
+                tf = e["flops"] / e["ms"] / 1e9
+                log(f"  {names.get(tag, tag)!s:6s} {e['ms'] / e['n']:12.4f} {tf:9.2f} {tf / PEAK_FP32_MFMA_TFLOPS:8.3f}")
+            c = fam.get("conv_mfma")
+            if c and c["ms"] > 0:
+                achieved = c["flops"] / c["ms"] / 1e9            # TFLOP/s over all MFMA-conv launches
+                traffic = None
+                tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+                if os.path.exists(tpath):
+                    try:
+                        traffic = json.load(open(tpath)).get("conv_mfma_hbm_bytes_per_step")
+                    except Exception:
+                        traffic = None
+                roof = {"bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv)",
+                        "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                        "launches_per_step": c["n"] // args.steps,
+                        "algorithmic_gflop_per_step": round(c["flops"] / args.steps / 1e9, 3),
+                        "kernel_ms_per_step": round(c["ms"] / args.steps, 4)}
+        out = {
+            "metric": "stereo pairs/s forward (batch 32, 224x224 -> 32^3 voxel)" if args.variant == "voxel"
+                      else "stereo pairs/s forward (batch 32, 224x224 -> 2048-pt cloud)",
+            "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Stereo2{'Voxel' if args.variant == 'voxel' else 'Point'} forward, batch={B} per GPU, "
+                                   f"224x224 RGB stereo pair, fp32, random-init weights, build-specified arch_spec "
+                                   f"({fl['total'] / 1e9:.2f} GFLOP/pair)",
+                       "per_gpu_batch": B, "global_batch": world * B,
+                       "parallelism": f"batch-sharded x{world}, all-gather of predictions" if world > 1 else "single GPU"},
+            "end_to_end_tflops": round(value * fl["total"] / 1e12, 3),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+/* s3r.h — C-ABI of libs3r_hip.so: the MI355X (gfx950) forward path of the Stereo2Voxel /
+ * Stereo2Point network.  Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * What each entry point replaces on the reference side (the reference's model code lives on the
+ * unmounted Stereo2Voxel / Stereo2Point branches, /root/reference/README.md:5, so the most specific
+ * citation the mount supports is given):
+ *
+ *   s3r_conv_forward, s3r_encoder_forward   the torch conv2d+BatchNorm+ReLU calls inside the stereo
+ *                                           feature encoder's nn.Module.forward        (README.md:5,73-74)
+ *   s3r_cost_volume_forward                 the per-disparity shift/subtract Python loop that builds the
+ *                                           disparity cost volume                       (README.md:75-76)
+ *   s3r_decoder_forward (+conv/deconv/head) the torch conv3d / ConvTranspose3d + BN + ReLU + sigmoid
+ *                                           calls of the voxel decoder                  (README.md:77)
+ *   s3r_linear_forward                      the point decoder's nn.Linear layers        (README.md:36)
+ *   s3r_chamfer_forward                     extensions/chamfer_dist (the reference's one native op,
+ *                                           built by `python setup.py install`)         (README.md:64-65)
+ *   s3r_voxel_iou                           the IoU metric of `runner.py --test`        (README.md:88-92)
+ *
+ * Conventions
+ *   - every tensor is fp32, contiguous, NCHW / NCDHW, resident in device memory owned by the caller;
+ *     the library never allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t (NULL = the default stream); work is enqueued, not waited for;
+ *   - return value: S3R_OK (0) or a negative s3r_status; s3r_last_error() gives a message for the
+ *     calling thread; nothing throws across the ABI;
+ *   - every tensor of one call must be < 2^31 elements and < 4 GiB (32-bit buffer offsets).
+ */
+#ifndef S3R_H
+#define S3R_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S3R_ABI_VERSION 1
+
+typedef enum s3r_status {
+    S3R_OK = 0,
+    S3R_ERR_INVALID = -1,     /* bad argument / unsupported shape */
+    S3R_ERR_HIP = -2,         /* a HIP runtime call failed (message has hipGetErrorString) */
+    S3R_ERR_WORKSPACE = -3    /* workspace too small */
+} s3r_status;
+
+typedef enum s3r_op {
+    S3R_OP_CONV = 0,          /* Conv2d / Conv3d (ndim selects) */
+    S3R_OP_DECONV = 1,        /* ConvTranspose3d, k=4 s=2 p=1 only */
+    S3R_OP_LINEAR = 2         /* nn.Linear on the flattened input */
+} s3r_op;
+
+typedef enum s3r_act { S3R_ACT_NONE = 0, S3R_ACT_RELU = 1, S3R_ACT_SIGMOID = 2 } s3r_act;
+
+/* One layer's geometry.  Spatial sizes are cubic/square: `in_size` per axis, `ndim` axes. */
+typedef struct s3r_conv_desc {
+    int32_t op;        /* s3r_op */
+    int32_t ndim;      /* 2 or 3 (ignored for LINEAR) */
+    int32_t batch;     /* B */
+    int32_t cin, cout;
+    int32_t in_size;   /* input edge (H=W[=D]) */
+    int32_t k, stride, pad;
+    int32_t act;       /* s3r_act */
+    int32_t tag;       /* caller's label, echoed by the profiler */
+    int32_t tile;      /* -1: library picks the MFMA tile; >=0: force tile configuration (tuning) */
+} s3r_conv_desc;
+
+/* One layer of a stage: geometry + its packed weights + folded epilogue vectors (device pointers). */
+typedef struct s3r_layer {
+    s3r_conv_desc desc;
+    const float* packed_w;   /* from s3r_conv_pack_weights */
+    const float* scale;      /* [cout] gamma/sqrt(var+eps)            (NULL = 1) */
+    const float* shift;      /* [cout] beta + (bias-mean)*scale       (NULL = 0) */
+} s3r_layer;
+
+int s3r_abi_version(void);
+const char* s3r_last_error(void);
+
+/* output edge of a layer: conv (n+2p-k)/s+1, deconv (n-1)s-2p+k, linear 1 */
+int s3r_conv_out_size(const s3r_conv_desc* d);
+/* elements of the packed weight buffer for a layer (>= the torch weight's numel: couts are padded) */
+int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems);
+/* repack a torch-layout weight (Conv: [cout][cin][k..]; ConvTranspose: [cin][cout][k..]; Linear:
+ * [cout][cin]) into the kernel's K-major layout.  Device to device, on `stream`. */
+int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, float* packed, void* stream);
+/* y = act(conv(x) * scale + shift); dispatches to the stem / MFMA / head kernel by shape */
+int s3r_conv_forward(const s3r_conv_desc* d, const float* x, const float* packed_w, const float* scale,
+                     const float* shift, float* y, void* stream);
+
+/* Run a chain of layers x -> y with two ping-pong workspaces of `ws_elems` floats each
+ * (s3r_chain_workspace_elems gives the minimum). */
+int64_t s3r_chain_workspace_elems(const s3r_layer* layers, int n_layers);
+int s3r_chain_forward(const s3r_layer* layers, int n_layers, const float* x, float* y, float* ws_a, float* ws_b,
+                      int64_t ws_elems, void* stream);
+
+/* Stage entry points (thin, shape-checked views of s3r_chain_forward):
+ *   encoder: images (N,3,224,224) -> features (N,C,28,28); N = 2B (left batch then right batch)
+ *   decoder: cost volume (B,2C,D,H,W) -> occupancy (B,32,32,32)  */
+int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* images, float* features, float* ws_a,
+                        float* ws_b, int64_t ws_elems, void* stream);
+int s3r_decoder_forward(const s3r_layer* layers, int n_layers, const float* volume, float* occupancy, float* ws_a,
+                        float* ws_b, int64_t ws_elems, void* stream);
+
+/* vol[b,c,d,h,w] = L[b,c,h,w]-R[b,c,h,w-d] (w>=d), vol[b,C+c,d,h,w] = R[b,c,h,w]-L[b,c,h,w+d] (w+d<W), else 0 */
+int s3r_cost_volume_forward(const float* feat_left, const float* feat_right, float* volume, int batch, int channels,
+                            int max_disp, int height, int width, void* stream);
+
+/* y[b][o] = act(sum_i x[b][i] w[o][i] + bias[o]); w in torch Linear layout (no packing) */
+int s3r_linear_forward(const float* x, const float* w, const float* bias, float* y, int batch, int cin, int cout,
+                       int act, void* stream);
+
+/* squared-L2 nearest neighbours both ways; p (B,N,3), q (B,M,3) */
+int s3r_chamfer_forward(const float* p, const float* q, float* dist1, float* dist2, int32_t* idx1, int32_t* idx2,
+                        int batch, int n, int m, void* stream);
+
+/* per-sample IoU of (pred > th) vs (gt > th) over `voxels` elements */
+int s3r_voxel_iou(const float* pred, const float* gt, float threshold, float* iou, int batch, int64_t voxels,
+                  void* stream);
+
+/* Kernel-level profiler: when enabled, every kernel the library launches is bracketed by HIP events
+ * on the launch stream.  s3r_profile_read synchronises those events and returns, per launch, the
+ * kernel family (0 mfma conv, 1 stem, 2 head, 3 cost volume, 4 linear, 5 chamfer, 6 iou, 7 pack),
+ * the caller's tag, milliseconds, and the algorithmic flops / bytes of that launch. */
+typedef struct s3r_prof_record {
+    int32_t family;
+    int32_t tag;
+    float ms;
+    double flops;
+    double bytes;
+} s3r_prof_record;
+int s3r_profile_enable(int max_records);   /* 0 disables and frees the event pool */
+int s3r_profile_reset(void);
+int s3r_profile_read(s3r_prof_record* out, int max_records);   /* returns the number of records */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S3R_H */

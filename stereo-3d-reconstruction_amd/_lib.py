@@ -1,0 +1,122 @@
+"""ctypes binding of libs3r_hip.so (the C-ABI declared in include/s3r.h).
+
+There is NO fallback: if the library is missing or a call fails, the product path raises.  The
+oracle under oracle/ is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libs3r_hip.so")
+
+OP_CONV, OP_DECONV, OP_LINEAR = 0, 1, 2
+ACT = {"none": 0, "relu": 1, "sigmoid": 2}
+FAMILY = {0: "conv_mfma", 1: "stem", 2: "head", 3: "cost_volume", 4: "linear", 5: "chamfer", 6: "iou", 7: "pack"}
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("op", "ndim", "batch", "cin", "cout", "in_size", "k", "stride", "pad", "act", "tag", "tile")]
+
+
+class Layer(C.Structure):
+    _fields_ = [("desc", ConvDesc), ("packed_w", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p)]
+
+
+class ProfRecord(C.Structure):
+    _fields_ = [("family", C.c_int32), ("tag", C.c_int32), ("ms", C.c_float), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+class S3RError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+# name -> (restype, argtypes); must list every symbol include/s3r.h declares (tests check this)
+SIGNATURES = {
+    "s3r_abi_version": (C.c_int, []),
+    "s3r_last_error": (C.c_char_p, []),
+    "s3r_conv_out_size": (C.c_int, [C.POINTER(ConvDesc)]),
+    "s3r_conv_packed_elems": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int64)]),
+    "s3r_conv_pack_weights": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "s3r_conv_forward": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "s3r_chain_workspace_elems": (C.c_int64, [C.POINTER(Layer), C.c_int]),
+    "s3r_chain_forward": (C.c_int, [C.POINTER(Layer), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int64, C.c_void_p]),
+    "s3r_encoder_forward": (C.c_int, [C.POINTER(Layer), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int64, C.c_void_p]),
+    "s3r_decoder_forward": (C.c_int, [C.POINTER(Layer), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int64, C.c_void_p]),
+    "s3r_cost_volume_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_void_p]),
+    "s3r_linear_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p]),
+    "s3r_chamfer_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "s3r_voxel_iou": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "s3r_profile_enable": (C.c_int, [C.c_int]),
+    "s3r_profile_reset": (C.c_int, []),
+    "s3r_profile_read": (C.c_int, [C.POINTER(ProfRecord), C.c_int]),
+}
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises S3RError when the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise S3RError(
+                f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (or `make -C stereo-3d-reconstruction_amd/csrc`). There is no CPU fallback.")
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise S3RError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.s3r_abi_version() != 1:
+            raise S3RError("libs3r_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc < 0:
+        msg = load().s3r_last_error().decode("utf-8", "replace")
+        raise S3RError(f"{what}: {msg} (code {rc})")
+    return rc
+
+
+def make_desc(layer, batch, in_size, tag=0, tile=-1):
+    """arch_spec.Layer -> ConvDesc."""
+    op = {"conv2d": OP_CONV, "conv3d": OP_CONV, "deconv3d": OP_DECONV, "linear": OP_LINEAR}[layer.op]
+    nd = {"conv2d": 2, "conv3d": 3, "deconv3d": 3, "linear": 0}[layer.op]
+    return ConvDesc(op, nd, batch, layer.cin, layer.cout, in_size, layer.k, layer.s, layer.p, ACT[layer.act], tag,
+                    tile)
+
+
+def profile_enable(max_records):
+    check(load().s3r_profile_enable(int(max_records)), "profile_enable")
+
+
+def profile_reset():
+    check(load().s3r_profile_reset(), "profile_reset")
+
+
+def profile_read(max_records=4096):
+    buf = (ProfRecord * max_records)()
+    n = check(load().s3r_profile_read(buf, max_records), "profile_read")
+    return [dict(family=FAMILY.get(r.family, str(r.family)), tag=r.tag, ms=r.ms, flops=r.flops, bytes=r.bytes)
+            for r in buf[:n]]

@@ -1,0 +1,403 @@
+// C-ABI of libs3r_hip.so (declared in include/s3r.h): argument validation, kernel dispatch by
+// layer shape, the chain/stage runners and the event-based kernel profiler.  Host code only.
+#include "../../include/s3r.h"
+#include "s3r_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    return fail(S3R_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+int64_t ipow(int64_t b, int e) {
+    int64_t r = 1;
+    while (e-- > 0) r *= b;
+    return r;
+}
+
+constexpr int64_t kMaxElems = (int64_t)1 << 31;
+constexpr int64_t kMaxBytes = (int64_t)1 << 32;
+
+// ---------------------------------------------------------------- profiler
+enum Family { F_MFMA = 0, F_STEM = 1, F_HEAD = 2, F_COSTVOL = 3, F_LINEAR = 4, F_CHAMFER = 5, F_IOU = 6, F_PACK = 7 };
+
+struct Prof {
+    std::mutex mu;
+    bool on = false;
+    int cap = 0;
+    std::vector<hipEvent_t> ev;   // 2 per record
+    std::vector<s3r_prof_record> rec;
+} g_prof;
+
+struct ProfScope {
+    bool active = false;
+    int slot = -1;
+    hipStream_t stream;
+    ProfScope(hipStream_t s, int family, int tag, double flops, double bytes) : stream(s) {
+        if (!g_prof.on) return;
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        if (!g_prof.on || (int)g_prof.rec.size() >= g_prof.cap) return;
+        slot = (int)g_prof.rec.size();
+        s3r_prof_record r;
+        r.family = family; r.tag = tag; r.ms = 0.f; r.flops = flops; r.bytes = bytes;
+        g_prof.rec.push_back(r);
+        active = true;
+        (void)hipEventRecord(g_prof.ev[2 * slot], stream);
+    }
+    ~ProfScope() {
+        if (active) (void)hipEventRecord(g_prof.ev[2 * slot + 1], stream);
+    }
+};
+
+// ---------------------------------------------------------------- layer geometry
+struct Geo {
+    int nd;            // spatial dims actually walked (1 for unused axes)
+    int in, out;       // edge sizes
+    int64_t in_sp, out_sp;
+    int64_t x_elems, y_elems, w_elems;
+    double flops;
+};
+
+int out_size(const s3r_conv_desc* d) {
+    if (d->op == S3R_OP_LINEAR) return 1;
+    if (d->op == S3R_OP_DECONV) return (d->in_size - 1) * d->stride - 2 * d->pad + d->k;
+    return (d->in_size + 2 * d->pad - d->k) / d->stride + 1;
+}
+
+int geometry(const s3r_conv_desc* d, Geo* g) {
+    if (!d) return fail(S3R_ERR_INVALID, "null descriptor");
+    if (d->batch <= 0 || d->cin <= 0 || d->cout <= 0) return fail(S3R_ERR_INVALID, "batch/cin/cout must be positive");
+    if (d->op == S3R_OP_LINEAR) {
+        g->nd = 0; g->in = 1; g->out = 1; g->in_sp = 1; g->out_sp = 1;
+        g->x_elems = (int64_t)d->batch * d->cin;
+        g->y_elems = (int64_t)d->batch * d->cout;
+        g->w_elems = (int64_t)d->cin * d->cout;
+        g->flops = 2.0 * d->batch * (double)d->cin * d->cout;
+        return S3R_OK;
+    }
+    if (d->op != S3R_OP_CONV && d->op != S3R_OP_DECONV) return fail(S3R_ERR_INVALID, "unknown op %d", d->op);
+    if (d->ndim != 2 && d->ndim != 3) return fail(S3R_ERR_INVALID, "ndim must be 2 or 3");
+    if (d->in_size <= 0 || d->k <= 0 || d->stride <= 0 || d->pad < 0) return fail(S3R_ERR_INVALID, "bad size/k/stride/pad");
+    if (d->op == S3R_OP_DECONV && !(d->ndim == 3 && d->k == 4 && d->stride == 2 && d->pad == 1))
+        return fail(S3R_ERR_INVALID, "ConvTranspose is supported for ndim=3,k=4,s=2,p=1 only");
+    g->nd = d->ndim;
+    g->in = d->in_size;
+    g->out = out_size(d);
+    if (g->out <= 0) return fail(S3R_ERR_INVALID, "empty output");
+    g->in_sp = ipow(g->in, g->nd);
+    g->out_sp = ipow(g->out, g->nd);
+    g->x_elems = (int64_t)d->batch * d->cin * g->in_sp;
+    g->y_elems = (int64_t)d->batch * d->cout * g->out_sp;
+    g->w_elems = (int64_t)d->cin * d->cout * ipow(d->k, g->nd);
+    if (d->op == S3R_OP_DECONV)
+        g->flops = 2.0 * d->batch * (double)d->cin * g->in_sp * d->cout * ipow(d->k, g->nd);
+    else
+        g->flops = 2.0 * d->batch * (double)d->cout * g->out_sp * d->cin * ipow(d->k, g->nd);
+    if (g->x_elems >= kMaxElems || g->y_elems >= kMaxElems || g->x_elems * 4 >= kMaxBytes || g->y_elems * 4 >= kMaxBytes)
+        return fail(S3R_ERR_INVALID, "tensor too large for one call (>= 2^31 elements / 4 GiB): split the batch");
+    return S3R_OK;
+}
+
+enum Route { R_STEM, R_HEAD, R_MFMA, R_LINEAR };
+
+int route(const s3r_conv_desc* d, Route* r) {
+    if (d->op == S3R_OP_LINEAR) { *r = R_LINEAR; return S3R_OK; }
+    if (d->op == S3R_OP_CONV && d->ndim == 2 && d->cin == 3 && d->cout == 32 && d->k == 3 && d->stride == 2 &&
+        d->pad == 1 && d->act == S3R_ACT_RELU) { *r = R_STEM; return S3R_OK; }
+    if (d->op == S3R_OP_CONV && d->cout == 1 && d->k == 1 && d->stride == 1 && d->pad == 0 &&
+        (ipow(d->in_size, d->ndim) % 4) == 0) { *r = R_HEAD; return S3R_OK; }
+    if (d->cin % 16 == 0) { *r = R_MFMA; return S3R_OK; }
+    return fail(S3R_ERR_INVALID, "no kernel for this layer shape (cin=%d cout=%d k=%d s=%d p=%d ndim=%d): the MFMA path "
+                "needs cin %% 16 == 0", d->cin, d->cout, d->k, d->stride, d->pad, d->ndim);
+}
+
+int cout_pad(int cout) { return (cout + 127) / 128 * 128; }
+
+s3r::ConvParams make_params(const s3r_conv_desc* d, const Geo& g) {
+    s3r::ConvParams p;
+    memset(&p, 0, sizeof(p));
+    const bool is3 = d->ndim == 3;
+    p.B = d->batch; p.Cin = d->cin; p.Cout = d->cout; p.CoutPad = cout_pad(d->cout);
+    p.Di = is3 ? g.in : 1; p.Hi = g.in; p.Wi = g.in;
+    p.Do = is3 ? g.out : 1; p.Ho = g.out; p.Wo = g.out;
+    p.act = d->act;
+    if (d->op == S3R_OP_DECONV) {
+        p.transposed = 1;
+        p.Nd = p.Di; p.Nh = p.Hi; p.Nw = p.Wi;
+        p.kd = p.kh = p.kw = 2;
+        p.stride = 1; p.pad_d = p.pad_h = p.pad_w = 0;
+    } else {
+        p.transposed = 0;
+        p.Nd = p.Do; p.Nh = p.Ho; p.Nw = p.Wo;
+        p.kd = is3 ? d->k : 1; p.kh = d->k; p.kw = d->k;
+        p.stride = d->stride;
+        p.pad_d = is3 ? d->pad : 0; p.pad_h = d->pad; p.pad_w = d->pad;
+    }
+    p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int s3r_abi_version(void) { return S3R_ABI_VERSION; }
+
+const char* s3r_last_error(void) { return g_err; }
+
+int s3r_conv_out_size(const s3r_conv_desc* d) { return d ? out_size(d) : S3R_ERR_INVALID; }
+
+int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems) {
+    Geo g; Route r;
+    int rc = geometry(d, &g);
+    if (rc) return rc;
+    if ((rc = route(d, &r))) return rc;
+    if (!elems) return fail(S3R_ERR_INVALID, "null output");
+    switch (r) {
+        case R_STEM: *elems = 27 * 32; break;
+        case R_HEAD: *elems = d->cin; break;
+        case R_LINEAR: *elems = g.w_elems; break;
+        case R_MFMA: {
+            const int64_t taps = d->op == S3R_OP_DECONV ? 64 : ipow(d->k, g.nd);
+            *elems = taps * d->cin * cout_pad(d->cout);
+            break;
+        }
+    }
+    return S3R_OK;
+}
+
+int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, float* packed, void* stream) {
+    Geo g; Route r;
+    int rc = geometry(d, &g);
+    if (rc) return rc;
+    if ((rc = route(d, &r))) return rc;
+    if (!w || !packed) return fail(S3R_ERR_INVALID, "null weight pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(s, F_PACK, d->tag, 0.0, 8.0 * g.w_elems);
+    hipError_t e = hipSuccess;
+    switch (r) {
+        case R_STEM: e = s3r::launch_pack_stem(w, packed, s); break;
+        case R_HEAD: e = hipMemcpyAsync(packed, w, sizeof(float) * d->cin, hipMemcpyDeviceToDevice, s); break;
+        case R_LINEAR: e = hipMemcpyAsync(packed, w, sizeof(float) * g.w_elems, hipMemcpyDeviceToDevice, s); break;
+        case R_MFMA:
+            if (d->op == S3R_OP_DECONV) e = s3r::launch_pack_deconv_k4s2(w, packed, d->cin, d->cout, cout_pad(d->cout), s);
+            else e = s3r::launch_pack_conv(w, packed, d->cout, d->cin, (int)ipow(d->k, g.nd), cout_pad(d->cout), s);
+            break;
+    }
+    if (e != hipSuccess) return hip_fail(e, "pack weights");
+    return S3R_OK;
+}
+
+int s3r_conv_forward(const s3r_conv_desc* d, const float* x, const float* packed_w, const float* scale,
+                     const float* shift, float* y, void* stream) {
+    Geo g; Route r;
+    int rc = geometry(d, &g);
+    if (rc) return rc;
+    if ((rc = route(d, &r))) return rc;
+    if (!x || !packed_w || !y) return fail(S3R_ERR_INVALID, "null tensor pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const double bytes = 4.0 * (g.x_elems + g.y_elems + g.w_elems);
+    hipError_t e = hipSuccess;
+    switch (r) {
+        case R_STEM: {
+            if (!scale || !shift) return fail(S3R_ERR_INVALID, "stem needs scale and shift");
+            ProfScope ps(s, F_STEM, d->tag, g.flops, bytes);
+            e = s3r::launch_stem(x, packed_w, scale, shift, y, d->batch, g.in, g.in, g.out, g.out, s);
+            break;
+        }
+        case R_HEAD: {
+            ProfScope ps(s, F_HEAD, d->tag, g.flops, bytes);
+            e = s3r::launch_head(x, packed_w, scale, shift, y, d->batch, d->cin, g.in_sp, d->act, s);
+            break;
+        }
+        case R_LINEAR: {
+            ProfScope ps(s, F_LINEAR, d->tag, g.flops, bytes);
+            e = s3r::launch_linear(x, packed_w, scale, shift, y, d->batch, d->cin, d->cout, d->act, s);
+            break;
+        }
+        case R_MFMA: {
+            s3r::ConvParams p = make_params(d, g);
+            p.x = x; p.w = packed_w; p.scale = scale; p.shift = shift; p.y = y;
+            const int cfg = d->tile >= 0 ? d->tile : s3r::conv_pick_tile(p);
+            ProfScope ps(s, F_MFMA, d->tag, g.flops, bytes);
+            e = s3r::launch_conv_mfma(p, cfg, s);
+            break;
+        }
+    }
+    if (e != hipSuccess) return hip_fail(e, "conv forward launch");
+    return S3R_OK;
+}
+
+int64_t s3r_chain_workspace_elems(const s3r_layer* layers, int n_layers) {
+    if (!layers || n_layers <= 0) return fail(S3R_ERR_INVALID, "empty chain");
+    int64_t m = 0;
+    for (int i = 0; i + 1 < n_layers; ++i) {   // the last layer writes into y
+        Geo g;
+        int rc = geometry(&layers[i].desc, &g);
+        if (rc) return rc;
+        if (g.y_elems > m) m = g.y_elems;
+    }
+    return m;
+}
+
+int s3r_chain_forward(const s3r_layer* layers, int n_layers, const float* x, float* y, float* ws_a, float* ws_b,
+                      int64_t ws_elems, void* stream) {
+    if (!layers || n_layers <= 0) return fail(S3R_ERR_INVALID, "empty chain");
+    const int64_t need = s3r_chain_workspace_elems(layers, n_layers);
+    if (need < 0) return (int)need;
+    if (n_layers > 1 && (!ws_a || (n_layers > 2 && !ws_b) || ws_elems < need))
+        return fail(S3R_ERR_WORKSPACE, "chain needs two workspaces of %lld floats, got %lld", (long long)need,
+                    (long long)ws_elems);
+    const float* cur = x;
+    for (int i = 0; i < n_layers; ++i) {
+        const s3r_layer& L = layers[i];
+        if (i > 0) {   // shapes must chain
+            Geo gp;
+            geometry(&layers[i - 1].desc, &gp);
+            const s3r_conv_desc& a = layers[i - 1].desc;
+            const int64_t prev_out = (int64_t)a.cout * gp.out_sp;
+            Geo gc;
+            int rc = geometry(&L.desc, &gc);
+            if (rc) return rc;
+            const int64_t cur_in = (int64_t)L.desc.cin * gc.in_sp;
+            if (prev_out != cur_in || a.batch != L.desc.batch)
+                return fail(S3R_ERR_INVALID, "layer %d input (%lld/sample) does not match layer %d output (%lld/sample)", i,
+                            (long long)cur_in, i - 1, (long long)prev_out);
+        }
+        float* out = (i == n_layers - 1) ? y : ((i & 1) ? ws_b : ws_a);
+        int rc = s3r_conv_forward(&L.desc, cur, L.packed_w, L.scale, L.shift, out, stream);
+        if (rc) return rc;
+        cur = out;
+    }
+    return S3R_OK;
+}
+
+int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* images, float* features, float* ws_a,
+                        float* ws_b, int64_t ws_elems, void* stream) {
+    if (!layers || n_layers <= 0) return fail(S3R_ERR_INVALID, "empty encoder");
+    const s3r_conv_desc& f = layers[0].desc;
+    if (f.op != S3R_OP_CONV || f.ndim != 2 || f.cin != 3)
+        return fail(S3R_ERR_INVALID, "encoder must start with a 2D convolution over 3-channel renders");
+    for (int i = 0; i < n_layers; ++i)
+        if (layers[i].desc.op != S3R_OP_CONV || layers[i].desc.ndim != 2)
+            return fail(S3R_ERR_INVALID, "encoder layer %d is not a 2D convolution", i);
+    return s3r_chain_forward(layers, n_layers, images, features, ws_a, ws_b, ws_elems, stream);
+}
+
+int s3r_decoder_forward(const s3r_layer* layers, int n_layers, const float* volume, float* occupancy, float* ws_a,
+                        float* ws_b, int64_t ws_elems, void* stream) {
+    if (!layers || n_layers <= 0) return fail(S3R_ERR_INVALID, "empty decoder");
+    for (int i = 0; i < n_layers; ++i)
+        if (layers[i].desc.op == S3R_OP_LINEAR || layers[i].desc.ndim != 3)
+            return fail(S3R_ERR_INVALID, "decoder layer %d is not a 3D (transposed) convolution", i);
+    return s3r_chain_forward(layers, n_layers, volume, occupancy, ws_a, ws_b, ws_elems, stream);
+}
+
+int s3r_cost_volume_forward(const float* fl, const float* fr, float* vol, int batch, int channels, int max_disp,
+                            int height, int width, void* stream) {
+    if (!fl || !fr || !vol) return fail(S3R_ERR_INVALID, "null tensor pointer");
+    if (batch <= 0 || channels <= 0 || max_disp <= 0 || height <= 0 || width <= 0)
+        return fail(S3R_ERR_INVALID, "cost volume dims must be positive");
+    const int64_t hw = (int64_t)height * width;
+    if (2 * hw * 4 > 64 * 1024) return fail(S3R_ERR_INVALID, "feature plane %dx%d does not fit the LDS staging", height, width);
+    const int64_t out = (int64_t)batch * 2 * channels * max_disp * hw;
+    if (out >= kMaxElems) return fail(S3R_ERR_INVALID, "cost volume too large for one call: split the batch");
+    hipStream_t s = (hipStream_t)stream;
+    const double bytes = 4.0 * (2.0 * batch * channels * hw + (double)out);
+    ProfScope ps(s, F_COSTVOL, 0, (double)out, bytes);
+    hipError_t e = s3r::launch_cost_volume(fl, fr, vol, batch, channels, max_disp, height, width, s);
+    if (e != hipSuccess) return hip_fail(e, "cost volume launch");
+    return S3R_OK;
+}
+
+int s3r_linear_forward(const float* x, const float* w, const float* bias, float* y, int batch, int cin, int cout,
+                       int act, void* stream) {
+    if (!x || !w || !y) return fail(S3R_ERR_INVALID, "null tensor pointer");
+    if (batch <= 0 || cin <= 0 || cout <= 0) return fail(S3R_ERR_INVALID, "linear dims must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(s, F_LINEAR, 0, 2.0 * batch * (double)cin * cout, 4.0 * ((double)cin * cout + (double)batch * (cin + cout)));
+    hipError_t e = s3r::launch_linear(x, w, nullptr, bias, y, batch, cin, cout, act, s);
+    if (e != hipSuccess) return hip_fail(e, "linear launch");
+    return S3R_OK;
+}
+
+int s3r_chamfer_forward(const float* p, const float* q, float* dist1, float* dist2, int32_t* idx1, int32_t* idx2,
+                        int batch, int n, int m, void* stream) {
+    if (!p || !q || !dist1 || !dist2 || !idx1 || !idx2) return fail(S3R_ERR_INVALID, "null tensor pointer");
+    if (batch <= 0 || n <= 0 || m <= 0) return fail(S3R_ERR_INVALID, "chamfer needs non-empty clouds (batch=%d n=%d m=%d)", batch, n, m);
+    if (batch > 65535) return fail(S3R_ERR_INVALID, "batch > 65535: split the call");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(s, F_CHAMFER, 0, 2.0 * 8.0 * batch * (double)n * m, 4.0 * batch * (5.0 * n + 5.0 * m));
+    hipError_t e = s3r::launch_chamfer(p, q, dist1, dist2, idx1, idx2, batch, n, m, s);
+    if (e != hipSuccess) return hip_fail(e, "chamfer launch");
+    return S3R_OK;
+}
+
+int s3r_voxel_iou(const float* pred, const float* gt, float threshold, float* iou, int batch, int64_t voxels,
+                  void* stream) {
+    if (!pred || !gt || !iou) return fail(S3R_ERR_INVALID, "null tensor pointer");
+    if (batch <= 0 || voxels <= 0) return fail(S3R_ERR_INVALID, "iou dims must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(s, F_IOU, 0, 0.0, 8.0 * batch * (double)voxels);
+    hipError_t e = s3r::launch_iou(pred, gt, threshold, iou, batch, voxels, s);
+    if (e != hipSuccess) return hip_fail(e, "iou launch");
+    return S3R_OK;
+}
+
+int s3r_profile_enable(int max_records) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    for (hipEvent_t ev : g_prof.ev) (void)hipEventDestroy(ev);
+    g_prof.ev.clear();
+    g_prof.rec.clear();
+    g_prof.on = false;
+    g_prof.cap = 0;
+    if (max_records <= 0) return S3R_OK;
+    g_prof.ev.resize((size_t)2 * max_records);
+    for (auto& ev : g_prof.ev) {
+        hipError_t e = hipEventCreate(&ev);
+        if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
+    }
+    g_prof.rec.reserve(max_records);
+    g_prof.cap = max_records;
+    g_prof.on = true;
+    return S3R_OK;
+}
+
+int s3r_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.rec.clear();
+    return S3R_OK;
+}
+
+int s3r_profile_read(s3r_prof_record* out, int max_records) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    const int n = (int)g_prof.rec.size() < max_records ? (int)g_prof.rec.size() : max_records;
+    for (int i = 0; i < n; ++i) {
+        hipError_t e = hipEventSynchronize(g_prof.ev[2 * i + 1]);
+        if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize");
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+        if (e != hipSuccess) return hip_fail(e, "hipEventElapsedTime");
+        g_prof.rec[i].ms = ms;
+        if (out) out[i] = g_prof.rec[i];
+    }
+    return n;
+}
+
+}  // extern "C"

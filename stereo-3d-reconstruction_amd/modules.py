@@ -1,0 +1,375 @@
+"""Host-side mirror of the reference's plugin surface for this path: ordinary `torch.nn.Module`s
+named `encoder`, `cost_volume`, `decoder` (BASELINE.json north_star; the reference's own class
+names live on unmounted branches, /root/reference/README.md:5) whose parameters are plain
+nn.Conv/BatchNorm parameters — so `state_dict()` / `load_state_dict()` behave exactly like a stock
+PyTorch model — but whose `forward` enqueues the hand-written HIP kernels of libs3r_hip.so through
+its C-ABI.  PyTorch is plumbing here (device memory, streams); no torch conv / BN op runs in any
+forward below, and nothing falls back to the CPU: without the HIP library every forward raises.
+
+Forward-only (inference, eval-mode BatchNorm): outputs carry no autograd graph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import arch_spec as spec
+
+MAX_CHUNK = 256      # pairs per C-ABI call: keeps every activation < 2^31 elements / 4 GiB
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _check_input(x: torch.Tensor, name: str, shape_tail: Sequence[int]):
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not x.is_cuda:
+        raise RuntimeError(f"{name} must live on a HIP device (got {x.device}); this path has no CPU fallback")
+    if x.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32 (got {x.dtype})")
+    if tuple(x.shape[1:]) != tuple(shape_tail):
+        raise RuntimeError(f"{name} must have shape (B, {', '.join(map(str, shape_tail))}), got {tuple(x.shape)}")
+    return x.contiguous()
+
+
+_WS: Dict[tuple, torch.Tensor] = {}
+
+
+def _workspace(device, slot: str, elems: int) -> torch.Tensor:
+    key = (str(device), slot)
+    t = _WS.get(key)
+    if t is None or t.numel() < elems:
+        t = torch.empty(max(elems, 1), dtype=torch.float32, device=device)
+        _WS[key] = t
+    return t
+
+
+class _Block(nn.Module):
+    """Parameter holder for one arch_spec.Layer (conv [+ bn]); never called."""
+
+    def __init__(self, layer: spec.Layer):
+        super().__init__()
+        self.layer = layer
+        if layer.op == "conv2d":
+            self.conv = nn.Conv2d(layer.cin, layer.cout, layer.k, layer.s, layer.p, bias=True)
+            self.bn = nn.BatchNorm2d(layer.cout, eps=spec.BN_EPS) if layer.bn else None
+        elif layer.op == "conv3d":
+            self.conv = nn.Conv3d(layer.cin, layer.cout, layer.k, layer.s, layer.p, bias=True)
+            self.bn = nn.BatchNorm3d(layer.cout, eps=spec.BN_EPS) if layer.bn else None
+        elif layer.op == "deconv3d":
+            self.conv = nn.ConvTranspose3d(layer.cin, layer.cout, layer.k, layer.s, layer.p, bias=True)
+            self.bn = nn.BatchNorm3d(layer.cout, eps=spec.BN_EPS) if layer.bn else None
+        elif layer.op == "linear":
+            self.conv = nn.Linear(layer.cin, layer.cout, bias=True)
+            self.bn = None
+        else:
+            raise ValueError(layer.op)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("parameter holder: the enclosing HIP module runs the kernel")
+
+    @torch.no_grad()
+    def folded(self):
+        """(scale, shift) of the fused epilogue y = conv_nobias(x) * scale + shift."""
+        bias = self.conv.bias.detach().float()
+        if self.bn is None:
+            return None, bias.contiguous()
+        bn = self.bn
+        scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+        shift = bn.bias.detach().float() + (bias - bn.running_mean.detach().float()) * scale
+        return scale.contiguous(), shift.contiguous()
+
+
+class _HipChain(nn.Module):
+    """A sequence of arch_spec layers executed by one C-ABI stage call."""
+
+    _entry = "s3r_chain_forward"
+
+    def __init__(self, layers: Sequence[spec.Layer], in_size: int, tag_base: int = 0):
+        super().__init__()
+        self._layers = tuple(layers)
+        self._in_size = in_size
+        self._tag_base = tag_base
+        self.names = [l.name for l in layers]
+        for l in layers:
+            self.add_module(l.name, _Block(l))
+        self._packed = None          # (key, [(packed_w, scale, shift)])
+        self.tile_override: Dict[str, int] = {}
+        if self.training:
+            self.eval()              # inference path: eval-mode BatchNorm is the only mode implemented
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise RuntimeError("this build implements the forward/inference path only (eval-mode BatchNorm)")
+        return super().train(False)
+
+    # -- weight packing cache ------------------------------------------------------------------
+    def _cache_key(self, device):
+        items = [str(device)]
+        for t in list(self.parameters()) + list(self.buffers()):
+            items.append((id(t), t._version, t.device.type))
+        return tuple(items)
+
+    def _sizes(self):
+        rows, n = [], self._in_size
+        for l in self._layers:
+            m = spec.out_size(l, n)
+            rows.append((n, m))
+            n = m
+        return rows
+
+    @torch.no_grad()
+    def _ensure_packed(self, device):
+        key = self._cache_key(device)
+        if self._packed is not None and self._packed[0] == key:
+            return self._packed[1]
+        lib = _lib.load()
+        packed = []
+        stream = _stream_ptr(device)
+        for l, (n_in, _) in zip(self._layers, self._sizes()):
+            blk: _Block = getattr(self, l.name)
+            w = blk.conv.weight.detach()
+            if w.device != device:
+                raise RuntimeError(f"{l.name}: parameters are on {w.device}, input on {device}; call .to(device) first")
+            w = w.float().contiguous()
+            desc = _lib.make_desc(l, 1, n_in)
+            n = C.c_int64(0)
+            _lib.check(lib.s3r_conv_packed_elems(C.byref(desc), C.byref(n)), f"{l.name}: packed_elems")
+            pw = torch.empty(n.value, dtype=torch.float32, device=device)
+            _lib.check(lib.s3r_conv_pack_weights(C.byref(desc), w.data_ptr(), pw.data_ptr(), stream),
+                       f"{l.name}: pack_weights")
+            scale, shift = blk.folded()
+            packed.append((pw, scale, shift, w))   # keep w alive until the pack kernel has run
+        self._packed = (key, packed)
+        return packed
+
+    def _layer_array(self, batch: int, device, upto: Optional[str] = None):
+        packed = self._ensure_packed(device)
+        n_layers = len(self._layers) if upto is None else self.names.index(upto) + 1
+        arr = (_lib.Layer * n_layers)()
+        for i, (l, (n_in, _)) in enumerate(zip(self._layers[:n_layers], self._sizes())):
+            pw, scale, shift, _ = packed[i]
+            tile = int(os.environ.get(f"S3R_TILE_{l.name}", self.tile_override.get(l.name, -1)))
+            arr[i].desc = _lib.make_desc(l, batch, n_in, tag=self._tag_base + i, tile=tile)
+            arr[i].packed_w = pw.data_ptr()
+            arr[i].scale = scale.data_ptr() if scale is not None else None
+            arr[i].shift = shift.data_ptr() if shift is not None else None
+        return arr, n_layers
+
+    def _out_shape(self, batch: int, n_layers: int):
+        l = self._layers[n_layers - 1]
+        m = self._sizes()[n_layers - 1][1]
+        nd = spec.ndim(l)
+        return (batch, l.cout) + (m,) * nd
+
+    @torch.no_grad()
+    def _run(self, x: torch.Tensor, upto: Optional[str] = None) -> torch.Tensor:
+        lib = _lib.load()
+        device, batch = x.device, x.shape[0]
+        if batch == 0:
+            return x.new_empty(self._out_shape(0, len(self._layers) if upto is None else self.names.index(upto) + 1))
+        arr, n = self._layer_array(batch, device, upto)
+        y = torch.empty(self._out_shape(batch, n), dtype=torch.float32, device=device)
+        need = _lib.check(lib.s3r_chain_workspace_elems(arr, n), "workspace query")
+        ws_a = _workspace(device, "a", need)
+        ws_b = _workspace(device, "b", need)
+        entry = getattr(lib, self._entry if upto is None else "s3r_chain_forward")
+        _lib.check(entry(arr, n, x.data_ptr(), y.data_ptr(), ws_a.data_ptr(), ws_b.data_ptr(), need,
+                         _stream_ptr(device)), type(self).__name__)
+        return y
+
+
+class Encoder(_HipChain):
+    """Shared-weight 2D conv tower: (N,3,224,224) renders -> (N,32,28,28) features.
+
+    Call it on `torch.cat([left, right])`; the same weights serve both views.
+    """
+    _entry = "s3r_encoder_forward"
+
+    def __init__(self):
+        super().__init__(spec.ENCODER, spec.IMG_HW, tag_base=100)
+
+    def forward(self, images: torch.Tensor) -> torch.Tensor:
+        x = _check_input(images, "images", (3, spec.IMG_HW, spec.IMG_HW))
+        return self._run(x)
+
+
+class CostVolume(nn.Module):
+    """Bidirectional shift-and-diff disparity cost volume, (B,C,H,W) x2 -> (B,2C,D,H,W)."""
+
+    def __init__(self, max_disp: int = spec.MAX_DISP):
+        super().__init__()
+        self.max_disp = max_disp
+
+    @torch.no_grad()
+    def forward(self, feat_left: torch.Tensor, feat_right: torch.Tensor) -> torch.Tensor:
+        if feat_left.shape != feat_right.shape or feat_left.dim() != 4:
+            raise RuntimeError(f"feature maps must both be (B,C,H,W), got {tuple(feat_left.shape)} and "
+                               f"{tuple(feat_right.shape)}")
+        fl = _check_input(feat_left, "feat_left", feat_left.shape[1:])
+        fr = _check_input(feat_right, "feat_right", feat_left.shape[1:])
+        B, Cc, H, W = fl.shape
+        vol = torch.empty((B, 2 * Cc, self.max_disp, H, W), dtype=torch.float32, device=fl.device)
+        if B == 0:
+            return vol
+        _lib.check(_lib.load().s3r_cost_volume_forward(fl.data_ptr(), fr.data_ptr(), vol.data_ptr(), B, Cc,
+                                                       self.max_disp, H, W, _stream_ptr(fl.device)), "cost_volume")
+        return vol
+
+
+class Decoder(_HipChain):
+    """3D conv hourglass: cost volume (B,64,28,28,28) -> occupancy probabilities (B,32,32,32)."""
+    _entry = "s3r_decoder_forward"
+
+    def __init__(self):
+        super().__init__(spec.DECODER, spec.MAX_DISP, tag_base=200)
+
+    def forward(self, volume: torch.Tensor, upto: Optional[str] = None) -> torch.Tensor:
+        x = _check_input(volume, "volume", (2 * spec.FEAT_C, spec.MAX_DISP, spec.FEAT_HW, spec.FEAT_HW))
+        y = self._run(x, upto)
+        return y.squeeze(1) if upto is None or upto == self.names[-1] else y
+
+
+class VolumeEncoder(_HipChain):
+    """The down half of the hourglass alone (Stereo2Point): cost volume -> (B,512,4,4,4) latent."""
+    _entry = "s3r_decoder_forward"
+
+    def __init__(self):
+        super().__init__(spec.DECODER_DOWN, spec.MAX_DISP, tag_base=200)
+
+    def forward(self, volume: torch.Tensor) -> torch.Tensor:
+        x = _check_input(volume, "volume", (2 * spec.FEAT_C, spec.MAX_DISP, spec.FEAT_HW, spec.FEAT_HW))
+        return self._run(x)
+
+
+class PointHead(_HipChain):
+    """MLP on the flattened latent: (B,512,4,4,4) -> (B,2048,3)."""
+
+    def __init__(self):
+        super().__init__(spec.POINT_HEAD, 1, tag_base=300)
+
+    def forward(self, latent: torch.Tensor) -> torch.Tensor:
+        x = _check_input(latent, "latent", (spec.LATENT_C, 4, 4, 4))
+        return self._run(x.view(x.shape[0], -1)).view(-1, spec.N_POINTS, 3)
+
+
+class Stereo2Voxel(nn.Module):
+    """left,right (B,3,224,224) -> (B,32,32,32) occupancy.  state_dict keys: encoder.*, decoder.*"""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = Encoder()
+        self.cost_volume = CostVolume()
+        self.decoder = Decoder()
+        self.eval()
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise RuntimeError("forward/inference path only")
+        return super().train(False)
+
+    @torch.no_grad()
+    def forward(self, left: torch.Tensor, right: torch.Tensor) -> torch.Tensor:
+        left = _check_input(left, "left", (3, spec.IMG_HW, spec.IMG_HW))
+        right = _check_input(right, "right", (3, spec.IMG_HW, spec.IMG_HW))
+        if left.shape[0] != right.shape[0]:
+            raise RuntimeError("left and right batch sizes differ")
+        outs = []
+        for s in range(0, max(left.shape[0], 1), MAX_CHUNK):
+            l, r = left[s:s + MAX_CHUNK], right[s:s + MAX_CHUNK]
+            b = l.shape[0]
+            feats = self.encoder(torch.cat([l, r], 0))
+            vol = self.cost_volume(feats[:b], feats[b:])
+            outs.append(self.decoder(vol))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+
+class Stereo2Point(nn.Module):
+    """left,right (B,3,224,224) -> (B,2048,3) point cloud.  Keys: encoder.*, decoder.*, point_head.*"""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = Encoder()
+        self.cost_volume = CostVolume()
+        self.decoder = VolumeEncoder()
+        self.point_head = PointHead()
+        self.eval()
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise RuntimeError("forward/inference path only")
+        return super().train(False)
+
+    @torch.no_grad()
+    def forward(self, left: torch.Tensor, right: torch.Tensor) -> torch.Tensor:
+        left = _check_input(left, "left", (3, spec.IMG_HW, spec.IMG_HW))
+        right = _check_input(right, "right", (3, spec.IMG_HW, spec.IMG_HW))
+        if left.shape[0] != right.shape[0]:
+            raise RuntimeError("left and right batch sizes differ")
+        outs = []
+        for s in range(0, max(left.shape[0], 1), MAX_CHUNK):
+            l, r = left[s:s + MAX_CHUNK], right[s:s + MAX_CHUNK]
+            b = l.shape[0]
+            feats = self.encoder(torch.cat([l, r], 0))
+            vol = self.cost_volume(feats[:b], feats[b:])
+            outs.append(self.point_head(self.decoder(vol)))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+
+@torch.no_grad()
+def chamfer_distance(p: torch.Tensor, q: torch.Tensor):
+    """(dist1 (B,N), dist2 (B,M), idx1 (B,N) int32, idx2 (B,M) int32): squared-L2 nearest neighbours."""
+    if p.dim() != 3 or q.dim() != 3 or p.shape[-1] != 3 or q.shape[-1] != 3 or p.shape[0] != q.shape[0]:
+        raise RuntimeError(f"chamfer_distance expects (B,N,3) and (B,M,3), got {tuple(p.shape)} and {tuple(q.shape)}")
+    p = _check_input(p, "p", p.shape[1:])
+    q = _check_input(q, "q", q.shape[1:])
+    B, N, M = p.shape[0], p.shape[1], q.shape[1]
+    if N == 0 or M == 0:
+        raise RuntimeError("chamfer_distance needs non-empty point clouds")
+    d1 = torch.empty((B, N), dtype=torch.float32, device=p.device)
+    d2 = torch.empty((B, M), dtype=torch.float32, device=p.device)
+    i1 = torch.empty((B, N), dtype=torch.int32, device=p.device)
+    i2 = torch.empty((B, M), dtype=torch.int32, device=p.device)
+    if B:
+        _lib.check(_lib.load().s3r_chamfer_forward(p.data_ptr(), q.data_ptr(), d1.data_ptr(), d2.data_ptr(),
+                                                   i1.data_ptr(), i2.data_ptr(), B, N, M, _stream_ptr(p.device)),
+                   "chamfer")
+    return d1, d2, i1, i2
+
+
+class ChamferDistance(nn.Module):
+    """Drop-in for the reference's extensions/chamfer_dist module (README.md:64-65): forward(p, q)
+    returns mean(dist1) + mean(dist2).  (Whether the reference reduces with mean or sum, squared or
+    not, is unknown — SURVEY.md §8a row 5; `chamfer_distance` exposes the unreduced tensors.)"""
+
+    def forward(self, p, q):
+        d1, d2, _, _ = chamfer_distance(p, q)
+        return d1.mean() + d2.mean()
+
+
+@torch.no_grad()
+def voxel_iou(pred: torch.Tensor, gt: torch.Tensor, threshold: float = 0.5) -> torch.Tensor:
+    """Per-sample IoU of (pred > th) vs (gt > th), computed on the device: (B,...) -> (B,)."""
+    if pred.shape != gt.shape:
+        raise RuntimeError("pred and gt shapes differ")
+    pred = _check_input(pred, "pred", pred.shape[1:])
+    gt = _check_input(gt, "gt", gt.shape[1:])
+    B = pred.shape[0]
+    out = torch.empty((B,), dtype=torch.float32, device=pred.device)
+    if B:
+        _lib.check(_lib.load().s3r_voxel_iou(pred.data_ptr(), gt.data_ptr(), float(threshold), out.data_ptr(), B,
+                                             pred[0].numel(), _stream_ptr(pred.device)), "voxel_iou")
+    return out
+
+
+# the names BASELINE.json's north_star uses for the module API
+encoder = Encoder
+cost_volume = CostVolume
+decoder = Decoder

@@ -1,0 +1,298 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the oracle on the same seeded inputs.
+
+The oracle is this build's own PyTorch-CPU restatement of arch_spec — PARITY UNPINNED with respect to
+the reference, whose model code is not in the mount.  Tolerance: BASELINE.json's
+north_star states 1e-4 relative for fp32 outputs and IoU within 1e-3; the tests below hold the HIP
+path to tighter bounds where fp32 allows (written next to each assert).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def rel_l2(a, b):
+    return ((a - b).norm() / b.norm().clamp(min=1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def models(s3r, oracle):
+    hip = s3r.Stereo2Voxel()
+    s3r.seed_module(hip, 0)
+    ref = oracle.OracleStereo2Voxel().eval()
+    ref.load_state_dict(hip.state_dict())
+    hip.to(DEV)
+    return hip, ref
+
+
+def _single(s3r, layer, in_size):
+    ch = s3r.modules._HipChain([layer], in_size)
+    s3r.seed_module(ch, 7)
+    return ch
+
+
+def _oracle_block(oracle, layer, sd):
+    blk = oracle._Block(layer).eval()
+    blk.load_state_dict(sd)
+    return blk
+
+
+# ------------------------------------------------------------------ MFMA operand/accumulator maps
+def test_mfma_layout_exact_integers(s3r):
+    """A 1x1 conv with small-integer data is exact in fp32: any swapped lane/register map shows up
+    as a mismatch (asymmetric weights, asymmetric input)."""
+    L = s3r.arch_spec.Layer("t", "conv2d", 16, 32, 1, 1, 0, bn=False, act="none")
+    ch = _single(s3r, L, 8)
+    w = torch.arange(32 * 16, dtype=torch.float32).reshape(32, 16, 1, 1) % 7 - 3
+    w[5, 3] = 11
+    ch.t.conv.weight.data.copy_(w)
+    ch.t.conv.bias.data.zero_()
+    x = (torch.arange(2 * 16 * 64, dtype=torch.float32).reshape(2, 16, 8, 8) % 5) - 2
+    x[1, 2, 3, 4] = 9
+    want = F.conv2d(x, w)
+    got = ch.to(DEV)._run(x.to(DEV)).cpu()
+    assert torch.equal(got, want)
+
+
+# ------------------------------------------------------------------ every layer of the arch, alone
+def _layer_cases(spec):
+    cases = []
+    for stage, layers, n0 in (("enc", spec.ENCODER, spec.IMG_HW), ("dec", spec.DECODER, spec.MAX_DISP)):
+        for l, n_in, _ in spec.trace(layers, n0):
+            cases.append((l, n_in))
+    return cases
+
+
+@pytest.mark.parametrize("idx", range(18))
+def test_each_layer_vs_oracle(s3r, oracle, idx):
+    spec = s3r.arch_spec
+    layer, n_in = _layer_cases(spec)[idx]
+    B = 2
+    ch = _single(s3r, layer, n_in)
+    blk = _oracle_block(oracle, layer, getattr(ch, layer.name).state_dict())
+    g = torch.Generator().manual_seed(idx)
+    x = torch.randn((B, layer.cin) + (n_in,) * spec.ndim(layer), generator=g)
+    with torch.no_grad():
+        want = blk(x)
+    got = ch.to(DEV)._run(x.to(DEV)).cpu()
+    assert got.shape == want.shape
+    # fp32 FMA chain vs MKL-DNN blocked summation: differences are pure rounding order
+    assert rel_l2(got, want) < 2e-6, (layer.name, rel_l2(got, want))
+    assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("tile", range(6))
+@pytest.mark.parametrize("kind", ["conv3d_s1", "conv3d_s2", "deconv", "conv2d_s2"])
+def test_every_tile_configuration(s3r, oracle, tile, kind):
+    """All six MFMA tile shapes on ragged problem sizes (N not a tile multiple, Cout not a BM multiple)."""
+    Layer = s3r.arch_spec.Layer
+    layer, n_in, B = {
+        "conv3d_s1": (Layer("t", "conv3d", 32, 96, 3, 1, 1), 7, 3),
+        "conv3d_s2": (Layer("t", "conv3d", 16, 160, 3, 2, 1), 9, 2),
+        "deconv": (Layer("t", "deconv3d", 32, 48, 4, 2, 1), 5, 3),
+        "conv2d_s2": (Layer("t", "conv2d", 48, 64, 3, 2, 1), 13, 5),
+    }[kind]
+    ch = _single(s3r, layer, n_in)
+    ch.tile_override["t"] = tile
+    blk = _oracle_block(oracle, layer, ch.t.state_dict())
+    x = torch.randn((B, layer.cin) + (n_in,) * s3r.arch_spec.ndim(layer), generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        want = blk(x)
+    got = ch.to(DEV)._run(x.to(DEV)).cpu()
+    assert rel_l2(got, want) < 2e-6
+
+
+def test_conv_linearity_full_size(s3r):
+    """Size-independent property at BASELINE size (B=32): conv(2x) == 2*conv(x) bit-exactly when the
+    epilogue is the identity (scaling by 2 is exact in fp32)."""
+    L = s3r.arch_spec.Layer("t", "conv3d", 64, 64, 3, 1, 1, bn=False, act="none")
+    ch = _single(s3r, L, 28)
+    ch.t.conv.bias.data.zero_()
+    ch.to(DEV)
+    x = torch.randn(32, 64, 28, 28, 28, device=DEV)
+    y1 = ch._run(x)
+    y2 = ch._run(2 * x)
+    assert torch.equal(y2, 2 * y1)
+
+
+# ------------------------------------------------------------------ cost volume: bit exact
+@pytest.mark.parametrize("shape", [(2, 32, 28, 28, 28), (1, 5, 7, 6, 10), (3, 4, 12, 5, 8), (2, 3, 9, 4, 7)])
+def test_cost_volume_bit_exact(s3r, oracle, shape):
+    B, Cc, D, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    fl, fr = torch.randn(B, Cc, H, W, generator=g), torch.randn(B, Cc, H, W, generator=g)
+    want = oracle.cost_volume(fl, fr, D)
+    got = s3r.CostVolume(D)(fl.to(DEV), fr.to(DEV)).cpu()
+    assert torch.equal(got, want)
+
+
+# ------------------------------------------------------------------ whole network
+def test_stereo2voxel_vs_oracle_b2(s3r, oracle, models):
+    hip, ref = models
+    left, right = s3r.synthetic_pairs(2, seed=0)
+    with torch.no_grad():
+        want = ref(left, right)
+    got = hip(left.to(DEV), right.to(DEV)).cpu()
+    assert got.shape == (2, 32, 32, 32)
+    assert rel_l2(got, want) < 1e-5                    # north_star bound: 1e-4 relative
+    assert (got - want).abs().max().item() < 1e-4
+    assert oracle.voxel_iou(got, want).min().item() > 1 - 1e-3   # north_star: IoU within 1e-3
+
+
+def test_stereo2voxel_vs_golden(s3r, models, golden_dir):
+    hip, _ = models
+    z = np.load(f"{golden_dir}/s2v_b2_seed0.npz")
+    left, right = s3r.synthetic_pairs(2, seed=0)
+    got = hip(left.to(DEV), right.to(DEV)).cpu()
+    want = torch.from_numpy(z["occupancy"])
+    assert rel_l2(got, want) < 1e-5
+    feats = hip.encoder(torch.cat([left, right]).to(DEV)).cpu()
+    assert rel_l2(feats, torch.from_numpy(z["features"])) < 1e-5
+
+
+def test_stage_by_stage_vs_oracle(s3r, oracle, models):
+    hip, ref = models
+    left, right = s3r.synthetic_pairs(2, seed=5)
+    with torch.no_grad():
+        f_ref = ref.encoder(torch.cat([left, right]))
+        v_ref = oracle.cost_volume(f_ref[:2], f_ref[2:])
+    f = hip.encoder(torch.cat([left, right]).to(DEV))
+    assert rel_l2(f.cpu(), f_ref) < 5e-6
+    v = hip.cost_volume(f[:2], f[2:])
+    assert rel_l2(v.cpu(), v_ref) < 1e-5
+    for name in hip.decoder.names[:-1]:
+        with torch.no_grad():
+            d_ref = ref.decoder(v_ref, upto=name)
+        d = hip.decoder(v_ref.to(DEV), upto=name).cpu()
+        assert rel_l2(d, d_ref) < 5e-6, name
+
+
+def test_batch32_matches_per_sample_bitwise(s3r, models):
+    """BASELINE size (B=32).  Every output voxel's K-order is fixed by the kernel, so a sample's result
+    cannot depend on where it sits in the batch: batch-32 outputs equal batch-1/2 outputs bit for bit."""
+    hip, _ = models
+    left, right = s3r.synthetic_pairs(32, seed=3)
+    left, right = left.to(DEV), right.to(DEV)
+    full = hip(left, right)
+    assert full.shape == (32, 32, 32, 32)
+    assert torch.isfinite(full).all() and full.min() >= 0 and full.max() <= 1
+    for s in (0, 13, 31):
+        one = hip(left[s:s + 1], right[s:s + 1])
+        assert torch.equal(one[0], full[s])
+    again = hip(left, right)
+    assert torch.equal(again, full)            # deterministic (no atomics on the voxel path)
+
+
+def test_batch32_sample_vs_oracle(s3r, models):
+    hip, ref = models
+    left, right = s3r.synthetic_pairs(32, seed=3)
+    got = hip(left.to(DEV), right.to(DEV)).cpu()
+    with torch.no_grad():
+        want = ref(left[20:22], right[20:22])
+    assert rel_l2(got[20:22], want) < 1e-5
+
+
+def test_odd_and_empty_batches(s3r, models):
+    hip, ref = models
+    left, right = s3r.synthetic_pairs(3, seed=9)
+    got = hip(left.to(DEV), right.to(DEV)).cpu()
+    with torch.no_grad():
+        want = ref(left, right)
+    assert rel_l2(got, want) < 1e-5
+    empty = hip(left[:0].to(DEV), right[:0].to(DEV))
+    assert empty.shape == (0, 32, 32, 32)
+
+
+def test_state_dict_roundtrip_changes_output(s3r, models):
+    """load_state_dict must invalidate the packed-weight cache."""
+    hip, _ = models
+    left, right = s3r.synthetic_pairs(1, seed=0)
+    left, right = left.to(DEV), right.to(DEV)
+    y0 = hip(left, right).clone()
+    sd0 = {k: v.clone() for k, v in hip.state_dict().items()}
+    other = s3r.Stereo2Voxel()
+    s3r.seed_module(other, 123)
+    hip.load_state_dict(other.state_dict())
+    y1 = hip(left, right).clone()
+    assert not torch.equal(y0, y1)
+    hip.load_state_dict(sd0)
+    assert torch.equal(hip(left, right), y0)
+
+
+# ------------------------------------------------------------------ Stereo2Point + Chamfer + IoU
+def test_stereo2point_vs_oracle(s3r, oracle):
+    hip = s3r.Stereo2Point()
+    s3r.seed_module(hip, 1)
+    ref = oracle.OracleStereo2Point().eval()
+    ref.load_state_dict(hip.state_dict())
+    hip.to(DEV)
+    left, right = s3r.synthetic_pairs(2, seed=2)
+    with torch.no_grad():
+        want = ref(left, right)
+    got = hip(left.to(DEV), right.to(DEV)).cpu()
+    assert got.shape == (2, 2048, 3)
+    assert rel_l2(got, want) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 2048, 2048), (3, 100, 1500), (1, 1, 1), (2, 1025, 7)])
+def test_chamfer_exact(s3r, oracle, shape):
+    B, N, M = shape
+    g = torch.Generator().manual_seed(4)
+    p, q = torch.rand(B, N, 3, generator=g), torch.rand(B, M, 3, generator=g)
+    w1, w2, wi1, wi2 = oracle.chamfer_distance(p, q)
+    d1, d2, i1, i2 = s3r.chamfer_distance(p.to(DEV), q.to(DEV))
+    assert torch.equal(d1.cpu(), w1) and torch.equal(d2.cpu(), w2)      # same fp32 operation order: bit exact
+    assert torch.equal(i1.cpu(), wi1) and torch.equal(i2.cpu(), wi2)
+    loss = s3r.ChamferDistance()(p.to(DEV), q.to(DEV)).item()
+    assert abs(loss - oracle.chamfer_loss(p, q).item()) < 1e-6
+
+
+def test_chamfer_collisions_first_minimum(s3r, oracle):
+    p = torch.tensor([[[0.0, 0, 0], [1, 1, 1]]])
+    q = torch.tensor([[[1.0, 1, 1], [0, 0, 0], [0, 0, 0], [1, 1, 1]]])
+    d1, d2, i1, i2 = s3r.chamfer_distance(p.to(DEV), q.to(DEV))
+    assert i1.cpu().tolist() == [[1, 0]] and i2.cpu().tolist() == [[1, 0, 0, 1]]
+    assert d1.abs().max().item() == 0 and d2.abs().max().item() == 0
+
+
+def test_voxel_iou_exact(s3r, oracle):
+    g = torch.Generator().manual_seed(8)
+    a, b = torch.rand(5, 32, 32, 32, generator=g), torch.rand(5, 32, 32, 32, generator=g)
+    b[4] = 0                      # empty ground truth
+    a[4] = 0                      # and empty prediction -> IoU defined as 1
+    got = s3r.voxel_iou(a.to(DEV), b.to(DEV)).cpu()
+    assert torch.equal(got, oracle.voxel_iou(a, b))
+
+
+# ------------------------------------------------------------------ error behaviour of the boundary
+def test_errors(s3r, models):
+    hip, _ = models
+    with pytest.raises(RuntimeError):
+        hip(torch.zeros(1, 3, 224, 224), torch.zeros(1, 3, 224, 224))                 # CPU tensors
+    with pytest.raises(RuntimeError):
+        hip(torch.zeros(1, 3, 224, 224, device=DEV).half(), torch.zeros(1, 3, 224, 224, device=DEV).half())
+    with pytest.raises(RuntimeError):
+        hip(torch.zeros(1, 3, 200, 224, device=DEV), torch.zeros(1, 3, 200, 224, device=DEV))
+    with pytest.raises(RuntimeError):
+        hip(torch.zeros(2, 3, 224, 224, device=DEV), torch.zeros(1, 3, 224, 224, device=DEV))
+    with pytest.raises(RuntimeError):
+        hip.train()
+    with pytest.raises(RuntimeError):
+        s3r.chamfer_distance(torch.zeros(1, 0, 3, device=DEV), torch.zeros(1, 4, 3, device=DEV))
+
+
+def test_non_default_stream(s3r, models):
+    hip, _ = models
+    left, right = s3r.synthetic_pairs(1, seed=0)
+    left, right = left.to(DEV), right.to(DEV)
+    want = hip(left, right)
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream(device=DEV)
+    with torch.cuda.stream(st):
+        got = hip(left, right)
+    st.synchronize()
+    assert torch.equal(got, want)
