@@ -29,12 +29,26 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def usable_cpus():
+    """CPUs this process may actually run on: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(budget_s=12.0):
     """The oracle (this build's PyTorch-CPU restatement, NOT the reference) timed on the host cores."""
     import torch
     import s3r
     from oracle import s2v_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    ncpu = usable_cpus()
+    log(f"cpu_baseline: os.cpu_count()={os.cpu_count()} usable={ncpu}")
+    torch.set_num_threads(ncpu)
     m = O.OracleStereo2Voxel().eval()
     s3r.seed_module(m, 0)
     B = 2                                           # BASELINE.json configs[0]

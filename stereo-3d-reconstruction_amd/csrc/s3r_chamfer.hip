@@ -35,9 +35,11 @@ __global__ __launch_bounds__(256) void chamfer_kernel(const float* __restrict__ 
         __syncthreads();
 #pragma unroll 8
         for (int t = 0; t < cnt; ++t) {
+#pragma clang fp contract(off)   // (dx*dx + dy*dy) + dz*dz with three roundings each, as the oracle computes it
             const v4f v = qs[t];
             const float dx = px - v[0], dy = py - v[1], dz = pz - v[2];
-            const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+            const float d = (xx + yy) + zz;
             if (d < best) { best = d; besti = j0 + t; }
         }
     }
