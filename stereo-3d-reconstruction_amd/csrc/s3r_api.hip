@@ -4,10 +4,15 @@
 #include "s3r_kernels.h"
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <vector>
+
+#ifndef S3R_DEFAULT_DIRECT
+#define S3R_DEFAULT_DIRECT 0
+#endif
 
 namespace {
 
@@ -31,6 +36,18 @@ int64_t ipow(int64_t b, int e) {
     return r;
 }
 
+// S3R_KERNEL=lds|direct selects the MFMA convolution kernel family (packing layout follows it)
+bool use_direct() {
+    static const int mode = [] {
+        const char* e = getenv("S3R_KERNEL");
+        return (e && strcmp(e, "lds") == 0) ? 0 : (e && strcmp(e, "direct") == 0) ? 1 : S3R_DEFAULT_DIRECT;
+    }();
+    return mode == 1;
+}
+
+#ifndef S3R_DEFAULT_VARIANT
+#define S3R_DEFAULT_VARIANT 0
+#endif
 constexpr int64_t kMaxElems = (int64_t)1 << 31;
 constexpr int64_t kMaxBytes = (int64_t)1 << 32;
 
@@ -196,7 +213,10 @@ int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, float* packed,
         case R_HEAD: e = hipMemcpyAsync(packed, w, sizeof(float) * d->cin, hipMemcpyDeviceToDevice, s); break;
         case R_LINEAR: e = hipMemcpyAsync(packed, w, sizeof(float) * g.w_elems, hipMemcpyDeviceToDevice, s); break;
         case R_MFMA:
-            if (d->op == S3R_OP_DECONV) e = s3r::launch_pack_deconv_k4s2(w, packed, d->cin, d->cout, cout_pad(d->cout), s);
+            if (use_direct())
+                e = s3r::launch_pack_direct(w, packed, d->cin, d->cout, cout_pad(d->cout),
+                                            d->op == S3R_OP_DECONV ? 8 : (int)ipow(d->k, g.nd), d->op == S3R_OP_DECONV, s);
+            else if (d->op == S3R_OP_DECONV) e = s3r::launch_pack_deconv_k4s2(w, packed, d->cin, d->cout, cout_pad(d->cout), s);
             else e = s3r::launch_pack_conv(w, packed, d->cout, d->cin, (int)ipow(d->k, g.nd), cout_pad(d->cout), s);
             break;
     }
@@ -234,9 +254,15 @@ int s3r_conv_forward(const s3r_conv_desc* d, const float* x, const float* packed
         case R_MFMA: {
             s3r::ConvParams p = make_params(d, g);
             p.x = x; p.w = packed_w; p.scale = scale; p.shift = shift; p.y = y;
-            const int cfg = d->tile >= 0 ? d->tile : s3r::conv_pick_tile(p);
+            const int cfg = d->tile >= 0 ? d->tile : (15 + 16 * S3R_DEFAULT_VARIANT);
             ProfScope ps(s, F_MFMA, d->tag, g.flops, bytes);
-            e = s3r::launch_conv_mfma(p, cfg, s);
+            if (use_direct()) {
+                if (g.x_elems * 4 >= ((int64_t)1 << 31))
+                    return fail(S3R_ERR_INVALID, "input >= 2 GiB: split the batch (direct kernel uses 31-bit byte offsets)");
+                e = s3r::launch_conv_direct(p, cfg & 15, s);
+            } else {
+                e = s3r::launch_conv_mfma(p, cfg, s);
+            }
             break;
         }
     }

@@ -31,14 +31,13 @@ namespace s3r {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 16;
-
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int VAR, int BK>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     constexpr int BM = 32 * WM * TM;
     constexpr int BN = 32 * WN * TN;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(BN == 64 || BN == 128 || BN == 256, "gather mapping assumes BN in {64,128,256}");
+    static_assert(BK == 16 || BK == 32, "K tile depth");
     constexpr int KG = 256 / BN;              // k-groups among the 256 threads
     constexpr int LPT = BK / KG;              // gathered dwords per thread per K tile
     constexpr int A_F4 = BK * BM / 4;         // float4s in one weight tile
@@ -131,14 +130,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             areg0 = *reinterpret_cast<const v4f*>(wrow + (size_t)ak0 * p.CoutPad + am0);                   \
         if (A_PT == 2) areg1 = *reinterpret_cast<const v4f*>(wrow + (size_t)ak1 * p.CoutPad + am1);        \
         const bool v = ((md >> c_td) & (mh >> c_th) & (mw >> c_tw) & 1u) != 0;                             \
-        const int off = base + (sd * c_td * p.Hi + sh * c_th) * p.Wi + sw * c_tw + c_cc * BK * DHWi;       \
-        if (v) {                                                                                           \
+        const int off = (VAR == 3) ? (gn & 1023)                                                            \
+                      : base + (sd * c_td * p.Hi + sh * c_th) * p.Wi + sw * c_tw + c_cc * BK * DHWi;       \
+        if (v || VAR == 3) {                                                                               \
             _Pragma("unroll") for (int i = 0; i < LPT; ++i) breg[i] = __builtin_bit_cast(                  \
                 float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, off * 4, i * chan_step, 0));            \
         } else {                                                                                           \
             _Pragma("unroll") for (int i = 0; i < LPT; ++i) breg[i] = 0.f;                                 \
         }                                                                                                  \
-        if (++c_cc == nchunk) {                                                                            \
+        if (VAR >= 2) { /* chunk-major, tap-minor: the taps of one 16-channel chunk run back to back */     \
+            if (++c_tw == p.kw) { c_tw = 0; if (++c_th == p.kh) { c_th = 0; ++c_td; } }                    \
+            if (++c_tap == T) { c_tap = 0; c_td = 0; c_th = 0; c_tw = 0; ++c_cc; }                         \
+        } else if (++c_cc == nchunk) {                                                                     \
             c_cc = 0; ++c_tap;                                                                             \
             if (++c_tw == p.kw) { c_tw = 0; if (++c_th == p.kh) { c_th = 0; ++c_td; } }                    \
         }                                                                                                  \
@@ -167,27 +170,65 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     const int a_off = wm * TM * 32 + j;
     const int b_off = wn * TN * 32 + j;
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const bool more = (kt + 1 < nkt);
-        if (more) S3R_FETCH();
-        const float* a = As + cur * BK * BM + h * BM + a_off;
-        const float* b = Bs + cur * BK * BN + h * BN + b_off;
+    if (VAR == 0) {
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            const bool more = (kt + 1 < nkt);
+            if (more) S3R_FETCH();
+            const float* a = As + cur * BK * BM + h * BM + a_off;
+            const float* b = Bs + cur * BK * BN + h * BN + b_off;
 #pragma unroll
-        for (int ks = 0; ks < BK / 2; ++ks) {
-            float av[TM], bv[TN];
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                float av[TM], bv[TN];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) av[tm] = a[ks * 2 * BM + tm * 32];
+                for (int tm = 0; tm < TM; ++tm) av[tm] = a[ks * 2 * BM + tm * 32];
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) bv[tn] = b[ks * 2 * BN + tn * 32];
+                for (int tn = 0; tn < TN; ++tn) bv[tn] = b[ks * 2 * BN + tn * 32];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+                for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+            }
+            if (more) S3R_STAGE(cur ^ 1);
+            __syncthreads();
         }
-        if (more) S3R_STAGE(cur ^ 1);
-        __syncthreads();
+    } else {
+        // VAR 1: operand fragments of k-step ks+1 are read from LDS BEFORE the MFMAs of k-step ks are
+        // issued (an in-order wave otherwise reaches its next ds_read only after its 4th MFMA has been
+        // accepted by the pipe, and the read latency shows as an idle matrix pipe), and the next tile's
+        // registers are written to the other LDS buffer in the MIDDLE of the tile, under MFMAs in flight.
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            const bool more = (kt + 1 < nkt);
+            if (more) S3R_FETCH();
+            const float* a = As + cur * BK * BM + h * BM + a_off;
+            const float* b = Bs + cur * BK * BN + h * BN + b_off;
+            float av[2][TM], bv[2][TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) av[0][tm] = a[tm * 32];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bv[0][tn] = b[tn * 32];
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                const int c = ks & 1, n = c ^ 1;
+                if (ks + 1 < BK / 2) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) av[n][tm] = a[(ks + 1) * 2 * BM + tm * 32];
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) bv[n][tn] = b[(ks + 1) * 2 * BN + tn * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);     // keep the prefetch reads ABOVE this step's MFMAs
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][tm], bv[c][tn], acc[tm][tn], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == BK / 4 && more) S3R_STAGE(cur ^ 1);
+            }
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: y = act(acc * scale[cout] + shift[cout]), NC(D)HW, 32 consecutive positions per store
@@ -237,8 +278,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 //    3   2  2  1  1   64 x  64   small N: more workgroups
 //    4   1  4  2  1   64 x 128
 //    5   2  2  2  1  128 x  64
-static const int kTileDims[][2] = {{128, 128}, {64, 256}, {32, 256}, {64, 64}, {64, 128}, {128, 64}};
-constexpr int kNumTiles = 6;
+static const int kTileDims[][2] = {{128, 128}, {64, 256}, {32, 256}, {64, 64}, {64, 128}, {128, 64},
+                                  {64, 64}, {32, 128}, {32, 128}, {64, 128}, {128, 64}};
 
 void conv_tile_dims(int cfg, int* bm, int* bn) {
     *bm = kTileDims[cfg][0];
@@ -246,42 +287,55 @@ void conv_tile_dims(int cfg, int* bm, int* bn) {
 }
 
 int conv_pick_tile(const ConvParams& p) {
-    const int classes = p.transposed ? 8 : 1;
-    auto wgs = [&](int cfg) {
-        const long bm = kTileDims[cfg][0], bn = kTileDims[cfg][1];
-        return ((p.Cout + bm - 1) / bm) * ((p.Ntotal + bn - 1) / bn) * classes;
-    };
-    if (p.Cout <= 32) return 2;
-    if (p.Cout <= 64) {
-        if (wgs(1) >= 512) return 1;
-        if (wgs(4) >= 512) return 4;
-        return 3;
-    }
-    if (wgs(0) >= 512) return 0;
-    if (wgs(5) >= 512) return 5;
-    if (wgs(4) >= 512) return 4;
-    return 3;
+    // Measured on MI355X (tools/layer_bench.py, B=32, every layer of arch_spec, all tile shapes): the
+    // 64x64 tile (one MFMA tile per wave, 8 workgroups per CU at BK=16 / 5 at BK=32) wins or ties on
+    // every layer: the finer grain shortens the last partial round of workgroups, and many resident
+    // waves per SIMD cover each other's barrier waits.  BK=32 halves the barriers per MFMA and is
+    // worth +2 % overall (+20 % on the layers with fewer workgroups than CU slots: v4, v5, v6, d1).
+    const bool k32 = (p.Cin % 32) == 0;
+    if (p.Cout <= 32) return k32 ? 8 : 7;
+    return k32 ? 6 : 3;
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int VAR, int BK = 16>
 static hipError_t launch_cfg(ConvParams p, hipStream_t stream) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    if (p.Cin % BK != 0) return hipErrorInvalidValue;
     p.m_tiles = (p.Cout + BM - 1) / BM;
     p.n_tiles = (p.Ntotal + BN - 1) / BN;
     const size_t lds = (size_t)2 * BK * (BM + BN) * sizeof(float);
     dim3 grid(p.m_tiles * p.n_tiles, p.transposed ? 8 : 1, 1);
-    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, VAR, BK>), grid, dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
-hipError_t launch_conv_mfma(const ConvParams& p, int cfg, hipStream_t stream) {
+template <int VAR>
+static hipError_t launch_var(const ConvParams& p, int cfg, hipStream_t stream) {
     switch (cfg) {
-        case 0: return launch_cfg<2, 2, 2, 2>(p, stream);
-        case 1: return launch_cfg<1, 4, 2, 2>(p, stream);
-        case 2: return launch_cfg<1, 4, 1, 2>(p, stream);
-        case 3: return launch_cfg<2, 2, 1, 1>(p, stream);
-        case 4: return launch_cfg<1, 4, 2, 1>(p, stream);
-        case 5: return launch_cfg<2, 2, 2, 1>(p, stream);
+        case 0: return launch_cfg<2, 2, 2, 2, VAR>(p, stream);
+        case 1: return launch_cfg<1, 4, 2, 2, VAR>(p, stream);
+        case 2: return launch_cfg<1, 4, 1, 2, VAR>(p, stream);
+        case 3: return launch_cfg<2, 2, 1, 1, VAR>(p, stream);
+        case 4: return launch_cfg<1, 4, 2, 1, VAR>(p, stream);
+        case 5: return launch_cfg<2, 2, 2, 1, VAR>(p, stream);
+        case 6: return launch_cfg<2, 2, 1, 1, VAR, 32>(p, stream);   // 64 x 64, BK 32
+        case 7: return launch_cfg<1, 4, 1, 1, VAR>(p, stream);       // 32 x 128
+        case 8: return launch_cfg<1, 4, 1, 1, VAR, 32>(p, stream);   // 32 x 128, BK 32
+        case 9: return launch_cfg<1, 4, 2, 1, VAR, 32>(p, stream);   // 64 x 128, BK 32
+        case 10: return launch_cfg<4, 1, 1, 2, VAR>(p, stream);      // 128 x 64 (4 waves along M)
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// code = tile_cfg + 16 * variant; tile_cfg 15 = heuristic
+hipError_t launch_conv_mfma(const ConvParams& p, int code, hipStream_t stream) {
+    int cfg = code & 15;
+    const int var = code >> 4;
+    if (cfg == 15) cfg = conv_pick_tile(p);
+    switch (var) {
+        case 1: return launch_var<1>(p, cfg, stream);   // tap-major K order
+        case 0:
+        case 2: return launch_var<2>(p, cfg, stream);   // chunk-major K order (default)
         default: return hipErrorInvalidValue;
     }
 }

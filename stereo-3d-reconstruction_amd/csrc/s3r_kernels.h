@@ -33,6 +33,9 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
 hipError_t launch_conv_mfma(const ConvParams& p, int tile_cfg, hipStream_t stream);
 int conv_pick_tile(const ConvParams& p);                     // heuristic tile choice
 void conv_tile_dims(int tile_cfg, int* bm, int* bn);
+hipError_t launch_conv_direct(const ConvParams& p, int tile_cfg, hipStream_t stream);
+hipError_t launch_pack_direct(const float* w, float* wd, int Cin, int Cout, int CoutPad, int T, int transposed,
+                              hipStream_t s);
 hipError_t launch_pack_conv(const float* w, float* wp, int Cout, int Cin, int T, int CoutPad, hipStream_t s);
 hipError_t launch_pack_deconv_k4s2(const float* w, float* wp, int Cin, int Cout, int CoutPad, hipStream_t s);
 hipError_t launch_stem(const float* x, const float* w, const float* scale, const float* shift, float* y,

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Per-layer microbenchmark of the MFMA conv kernel at BASELINE batch (B=32 pairs), interleaved A/B of
+tile configurations / kernel variants in ONE process (cdna guide §5.4 rule 24).
+
+  python tools/layer_bench.py [--layers v1,d3] [--tiles -1,0,1] [--variants 0,1] [--rounds 5] [--batch 32]
+
+`tile` passed to the C-ABI = tile_cfg + 16*variant (tile_cfg -1 = library heuristic).
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import s3r  # noqa: E402
+
+PEAK = 157.3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", default="")
+    ap.add_argument("--tiles", default="-1")
+    ap.add_argument("--variants", default="0")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32)
+    args = ap.parse_args()
+    spec = s3r.arch_spec
+    dev = torch.device("cuda:0")
+    cases = []
+    for layers, n0, mult in ((spec.ENCODER, spec.IMG_HW, 2), (spec.DECODER, spec.MAX_DISP, 1)):
+        for l, n_in, _ in spec.trace(layers, n0):
+            if l.name in ("e1", "d4"):
+                continue
+            if args.layers and l.name not in args.layers.split(","):
+                continue
+            cases.append((l, n_in, mult * args.batch))
+    tiles = [int(t) for t in args.tiles.split(",")]
+    variants = [int(v) for v in args.variants.split(",")]
+    total = {}
+    for l, n_in, B in cases:
+        ch = s3r.modules._HipChain([l], n_in)
+        s3r.seed_module(ch, 1)
+        ch.to(dev)
+        x = torch.randn((B, l.cin) + (n_in,) * spec.ndim(l), device=dev)
+        flops = 2.0 * spec.layer_macs(l, n_in) * B
+        res = {}
+        ref = None
+        for rnd in range(args.rounds + 1):
+            for t in tiles:
+                for v in variants:
+                    code = (15 if t < 0 else t) + 16 * v
+                    ch.tile_override[l.name] = code
+                    s3r.profile_enable(8)
+                    y = ch._run(x)
+                    rec = s3r.profile_read(8)
+                    s3r.profile_enable(0)
+                    if rnd == 0:
+                        if ref is None:
+                            ref = y.clone()
+                        elif not torch.allclose(y, ref, rtol=1e-4, atol=1e-4):
+                            print(f"!! {l.name} tile {t} variant {v}: output differs from first config "
+                                  f"(max {float((y - ref).abs().max()):.3e})")
+                        continue
+                    res.setdefault((t, v), []).append(rec[0]["ms"])
+        line = f"{l.name:4s}"
+        for (t, v), ms in sorted(res.items()):
+            ms.sort()
+            med = ms[len(ms) // 2]
+            tf = flops / med / 1e9
+            line += f" | t{t} v{v}: {med:7.4f} ms {tf:6.1f} TF {tf / PEAK:5.3f}"
+            total.setdefault((t, v), [0.0, 0.0])
+            total[(t, v)][0] += med
+            total[(t, v)][1] += flops
+        print(line, flush=True)
+    for (t, v), (ms, fl) in sorted(total.items()):
+        print(f"TOTAL t{t} v{v}: {ms:8.4f} ms  {fl / ms / 1e9:6.1f} TF  frac {fl / ms / 1e9 / PEAK:5.3f}")
+
+
+if __name__ == "__main__":
+    main()
