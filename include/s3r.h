@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define S3R_ABI_VERSION 1
+#define S3R_ABI_VERSION 2
 
 typedef enum s3r_status {
     S3R_OK = 0,
@@ -51,7 +51,15 @@ typedef enum s3r_op {
 
 typedef enum s3r_act { S3R_ACT_NONE = 0, S3R_ACT_RELU = 1, S3R_ACT_SIGMOID = 2 } s3r_act;
 
-/* One layer's geometry.  Spatial sizes are cubic/square: `in_size` per axis, `ndim` axes. */
+/* One layer's geometry.  Spatial sizes are cubic/square: `in_size` per axis, `ndim` axes.
+ *
+ * Halos.  The MFMA convolution kernels read their zero padding from memory: an activation may be
+ * stored with a ZERO HALO of `halo` elements on every spatial axis, i.e. as a contiguous
+ * (B, C, n+2*halo, ...) tensor whose border is zero and whose interior is the logical (B, C, n, ...)
+ * tensor.  `in_halo` / `out_halo` describe the buffers `x` / `y` of s3r_conv_forward.  A layer with
+ * padding p (or a ConvTranspose) served by the MFMA kernel needs in_halo >= p (>= 1); kernels write
+ * interiors only, so a buffer zeroed once keeps its halo.  s3r_chain_forward plans the halos of all
+ * intermediates itself and pads an unpadded chain input on the fly. */
 typedef struct s3r_conv_desc {
     int32_t op;        /* s3r_op */
     int32_t ndim;      /* 2 or 3 (ignored for LINEAR) */
@@ -61,7 +69,9 @@ typedef struct s3r_conv_desc {
     int32_t k, stride, pad;
     int32_t act;       /* s3r_act */
     int32_t tag;       /* caller's label, echoed by the profiler */
-    int32_t tile;      /* -1: library picks the MFMA tile; >=0: force tile configuration (tuning) */
+    int32_t tile;      /* -1: library picks; >=0: force MFMA tile cfg + 16*gather_width (tuning) */
+    int32_t in_halo;   /* zero halo of the input buffer  (elements per spatial axis side) */
+    int32_t out_halo;  /* zero halo of the output buffer */
 } s3r_conv_desc;
 
 /* One layer of a stage: geometry + its packed weights + folded epilogue vectors (device pointers). */
@@ -86,23 +96,28 @@ int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, float* packed,
 int s3r_conv_forward(const s3r_conv_desc* d, const float* x, const float* packed_w, const float* scale,
                      const float* shift, float* y, void* stream);
 
-/* Run a chain of layers x -> y with two ping-pong workspaces of `ws_elems` floats each
- * (s3r_chain_workspace_elems gives the minimum). */
+/* Run a chain of layers x -> y.  Every intermediate activation gets its own region of `ws`
+ * (s3r_chain_workspace_elems floats; with 288 GB of HBM nothing is recycled), laid out with the halo
+ * the next layer wants.  layers[0].desc.in_halo / layers[n-1].desc.out_halo describe x / y; the halos
+ * of the intermediates are planned by the library (the descriptors' values are ignored for them).
+ * `ws_fresh` != 0 makes the call zero the workspace first: pass 1 the first time a (chain, batch,
+ * workspace) combination is used — or whenever anything else wrote to `ws` — and 0 afterwards. */
 int64_t s3r_chain_workspace_elems(const s3r_layer* layers, int n_layers);
-int s3r_chain_forward(const s3r_layer* layers, int n_layers, const float* x, float* y, float* ws_a, float* ws_b,
-                      int64_t ws_elems, void* stream);
+int s3r_chain_forward(const s3r_layer* layers, int n_layers, const float* x, float* y, float* ws, int64_t ws_elems,
+                      int ws_fresh, void* stream);
 
 /* Stage entry points (thin, shape-checked views of s3r_chain_forward):
  *   encoder: images (N,3,224,224) -> features (N,C,28,28); N = 2B (left batch then right batch)
  *   decoder: cost volume (B,2C,D,H,W) -> occupancy (B,32,32,32)  */
-int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* images, float* features, float* ws_a,
-                        float* ws_b, int64_t ws_elems, void* stream);
-int s3r_decoder_forward(const s3r_layer* layers, int n_layers, const float* volume, float* occupancy, float* ws_a,
-                        float* ws_b, int64_t ws_elems, void* stream);
+int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* images, float* features, float* ws,
+                        int64_t ws_elems, int ws_fresh, void* stream);
+int s3r_decoder_forward(const s3r_layer* layers, int n_layers, const float* volume, float* occupancy, float* ws,
+                        int64_t ws_elems, int ws_fresh, void* stream);
 
-/* vol[b,c,d,h,w] = L[b,c,h,w]-R[b,c,h,w-d] (w>=d), vol[b,C+c,d,h,w] = R[b,c,h,w]-L[b,c,h,w+d] (w+d<W), else 0 */
+/* vol[b,c,d,h,w] = L[b,c,h,w]-R[b,c,h,w-d] (w>=d), vol[b,C+c,d,h,w] = R[b,c,h,w]-L[b,c,h,w+d] (w+d<W), else 0.
+ * `out_halo` > 0 writes the interior of a (B,2C,D+2h,H+2h,W+2h) buffer whose halo the caller zeroed. */
 int s3r_cost_volume_forward(const float* feat_left, const float* feat_right, float* volume, int batch, int channels,
-                            int max_disp, int height, int width, void* stream);
+                            int max_disp, int height, int width, int out_halo, void* stream);
 
 /* y[b][o] = act(sum_i x[b][i] w[o][i] + bias[o]); w in torch Linear layout (no packing) */
 int s3r_linear_forward(const float* x, const float* w, const float* bias, float* y, int batch, int cin, int cout,
@@ -118,7 +133,7 @@ int s3r_voxel_iou(const float* pred, const float* gt, float threshold, float* io
 
 /* Kernel-level profiler: when enabled, every kernel the library launches is bracketed by HIP events
  * on the launch stream.  s3r_profile_read synchronises those events and returns, per launch, the
- * kernel family (0 mfma conv, 1 stem, 2 head, 3 cost volume, 4 linear, 5 chamfer, 6 iou, 7 pack),
+ * kernel family (0 mfma conv, 1 stem, 2 head, 3 cost volume, 4 linear, 5 chamfer, 6 iou, 7 pack, 8 pad copy),
  * the caller's tag, milliseconds, and the algorithmic flops / bytes of that launch. */
 typedef struct s3r_prof_record {
     int32_t family;

@@ -14,12 +14,15 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libs3r_hip.so")
 
 OP_CONV, OP_DECONV, OP_LINEAR = 0, 1, 2
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}
-FAMILY = {0: "conv_mfma", 1: "stem", 2: "head", 3: "cost_volume", 4: "linear", 5: "chamfer", 6: "iou", 7: "pack"}
+FAMILY = {0: "conv_mfma", 1: "stem", 2: "head", 3: "cost_volume", 4: "linear", 5: "chamfer", 6: "iou", 7: "pack",
+          8: "pad_copy"}
+ABI_VERSION = 2
 
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("op", "ndim", "batch", "cin", "cout", "in_size", "k", "stride", "pad", "act", "tag", "tile")]
+                ("op", "ndim", "batch", "cin", "cout", "in_size", "k", "stride", "pad", "act", "tag", "tile",
+                 "in_halo", "out_halo")]
 
 
 class Layer(C.Structure):
@@ -48,14 +51,14 @@ SIGNATURES = {
     "s3r_conv_forward": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
     "s3r_chain_workspace_elems": (C.c_int64, [C.POINTER(Layer), C.c_int]),
-    "s3r_chain_forward": (C.c_int, [C.POINTER(Layer), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                    C.c_int64, C.c_void_p]),
-    "s3r_encoder_forward": (C.c_int, [C.POINTER(Layer), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.c_int64, C.c_void_p]),
-    "s3r_decoder_forward": (C.c_int, [C.POINTER(Layer), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.c_int64, C.c_void_p]),
+    "s3r_chain_forward": (C.c_int, [C.POINTER(Layer), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                    C.c_int, C.c_void_p]),
+    "s3r_encoder_forward": (C.c_int, [C.POINTER(Layer), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_int, C.c_void_p]),
+    "s3r_decoder_forward": (C.c_int, [C.POINTER(Layer), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_int, C.c_void_p]),
     "s3r_cost_volume_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                          C.c_int, C.c_void_p]),
+                                          C.c_int, C.c_int, C.c_void_p]),
     "s3r_linear_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p]),
     "s3r_chamfer_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -86,7 +89,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.s3r_abi_version() != 1:
+        if lib.s3r_abi_version() != ABI_VERSION:
             raise S3RError("libs3r_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -99,12 +102,12 @@ def check(rc, what=""):
     return rc
 
 
-def make_desc(layer, batch, in_size, tag=0, tile=-1):
+def make_desc(layer, batch, in_size, tag=0, tile=-1, in_halo=0, out_halo=0):
     """arch_spec.Layer -> ConvDesc."""
     op = {"conv2d": OP_CONV, "conv3d": OP_CONV, "deconv3d": OP_DECONV, "linear": OP_LINEAR}[layer.op]
     nd = {"conv2d": 2, "conv3d": 3, "deconv3d": 3, "linear": 0}[layer.op]
     return ConvDesc(op, nd, batch, layer.cin, layer.cout, in_size, layer.k, layer.s, layer.p, ACT[layer.act], tag,
-                    tile)
+                    tile, in_halo, out_halo)
 
 
 def profile_enable(max_records):

@@ -10,10 +10,6 @@
 #include <mutex>
 #include <vector>
 
-#ifndef S3R_DEFAULT_DIRECT
-#define S3R_DEFAULT_DIRECT 0
-#endif
-
 namespace {
 
 thread_local char g_err[512] = "";
@@ -36,23 +32,11 @@ int64_t ipow(int64_t b, int e) {
     return r;
 }
 
-// S3R_KERNEL=lds|direct selects the MFMA convolution kernel family (packing layout follows it)
-bool use_direct() {
-    static const int mode = [] {
-        const char* e = getenv("S3R_KERNEL");
-        return (e && strcmp(e, "lds") == 0) ? 0 : (e && strcmp(e, "direct") == 0) ? 1 : S3R_DEFAULT_DIRECT;
-    }();
-    return mode == 1;
-}
-
-#ifndef S3R_DEFAULT_VARIANT
-#define S3R_DEFAULT_VARIANT 0
-#endif
 constexpr int64_t kMaxElems = (int64_t)1 << 31;
 constexpr int64_t kMaxBytes = (int64_t)1 << 32;
 
 // ---------------------------------------------------------------- profiler
-enum Family { F_MFMA = 0, F_STEM = 1, F_HEAD = 2, F_COSTVOL = 3, F_LINEAR = 4, F_CHAMFER = 5, F_IOU = 6, F_PACK = 7 };
+enum Family { F_MFMA = 0, F_STEM = 1, F_HEAD = 2, F_COSTVOL = 3, F_LINEAR = 4, F_CHAMFER = 5, F_IOU = 6, F_PACK = 7, F_PAD = 8 };
 
 struct Prof {
     std::mutex mu;
@@ -84,11 +68,13 @@ struct ProfScope {
 
 // ---------------------------------------------------------------- layer geometry
 struct Geo {
-    int nd;            // spatial dims actually walked (1 for unused axes)
-    int in, out;       // edge sizes
-    int64_t in_sp, out_sp;
-    int64_t x_elems, y_elems, w_elems;
-    double flops;
+    int nd;            // spatial dims
+    int in, out;       // logical edge sizes
+    int in_p, out_p;   // edge sizes of the halo-padded buffers
+    int64_t in_sp, out_sp;         // logical voxels per channel
+    int64_t x_elems, y_elems;      // elements of the (padded) buffers
+    int64_t w_elems;
+    double flops, bytes;           // algorithmic (unpadded) work of the layer
 };
 
 int out_size(const s3r_conv_desc* d) {
@@ -100,12 +86,16 @@ int out_size(const s3r_conv_desc* d) {
 int geometry(const s3r_conv_desc* d, Geo* g) {
     if (!d) return fail(S3R_ERR_INVALID, "null descriptor");
     if (d->batch <= 0 || d->cin <= 0 || d->cout <= 0) return fail(S3R_ERR_INVALID, "batch/cin/cout must be positive");
+    if (d->in_halo < 0 || d->out_halo < 0 || d->in_halo > 8 || d->out_halo > 8)
+        return fail(S3R_ERR_INVALID, "halo must be in [0, 8]");
     if (d->op == S3R_OP_LINEAR) {
-        g->nd = 0; g->in = 1; g->out = 1; g->in_sp = 1; g->out_sp = 1;
+        if (d->in_halo || d->out_halo) return fail(S3R_ERR_INVALID, "linear layers take no halo");
+        g->nd = 0; g->in = g->out = g->in_p = g->out_p = 1; g->in_sp = 1; g->out_sp = 1;
         g->x_elems = (int64_t)d->batch * d->cin;
         g->y_elems = (int64_t)d->batch * d->cout;
         g->w_elems = (int64_t)d->cin * d->cout;
         g->flops = 2.0 * d->batch * (double)d->cin * d->cout;
+        g->bytes = 4.0 * (g->x_elems + g->y_elems + g->w_elems);
         return S3R_OK;
     }
     if (d->op != S3R_OP_CONV && d->op != S3R_OP_DECONV) return fail(S3R_ERR_INVALID, "unknown op %d", d->op);
@@ -117,15 +107,18 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
     g->in = d->in_size;
     g->out = out_size(d);
     if (g->out <= 0) return fail(S3R_ERR_INVALID, "empty output");
+    g->in_p = g->in + 2 * d->in_halo;
+    g->out_p = g->out + 2 * d->out_halo;
     g->in_sp = ipow(g->in, g->nd);
     g->out_sp = ipow(g->out, g->nd);
-    g->x_elems = (int64_t)d->batch * d->cin * g->in_sp;
-    g->y_elems = (int64_t)d->batch * d->cout * g->out_sp;
+    g->x_elems = (int64_t)d->batch * d->cin * ipow(g->in_p, g->nd);
+    g->y_elems = (int64_t)d->batch * d->cout * ipow(g->out_p, g->nd);
     g->w_elems = (int64_t)d->cin * d->cout * ipow(d->k, g->nd);
     if (d->op == S3R_OP_DECONV)
         g->flops = 2.0 * d->batch * (double)d->cin * g->in_sp * d->cout * ipow(d->k, g->nd);
     else
         g->flops = 2.0 * d->batch * (double)d->cout * g->out_sp * d->cin * ipow(d->k, g->nd);
+    g->bytes = 4.0 * ((double)d->batch * (d->cin * (double)g->in_sp + d->cout * (double)g->out_sp) + (double)g->w_elems);
     if (g->x_elems >= kMaxElems || g->y_elems >= kMaxElems || g->x_elems * 4 >= kMaxBytes || g->y_elems * 4 >= kMaxBytes)
         return fail(S3R_ERR_INVALID, "tensor too large for one call (>= 2^31 elements / 4 GiB): split the batch");
     return S3R_OK;
@@ -133,6 +126,7 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
 
 enum Route { R_STEM, R_HEAD, R_MFMA, R_LINEAR };
 
+// which kernel serves a layer shape (halos are checked separately, by check_halos)
 int route(const s3r_conv_desc* d, Route* r) {
     if (d->op == S3R_OP_LINEAR) { *r = R_LINEAR; return S3R_OK; }
     if (d->op == S3R_OP_CONV && d->ndim == 2 && d->cin == 3 && d->cout == 32 && d->k == 3 && d->stride == 2 &&
@@ -144,6 +138,22 @@ int route(const s3r_conv_desc* d, Route* r) {
                 "needs cin %% 16 == 0", d->cin, d->cout, d->k, d->stride, d->pad, d->ndim);
 }
 
+// input halo the layer's kernel needs (the MFMA gather reads its zero padding from memory)
+int need_halo(const s3r_conv_desc* d, Route r) {
+    if (r != R_MFMA) return 0;
+    return d->op == S3R_OP_DECONV ? 1 : d->pad;
+}
+
+int check_halos(const s3r_conv_desc* d, Route r) {
+    if (d->in_halo < need_halo(d, r))
+        return fail(S3R_ERR_INVALID, "this layer's kernel reads its zero padding from memory: the input must carry a "
+                    "zero halo of >= %d (got in_halo=%d); s3r_chain_forward pads unpadded inputs itself",
+                    need_halo(d, r), d->in_halo);
+    if ((r == R_STEM || r == R_HEAD) && d->in_halo != 0) return fail(S3R_ERR_INVALID, "stem / head kernels take an unpadded input");
+    if (r == R_HEAD && d->out_halo != 0) return fail(S3R_ERR_INVALID, "head kernel writes an unpadded output");
+    return S3R_OK;
+}
+
 int cout_pad(int cout) { return (cout + 127) / 128 * 128; }
 
 s3r::ConvParams make_params(const s3r_conv_desc* d, const Geo& g) {
@@ -151,23 +161,86 @@ s3r::ConvParams make_params(const s3r_conv_desc* d, const Geo& g) {
     memset(&p, 0, sizeof(p));
     const bool is3 = d->ndim == 3;
     p.B = d->batch; p.Cin = d->cin; p.Cout = d->cout; p.CoutPad = cout_pad(d->cout);
-    p.Di = is3 ? g.in : 1; p.Hi = g.in; p.Wi = g.in;
-    p.Do = is3 ? g.out : 1; p.Ho = g.out; p.Wo = g.out;
     p.act = d->act;
+    // strides of the padded buffers; a 2D layer has no depth axis (x_ds = y_ds = 0, Nd = kd = 1)
+    p.x_hs = g.in_p; p.x_ds = is3 ? g.in_p * g.in_p : 0; p.x_cs = (int)ipow(g.in_p, g.nd);
+    p.y_hs = g.out_p; p.y_ds = is3 ? g.out_p * g.out_p : 0; p.y_cs = (int)ipow(g.out_p, g.nd);
+    p.y_org = d->out_halo * (p.y_ds + p.y_hs + 1);
+    p.x_bytes = (unsigned)(g.x_elems * 4);
     if (d->op == S3R_OP_DECONV) {
         p.transposed = 1;
-        p.Nd = p.Di; p.Nh = p.Hi; p.Nw = p.Wi;
-        p.kd = p.kh = p.kw = 2;
-        p.stride = 1; p.pad_d = p.pad_h = p.pad_w = 0;
+        p.Nd = g.in; p.Nh = g.in; p.Nw = g.in;
+        p.kd = p.kh = p.kw = 2; p.T = 8;
+        p.stride = 1;
+        p.x_org = d->in_halo * (p.x_ds + p.x_hs + 1);
     } else {
         p.transposed = 0;
-        p.Nd = p.Do; p.Nh = p.Ho; p.Nw = p.Wo;
-        p.kd = is3 ? d->k : 1; p.kh = d->k; p.kw = d->k;
+        p.Nd = is3 ? g.out : 1; p.Nh = g.out; p.Nw = g.out;
+        p.kd = is3 ? d->k : 1; p.kh = d->k; p.kw = d->k; p.T = p.kd * p.kh * p.kw;
         p.stride = d->stride;
-        p.pad_d = is3 ? d->pad : 0; p.pad_h = d->pad; p.pad_w = d->pad;
+        p.x_org = (d->in_halo - d->pad) * (p.x_ds + p.x_hs + 1);
     }
     p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
     return p;
+}
+
+// ---------------------------------------------------------------- chain planning
+// A chain gives every intermediate activation its own region of the caller's workspace, with the zero
+// halo the NEXT layer's gather wants; regions are written interior-only, so the halos stay zero from
+// the one memset that initialises the workspace (ws_fresh).
+struct Plan {
+    std::vector<s3r_conv_desc> d;     // descriptors with planned halos
+    std::vector<Route> r;
+    std::vector<Geo> g;
+    std::vector<int64_t> off;         // workspace offset of layer i's OUTPUT (-1: the caller's y)
+    bool pad_input = false;
+    int64_t pad_off = 0;
+    int64_t total = 0;
+};
+
+int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
+    if (!layers || n <= 0) return fail(S3R_ERR_INVALID, "empty chain");
+    pl->d.resize(n); pl->r.resize(n); pl->g.resize(n); pl->off.assign(n, -1);
+    for (int i = 0; i < n; ++i) {
+        pl->d[i] = layers[i].desc;
+        int rc = route(&pl->d[i], &pl->r[i]);
+        if (rc) return rc;
+    }
+    const int need0 = need_halo(&pl->d[0], pl->r[0]);
+    pl->pad_input = pl->d[0].in_halo < need0;
+    const int user_in_halo = pl->d[0].in_halo;
+    if (pl->pad_input) pl->d[0].in_halo = need0;
+    for (int i = 0; i < n; ++i) {
+        if (i > 0) pl->d[i].in_halo = pl->d[i - 1].out_halo;
+        if (i + 1 < n) pl->d[i].out_halo = need_halo(&pl->d[i + 1], pl->r[i + 1]);
+        int rc = geometry(&pl->d[i], &pl->g[i]);
+        if (rc) return rc;
+        if ((rc = check_halos(&pl->d[i], pl->r[i]))) return rc;
+        if (i > 0) {   // shapes must chain
+            const s3r_conv_desc& a = pl->d[i - 1];
+            const int64_t prev_out = (int64_t)a.cout * pl->g[i - 1].out_sp, cur_in = (int64_t)pl->d[i].cin * pl->g[i].in_sp;
+            if (prev_out != cur_in || a.batch != pl->d[i].batch)
+                return fail(S3R_ERR_INVALID, "layer %d input (%lld/sample) does not match layer %d output (%lld/sample)", i,
+                            (long long)cur_in, i - 1, (long long)prev_out);
+            if (pl->d[i].in_halo && (pl->g[i - 1].out != pl->g[i].in || a.cout != pl->d[i].cin))
+                return fail(S3R_ERR_INVALID, "layer %d needs a halo but reshapes layer %d's output", i, i - 1);
+        }
+    }
+    int64_t off = 0;
+    if (pl->pad_input) {
+        if (user_in_halo != 0) return fail(S3R_ERR_INVALID, "chain input halo %d is smaller than the %d its first layer needs",
+                                           user_in_halo, need0);
+        pl->pad_off = 0;
+        off = align_up(pl->g[0].x_elems, 256);
+    }
+    for (int i = 0; i + 1 < n; ++i) {
+        pl->off[i] = off;
+        off = align_up(off + pl->g[i].y_elems, 256);
+    }
+    pl->total = off;
+    return S3R_OK;
 }
 
 }  // namespace
@@ -213,11 +286,8 @@ int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, float* packed,
         case R_HEAD: e = hipMemcpyAsync(packed, w, sizeof(float) * d->cin, hipMemcpyDeviceToDevice, s); break;
         case R_LINEAR: e = hipMemcpyAsync(packed, w, sizeof(float) * g.w_elems, hipMemcpyDeviceToDevice, s); break;
         case R_MFMA:
-            if (use_direct())
-                e = s3r::launch_pack_direct(w, packed, d->cin, d->cout, cout_pad(d->cout),
-                                            d->op == S3R_OP_DECONV ? 8 : (int)ipow(d->k, g.nd), d->op == S3R_OP_DECONV, s);
-            else if (d->op == S3R_OP_DECONV) e = s3r::launch_pack_deconv_k4s2(w, packed, d->cin, d->cout, cout_pad(d->cout), s);
-            else e = s3r::launch_pack_conv(w, packed, d->cout, d->cin, (int)ipow(d->k, g.nd), cout_pad(d->cout), s);
+            e = s3r::launch_pack_conv(w, packed, d->cin, d->cout, cout_pad(d->cout),
+                                      d->op == S3R_OP_DECONV ? 8 : (int)ipow(d->k, g.nd), d->op == S3R_OP_DECONV, s);
             break;
     }
     if (e != hipSuccess) return hip_fail(e, "pack weights");
@@ -230,39 +300,36 @@ int s3r_conv_forward(const s3r_conv_desc* d, const float* x, const float* packed
     int rc = geometry(d, &g);
     if (rc) return rc;
     if ((rc = route(d, &r))) return rc;
+    if ((rc = check_halos(d, r))) return rc;
     if (!x || !packed_w || !y) return fail(S3R_ERR_INVALID, "null tensor pointer");
     hipStream_t s = (hipStream_t)stream;
-    const double bytes = 4.0 * (g.x_elems + g.y_elems + g.w_elems);
     hipError_t e = hipSuccess;
     switch (r) {
         case R_STEM: {
             if (!scale || !shift) return fail(S3R_ERR_INVALID, "stem needs scale and shift");
-            ProfScope ps(s, F_STEM, d->tag, g.flops, bytes);
-            e = s3r::launch_stem(x, packed_w, scale, shift, y, d->batch, g.in, g.in, g.out, g.out, s);
+            ProfScope ps(s, F_STEM, d->tag, g.flops, g.bytes);
+            e = s3r::launch_stem(x, packed_w, scale, shift, y, d->batch, g.in, g.in, g.out, g.out, g.out_p * g.out_p,
+                                 g.out_p, d->out_halo * (g.out_p + 1), s);
             break;
         }
         case R_HEAD: {
-            ProfScope ps(s, F_HEAD, d->tag, g.flops, bytes);
+            ProfScope ps(s, F_HEAD, d->tag, g.flops, g.bytes);
             e = s3r::launch_head(x, packed_w, scale, shift, y, d->batch, d->cin, g.in_sp, d->act, s);
             break;
         }
         case R_LINEAR: {
-            ProfScope ps(s, F_LINEAR, d->tag, g.flops, bytes);
+            ProfScope ps(s, F_LINEAR, d->tag, g.flops, g.bytes);
             e = s3r::launch_linear(x, packed_w, scale, shift, y, d->batch, d->cin, d->cout, d->act, s);
             break;
         }
         case R_MFMA: {
             s3r::ConvParams p = make_params(d, g);
             p.x = x; p.w = packed_w; p.scale = scale; p.shift = shift; p.y = y;
-            const int cfg = d->tile >= 0 ? d->tile : (15 + 16 * S3R_DEFAULT_VARIANT);
-            ProfScope ps(s, F_MFMA, d->tag, g.flops, bytes);
-            if (use_direct()) {
-                if (g.x_elems * 4 >= ((int64_t)1 << 31))
-                    return fail(S3R_ERR_INVALID, "input >= 2 GiB: split the batch (direct kernel uses 31-bit byte offsets)");
-                e = s3r::launch_conv_direct(p, cfg & 15, s);
-            } else {
-                e = s3r::launch_conv_mfma(p, cfg, s);
-            }
+            const int cfg = d->tile >= 0 ? d->tile : 15;
+            if ((cfg & 15) != 15 && (cfg & 15) >= s3r::conv_num_tiles())
+                return fail(S3R_ERR_INVALID, "unknown tile configuration %d", cfg & 15);
+            ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
+            e = s3r::launch_conv_mfma(p, cfg, s);
             break;
         }
     }
@@ -271,51 +338,48 @@ int s3r_conv_forward(const s3r_conv_desc* d, const float* x, const float* packed
 }
 
 int64_t s3r_chain_workspace_elems(const s3r_layer* layers, int n_layers) {
-    if (!layers || n_layers <= 0) return fail(S3R_ERR_INVALID, "empty chain");
-    int64_t m = 0;
-    for (int i = 0; i + 1 < n_layers; ++i) {   // the last layer writes into y
-        Geo g;
-        int rc = geometry(&layers[i].desc, &g);
-        if (rc) return rc;
-        if (g.y_elems > m) m = g.y_elems;
-    }
-    return m;
+    Plan pl;
+    int rc = plan_chain(layers, n_layers, &pl);
+    if (rc) return rc;
+    return pl.total;
 }
 
-int s3r_chain_forward(const s3r_layer* layers, int n_layers, const float* x, float* y, float* ws_a, float* ws_b,
-                      int64_t ws_elems, void* stream) {
-    if (!layers || n_layers <= 0) return fail(S3R_ERR_INVALID, "empty chain");
-    const int64_t need = s3r_chain_workspace_elems(layers, n_layers);
-    if (need < 0) return (int)need;
-    if (n_layers > 1 && (!ws_a || (n_layers > 2 && !ws_b) || ws_elems < need))
-        return fail(S3R_ERR_WORKSPACE, "chain needs two workspaces of %lld floats, got %lld", (long long)need,
+int s3r_chain_forward(const s3r_layer* layers, int n_layers, const float* x, float* y, float* ws, int64_t ws_elems,
+                      int ws_fresh, void* stream) {
+    Plan pl;
+    int rc = plan_chain(layers, n_layers, &pl);
+    if (rc) return rc;
+    if (!x || !y) return fail(S3R_ERR_INVALID, "null tensor pointer");
+    if (pl.total > 0 && (!ws || ws_elems < pl.total))
+        return fail(S3R_ERR_WORKSPACE, "chain needs a workspace of %lld floats, got %lld", (long long)pl.total,
                     (long long)ws_elems);
+    hipStream_t s = (hipStream_t)stream;
+    if (ws_fresh && pl.total > 0) {   // zero halos (and everything else) once; later calls write interiors only
+        hipError_t e = hipMemsetAsync(ws, 0, (size_t)pl.total * sizeof(float), s);
+        if (e != hipSuccess) return hip_fail(e, "workspace memset");
+    }
     const float* cur = x;
+    if (pl.pad_input) {
+        const s3r_conv_desc& d0 = pl.d[0];
+        const int hl = d0.in_halo, is3 = d0.ndim == 3;
+        ProfScope ps(s, F_PAD, d0.tag, 0.0, 8.0 * d0.batch * d0.cin * (double)pl.g[0].in_sp);
+        hipError_t e = s3r::launch_pad_copy(x, ws + pl.pad_off, (int64_t)d0.batch * d0.cin, is3 ? d0.in_size : 1, d0.in_size,
+                                            d0.in_size, is3 ? hl : 0, hl, hl, s);
+        if (e != hipSuccess) return hip_fail(e, "pad copy launch");
+        cur = ws + pl.pad_off;
+    }
     for (int i = 0; i < n_layers; ++i) {
         const s3r_layer& L = layers[i];
-        if (i > 0) {   // shapes must chain
-            Geo gp;
-            geometry(&layers[i - 1].desc, &gp);
-            const s3r_conv_desc& a = layers[i - 1].desc;
-            const int64_t prev_out = (int64_t)a.cout * gp.out_sp;
-            Geo gc;
-            int rc = geometry(&L.desc, &gc);
-            if (rc) return rc;
-            const int64_t cur_in = (int64_t)L.desc.cin * gc.in_sp;
-            if (prev_out != cur_in || a.batch != L.desc.batch)
-                return fail(S3R_ERR_INVALID, "layer %d input (%lld/sample) does not match layer %d output (%lld/sample)", i,
-                            (long long)cur_in, i - 1, (long long)prev_out);
-        }
-        float* out = (i == n_layers - 1) ? y : ((i & 1) ? ws_b : ws_a);
-        int rc = s3r_conv_forward(&L.desc, cur, L.packed_w, L.scale, L.shift, out, stream);
+        float* out = (i == n_layers - 1) ? y : ws + pl.off[i];
+        rc = s3r_conv_forward(&pl.d[i], cur, L.packed_w, L.scale, L.shift, out, stream);
         if (rc) return rc;
         cur = out;
     }
     return S3R_OK;
 }
 
-int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* images, float* features, float* ws_a,
-                        float* ws_b, int64_t ws_elems, void* stream) {
+int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* images, float* features, float* ws,
+                        int64_t ws_elems, int ws_fresh, void* stream) {
     if (!layers || n_layers <= 0) return fail(S3R_ERR_INVALID, "empty encoder");
     const s3r_conv_desc& f = layers[0].desc;
     if (f.op != S3R_OP_CONV || f.ndim != 2 || f.cin != 3)
@@ -323,31 +387,34 @@ int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* imag
     for (int i = 0; i < n_layers; ++i)
         if (layers[i].desc.op != S3R_OP_CONV || layers[i].desc.ndim != 2)
             return fail(S3R_ERR_INVALID, "encoder layer %d is not a 2D convolution", i);
-    return s3r_chain_forward(layers, n_layers, images, features, ws_a, ws_b, ws_elems, stream);
+    return s3r_chain_forward(layers, n_layers, images, features, ws, ws_elems, ws_fresh, stream);
 }
 
-int s3r_decoder_forward(const s3r_layer* layers, int n_layers, const float* volume, float* occupancy, float* ws_a,
-                        float* ws_b, int64_t ws_elems, void* stream) {
+int s3r_decoder_forward(const s3r_layer* layers, int n_layers, const float* volume, float* occupancy, float* ws,
+                        int64_t ws_elems, int ws_fresh, void* stream) {
     if (!layers || n_layers <= 0) return fail(S3R_ERR_INVALID, "empty decoder");
     for (int i = 0; i < n_layers; ++i)
         if (layers[i].desc.op == S3R_OP_LINEAR || layers[i].desc.ndim != 3)
             return fail(S3R_ERR_INVALID, "decoder layer %d is not a 3D (transposed) convolution", i);
-    return s3r_chain_forward(layers, n_layers, volume, occupancy, ws_a, ws_b, ws_elems, stream);
+    return s3r_chain_forward(layers, n_layers, volume, occupancy, ws, ws_elems, ws_fresh, stream);
 }
 
 int s3r_cost_volume_forward(const float* fl, const float* fr, float* vol, int batch, int channels, int max_disp,
-                            int height, int width, void* stream) {
+                            int height, int width, int out_halo, void* stream) {
     if (!fl || !fr || !vol) return fail(S3R_ERR_INVALID, "null tensor pointer");
     if (batch <= 0 || channels <= 0 || max_disp <= 0 || height <= 0 || width <= 0)
         return fail(S3R_ERR_INVALID, "cost volume dims must be positive");
     const int64_t hw = (int64_t)height * width;
     if (2 * hw * 4 > 64 * 1024) return fail(S3R_ERR_INVALID, "feature plane %dx%d does not fit the LDS staging", height, width);
+    if (out_halo < 0 || out_halo > 8) return fail(S3R_ERR_INVALID, "halo must be in [0, 8]");
     const int64_t out = (int64_t)batch * 2 * channels * max_disp * hw;
-    if (out >= kMaxElems) return fail(S3R_ERR_INVALID, "cost volume too large for one call: split the batch");
+    const int64_t out_p = (int64_t)batch * 2 * channels * (max_disp + 2 * out_halo) * (height + 2 * out_halo) *
+                          (width + 2 * out_halo);
+    if (out_p >= kMaxElems) return fail(S3R_ERR_INVALID, "cost volume too large for one call: split the batch");
     hipStream_t s = (hipStream_t)stream;
     const double bytes = 4.0 * (2.0 * batch * channels * hw + (double)out);
     ProfScope ps(s, F_COSTVOL, 0, (double)out, bytes);
-    hipError_t e = s3r::launch_cost_volume(fl, fr, vol, batch, channels, max_disp, height, width, s);
+    hipError_t e = s3r::launch_cost_volume(fl, fr, vol, batch, channels, max_disp, height, width, out_halo, s);
     if (e != hipSuccess) return hip_fail(e, "cost volume launch");
     return S3R_OK;
 }

@@ -1,0 +1,405 @@
+// Direct (im2col-free) 2D/3D convolution and transposed convolution as an implicit GEMM on the
+// gfx950 fp32 matrix cores, operands staged HBM/L2 -> LDS by LDS-DMA (buffer_load ... lds), with the
+// folded-BN affine + activation fused into the epilogue.
+//
+//   D[cout][pos] = sum_{chunk, tap, c} Wp[(chunk*T + tap)*16 + c][cout] * X[b(pos)][chunk*16 + c][in(pos) + tap]
+//
+//   GEMM M = Cout, N = B*Nd*Nh*Nw positions, K = Cin*T walked chunk-major / tap-minor in K tiles of
+//   BK = 16 = ONE tap x 16 consecutive input channels, so the T taps of a channel chunk re-read the
+//   same input patch back to back (L1/L2 hits) and everything that changes from one K tile to the
+//   next is a scalar byte offset.
+//
+// Activations live in HBM with a one-element ZERO HALO on every spatial axis ("padded NC(D)HW",
+// DESIGN.md §3): the gather needs no validity predicate at all, so a lane's VEC consecutive output
+// positions of one row are VEC consecutive input dwords for every tap (stride-1 layers) and are
+// fetched by ONE buffer_load_dwordx{VEC} ... lds.  Per K tile a wave issues NPB+NPA such DMAs and
+// nothing else memory-side: no staging VGPRs, no ds_write, no address VALU (per-lane voffsets are
+// loop-invariant; the per-tile part sits in the SGPR soffset).
+//
+// Matrix instruction: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain; 64 FLOP/clk/SIMD = the chip's
+// 157 TFLOP/s fp32 roof — gfx950 has no TF32-style shortcut).  Operand maps (64-lane wave):
+//   A: lane l holds A[i = l&31][k = l>>5]     B: lane l holds B[k = l>>5][j = l&31]
+//   D: reg r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31]
+// A wave owns (32*TM) couts x (32*TN) positions as TM x TN MFMA tiles INTERLEAVED at element
+// granularity: MFMA tile (tm,tn) row i / column j is cout m0 + i*TM + tm / position n0 + j*TN + tn.
+// With the LDS images As[k][cout], Bs[k][pos] (exactly what the DMA writes: lane-linear rows), lane
+// (i,h) fetches its TM A values of a k-step with ONE ds_read_b{32*TM} and its TN B values with ONE
+// ds_read_b{32*TN} (conflict-free: consecutive lanes, consecutive addresses), and in the epilogue
+// every accumulator register row is TN consecutive positions per lane -> dwordx{TN} stores.
+//
+// Pipeline: two LDS buffers; the DMAs of K tile t+1 are issued before the MFMAs of tile t and waited
+// for (vmcnt(0)) just before the one barrier that ends tile t.
+//
+// ConvTranspose3d(k=4,s=2,p=1) runs as 8 output-parity classes (blockIdx.y); each class is a
+// 2x2x2-tap gather over the input grid with its own packed weight slab: output-stationary, no atomics,
+// no zero-stuffed taps.
+#include "s3r_kernels.h"
+
+namespace s3r {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned vector access
+typedef float v2f_u __attribute__((ext_vector_type(2), aligned(4)));
+
+#define S3R_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int N> struct FVec;
+template <> struct FVec<1> { typedef float type; };
+template <> struct FVec<2> { typedef v2f type; };
+template <> struct FVec<4> { typedef v4f type; };
+
+template <int N>
+__device__ __forceinline__ float vget(const typename FVec<N>::type& v, int i) {
+    if constexpr (N == 1) return v; else return v[i];
+}
+
+template <int BYTES>
+__device__ __forceinline__ void dma_to_lds(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, int voffset, int soffset) {
+    // the size operand must be a literal
+    // the size operand must be a literal; LDS-DMA exists for 1, 2, 4, 12 and 16 bytes per lane (no 8)
+    static_assert(BYTES == 16 || BYTES == 4, "LDS-DMA width");
+    if constexpr (BYTES == 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, S3R_LDS_PTR(lds_dst), 16, voffset, soffset, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, S3R_LDS_PTR(lds_dst), 4, voffset, soffset, 0, 0);
+}
+
+constexpr int GBK = 16;   // K tile depth: one tap x 16 input channels
+
+// waves per SIMD the register allocator must leave room for: 16*TM*TN accumulator registers + ~48
+constexpr int min_waves(int tm, int tn) { return tm * tn >= 8 ? 2 : (tm * tn >= 4 ? 4 : 5); }
+
+template <int WM, int WN, int TM, int TN, int VEC>
+__global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const ConvParams p) {
+    constexpr int BM = 32 * WM * TM;
+    constexpr int BN = 32 * WN * TN;
+    constexpr int BK = GBK;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    // ---- DMA piece geometry (one wave-instruction = 64 lanes x 4*VEC bytes (B) or x 16 bytes (A))
+    constexpr int PB = 64 * VEC;                              // floats per B piece
+    constexpr int NPIECE_B = BK * BN / PB;
+    static_assert(NPIECE_B % 4 == 0, "B pieces divide over the 4 waves");
+    constexpr int NPB = NPIECE_B / 4;                         // B pieces per wave per K tile
+    constexpr bool B_WIDE = BN >= PB;                         // a piece is (part of) one k row
+    constexpr int PPR = B_WIDE ? BN / PB : 1;                 // pieces per row
+    constexpr int RPP = B_WIDE ? 1 : PB / BN;                 // rows per piece
+    static_assert(PPR == 1 || PPR == 2 || PPR == 4, "pieces per row");
+    constexpr int LPR_B = BN / VEC;                           // lanes per row (when RPP > 1)
+    constexpr int NPIECE_A = BK * BM / 256;                   // A pieces of 256 floats (x4 per lane)
+    constexpr int NPA = (NPIECE_A + 3) / 4;
+    constexpr int RPP_A = 256 / BM;                           // rows per A piece (BM <= 256)
+    static_assert(BM <= 256 && 256 % BM == 0, "BM");
+    constexpr int LPR_A = BM / 4;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                  // [2][BK][BM]
+    float* Bs = smem + 2 * BK * BM;    // [2][BK][BN]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int j = lane & 31, h = lane >> 5;
+
+    // ---- XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a
+    // contiguous run of tiles so neighbouring N tiles find their shared input rows in that XCD's L2.
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int m_tile = bid % p.m_tiles;
+    const int n_tile = bid / p.m_tiles;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int cls = blockIdx.y;                       // output parity class (transposed only)
+    const int rd = (cls >> 2) & 1, rh = (cls >> 1) & 1, rw = cls & 1;
+
+    const int S = p.Nd * p.Nh * p.Nw;
+    const int T = p.T;
+    const int nkt = T * (p.Cin / BK);
+
+    // ---- per-lane loop-invariant DMA offsets (bytes)
+    int bvoff;     // B: this lane's VEC positions (+ its row inside a multi-row piece)
+    {
+        int col, lrow;
+        if (B_WIDE) { col = (wave % PPR) * PB + lane * VEC; lrow = 0; }
+        else        { col = (lane % LPR_B) * VEC;           lrow = lane / LPR_B; }
+        int n = n0 + col;
+        if (n >= p.Ntotal) n = p.Ntotal - VEC;          // tail tile: fetch a valid group, never stored
+        const int b = n / S;
+        int rem = n - b * S;
+        const int pd = rem / (p.Nh * p.Nw);
+        rem -= pd * p.Nh * p.Nw;
+        const int ph = rem / p.Nw;
+        const int pw = rem - ph * p.Nw;
+        int e = b * p.Cin * p.x_cs + p.x_org + (pd * p.x_ds + ph * p.x_hs + pw) * p.stride + lrow * p.x_cs;
+        if (p.transposed) e += (rd - 1) * p.x_ds + (rh - 1) * p.x_hs + (rw - 1);
+        bvoff = e * 4;
+    }
+    const int avoff = ((lane / LPR_A) * p.CoutPad + (lane % LPR_A) * 4) * 4;
+
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const size_t w_cls = (size_t)cls * T * p.Cin * p.CoutPad;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w + w_cls), 0, (int)((unsigned)T * (unsigned)p.Cin * (unsigned)p.CoutPad * 4u), 0x00020000);
+
+    // wave-uniform piece placement
+    const int b_row0 = B_WIDE ? wave / PPR : wave * RPP;               // first k row this wave fetches
+    constexpr int B_ROW_STEP = B_WIDE ? 4 / PPR : 4 * RPP;             // k rows between its pieces
+    const int b_lds0 = B_WIDE ? b_row0 * BN + (wave % PPR) * PB : wave * PB;
+    constexpr int B_LDS_STEP = B_WIDE ? B_ROW_STEP * BN : 4 * PB;
+    const int cs4 = p.x_cs * 4;
+
+    // K-tile cursor of the NEXT tile to fetch (all scalar)
+    int c_td = 0, c_th = 0, c_tw = 0, c_tap = 0, c_cc = 0, c_kt = 0;
+
+    auto issue = [&](int buf) {
+        // ---- weights: rows [c_kt*16, +16) of the packed slab, couts [m0, m0+BM)
+        float* sa = As + buf * BK * BM;
+        const int a_base = (c_kt * BK * p.CoutPad + m0) * 4;
+#pragma unroll
+        for (int q = 0; q < NPA; ++q) {
+            const int piece = wave + 4 * q;
+            if (NPIECE_A % 4 == 0 || piece < NPIECE_A)
+                dma_to_lds<16>(wrsrc, sa + piece * 256, avoff, a_base + piece * RPP_A * p.CoutPad * 4);
+        }
+        // ---- gathered input: 16 channels of chunk c_cc at tap (c_td, c_th, c_tw)
+        float* sb = Bs + buf * BK * BN + b_lds0;
+        const int b_base = ((c_cc * BK + b_row0) * p.x_cs + c_td * p.x_ds + c_th * p.x_hs + c_tw) * 4;
+#pragma unroll
+        for (int q = 0; q < NPB; ++q)
+            dma_to_lds<4 * VEC>(xrsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
+        // ---- advance the cursor: chunk-major, tap-minor
+        ++c_kt;
+        if (++c_tw == p.kw) { c_tw = 0; if (++c_th == p.kh) { c_th = 0; ++c_td; } }
+        if (++c_tap == T) { c_tap = 0; c_td = 0; c_th = 0; c_tw = 0; ++c_cc; }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int a_off = h * BM + wm * TM * 32 + j * TM;
+    const int b_off = h * BN + wn * TN * 32 + j * TN;
+    typedef typename FVec<TM>::type AV;
+    typedef typename FVec<TN>::type BV;
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) issue(cur ^ 1);
+        const float* a = As + cur * BK * BM + a_off;
+        const float* b = Bs + cur * BK * BN + b_off;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const AV av = *reinterpret_cast<const AV*>(a + ks * 2 * BM);
+            const BV bv = *reinterpret_cast<const BV*>(b + ks * 2 * BN);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(vget<TM>(av, tm), vget<TN>(bv, tn),
+                                                                       acc[tm][tn], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of tile kt+1 have landed
+        __syncthreads();                                    // ... everyone's have, and buffer `cur` is free
+    }
+
+    // ---- epilogue: y = act(acc * scale[cout] + shift[cout]) into the (halo-padded) NC(D)HW output;
+    // a lane's TN positions are consecutive in one output row when Nw % TN == 0 (convolutions).
+    const int nl = n0 + wn * TN * 32 + j * TN;          // this lane's first position
+    const int ostep = p.transposed ? 2 : 1;
+    const bool vec_ok = !p.transposed && (p.Nw % TN == 0);
+    int yoff[TN];
+    bool yok[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = nl + tn;
+        yok[tn] = n < p.Ntotal;
+        const int nn = yok[tn] ? n : 0;
+        const int b = nn / S;
+        int rem = nn - b * S;
+        const int pd = rem / (p.Nh * p.Nw);
+        rem -= pd * p.Nh * p.Nw;
+        const int ph = rem / p.Nw;
+        const int pw = rem - ph * p.Nw;
+        int e = b * p.Cout * p.y_cs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw) * ostep;
+        if (p.transposed) e += rd * p.y_ds + rh * p.y_hs + rw;
+        yoff[tn] = e;
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * TM * 32 + ((r & 3) + 8 * (r >> 2) + 4 * h) * TM + tm;
+            if (m >= p.Cout) continue;
+            const float sc = p.scale ? p.scale[m] : 1.f;
+            const float sf = p.shift ? p.shift[m] : 0.f;
+            float v[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                float t = fmaf(acc[tm][tn][r], sc, sf);
+                if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
+                else if (p.act == ACT_SIGMOID) t = 1.f / (1.f + __expf(-t));
+                v[tn] = t;
+            }
+            float* __restrict__ yrow = p.y + (size_t)m * p.y_cs;
+            if (TN > 1 && vec_ok && yok[TN - 1]) {
+                // dword-aligned (not 16-B aligned) vector store: legal for global memory on gfx950
+                if constexpr (TN == 2) {
+                    const v2f t = {v[0], v[1]};
+                    *reinterpret_cast<v2f_u*>(yrow + yoff[0]) = t;
+                } else if constexpr (TN == 4) {
+                    const v4f t = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<v4f_u*>(yrow + yoff[0]) = t;
+                }
+            } else {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    if (yok[tn]) yrow[yoff[tn]] = v[tn];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile configurations:  id -> (WM, WN, TM, TN); the gather width VEC is chosen per layer
+//   id  WM WN TM TN   BM x BN
+//    0   2  2  2  2  128 x 128   Cout >= 128
+//    1   1  4  2  2   64 x 256   Cout == 64
+//    2   1  4  1  2   32 x 256   Cout <= 32
+//    3   2  2  1  1   64 x  64   small N (more workgroups)
+//    4   2  2  2  4  128 x 256   Cout >= 128, large N
+//    5   1  4  2  4   64 x 512   Cout == 64, large N
+//    6   2  2  2  1  128 x  64   small N, Cout >= 128
+//    7   1  4  2  1   64 x 128
+static const int kTileDims[][2] = {{128, 128}, {64, 256}, {32, 256}, {64, 64}, {128, 256}, {64, 512}, {128, 64}, {64, 128}};
+constexpr int kNumTiles = 8;
+
+void conv_tile_dims(int cfg, int* bm, int* bn) {
+    *bm = kTileDims[cfg][0];
+    *bn = kTileDims[cfg][1];
+}
+int conv_num_tiles() { return kNumTiles; }
+
+int conv_pick_tile(const ConvParams& p) {
+    const int classes = p.transposed ? 8 : 1;
+    auto wgs = [&](int cfg) {
+        const long bm = kTileDims[cfg][0], bn = kTileDims[cfg][1];
+        return ((p.Cout + bm - 1) / bm) * ((p.Ntotal + bn - 1) / bn) * classes;
+    };
+    if (p.Cout <= 32) return 2;
+    if (p.Cout <= 64) return wgs(1) >= 768 ? 1 : (wgs(7) >= 768 ? 7 : 3);
+    return wgs(0) >= 768 ? 0 : (wgs(6) >= 768 ? 6 : 3);
+}
+
+// widest gather the layer geometry allows: VEC consecutive positions of a row must be VEC consecutive
+// input dwords (stride 1) and must not straddle rows (Nw % VEC == 0)
+int conv_pick_vec(const ConvParams& p) {
+    if (p.stride != 1) return 1;
+    return (p.Nw % 4 == 0) ? 4 : 1;   // (there is no 8-byte LDS-DMA)
+}
+
+template <int WM, int WN, int TM, int TN, int VEC>
+static hipError_t launch_cfg(ConvParams p, hipStream_t stream) {
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    if constexpr (GBK * BN % (256 * VEC) != 0 || BN > 256 * VEC) {
+        return hipErrorInvalidValue;   // tile too narrow / too wide for this gather width
+    } else {
+        p.m_tiles = (p.Cout + BM - 1) / BM;
+        p.n_tiles = (p.Ntotal + BN - 1) / BN;
+        const size_t lds = (size_t)2 * GBK * (BM + BN) * sizeof(float);
+        if (lds > 48 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation
+            static const hipError_t attr = hipFuncSetAttribute(
+                reinterpret_cast<const void*>(&conv_glds_kernel<WM, WN, TM, TN, VEC>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (attr != hipSuccess) return attr;
+        }
+        dim3 grid(p.m_tiles * p.n_tiles, p.transposed ? 8 : 1, 1);
+        hipLaunchKernelGGL((conv_glds_kernel<WM, WN, TM, TN, VEC>), grid, dim3(256), lds, stream, p);
+        return hipGetLastError();
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+static hipError_t launch_vec(const ConvParams& p, int vec, hipStream_t stream) {
+    switch (vec) {
+        case 4: return launch_cfg<WM, WN, TM, TN, 4>(p, stream);
+        case 1: return launch_cfg<WM, WN, TM, TN, 1>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// code = tile_cfg (15 = heuristic) + 16 * forced_vec (0 = widest legal)
+hipError_t launch_conv_mfma(const ConvParams& p, int code, hipStream_t stream) {
+    int cfg = code & 15;
+    int vec = code >> 4;
+    if (cfg == 15) cfg = conv_pick_tile(p);
+    const int vmax = conv_pick_vec(p);
+    if (vec != 1 && vec != 4) vec = vmax;
+    if (vec > vmax) vec = vmax;
+    if (p.Cin % GBK != 0 || p.Ntotal % vec != 0) return hipErrorInvalidValue;
+    switch (cfg) {
+        case 0: return launch_vec<2, 2, 2, 2>(p, vec, stream);
+        case 1: return launch_vec<1, 4, 2, 2>(p, vec, stream);
+        case 2: return launch_vec<1, 4, 1, 2>(p, vec, stream);
+        case 3: return launch_vec<2, 2, 1, 1>(p, vec, stream);
+        case 4: return launch_vec<2, 2, 2, 4>(p, vec, stream);
+        case 5: return launch_vec<1, 4, 2, 4>(p, vec, stream);
+        case 6: return launch_vec<2, 2, 2, 1>(p, vec, stream);
+        case 7: return launch_vec<1, 4, 2, 1>(p, vec, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing (device-side, once per parameter update): K rows of CoutPad couts in the kernel's
+// K order (chunk-major, tap-minor):   row = (chunk*T + tap)*16 + c,  cin = chunk*16 + c
+//   conv   : w[Cout][Cin][T]        -> wp[row][cout]
+//   deconv : w[Cin][Cout][4][4][4]  -> wp[cls][row][cout], tap = (td,th,tw) in 2x2x2; along an axis with
+//            output parity r, tap t reads input offset t-1+r and kernel index 3 - r - 2t
+__global__ void pack_glds_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int CoutPad,
+                                 int T, int transposed) {
+    const size_t per_cls = (size_t)T * Cin * CoutPad;
+    const size_t total = (transposed ? 8 : 1) * per_cls;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cls = (int)(i / per_cls);
+        size_t r = i % per_cls;
+        const int co = (int)(r % CoutPad);
+        r /= CoutPad;
+        const int c = (int)(r & 15);
+        r >>= 4;
+        const int tap = (int)(r % T);
+        const int cc = (int)(r / T);
+        const int cin = cc * 16 + c;
+        float v = 0.f;
+        if (co < Cout) {
+            if (!transposed) {
+                v = w[((size_t)co * Cin + cin) * T + tap];
+            } else {
+                const int rd = (cls >> 2) & 1, rh = (cls >> 1) & 1, rw = cls & 1;
+                const int td = (tap >> 2) & 1, th = (tap >> 1) & 1, tw = tap & 1;
+                const int kd = 3 - rd - 2 * td, kh = 3 - rh - 2 * th, kw = 3 - rw - 2 * tw;
+                v = w[((size_t)cin * Cout + co) * 64 + (kd * 4 + kh) * 4 + kw];
+            }
+        }
+        wp[i] = v;
+    }
+}
+
+hipError_t launch_pack_conv(const float* w, float* wp, int Cin, int Cout, int CoutPad, int T, int transposed,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(pack_glds_kernel, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CoutPad, T, transposed);
+    return hipGetLastError();
+}
+
+}  // namespace s3r

@@ -6,21 +6,25 @@
 
 namespace s3r {
 
-// Kernel-side view of one convolution launch.  All tensors are fp32, contiguous NC(D)HW.
+// Kernel-side view of one convolution launch.  All tensors are fp32 NC(D)HW; activations may carry a
+// zero halo of `halo` elements on every spatial axis (padded edge = edge + 2*halo), described here
+// purely by element strides and origin offsets.
 struct ConvParams {
-    const float* x;       // (B, Cin, Di, Hi, Wi)
-    const float* w;       // packed weights, see pack kernels: [cls][tap][cin][CoutPad]
+    const float* x;       // input  (B, Cin,  Dp, Hp, Wp)   (padded)
+    const float* w;       // packed weights [cls][(chunk*T + tap)*16 + c][CoutPad]
     const float* scale;   // per-cout epilogue scale  (folded BN gamma/sqrt(var+eps)), may be null -> 1
     const float* shift;   // per-cout epilogue shift  (folded bias/BN beta/mean),      may be null -> 0
-    float* y;             // (B, Cout, Do, Ho, Wo)
+    float* y;             // output (B, Cout, Dp', Hp', Wp') (padded)
     int B, Cin, Cout, CoutPad;
-    int Di, Hi, Wi;
-    int Do, Ho, Wo;
     int Nd, Nh, Nw;       // per-sample position grid walked by the GEMM N index
                           //   conv: output grid; transposed conv: input grid (one parity class per blockIdx.y)
-    int kd, kh, kw;       // taps per axis (transposed k4s2p1: 2,2,2 per parity class)
-    int stride;
-    int pad_d, pad_h, pad_w;
+    int kd, kh, kw, T;    // taps per axis and in total (transposed k4s2p1: 2,2,2 per parity class)
+    int stride;           // input step per position (transposed: 1)
+    int x_cs, x_ds, x_hs; // input element strides: channel, depth, row   (batch stride = Cin * x_cs)
+    int x_org;            // element offset of tap (0,0,0) of position (0,0,0): (halo_in - pad) per axis
+    int y_cs, y_ds, y_hs; // output element strides
+    int y_org;            // element offset of output (0,0,0): halo_out per axis
+    unsigned x_bytes;     // size of the input buffer (buffer descriptor range)
     int transposed;       // 0: convolution, 1: ConvTranspose3d(k=4,s=2,p=1) split into 8 parity classes
     int act;              // 0 none, 1 relu, 2 sigmoid
     int Ntotal;           // B*Nd*Nh*Nw
@@ -30,18 +34,20 @@ struct ConvParams {
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
 
 // launchers (defined in the .hip files); every launcher enqueues on `stream` and returns hipGetLastError()
-hipError_t launch_conv_mfma(const ConvParams& p, int tile_cfg, hipStream_t stream);
-int conv_pick_tile(const ConvParams& p);                     // heuristic tile choice
+hipError_t launch_conv_mfma(const ConvParams& p, int tile_code, hipStream_t stream);   // code = cfg + 16*vec
+int conv_pick_tile(const ConvParams& p);
+int conv_pick_vec(const ConvParams& p);
+int conv_num_tiles();
 void conv_tile_dims(int tile_cfg, int* bm, int* bn);
-hipError_t launch_conv_direct(const ConvParams& p, int tile_cfg, hipStream_t stream);
-hipError_t launch_pack_direct(const float* w, float* wd, int Cin, int Cout, int CoutPad, int T, int transposed,
-                              hipStream_t s);
-hipError_t launch_pack_conv(const float* w, float* wp, int Cout, int Cin, int T, int CoutPad, hipStream_t s);
-hipError_t launch_pack_deconv_k4s2(const float* w, float* wp, int Cin, int Cout, int CoutPad, hipStream_t s);
+hipError_t launch_pack_conv(const float* w, float* wp, int Cin, int Cout, int CoutPad, int T, int transposed,
+                            hipStream_t s);
+// y (N,32,Ho+2h,Wo+2h) <- stem conv of x (N,3,Hi,Wi); y_hs / y_cs / y_org describe the padded output
 hipError_t launch_stem(const float* x, const float* w, const float* scale, const float* shift, float* y,
-                       int N, int Hi, int Wi, int Ho, int Wo, hipStream_t s);
+                       int N, int Hi, int Wi, int Ho, int Wo, int y_cs, int y_hs, int y_org, hipStream_t s);
 hipError_t launch_cost_volume(const float* fl, const float* fr, float* vol, int B, int C, int D, int H, int W,
-                              hipStream_t s);
+                              int halo, hipStream_t s);
+hipError_t launch_pad_copy(const float* x, float* y, int64_t planes, int D, int H, int W, int hd, int hh, int hw,
+                           hipStream_t s);
 hipError_t launch_pack_stem(const float* w, float* wt, hipStream_t s);
 hipError_t launch_head(const float* x, const float* w, const float* scale, const float* shift, float* y, int B, int C,
                        int64_t S, int act, hipStream_t s);

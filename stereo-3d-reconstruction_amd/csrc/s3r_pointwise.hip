@@ -21,7 +21,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 //   wt: packed [27][32] (k-major, cout fastest)
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
-                                                   float* __restrict__ y, int N, int Hi, int Wi, int Ho, int Wo) {
+                                                   float* __restrict__ y, int N, int Hi, int Wi, int Ho, int Wo,
+                                                   int y_cs, int y_hs, int y_org) {
     const int HWo = Ho * Wo;
     const long long total = (long long)N * HWo;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -52,9 +53,9 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
             }
         }
     }
-    float* __restrict__ yn = y + (size_t)n * 32 * HWo + sp;
+    float* __restrict__ yn = y + (size_t)n * 32 * y_cs + y_org + oh * y_hs + ow;   // (halo-padded) NCHW
 #pragma unroll
-    for (int c = 0; c < 32; ++c) yn[(size_t)c * HWo] = fmaxf(fmaf(acc[c], scale[c], shift[c]), 0.f);
+    for (int c = 0; c < 32; ++c) yn[(size_t)c * y_cs] = fmaxf(fmaf(acc[c], scale[c], shift[c]), 0.f);
 }
 
 __global__ void pack_stem_kernel(const float* __restrict__ w, float* __restrict__ wt) {
@@ -66,10 +67,10 @@ __global__ void pack_stem_kernel(const float* __restrict__ w, float* __restrict_
 }
 
 hipError_t launch_stem(const float* x, const float* wt, const float* scale, const float* shift, float* y, int N,
-                       int Hi, int Wi, int Ho, int Wo, hipStream_t s) {
+                       int Hi, int Wi, int Ho, int Wo, int y_cs, int y_hs, int y_org, hipStream_t s) {
     const long long total = (long long)N * Ho * Wo;
     hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, wt, scale, shift, y,
-                       N, Hi, Wi, Ho, Wo);
+                       N, Hi, Wi, Ho, Wo, y_cs, y_hs, y_org);
     return hipGetLastError();
 }
 
@@ -82,11 +83,15 @@ hipError_t launch_pack_stem(const float* w, float* wt, hipStream_t s) {
 // Cost volume: vol[b, c,   d, h, w] = L[b,c,h,w] - R[b,c,h,w-d]   (0 where w-d < 0)
 //              vol[b, C+c, d, h, w] = R[b,c,h,w] - L[b,c,h,w+d]   (0 where w+d >= W)
 // One workgroup per (b, c): both HxW planes are read from HBM exactly once into LDS, then the two
-// D*H*W output slabs are streamed out with 16-byte stores that are contiguous across the whole
-// (d,h,w) slab — the disparity axis is walked in the store order, so every HBM write is a full
-// line.  Algorithmic bytes = 4*(2*H*W + 2*D*H*W) per (b,c); the kernel moves exactly that.
+// D*H*W output slabs are streamed out with 16-byte stores (4 consecutive w of one row), rows walked in
+// (d,h) order so consecutive lanes write consecutive HBM lines.  The volume may carry a zero halo
+// (`halo` elements on the d, h and w axes) for the 3D conv that consumes it; only the interior is
+// written.  Algorithmic bytes = 4*(2*H*W + 2*D*H*W) per (b,c); the kernel moves exactly that.
+typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte access
+
 __global__ __launch_bounds__(256) void cost_volume_kernel(const float* __restrict__ fl, const float* __restrict__ fr,
-                                                          float* __restrict__ vol, int C, int D, int H, int W) {
+                                                          float* __restrict__ vol, int C, int D, int H, int W,
+                                                          int halo) {
     extern __shared__ __attribute__((aligned(16))) float cv_smem[];
     const int HW = H * W;
     float* sl = cv_smem;
@@ -101,15 +106,20 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(const float* __restric
     }
     __syncthreads();
     const int DHW = D * HW;
-    float* __restrict__ ol = vol + ((size_t)b * 2 * C + c) * DHW;
-    float* __restrict__ orr = vol + ((size_t)b * 2 * C + C + c) * DHW;
+    const int Wp = W + 2 * halo, Hp = H + 2 * halo, Dp = D + 2 * halo;
+    const int hs = Wp, ds = Hp * Wp;
+    const size_t cs = (size_t)Dp * ds;
+    const int org = halo * (ds + hs + 1);
+    float* __restrict__ ol = vol + ((size_t)b * 2 * C + c) * cs + org;
+    float* __restrict__ orr = vol + ((size_t)b * 2 * C + C + c) * cs + org;
     if ((W & 3) == 0) {
         const int nq = DHW >> 2;
         for (int q = threadIdx.x; q < nq; q += 256) {
             const int e = q << 2;
             const int d = e / HW;
             const int hw = e - d * HW;
-            const int w0 = hw % W;
+            const int hh = hw / W;
+            const int w0 = hw - hh * W;
             v4f a, r;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -117,24 +127,54 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(const float* __restric
                 a[k] = (w >= d) ? sl[hw + k] - sr[hw + k - d] : 0.f;
                 r[k] = (w + d < W) ? sr[hw + k] - sl[hw + k + d] : 0.f;
             }
-            *reinterpret_cast<v4f*>(ol + e) = a;
-            *reinterpret_cast<v4f*>(orr + e) = r;
+            const int o = d * ds + hh * hs + w0;
+            *reinterpret_cast<v4f_u*>(ol + o) = a;
+            *reinterpret_cast<v4f_u*>(orr + o) = r;
         }
     } else {
         for (int e = threadIdx.x; e < DHW; e += 256) {
             const int d = e / HW;
             const int hw = e - d * HW;
-            const int w = hw % W;
-            ol[e] = (w >= d) ? sl[hw] - sr[hw - d] : 0.f;
-            orr[e] = (w + d < W) ? sr[hw] - sl[hw + d] : 0.f;
+            const int hh = hw / W;
+            const int w = hw - hh * W;
+            const int o = d * ds + hh * hs + w;
+            ol[o] = (w >= d) ? sl[hw] - sr[hw - d] : 0.f;
+            orr[o] = (w + d < W) ? sr[hw] - sl[hw + d] : 0.f;
         }
     }
 }
 
 hipError_t launch_cost_volume(const float* fl, const float* fr, float* vol, int B, int C, int D, int H, int W,
-                              hipStream_t s) {
+                              int halo, hipStream_t s) {
     const size_t lds = (size_t)2 * H * W * sizeof(float);
-    hipLaunchKernelGGL(cost_volume_kernel, dim3(B * C), dim3(256), lds, s, fl, fr, vol, C, D, H, W);
+    hipLaunchKernelGGL(cost_volume_kernel, dim3(B * C), dim3(256), lds, s, fl, fr, vol, C, D, H, W, halo);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// pad_copy: (planes, D, H, W) -> interior of a zero-halo (planes, D+2hd, H+2hh, W+2hw) buffer.  Used
+// when a caller hands an unpadded tensor to a layer whose gather wants the halo.
+__global__ __launch_bounds__(256) void pad_copy_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       long long total, int D, int H, int W, int hd, int hh, int hw) {
+    const int Hp = H + 2 * hh, Wp = W + 2 * hw;
+    const long long Dp = D + 2 * hd;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int w = (int)(i % W);
+        long long r = i / W;
+        const int h = (int)(r % H);
+        r /= H;
+        const int d = (int)(r % D);
+        const long long pl = r / D;
+        y[((pl * Dp + d + hd) * Hp + h + hh) * Wp + w + hw] = x[i];
+    }
+}
+
+hipError_t launch_pad_copy(const float* x, float* y, int64_t planes, int D, int H, int W, int hd, int hh, int hw,
+                           hipStream_t s) {
+    const long long total = (long long)planes * D * H * W;
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, x, y, total,
+                       D, H, W, hd, hh, hw);
     return hipGetLastError();
 }
 

@@ -39,16 +39,24 @@ def _check_input(x: torch.Tensor, name: str, shape_tail: Sequence[int]):
     return x.contiguous()
 
 
-_WS: Dict[tuple, torch.Tensor] = {}
+class _Workspace:
+    """A chain's activation arena.  Every intermediate of the chain has its own region in it, stored with
+    the zero halo the next layer's gather reads; the kernels write interiors only, so the
+    arena is zeroed ONCE per (layout = batch size) — `fresh` tells the C-ABI call to do that — and then
+    stays resident: nothing is re-allocated or re-zeroed on the steady-state path."""
 
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+        self.layout = None
 
-def _workspace(device, slot: str, elems: int) -> torch.Tensor:
-    key = (str(device), slot)
-    t = _WS.get(key)
-    if t is None or t.numel() < elems:
-        t = torch.empty(max(elems, 1), dtype=torch.float32, device=device)
-        _WS[key] = t
-    return t
+    def get(self, device, elems: int, layout):
+        fresh = 0
+        if self.buf is None or self.buf.device != device or self.buf.numel() < elems:
+            self.buf = torch.empty(max(elems, 1), dtype=torch.float32, device=device)
+            fresh = 1
+        if self.layout != layout:
+            self.layout, fresh = layout, 1
+        return self.buf, fresh
 
 
 class _Block(nn.Module):
@@ -101,6 +109,7 @@ class _HipChain(nn.Module):
         for l in layers:
             self.add_module(l.name, _Block(l))
         self._packed = None          # (key, [(packed_w, scale, shift)])
+        self._ws = _Workspace()
         self.tile_override: Dict[str, int] = {}
         if self.training:
             self.eval()              # inference path: eval-mode BatchNorm is the only mode implemented
@@ -150,14 +159,17 @@ class _HipChain(nn.Module):
         self._packed = (key, packed)
         return packed
 
-    def _layer_array(self, batch: int, device, upto: Optional[str] = None):
+    def _layer_array(self, batch: int, device, upto: Optional[str] = None, in_halo: int = 0):
         packed = self._ensure_packed(device)
         n_layers = len(self._layers) if upto is None else self.names.index(upto) + 1
         arr = (_lib.Layer * n_layers)()
         for i, (l, (n_in, _)) in enumerate(zip(self._layers[:n_layers], self._sizes())):
             pw, scale, shift, _ = packed[i]
             tile = int(os.environ.get(f"S3R_TILE_{l.name}", self.tile_override.get(l.name, -1)))
-            arr[i].desc = _lib.make_desc(l, batch, n_in, tag=self._tag_base + i, tile=tile)
+            # only the chain's own input / output halos are the caller's to state (the output is always
+            # a plain contiguous tensor); the library plans the intermediates
+            arr[i].desc = _lib.make_desc(l, batch, n_in, tag=self._tag_base + i, tile=tile,
+                                         in_halo=in_halo if i == 0 else 0, out_halo=0)
             arr[i].packed_w = pw.data_ptr()
             arr[i].scale = scale.data_ptr() if scale is not None else None
             arr[i].shift = shift.data_ptr() if shift is not None else None
@@ -170,19 +182,20 @@ class _HipChain(nn.Module):
         return (batch, l.cout) + (m,) * nd
 
     @torch.no_grad()
-    def _run(self, x: torch.Tensor, upto: Optional[str] = None) -> torch.Tensor:
+    def _run(self, x: torch.Tensor, upto: Optional[str] = None, in_halo: int = 0) -> torch.Tensor:
+        """x: the chain input; with in_halo > 0 it is a halo-padded buffer (B, C, n+2h, ...) whose border
+        is zero (internal hand-off from the cost-volume kernel), otherwise a plain contiguous tensor."""
         lib = _lib.load()
         device, batch = x.device, x.shape[0]
         if batch == 0:
             return x.new_empty(self._out_shape(0, len(self._layers) if upto is None else self.names.index(upto) + 1))
-        arr, n = self._layer_array(batch, device, upto)
+        arr, n = self._layer_array(batch, device, upto, in_halo)
         y = torch.empty(self._out_shape(batch, n), dtype=torch.float32, device=device)
         need = _lib.check(lib.s3r_chain_workspace_elems(arr, n), "workspace query")
-        ws_a = _workspace(device, "a", need)
-        ws_b = _workspace(device, "b", need)
+        ws, fresh = self._ws.get(device, need, (batch, n, in_halo))
         entry = getattr(lib, self._entry if upto is None else "s3r_chain_forward")
-        _lib.check(entry(arr, n, x.data_ptr(), y.data_ptr(), ws_a.data_ptr(), ws_b.data_ptr(), need,
-                         _stream_ptr(device)), type(self).__name__)
+        _lib.check(entry(arr, n, x.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), fresh, _stream_ptr(device)),
+                   type(self).__name__)
         return y
 
 
@@ -207,6 +220,25 @@ class CostVolume(nn.Module):
     def __init__(self, max_disp: int = spec.MAX_DISP):
         super().__init__()
         self.max_disp = max_disp
+        self._padded: Optional[torch.Tensor] = None      # resident halo-padded volume (internal hand-off)
+
+    @torch.no_grad()
+    def forward_padded(self, feat_left: torch.Tensor, feat_right: torch.Tensor, halo: int = 1) -> torch.Tensor:
+        """Internal hand-off to the decoder: the volume written straight into a resident
+        (B,2C,D+2h,H+2h,W+2h) buffer whose zero halo the decoder's first 3D conv reads as its padding.
+        The buffer is zeroed when (re)allocated; the kernel writes the interior only."""
+        fl = _check_input(feat_left, "feat_left", feat_left.shape[1:])
+        fr = _check_input(feat_right, "feat_right", feat_left.shape[1:])
+        B, Cc, H, W = fl.shape
+        shape = (B, 2 * Cc, self.max_disp + 2 * halo, H + 2 * halo, W + 2 * halo)
+        if self._padded is None or tuple(self._padded.shape) != shape or self._padded.device != fl.device:
+            self._padded = torch.zeros(shape, dtype=torch.float32, device=fl.device)
+        if B == 0:
+            return self._padded
+        _lib.check(_lib.load().s3r_cost_volume_forward(fl.data_ptr(), fr.data_ptr(), self._padded.data_ptr(), B, Cc,
+                                                       self.max_disp, H, W, halo, _stream_ptr(fl.device)),
+                   "cost_volume")
+        return self._padded
 
     @torch.no_grad()
     def forward(self, feat_left: torch.Tensor, feat_right: torch.Tensor) -> torch.Tensor:
@@ -220,7 +252,7 @@ class CostVolume(nn.Module):
         if B == 0:
             return vol
         _lib.check(_lib.load().s3r_cost_volume_forward(fl.data_ptr(), fr.data_ptr(), vol.data_ptr(), B, Cc,
-                                                       self.max_disp, H, W, _stream_ptr(fl.device)), "cost_volume")
+                                                       self.max_disp, H, W, 0, _stream_ptr(fl.device)), "cost_volume")
         return vol
 
 
@@ -236,6 +268,12 @@ class Decoder(_HipChain):
         y = self._run(x, upto)
         return y.squeeze(1) if upto is None or upto == self.names[-1] else y
 
+    def forward_padded(self, volume_padded: torch.Tensor, halo: int = 1) -> torch.Tensor:
+        """Decoder on the halo-padded volume CostVolume.forward_padded produced (no pad copy)."""
+        x = _check_input(volume_padded, "volume_padded", (2 * spec.FEAT_C, spec.MAX_DISP + 2 * halo,
+                                                           spec.FEAT_HW + 2 * halo, spec.FEAT_HW + 2 * halo))
+        return self._run(x, None, in_halo=halo).squeeze(1)
+
 
 class VolumeEncoder(_HipChain):
     """The down half of the hourglass alone (Stereo2Point): cost volume -> (B,512,4,4,4) latent."""
@@ -247,6 +285,11 @@ class VolumeEncoder(_HipChain):
     def forward(self, volume: torch.Tensor) -> torch.Tensor:
         x = _check_input(volume, "volume", (2 * spec.FEAT_C, spec.MAX_DISP, spec.FEAT_HW, spec.FEAT_HW))
         return self._run(x)
+
+    def forward_padded(self, volume_padded: torch.Tensor, halo: int = 1) -> torch.Tensor:
+        x = _check_input(volume_padded, "volume_padded", (2 * spec.FEAT_C, spec.MAX_DISP + 2 * halo,
+                                                           spec.FEAT_HW + 2 * halo, spec.FEAT_HW + 2 * halo))
+        return self._run(x, None, in_halo=halo)
 
 
 class PointHead(_HipChain):
@@ -286,8 +329,8 @@ class Stereo2Voxel(nn.Module):
             l, r = left[s:s + MAX_CHUNK], right[s:s + MAX_CHUNK]
             b = l.shape[0]
             feats = self.encoder(torch.cat([l, r], 0))
-            vol = self.cost_volume(feats[:b], feats[b:])
-            outs.append(self.decoder(vol))
+            vol = self.cost_volume.forward_padded(feats[:b], feats[b:])
+            outs.append(self.decoder.forward_padded(vol))
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
 
@@ -318,8 +361,8 @@ class Stereo2Point(nn.Module):
             l, r = left[s:s + MAX_CHUNK], right[s:s + MAX_CHUNK]
             b = l.shape[0]
             feats = self.encoder(torch.cat([l, r], 0))
-            vol = self.cost_volume(feats[:b], feats[b:])
-            outs.append(self.point_head(self.decoder(vol)))
+            vol = self.cost_volume.forward_padded(feats[:b], feats[b:])
+            outs.append(self.point_head(self.decoder.forward_padded(vol)))
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
 

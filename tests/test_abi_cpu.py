@@ -26,12 +26,12 @@ def test_header_symbols_all_exported(s3r, lib):
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.s3r_abi_version() == 1
+    assert lib.s3r_abi_version() == 2
 
 
 def test_struct_layouts_match_header(s3r):
-    assert C.sizeof(s3r._lib.ConvDesc) == 12 * 4
-    assert C.sizeof(s3r._lib.Layer) == 12 * 4 + 3 * 8
+    assert C.sizeof(s3r._lib.ConvDesc) == 14 * 4
+    assert C.sizeof(s3r._lib.Layer) == 14 * 4 + 3 * 8
     assert C.sizeof(s3r._lib.ProfRecord) == 32
 
 
@@ -66,7 +66,33 @@ def test_workspace_query(s3r, lib):
     for i, (l, n, m) in enumerate(rows):
         arr[i].desc = _desc(s3r, l, 4, n)
     need = lib.s3r_chain_workspace_elems(arr, len(rows))
-    assert need == 4 * 64 * 112 * 112          # e2's output is the largest intermediate
+    # every intermediate has its own region, stored with the zero halo its consumer's gather reads
+    # (3x3 pad-1 consumers: halo 1; the 1x1 e8: none), each region rounded up to 256 floats
+    want = 0
+    for i, (l, n, m) in enumerate(rows[:-1]):
+        halo = rows[i + 1][0].p
+        want += -(-(4 * l.cout * (m + 2 * halo) ** 2) // 256) * 256
+    assert need == want
+    # a chain whose first layer gathers with padding pads an unpadded input itself: one more region
+    sub = (s3r._lib.Layer * 2)()
+    sub[0].desc, sub[1].desc = _desc(s3r, rows[1][0], 4, rows[1][1]), _desc(s3r, rows[2][0], 4, rows[2][1])
+    need2 = lib.s3r_chain_workspace_elems(sub, 2)
+    assert need2 == -(-(4 * 32 * 114 * 114) // 256) * 256 + -(-(4 * 64 * 114 * 114) // 256) * 256
+    sub[0].desc.in_halo = 1                       # caller hands a padded input: no pad region
+    assert lib.s3r_chain_workspace_elems(sub, 2) == -(-(4 * 64 * 114 * 114) // 256) * 256
+
+
+def test_halo_contract(s3r, lib):
+    """The MFMA conv kernels read zero padding from memory: single-layer calls must state a halo."""
+    spec = s3r.arch_spec
+    l, n, _ = spec.stage_table("decoder")[0]                   # v1: conv3d k3 p1
+    d = _desc(s3r, l, 1, n)
+    one = C.c_void_p(16)                                       # non-null dummies: validation fails first
+    assert lib.s3r_conv_forward(C.byref(d), one, one, None, None, one, None) == -1
+    assert b"halo" in lib.s3r_last_error()
+    d.in_halo = 9
+    e = C.c_int64(0)
+    assert lib.s3r_conv_packed_elems(C.byref(d), C.byref(e)) == -1
 
 
 def test_invalid_arguments_are_reported_not_crashed(s3r, lib):
@@ -82,9 +108,9 @@ def test_invalid_arguments_are_reported_not_crashed(s3r, lib):
     huge = _desc(s3r, spec.Layer("x", "conv3d", 64, 64, 3, 1, 1), 4096, 28)
     assert lib.s3r_conv_packed_elems(C.byref(huge), C.byref(e)) == -1
     assert b"split the batch" in lib.s3r_last_error()
-    assert lib.s3r_cost_volume_forward(None, None, None, 1, 1, 1, 1, 1, None) == -1
+    assert lib.s3r_cost_volume_forward(None, None, None, 1, 1, 1, 1, 1, 0, None) == -1
     assert lib.s3r_chamfer_forward(None, None, None, None, None, None, 1, 1, 1, None) == -1
-    assert lib.s3r_chain_forward(None, 0, None, None, None, None, 0, None) == -1
+    assert lib.s3r_chain_forward(None, 0, None, None, None, 0, 0, None) == -1
 
 
 def test_missing_library_fails_loudly(s3r, monkeypatch, tmp_path):

@@ -86,23 +86,36 @@ def test_each_layer_vs_oracle(s3r, oracle, idx):
     assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
 
 
-@pytest.mark.parametrize("tile", range(6))
-@pytest.mark.parametrize("kind", ["conv3d_s1", "conv3d_s2", "deconv", "conv2d_s2"])
+@pytest.mark.parametrize("tile", range(8))
+@pytest.mark.parametrize("kind", ["conv3d_s1", "conv3d_s1_w8", "conv3d_s1_w8_dword", "conv3d_s2", "deconv",
+                                  "deconv_w4", "conv2d_s2", "conv2d_s1_w12", "conv3d_k4_valid"])
 def test_every_tile_configuration(s3r, oracle, tile, kind):
-    """All six MFMA tile shapes on ragged problem sizes (N not a tile multiple, Cout not a BM multiple)."""
+    """All eight MFMA tile shapes x both gather widths (dword / 16-byte LDS-DMA) on ragged problem sizes
+    (N not a tile multiple, Cout not a BM multiple, rows that are / are not a multiple of 4)."""
     Layer = s3r.arch_spec.Layer
-    layer, n_in, B = {
-        "conv3d_s1": (Layer("t", "conv3d", 32, 96, 3, 1, 1), 7, 3),
-        "conv3d_s2": (Layer("t", "conv3d", 16, 160, 3, 2, 1), 9, 2),
-        "deconv": (Layer("t", "deconv3d", 32, 48, 4, 2, 1), 5, 3),
-        "conv2d_s2": (Layer("t", "conv2d", 48, 64, 3, 2, 1), 13, 5),
+    layer, n_in, B, vec = {
+        "conv3d_s1": (Layer("t", "conv3d", 32, 96, 3, 1, 1), 7, 3, 0),             # Nw=7: dword gather
+        "conv3d_s1_w8": (Layer("t", "conv3d", 32, 96, 3, 1, 1), 8, 3, 0),          # Nw=8: 16-byte gather
+        "conv3d_s1_w8_dword": (Layer("t", "conv3d", 32, 96, 3, 1, 1), 8, 3, 1),    # same, dword forced
+        "conv3d_s2": (Layer("t", "conv3d", 16, 160, 3, 2, 1), 9, 2, 0),
+        "deconv": (Layer("t", "deconv3d", 32, 48, 4, 2, 1), 5, 3, 0),
+        "deconv_w4": (Layer("t", "deconv3d", 32, 48, 4, 2, 1), 4, 3, 0),           # input rows of 4: 16-byte
+        "conv2d_s2": (Layer("t", "conv2d", 48, 64, 3, 2, 1), 13, 5, 0),
+        "conv2d_s1_w12": (Layer("t", "conv2d", 48, 64, 3, 1, 1), 12, 5, 0),
+        "conv3d_k4_valid": (Layer("t", "conv3d", 16, 40, 4, 1, 0), 7, 2, 0),       # v6-like: k4, no padding
     }[kind]
     ch = _single(s3r, layer, n_in)
-    ch.tile_override["t"] = tile
+    ch.tile_override["t"] = tile + 16 * vec
     blk = _oracle_block(oracle, layer, ch.t.state_dict())
     x = torch.randn((B, layer.cin) + (n_in,) * s3r.arch_spec.ndim(layer), generator=torch.Generator().manual_seed(3))
     with torch.no_grad():
         want = blk(x)
+    out_w = want.shape[-1] if layer.op != "deconv3d" else n_in
+    dword = vec == 1 or (layer.op != "deconv3d" and layer.s != 1) or out_w % 4 != 0
+    if tile == 5 and dword:      # the 64 x 512 tile is wider than one dword-gather row piece allows
+        with pytest.raises(s3r.S3RError):
+            ch.to(DEV)._run(x.to(DEV))
+        return
     got = ch.to(DEV)._run(x.to(DEV)).cpu()
     assert rel_l2(got, want) < 2e-6
 
@@ -170,6 +183,47 @@ def test_stage_by_stage_vs_oracle(s3r, oracle, models):
             d_ref = ref.decoder(v_ref, upto=name)
         d = hip.decoder(v_ref.to(DEV), upto=name).cpu()
         assert rel_l2(d, d_ref) < 5e-6, name
+
+
+def test_padded_handoff_equals_plain_tensors_and_keeps_halo_zero(s3r, oracle, models):
+    """Stereo2Voxel.forward hands the cost volume to the decoder as a halo-padded resident buffer; the
+    module-level path (plain tensors, the library pads) must give the same bits, the halo must stay zero,
+    and the interior must be the oracle's volume exactly."""
+    hip, ref = models
+    left, right = s3r.synthetic_pairs(2, seed=11)
+    left, right = left.to(DEV), right.to(DEV)
+    fused = hip(left, right)
+    f = hip.encoder(torch.cat([left, right]))
+    plain = hip.decoder(hip.cost_volume(f[:2], f[2:]))
+    assert torch.equal(fused, plain)
+    vp = hip.cost_volume.forward_padded(f[:2], f[2:])
+    assert vp.shape == (2, 64, 30, 30, 30)
+    inner = vp[:, :, 1:-1, 1:-1, 1:-1]
+    assert torch.equal(inner, hip.cost_volume(f[:2], f[2:]))
+    assert vp.abs().sum().item() == inner.abs().sum().item() or torch.equal(
+        vp.sum(), inner.sum())                                      # nothing outside the interior
+    border = vp.clone()
+    border[:, :, 1:-1, 1:-1, 1:-1] = 0
+    assert border.abs().max().item() == 0.0
+    with torch.no_grad():
+        fr = ref.encoder(torch.cat([left, right]).cpu())
+    assert torch.equal(inner.cpu(), oracle.cost_volume(f[:2].cpu(), f[2:].cpu()))
+    assert rel_l2(f.cpu(), fr) < 5e-6
+
+
+def test_workspace_relayout_between_batch_sizes(s3r, models):
+    """The activation arena is laid out per batch size; alternating batch sizes must re-zero it
+    (stale interiors of one layout would sit in another layout's halos)."""
+    hip, _ = models
+    left, right = s3r.synthetic_pairs(5, seed=21)
+    left, right = left.to(DEV), right.to(DEV)
+    want5 = hip(left, right).clone()
+    want2 = hip(left[:2], right[:2]).clone()
+    assert torch.equal(want2, want5[:2])
+    for _ in range(2):
+        assert torch.equal(hip(left, right), want5)
+        assert torch.equal(hip(left[:2], right[:2]), want2)
+        assert torch.equal(hip(left[3:4], right[3:4])[0], want5[3])
 
 
 def test_batch32_matches_per_sample_bitwise(s3r, models):

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Per-layer microbenchmark of the MFMA conv kernel at BASELINE batch (B=32 pairs), interleaved A/B of
-tile configurations / kernel variants in ONE process (cdna guide §5.4 rule 24).
+tile configurations / gather widths in ONE process (cdna guide §5.4 rule 24).
 
   python tools/layer_bench.py [--layers v1,d3] [--tiles -1,0,1] [--variants 0,1] [--rounds 5] [--batch 32]
 
-`tile` passed to the C-ABI = tile_cfg + 16*variant (tile_cfg -1 = library heuristic).
+`tile` passed to the C-ABI = tile_cfg + 16*gather_width (tile_cfg -1 = library heuristic; width 0 = widest
+legal, 1 = dword LDS-DMA, 4 = 16-byte LDS-DMA).  Configurations a layer cannot run are skipped.
 """
 import argparse
 import os
@@ -39,6 +40,13 @@ def main():
     tiles = [int(t) for t in args.tiles.split(",")]
     variants = [int(v) for v in args.variants.split(",")]
     total = {}
+    dbg_clock = None
+    try:                                   # only present in -DS3R_ABLATE diagnostic builds
+        import ctypes
+        dbg_clock = s3r.load_library().s3r_debug_clock_ghz
+        dbg_clock.restype, dbg_clock.argtypes = ctypes.c_double, [ctypes.c_int]
+    except AttributeError:
+        pass
     for l, n_in, B in cases:
         ch = s3r.modules._HipChain([l], n_in)
         s3r.seed_module(ch, 1)
@@ -46,6 +54,7 @@ def main():
         x = torch.randn((B, l.cin) + (n_in,) * spec.ndim(l), device=dev)
         flops = 2.0 * spec.layer_macs(l, n_in) * B
         res = {}
+        clk = {}
         ref = None
         for rnd in range(args.rounds + 1):
             for t in tiles:
@@ -53,7 +62,11 @@ def main():
                     code = (15 if t < 0 else t) + 16 * v
                     ch.tile_override[l.name] = code
                     s3r.profile_enable(8)
-                    y = ch._run(x)
+                    try:
+                        y = ch._run(x)
+                    except s3r.S3RError:
+                        s3r.profile_enable(0)
+                        continue
                     rec = s3r.profile_read(8)
                     s3r.profile_enable(0)
                     if rnd == 0:
@@ -63,13 +76,18 @@ def main():
                             print(f"!! {l.name} tile {t} variant {v}: output differs from first config "
                                   f"(max {float((y - ref).abs().max()):.3e})")
                         continue
-                    res.setdefault((t, v), []).append(rec[0]["ms"])
+                    res.setdefault((t, v), []).append([r for r in rec if r["family"] == "conv_mfma"][0]["ms"])
+                    if dbg_clock is not None:
+                        torch.cuda.synchronize()
+                        clk[(t, v)] = dbg_clock(256)
         line = f"{l.name:4s}"
         for (t, v), ms in sorted(res.items()):
             ms.sort()
             med = ms[len(ms) // 2]
             tf = flops / med / 1e9
             line += f" | t{t} v{v}: {med:7.4f} ms {tf:6.1f} TF {tf / PEAK:5.3f}"
+            if (t, v) in clk:
+                line += f" @{clk[(t, v)]:.2f}GHz"
             total.setdefault((t, v), [0.0, 0.0])
             total[(t, v)][0] += med
             total[(t, v)][1] += flops
