@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--variant", default="voxel", choices=["voxel", "point"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="keep the library's shape heuristics instead of timing tile / split-K candidates in warm-up")
     args = ap.parse_args()
 
     import torch
@@ -115,6 +117,10 @@ def main():
             dist.all_gather_into_tensor(gathered, y)      # eval collation over xGMI (RCCL)
         return y
 
+    tuned = None
+    if not args.no_autotune and args.variant == "voxel":
+        # untimed warm-up work: each MFMA layer's (tile, split-K) is picked by measurement on this batch
+        tuned = model.autotune(left, right, rounds=3, log=log if rank == 0 else None)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -196,6 +202,7 @@ def main():
                        "per_gpu_batch": B, "global_batch": world * B,
                        "parallelism": f"batch-sharded x{world}, all-gather of predictions" if world > 1 else "single GPU"},
             "end_to_end_tflops": round(value * fl["total"] / 1e12, 3),
+            "autotuned": {k: [v["tile"], v["ksplit"]] for k, v in tuned.items()} if tuned else None,
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

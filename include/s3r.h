@@ -72,6 +72,7 @@ typedef struct s3r_conv_desc {
     int32_t tile;      /* -1: library picks; >=0: force MFMA tile cfg + 16*gather_width (tuning) */
     int32_t in_halo;   /* zero halo of the input buffer  (elements per spatial axis side) */
     int32_t out_halo;  /* zero halo of the output buffer */
+    int32_t ksplit;    /* 0: library picks; >=1: force the split-K factor (must divide cin/16) */
 } s3r_conv_desc;
 
 /* One layer of a stage: geometry + its packed weights + folded epilogue vectors (device pointers). */
@@ -92,9 +93,12 @@ int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems);
 /* repack a torch-layout weight (Conv: [cout][cin][k..]; ConvTranspose: [cin][cout][k..]; Linear:
  * [cout][cin]) into the kernel's K-major layout.  Device to device, on `stream`. */
 int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, float* packed, void* stream);
-/* y = act(conv(x) * scale + shift); dispatches to the stem / MFMA / head kernel by shape */
+/* floats of split-K scratch s3r_conv_forward wants for this layer (0 when it does not split K) */
+int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d);
+/* y = act(conv(x) * scale + shift); dispatches to the stem / MFMA / head kernel by shape.  `scratch`
+ * (may be NULL) holds split-K partial sums; without it a layer the library would split runs unsplit. */
 int s3r_conv_forward(const s3r_conv_desc* d, const float* x, const float* packed_w, const float* scale,
-                     const float* shift, float* y, void* stream);
+                     const float* shift, float* y, float* scratch, int64_t scratch_elems, void* stream);
 
 /* Run a chain of layers x -> y.  Every intermediate activation gets its own region of `ws`
  * (s3r_chain_workspace_elems floats; with 288 GB of HBM nothing is recycled), laid out with the halo

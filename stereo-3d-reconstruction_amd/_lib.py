@@ -22,7 +22,7 @@ ABI_VERSION = 2
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("op", "ndim", "batch", "cin", "cout", "in_size", "k", "stride", "pad", "act", "tag", "tile",
-                 "in_halo", "out_halo")]
+                 "in_halo", "out_halo", "ksplit")]
 
 
 class Layer(C.Structure):
@@ -48,8 +48,9 @@ SIGNATURES = {
     "s3r_conv_out_size": (C.c_int, [C.POINTER(ConvDesc)]),
     "s3r_conv_packed_elems": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int64)]),
     "s3r_conv_pack_weights": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "s3r_conv_scratch_elems": (C.c_int64, [C.POINTER(ConvDesc)]),
     "s3r_conv_forward": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.c_void_p]),
+                                   C.c_void_p, C.c_int64, C.c_void_p]),
     "s3r_chain_workspace_elems": (C.c_int64, [C.POINTER(Layer), C.c_int]),
     "s3r_chain_forward": (C.c_int, [C.POINTER(Layer), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                     C.c_int, C.c_void_p]),
@@ -102,12 +103,12 @@ def check(rc, what=""):
     return rc
 
 
-def make_desc(layer, batch, in_size, tag=0, tile=-1, in_halo=0, out_halo=0):
+def make_desc(layer, batch, in_size, tag=0, tile=-1, in_halo=0, out_halo=0, ksplit=0):
     """arch_spec.Layer -> ConvDesc."""
     op = {"conv2d": OP_CONV, "conv3d": OP_CONV, "deconv3d": OP_DECONV, "linear": OP_LINEAR}[layer.op]
     nd = {"conv2d": 2, "conv3d": 3, "deconv3d": 3, "linear": 0}[layer.op]
     return ConvDesc(op, nd, batch, layer.cin, layer.cout, in_size, layer.k, layer.s, layer.p, ACT[layer.act], tag,
-                    tile, in_halo, out_halo)
+                    tile, in_halo, out_halo, ksplit)
 
 
 def profile_enable(max_records):

@@ -181,7 +181,25 @@ s3r::ConvParams make_params(const s3r_conv_desc* d, const Geo& g) {
         p.x_org = (d->in_halo - d->pad) * (p.x_ds + p.x_hs + 1);
     }
     p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
+    p.ksplit = 1;
     return p;
+}
+
+// (tile cfg, gather width, split-K) of an MFMA-route layer: the caller's forced values or the heuristics
+struct Launch { int cfg, vec, ksplit; };
+
+int resolve_launch(const s3r_conv_desc* d, s3r::ConvParams* p, Launch* L) {
+    const int chunks = d->cin / 16;
+    if (d->ksplit < 0 || (d->ksplit > 0 && chunks % d->ksplit != 0))
+        return fail(S3R_ERR_INVALID, "ksplit=%d must divide cin/16=%d", d->ksplit, chunks);
+    L->ksplit = d->ksplit > 0 ? d->ksplit : s3r::conv_pick_ksplit(*p, 0);
+    p->ksplit = L->ksplit;
+    const int code = d->tile >= 0 ? d->tile : 15;
+    L->cfg = code & 15;
+    L->vec = code >> 4;
+    if (L->cfg != 15 && L->cfg >= s3r::conv_num_tiles()) return fail(S3R_ERR_INVALID, "unknown tile configuration %d", L->cfg);
+    if (L->cfg == 15) L->cfg = s3r::conv_pick_tile(*p);
+    return S3R_OK;
 }
 
 // ---------------------------------------------------------------- chain planning
@@ -195,6 +213,7 @@ struct Plan {
     std::vector<int64_t> off;         // workspace offset of layer i's OUTPUT (-1: the caller's y)
     bool pad_input = false;
     int64_t pad_off = 0;
+    int64_t scratch_off = 0, scratch_elems = 0;   // split-K slabs, shared by all layers of the chain
     int64_t total = 0;
 };
 
@@ -239,6 +258,13 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
         pl->off[i] = off;
         off = align_up(off + pl->g[i].y_elems, 256);
     }
+    for (int i = 0; i < n; ++i) {
+        const int64_t sc = s3r_conv_scratch_elems(&pl->d[i]);
+        if (sc < 0) return (int)sc;
+        if (sc > pl->scratch_elems) pl->scratch_elems = sc;
+    }
+    pl->scratch_off = off;
+    off = align_up(off + pl->scratch_elems, 256);
     pl->total = off;
     return S3R_OK;
 }
@@ -294,8 +320,20 @@ int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, float* packed,
     return S3R_OK;
 }
 
+int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d) {
+    Geo g; Route r;
+    int rc = geometry(d, &g);
+    if (rc) return rc;
+    if ((rc = route(d, &r))) return rc;
+    if (r != R_MFMA) return 0;
+    s3r::ConvParams p = make_params(d, g);
+    Launch L;
+    if ((rc = resolve_launch(d, &p, &L))) return rc;
+    return s3r::conv_scratch_elems(p, L.cfg);
+}
+
 int s3r_conv_forward(const s3r_conv_desc* d, const float* x, const float* packed_w, const float* scale,
-                     const float* shift, float* y, void* stream) {
+                     const float* shift, float* y, float* scratch, int64_t scratch_elems, void* stream) {
     Geo g; Route r;
     int rc = geometry(d, &g);
     if (rc) return rc;
@@ -325,11 +363,18 @@ int s3r_conv_forward(const s3r_conv_desc* d, const float* x, const float* packed
         case R_MFMA: {
             s3r::ConvParams p = make_params(d, g);
             p.x = x; p.w = packed_w; p.scale = scale; p.shift = shift; p.y = y;
-            const int cfg = d->tile >= 0 ? d->tile : 15;
-            if ((cfg & 15) != 15 && (cfg & 15) >= s3r::conv_num_tiles())
-                return fail(S3R_ERR_INVALID, "unknown tile configuration %d", cfg & 15);
+            Launch L;
+            if ((rc = resolve_launch(d, &p, &L))) return rc;
+            if (L.ksplit > 1) {
+                const int64_t need = s3r::conv_scratch_elems(p, L.cfg);
+                if (scratch && scratch_elems >= need) p.part = scratch;
+                else if (d->ksplit > 0)
+                    return fail(S3R_ERR_WORKSPACE, "ksplit=%d needs %lld floats of scratch, got %lld", L.ksplit,
+                                (long long)need, (long long)(scratch ? scratch_elems : 0));
+                else p.ksplit = L.ksplit = 1;     // no scratch offered: run unsplit (same result up to rounding order)
+            }
             ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
-            e = s3r::launch_conv_mfma(p, cfg, s);
+            e = s3r::launch_conv_mfma(p, L.cfg + 16 * L.vec, s);
             break;
         }
     }
@@ -371,7 +416,8 @@ int s3r_chain_forward(const s3r_layer* layers, int n_layers, const float* x, flo
     for (int i = 0; i < n_layers; ++i) {
         const s3r_layer& L = layers[i];
         float* out = (i == n_layers - 1) ? y : ws + pl.off[i];
-        rc = s3r_conv_forward(&pl.d[i], cur, L.packed_w, L.scale, L.shift, out, stream);
+        rc = s3r_conv_forward(&pl.d[i], cur, L.packed_w, L.scale, L.shift, out,
+                              pl.scratch_elems ? ws + pl.scratch_off : nullptr, pl.scratch_elems, stream);
         if (rc) return rc;
         cur = out;
     }

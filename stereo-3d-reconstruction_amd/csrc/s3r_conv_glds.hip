@@ -117,7 +117,10 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
 
     const int S = p.Nd * p.Nh * p.Nw;
     const int T = p.T;
-    const int nkt = T * (p.Cin / BK);
+    // split-K: blockIdx.z owns a contiguous range of 16-channel chunks (all taps of each)
+    const int chunks = (p.Cin / BK) / p.ksplit;
+    const int kz = blockIdx.z;
+    const int nkt = T * chunks;
 
     // ---- per-lane loop-invariant DMA offsets (bytes)
     int bvoff;     // B: this lane's VEC positions (+ its row inside a multi-row piece)
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
     const int cs4 = p.x_cs * 4;
 
     // K-tile cursor of the NEXT tile to fetch (all scalar)
-    int c_td = 0, c_th = 0, c_tw = 0, c_tap = 0, c_cc = 0, c_kt = 0;
+    int c_td = 0, c_th = 0, c_tw = 0, c_tap = 0, c_cc = kz * chunks, c_kt = kz * nkt;
 
     auto issue = [&](int buf) {
         // ---- weights: rows [c_kt*16, +16) of the packed slab, couts [m0, m0+BM)
@@ -214,6 +217,30 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
         __syncthreads();                                    // ... everyone's have, and buffer `cur` is free
     }
 
+    // ---- split-K: raw partial sums to the scratch slab [cls][kz][cout][n] (n = GEMM position index,
+    // padded to whole N tiles so no lane needs a bounds check); s3r::launch_conv_finish reduces the slabs
+    // in kz order and applies the epilogue.
+    if (p.ksplit > 1) {
+        const int npad = p.n_tiles * BN;
+        float* __restrict__ slab = p.part + ((size_t)(cls * p.ksplit + kz) * p.Cout) * npad + n0 + wn * TN * 32 + j * TN;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM * 32 + ((r & 3) + 8 * (r >> 2) + 4 * h) * TM + tm;
+                if (m >= p.Cout) continue;
+                typename FVec<TN>::type t;
+                if constexpr (TN == 1) t = acc[tm][0][r];
+                else {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) t[tn] = acc[tm][tn][r];
+                }
+                *reinterpret_cast<typename FVec<TN>::type*>(slab + (size_t)m * npad) = t;
+            }
+        }
+        return;
+    }
+
     // ---- epilogue: y = act(acc * scale[cout] + shift[cout]) into the (halo-padded) NC(D)HW output;
     // a lane's TN positions are consecutive in one output row when Nw % TN == 0 (convolutions).
     const int nl = n0 + wn * TN * 32 + j * TN;          // this lane's first position
@@ -272,6 +299,65 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------------
+// split-K finish: y = act(scale * sum_kz slab[cls][kz][m][n] + shift), summed in kz order (deterministic),
+// scattered to the (halo-padded) output position of n.  One thread per 4 consecutive n of one cout.
+__global__ __launch_bounds__(256) void conv_finish_kernel(const ConvParams p, int npad) {
+    const int S = p.Nd * p.Nh * p.Nw;
+    const int cls = blockIdx.y;
+    const int rd = (cls >> 2) & 1, rh = (cls >> 1) & 1, rw = cls & 1;
+    const int nq = npad >> 2;
+    const long long total = (long long)p.Cout * nq;
+    const int ostep = p.transposed ? 2 : 1;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / nq);
+        const int n = (int)(i - (long long)m * nq) * 4;
+        if (n >= p.Ntotal) continue;
+        const float* __restrict__ src = p.part + ((size_t)cls * p.ksplit * p.Cout + m) * npad + n;
+        v4f sum = *reinterpret_cast<const v4f*>(src);
+        for (int z = 1; z < p.ksplit; ++z) {
+            const v4f t = *reinterpret_cast<const v4f*>(src + (size_t)z * p.Cout * npad);
+            sum[0] += t[0]; sum[1] += t[1]; sum[2] += t[2]; sum[3] += t[3];
+        }
+        const float sc = p.scale ? p.scale[m] : 1.f, sf = p.shift ? p.shift[m] : 0.f;
+        float* __restrict__ yrow = p.y + (size_t)m * p.y_cs;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int nn = n + k;
+            if (nn >= p.Ntotal) break;
+            const int b = nn / S;
+            int rem = nn - b * S;
+            const int pd = rem / (p.Nh * p.Nw);
+            rem -= pd * p.Nh * p.Nw;
+            const int ph = rem / p.Nw;
+            const int pw = rem - ph * p.Nw;
+            int e = b * p.Cout * p.y_cs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw) * ostep;
+            if (p.transposed) e += rd * p.y_ds + rh * p.y_hs + rw;
+            float t = fmaf(sum[k], sc, sf);
+            if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
+            else if (p.act == ACT_SIGMOID) t = 1.f / (1.f + __expf(-t));
+            yrow[e] = t;
+        }
+    }
+}
+
+hipError_t launch_conv_finish(const ConvParams& p, int npad, hipStream_t stream) {
+    const long long total = (long long)p.Cout * (npad >> 2);
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(conv_finish_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096), p.transposed ? 8 : 1), dim3(256),
+                       0, stream, p, npad);
+    return hipGetLastError();
+}
+
+// floats of split-K scratch a launch with tile `cfg` needs
+int64_t conv_scratch_elems(const ConvParams& p, int cfg) {
+    if (p.ksplit <= 1) return 0;
+    int bm, bn;
+    conv_tile_dims(cfg, &bm, &bn);
+    const int64_t npad = (int64_t)((p.Ntotal + bn - 1) / bn) * bn;
+    return (int64_t)(p.transposed ? 8 : 1) * p.ksplit * p.Cout * npad;
+}
+
+// ------------------------------------------------------------------------------------------------
 // tile configurations:  id -> (WM, WN, TM, TN); the gather width VEC is chosen per layer
 //   id  WM WN TM TN   BM x BN
 //    0   2  2  2  2  128 x 128   Cout >= 128
@@ -291,15 +377,32 @@ void conv_tile_dims(int cfg, int* bm, int* bn) {
 }
 int conv_num_tiles() { return kNumTiles; }
 
+// Split-K factor.  Decided from the layer's PER-SAMPLE geometry at a nominal batch of 32 samples, never
+// from the actual batch, so that a sample's summation order (hence its bits) does not depend on the
+// batch it is computed in.  Splits deep-K layers whose 64x64-tile grid would leave the 256 CUs short of
+// workgroups (measured on MI355X, tools/layer_bench.py: v6 79 -> 118 TFLOP/s at 8 splits, v5 110 -> 121
+// at 4; layers with fewer than ~100 K tiles per split lose more to the extra prologues than they gain).
+int conv_pick_ksplit(const ConvParams& p, int /*tile_cfg*/) {
+    const int chunks = p.Cin / GBK;
+    const long S = (long)p.Nd * p.Nh * p.Nw;
+    const long wg_nom = ((p.Cout + 63) / 64) * ((32 * S + 63) / 64) * (p.transposed ? 8 : 1);
+    int ks = 1;
+    while (wg_nom * ks < 2048 && chunks % (2 * ks) == 0 && (chunks / (2 * ks)) * p.T >= 100) ks *= 2;
+    return ks;
+}
+
+// Tile shape by workgroup count (measured, same tool): tiles 64 couts tall win on every layer of this
+// network — finer work units balance the 256 CUs better than 128-tall tiles save in operand traffic —
+// and the position extent shrinks (256 -> 128 -> 64) as the layer offers fewer workgroups.
 int conv_pick_tile(const ConvParams& p) {
-    const int classes = p.transposed ? 8 : 1;
+    const int classes = (p.transposed ? 8 : 1) * (p.ksplit > 1 ? p.ksplit : 1);
     auto wgs = [&](int cfg) {
         const long bm = kTileDims[cfg][0], bn = kTileDims[cfg][1];
         return ((p.Cout + bm - 1) / bm) * ((p.Ntotal + bn - 1) / bn) * classes;
     };
     if (p.Cout <= 32) return 2;
-    if (p.Cout <= 64) return wgs(1) >= 768 ? 1 : (wgs(7) >= 768 ? 7 : 3);
-    return wgs(0) >= 768 ? 0 : (wgs(6) >= 768 ? 6 : 3);
+    if (p.Cout <= 64) return wgs(1) >= 2000 ? 1 : (wgs(7) >= 2000 ? 7 : 3);
+    return wgs(7) >= 1500 ? 7 : 3;
 }
 
 // widest gather the layer geometry allows: VEC consecutive positions of a row must be VEC consecutive
@@ -324,9 +427,11 @@ static hipError_t launch_cfg(ConvParams p, hipStream_t stream) {
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (attr != hipSuccess) return attr;
         }
-        dim3 grid(p.m_tiles * p.n_tiles, p.transposed ? 8 : 1, 1);
+        dim3 grid(p.m_tiles * p.n_tiles, p.transposed ? 8 : 1, p.ksplit);
         hipLaunchKernelGGL((conv_glds_kernel<WM, WN, TM, TN, VEC>), grid, dim3(256), lds, stream, p);
-        return hipGetLastError();
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess && p.ksplit > 1) e = launch_conv_finish(p, p.n_tiles * BN, stream);
+        return e;
     }
 }
 
@@ -348,6 +453,7 @@ hipError_t launch_conv_mfma(const ConvParams& p, int code, hipStream_t stream) {
     if (vec != 1 && vec != 4) vec = vmax;
     if (vec > vmax) vec = vmax;
     if (p.Cin % GBK != 0 || p.Ntotal % vec != 0) return hipErrorInvalidValue;
+    if (p.ksplit < 1 || (p.Cin / GBK) % p.ksplit != 0 || (p.ksplit > 1 && !p.part)) return hipErrorInvalidValue;
     switch (cfg) {
         case 0: return launch_vec<2, 2, 2, 2>(p, vec, stream);
         case 1: return launch_vec<1, 4, 2, 2>(p, vec, stream);

@@ -29,6 +29,8 @@ struct ConvParams {
     int act;              // 0 none, 1 relu, 2 sigmoid
     int Ntotal;           // B*Nd*Nh*Nw
     int n_tiles, m_tiles;
+    int ksplit;           // split-K factor (divides Cin/16); > 1: partial slabs to `part`, then conv_finish
+    float* part;          // split-K scratch: [cls][ksplit][Cout][n_tiles*BN]
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
@@ -37,6 +39,8 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
 hipError_t launch_conv_mfma(const ConvParams& p, int tile_code, hipStream_t stream);   // code = cfg + 16*vec
 int conv_pick_tile(const ConvParams& p);
 int conv_pick_vec(const ConvParams& p);
+int conv_pick_ksplit(const ConvParams& p, int tile_cfg);
+int64_t conv_scratch_elems(const ConvParams& p, int tile_cfg);
 int conv_num_tiles();
 void conv_tile_dims(int tile_cfg, int* bm, int* bn);
 hipError_t launch_pack_conv(const float* w, float* wp, int Cin, int Cout, int CoutPad, int T, int transposed,

@@ -110,7 +110,8 @@ class _HipChain(nn.Module):
             self.add_module(l.name, _Block(l))
         self._packed = None          # (key, [(packed_w, scale, shift)])
         self._ws = _Workspace()
-        self.tile_override: Dict[str, int] = {}
+        self.tile_override: Dict[str, int] = {}      # layer name -> tile cfg + 16*gather width  (tuning)
+        self.ksplit_override: Dict[str, int] = {}    # layer name -> split-K factor               (tuning)
         if self.training:
             self.eval()              # inference path: eval-mode BatchNorm is the only mode implemented
 
@@ -166,10 +167,11 @@ class _HipChain(nn.Module):
         for i, (l, (n_in, _)) in enumerate(zip(self._layers[:n_layers], self._sizes())):
             pw, scale, shift, _ = packed[i]
             tile = int(os.environ.get(f"S3R_TILE_{l.name}", self.tile_override.get(l.name, -1)))
+            ksplit = int(os.environ.get(f"S3R_KSPLIT_{l.name}", self.ksplit_override.get(l.name, 0)))
             # only the chain's own input / output halos are the caller's to state (the output is always
             # a plain contiguous tensor); the library plans the intermediates
             arr[i].desc = _lib.make_desc(l, batch, n_in, tag=self._tag_base + i, tile=tile,
-                                         in_halo=in_halo if i == 0 else 0, out_halo=0)
+                                         in_halo=in_halo if i == 0 else 0, out_halo=0, ksplit=ksplit)
             arr[i].packed_w = pw.data_ptr()
             arr[i].scale = scale.data_ptr() if scale is not None else None
             arr[i].shift = shift.data_ptr() if shift is not None else None
@@ -197,6 +199,55 @@ class _HipChain(nn.Module):
         _lib.check(entry(arr, n, x.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), fresh, _stream_ptr(device)),
                    type(self).__name__)
         return y
+
+
+    # -- measured per-layer configuration ----------------------------------------------------------
+    _TUNE_TILES = (1, 2, 3, 7, 0)
+    _TUNE_KSPLITS = (1, 2, 4, 8)
+
+    def _mfma_layers(self):
+        return [l for l in self._layers
+                if l.op in ("conv2d", "conv3d", "deconv3d") and l.cin % 16 == 0 and not (l.cout == 1 and l.k == 1)]
+
+    @torch.no_grad()
+    def autotune(self, x: torch.Tensor, in_halo: int = 0, rounds: int = 3, log=None):
+        """Pick every MFMA layer's (tile, split-K) by timing the candidates on `x` (HIP events around the
+        layer's own launches, median of `rounds` runs of the whole chain) and keep the winners in
+        tile_override / ksplit_override.  Split-K changes a sample's summation order, so an autotuned
+        module is deterministic for a given batch size but no longer bit-identical ACROSS batch sizes."""
+        chosen = {}
+        for l in self._mfma_layers():
+            tag = self._tag_base + self.names.index(l.name)
+            chunks = l.cin // 16
+            best = None
+            for ks in self._TUNE_KSPLITS:
+                if chunks % ks:
+                    continue
+                for t in self._TUNE_TILES:
+                    self.tile_override[l.name], self.ksplit_override[l.name] = t, ks
+                    ms = []
+                    try:
+                        for r in range(rounds + 1):
+                            _lib.profile_enable(8 * len(self._layers) + 8)
+                            self._run(x, None, in_halo)
+                            rec = _lib.profile_read(8 * len(self._layers) + 8)
+                            _lib.profile_enable(0)
+                            if r:
+                                ms.append(sum(q["ms"] for q in rec if q["tag"] == tag and q["family"] == "conv_mfma"))
+                    except _lib.S3RError:
+                        _lib.profile_enable(0)
+                        continue
+                    ms.sort()
+                    if best is None or ms[len(ms) // 2] < best[0]:
+                        best = (ms[len(ms) // 2], t, ks)
+            if best is None:
+                self.tile_override.pop(l.name, None), self.ksplit_override.pop(l.name, None)
+                continue
+            self.tile_override[l.name], self.ksplit_override[l.name] = best[1], best[2]
+            chosen[l.name] = {"tile": best[1], "ksplit": best[2], "ms": round(best[0], 4)}
+            if log:
+                log(f"autotune {l.name}: tile {best[1]} ksplit {best[2]} -> {best[0]:.4f} ms")
+        return chosen
 
 
 class Encoder(_HipChain):
@@ -332,6 +383,18 @@ class Stereo2Voxel(nn.Module):
             vol = self.cost_volume.forward_padded(feats[:b], feats[b:])
             outs.append(self.decoder.forward_padded(vol))
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+    @torch.no_grad()
+    def autotune(self, left: torch.Tensor, right: torch.Tensor, rounds: int = 3, log=None):
+        """Measure-and-pick the per-layer kernel configuration on a representative batch (see
+        _HipChain.autotune).  Returns {layer: {tile, ksplit, ms}}."""
+        b = left.shape[0]
+        images = torch.cat([left, right], 0)
+        chosen = dict(self.encoder.autotune(images, rounds=rounds, log=log))
+        feats = self.encoder(images)
+        vol = self.cost_volume.forward_padded(feats[:b], feats[b:])
+        chosen.update(self.decoder.autotune(vol, in_halo=1, rounds=rounds, log=log))
+        return chosen
 
 
 class Stereo2Point(nn.Module):

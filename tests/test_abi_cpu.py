@@ -21,7 +21,7 @@ def test_header_symbols_all_exported(s3r, lib):
     header = open(os.path.join(ROOT, "include", "s3r.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = set(re.findall(r"\b(s3r_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) >= 17
+    assert len(declared) >= 18
     bound = set(s3r._lib.SIGNATURES)
     assert declared == bound, declared ^ bound
     for name in declared:
@@ -30,8 +30,8 @@ def test_header_symbols_all_exported(s3r, lib):
 
 
 def test_struct_layouts_match_header(s3r):
-    assert C.sizeof(s3r._lib.ConvDesc) == 14 * 4
-    assert C.sizeof(s3r._lib.Layer) == 14 * 4 + 3 * 8
+    assert C.sizeof(s3r._lib.ConvDesc) == 15 * 4
+    assert C.sizeof(s3r._lib.Layer) == 16 * 4 + 3 * 8       # 4 bytes of padding before the pointers
     assert C.sizeof(s3r._lib.ProfRecord) == 32
 
 
@@ -72,14 +72,37 @@ def test_workspace_query(s3r, lib):
     for i, (l, n, m) in enumerate(rows[:-1]):
         halo = rows[i + 1][0].p
         want += -(-(4 * l.cout * (m + 2 * halo) ** 2) // 256) * 256
-    assert need == want
+    # ... plus ONE split-K scratch region sized for the hungriest layer
+    scratch = 0
+    for i, (l, n, m) in enumerate(rows):
+        d = _desc(s3r, l, 4, n)
+        d.in_halo = l.p
+        scratch = max(scratch, lib.s3r_conv_scratch_elems(C.byref(d)))
+    assert need == want + -(-scratch // 256) * 256
     # a chain whose first layer gathers with padding pads an unpadded input itself: one more region
     sub = (s3r._lib.Layer * 2)()
     sub[0].desc, sub[1].desc = _desc(s3r, rows[1][0], 4, rows[1][1]), _desc(s3r, rows[2][0], 4, rows[2][1])
-    need2 = lib.s3r_chain_workspace_elems(sub, 2)
+    need2 = lib.s3r_chain_workspace_elems(sub, 2)            # (e2, e3 do not split K: no scratch)
     assert need2 == -(-(4 * 32 * 114 * 114) // 256) * 256 + -(-(4 * 64 * 114 * 114) // 256) * 256
     sub[0].desc.in_halo = 1                       # caller hands a padded input: no pad region
     assert lib.s3r_chain_workspace_elems(sub, 2) == -(-(4 * 64 * 114 * 114) // 256) * 256
+
+
+def test_split_k_choice_is_batch_invariant(s3r, lib):
+    """Split-K changes a sample's summation order, so the library must pick it from per-sample geometry
+    only: the scratch it asks for scales exactly with the batch (never switches on or off with it)."""
+    spec = s3r.arch_spec
+    split = {}
+    for l, n, m in spec.stage_table("decoder"):
+        per_batch = []
+        for b in (1, 2, 32, 64):
+            d = _desc(s3r, l, b, n)
+            d.in_halo = 1
+            d.tile = 3                                   # fixed 64x64 tile: scratch = cls*ks*cout*ceil64(b*S)
+            per_batch.append(lib.s3r_conv_scratch_elems(C.byref(d)))
+        assert all((x > 0) == (per_batch[0] > 0) for x in per_batch), (l.name, per_batch)
+        split[l.name] = per_batch[0] > 0
+    assert split["v6"] and not split["v1"] and not split["d3"]
 
 
 def test_halo_contract(s3r, lib):
@@ -88,7 +111,7 @@ def test_halo_contract(s3r, lib):
     l, n, _ = spec.stage_table("decoder")[0]                   # v1: conv3d k3 p1
     d = _desc(s3r, l, 1, n)
     one = C.c_void_p(16)                                       # non-null dummies: validation fails first
-    assert lib.s3r_conv_forward(C.byref(d), one, one, None, None, one, None) == -1
+    assert lib.s3r_conv_forward(C.byref(d), one, one, None, None, one, None, 0, None) == -1
     assert b"halo" in lib.s3r_last_error()
     d.in_halo = 9
     e = C.c_int64(0)

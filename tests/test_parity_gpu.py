@@ -120,6 +120,34 @@ def test_every_tile_configuration(s3r, oracle, tile, kind):
     assert rel_l2(got, want) < 2e-6
 
 
+@pytest.mark.parametrize("ksplit", [1, 2, 4])
+@pytest.mark.parametrize("kind", ["conv3d_k4_valid", "deconv", "conv3d_s2"])
+def test_split_k(s3r, oracle, kind, ksplit):
+    """Split-K (partial slabs + the deterministic finish kernel) against the oracle, on ragged sizes."""
+    Layer = s3r.arch_spec.Layer
+    layer, n_in, B = {
+        "conv3d_k4_valid": (Layer("t", "conv3d", 64, 40, 4, 1, 0), 7, 3),
+        "deconv": (Layer("t", "deconv3d", 64, 48, 4, 2, 1, act="sigmoid"), 5, 3),
+        "conv3d_s2": (Layer("t", "conv3d", 128, 160, 3, 2, 1, bn=False, act="none"), 9, 2),
+    }[kind]
+    ch = _single(s3r, layer, n_in)
+    ch.ksplit_override["t"] = ksplit
+    blk = _oracle_block(oracle, layer, ch.t.state_dict())
+    x = torch.randn((B, layer.cin) + (n_in,) * 3, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        want = blk(x)
+    ch.to(DEV)
+    got = ch._run(x.to(DEV))
+    assert rel_l2(got.cpu(), want) < 2e-6
+    assert torch.equal(ch._run(x.to(DEV)), got)          # deterministic: slabs are summed in a fixed order
+    for tile in (0, 3, 7):
+        ch.tile_override["t"] = tile
+        assert torch.equal(ch._run(x.to(DEV)), got)      # the tile shape never changes the bits
+    ch.ksplit_override["t"] = 3                           # does not divide cin/16
+    with pytest.raises(s3r.S3RError):
+        ch._run(x.to(DEV))
+
+
 def test_conv_linearity_full_size(s3r):
     """Size-independent property at BASELINE size (B=32): conv(2x) == 2*conv(x) bit-exactly when the
     epilogue is the identity (scaling by 2 is exact in fp32)."""

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--layers", default="")
     ap.add_argument("--tiles", default="-1")
     ap.add_argument("--variants", default="0")
+    ap.add_argument("--ksplits", default="0", help="split-K factors to try (0 = library heuristic)")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
     args = ap.parse_args()
@@ -39,6 +40,7 @@ def main():
             cases.append((l, n_in, mult * args.batch))
     tiles = [int(t) for t in args.tiles.split(",")]
     variants = [int(v) for v in args.variants.split(",")]
+    ksplits = [int(v) for v in args.ksplits.split(",")]
     total = {}
     dbg_clock = None
     try:                                   # only present in -DS3R_ABLATE diagnostic builds
@@ -58,9 +60,12 @@ def main():
         ref = None
         for rnd in range(args.rounds + 1):
             for t in tiles:
-                for v in variants:
-                    code = (15 if t < 0 else t) + 16 * v
+                for v0 in variants:
+                  for ks in ksplits:
+                    v = (v0, ks)
+                    code = (15 if t < 0 else t) + 16 * v0
                     ch.tile_override[l.name] = code
+                    ch.ksplit_override[l.name] = ks
                     s3r.profile_enable(8)
                     try:
                         y = ch._run(x)
@@ -81,19 +86,24 @@ def main():
                         torch.cuda.synchronize()
                         clk[(t, v)] = dbg_clock(256)
         line = f"{l.name:4s}"
+        best = None
         for (t, v), ms in sorted(res.items()):
             ms.sort()
             med = ms[len(ms) // 2]
             tf = flops / med / 1e9
-            line += f" | t{t} v{v}: {med:7.4f} ms {tf:6.1f} TF {tf / PEAK:5.3f}"
+            if best is None or med < best[0]:
+                best = (med, t, v)
+            line += f" | t{t} v{v[0]} k{v[1]}: {med:7.4f} ms {tf:6.1f} TF {tf / PEAK:5.3f}"
             if (t, v) in clk:
                 line += f" @{clk[(t, v)]:.2f}GHz"
             total.setdefault((t, v), [0.0, 0.0])
             total[(t, v)][0] += med
             total[(t, v)][1] += flops
         print(line, flush=True)
+        print(f"{l.name:4s} BEST tile {best[1]} vec {best[2][0]} ksplit {best[2][1]}: {best[0]:.4f} ms "
+              f"{flops / best[0] / 1e9:6.1f} TF", flush=True)
     for (t, v), (ms, fl) in sorted(total.items()):
-        print(f"TOTAL t{t} v{v}: {ms:8.4f} ms  {fl / ms / 1e9:6.1f} TF  frac {fl / ms / 1e9 / PEAK:5.3f}")
+        print(f"TOTAL t{t} v{v[0]} k{v[1]}: {ms:8.4f} ms  {fl / ms / 1e9:6.1f} TF  frac {fl / ms / 1e9 / PEAK:5.3f}")
 
 
 if __name__ == "__main__":
