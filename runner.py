@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""runner.py — the reference's entry point for this path, on the MI355X-native modules.
+
+    python3 runner.py --test --weights=/path/to/Stereo2Voxel.pth          (/root/reference/README.md:91)
+    python -m torch.distributed.run --nproc-per-node 8 runner.py --test ...   (one process per GPU)
+
+Only `--test` exists here: the forward/inference path is what this build implements (training is out of
+scope) and `python3 runner.py` without --test says so.  Without --weights the model
+is seeded random-init (BASELINE.json configs[0]); with it the checkpoint goes through
+s3r.checkpoint.load_checkpoint (container unwrapping + keymap.json).  There is no dataset in this
+environment (README.md:29 is a download link), so the eval list is synthetic unless --data names an
+.npz with arrays left, right (N,3,224,224) and volume (N,32,32,32).
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser(description="Stereo2Voxel / Stereo2Point evaluation on MI355X")
+    ap.add_argument("--test", action="store_true", help="evaluate (the only mode this build implements)")
+    ap.add_argument("--weights", default=None, help="checkpoint (.pth) to load")
+    ap.add_argument("--keymap", default=None, help="JSON: reference state_dict key -> this build's key")
+    ap.add_argument("--data", default=None, help=".npz with left, right, volume; default: synthetic")
+    ap.add_argument("--samples", type=int, default=64, help="synthetic eval list length")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    if not args.test:
+        sys.exit("runner.py: only --test is implemented (forward/inference path; training is out of scope)")
+
+    import numpy as np
+    import torch
+    import s3r
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("runner.py --test needs an MI355X: this path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    model = s3r.Stereo2Voxel()
+    if args.weights:
+        keymap = json.load(open(args.keymap)) if args.keymap else None
+        s3r.checkpoint.load_checkpoint(model, args.weights, keymap)
+    else:
+        s3r.seed_module(model, args.seed)
+    model.to(dev)
+
+    if args.data:
+        z = np.load(args.data)
+        left, right, gt = (torch.from_numpy(z[k]).float() for k in ("left", "right", "volume"))
+    else:
+        left, right, gt = s3r.evaluate.synthetic_eval_set(args.samples, args.seed)
+    res = s3r.evaluate.test_net(model, left, right, gt, batch=args.batch, device=dev)
+    if rank == 0:
+        print(json.dumps({"samples": res["samples"], "n_gpus": world, "thresholds": res["thresholds"],
+                          "mean_iou": [round(x, 6) for x in res["mean_iou"]],
+                          "weights": args.weights or f"seeded random init (seed {args.seed})",
+                          "data": args.data or "synthetic"}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

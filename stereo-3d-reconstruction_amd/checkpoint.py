@@ -1,0 +1,90 @@
+"""`.pth` loading for the HIP modules.
+
+`runner.py --test --weights=<file>` (/root/reference/README.md:91) hands a torch checkpoint to the model.
+The released checkpoints (README.md:35-36) and the reference's state_dict key names are NOT in the mount
+(SURVEY.md §0), so compatibility with them cannot be claimed or tested here.  What this module provides
+is the mechanism a maintainer needs once the keys are known:
+
+  * container unwrapping: a bare state_dict, or a dict holding one under a usual key
+    ("state_dict", "model", "net", "network" ...), with or without DataParallel's "module." prefix;
+  * a key map (JSON, reference key -> build key; `keymap.json` beside this file, shipped EMPTY) applied
+    before load_state_dict — filling that file in is the only step needed to adopt reference weights
+    whose tensors have this build's shapes;
+  * strict shape checking with a readable report of what did not match.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, Optional
+
+import torch
+
+KEYMAP_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "keymap.json")
+_CONTAINER_KEYS = ("state_dict", "model_state_dict", "model", "net", "network", "weights")
+
+
+def load_keymap(path: Optional[str] = None) -> Dict[str, str]:
+    path = path or KEYMAP_PATH
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        m = json.load(f)
+    return {k: v for k, v in m.items() if not k.startswith("_")}
+
+
+def unwrap(obj) -> Dict[str, torch.Tensor]:
+    """Find the state_dict inside whatever torch.load returned."""
+    if isinstance(obj, torch.nn.Module):
+        obj = obj.state_dict()
+    if not isinstance(obj, dict):
+        raise TypeError(f"checkpoint holds a {type(obj).__name__}, not a state_dict")
+    if obj and all(isinstance(v, torch.Tensor) for v in obj.values()):
+        sd = obj
+    else:
+        for k in _CONTAINER_KEYS:
+            if k in obj and isinstance(obj[k], dict):
+                sd = unwrap(obj[k])
+                break
+        else:
+            raise KeyError(f"no state_dict found under any of {_CONTAINER_KEYS}; top-level keys: {list(obj)[:8]}")
+    return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+
+
+def remap(sd: Dict[str, torch.Tensor], keymap: Dict[str, str]) -> Dict[str, torch.Tensor]:
+    """Rename keys.  A map entry may name a full key or a prefix ending in '.' (longest prefix wins)."""
+    if not keymap:
+        return dict(sd)
+    prefixes = sorted((k for k in keymap if k.endswith(".")), key=len, reverse=True)
+    out = {}
+    for k, v in sd.items():
+        if k in keymap:
+            nk = keymap[k]
+        else:
+            nk = k
+            for p in prefixes:
+                if k.startswith(p):
+                    nk = keymap[p] + k[len(p):]
+                    break
+        if nk in out:
+            raise KeyError(f"key map sends two checkpoint keys to {nk!r}")
+        out[nk] = v
+    return out
+
+
+def load_checkpoint(model: torch.nn.Module, path: str, keymap: Optional[Dict[str, str]] = None, strict: bool = True):
+    """torch.load(path) -> unwrap -> key map -> model.load_state_dict.  Returns (missing, unexpected)."""
+    obj = torch.load(path, map_location="cpu", weights_only=True)
+    sd = remap(unwrap(obj), load_keymap() if keymap is None else keymap)
+    own = model.state_dict()
+    bad = [f"{k}: checkpoint {tuple(v.shape)} vs model {tuple(own[k].shape)}"
+           for k, v in sd.items() if k in own and tuple(v.shape) != tuple(own[k].shape)]
+    if bad:
+        raise RuntimeError("checkpoint tensors do not have this build's shapes (arch_spec is build-specified, "
+                           "SURVEY.md §0):\n  " + "\n  ".join(bad[:12]))
+    res = model.load_state_dict(sd, strict=False)
+    missing = [k for k in res.missing_keys if not k.endswith("num_batches_tracked")]
+    if strict and (missing or res.unexpected_keys):
+        raise RuntimeError(f"state_dict mismatch: missing {missing[:8]}{'...' if len(missing) > 8 else ''}, "
+                           f"unexpected {list(res.unexpected_keys)[:8]}; extend {KEYMAP_PATH}")
+    return missing, list(res.unexpected_keys)

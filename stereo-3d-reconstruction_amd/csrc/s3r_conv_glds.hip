@@ -377,12 +377,47 @@ void conv_tile_dims(int cfg, int* bm, int* bn) {
 }
 int conv_num_tiles() { return kNumTiles; }
 
+// ---- measured configurations -------------------------------------------------------------------
+// (tile, split-K) per layer shape, picked by Stereo2Voxel.autotune() on MI355X at the BASELINE batch
+// (32 pairs; profiles/r01_autotune.txt).  Keyed by PER-SAMPLE geometry only, so the split-K factor —
+// which changes a sample's summation order — never depends on the batch a sample is computed in.
+// Shapes not listed fall back to the rules below.
+struct Tuned { int cin, cout, T, stride, S, transposed, tile, ksplit; };
+static const Tuned kTuned[] = {
+    //  cin cout   T  s       S  tr  tile ks
+    {32,  64,  9, 1, 12544, 0, 1, 1},   // e2  112^2
+    {64,  64,  9, 2,  3136, 0, 3, 1},   // e3  -> 56^2
+    {64, 128,  9, 1,  3136, 0, 2, 1},   // e4
+    {128, 128, 9, 2,   784, 0, 3, 1},   // e5  -> 28^2
+    {128, 256, 9, 1,   784, 0, 2, 1},   // e6
+    {256, 256, 9, 1,   784, 0, 2, 1},   // e7
+    {256, 32,  1, 1,   784, 0, 2, 1},   // e8
+    {64,  64, 27, 1, 21952, 0, 1, 1},   // v1  28^3
+    {64, 128, 27, 2,  2744, 0, 3, 1},   // v2  -> 14^3
+    {128, 128, 27, 1, 2744, 0, 3, 1},   // v3
+    {128, 256, 27, 2,  343, 0, 3, 4},   // v4  -> 7^3
+    {256, 256, 27, 1,  343, 0, 3, 4},   // v5
+    {256, 512, 64, 1,   64, 0, 7, 8},   // v6  k4 valid -> 4^3
+    {512, 256,  8, 1,   64, 1, 2, 1},   // d1  4^3 -> 8^3
+    {256, 128,  8, 1,  512, 1, 1, 1},   // d2
+    {128,  64,  8, 1, 4096, 1, 1, 1},   // d3
+};
+
+static const Tuned* find_tuned(const ConvParams& p) {
+    const int S = p.Nd * p.Nh * p.Nw;
+    for (const Tuned& t : kTuned)
+        if (t.cin == p.Cin && t.cout == p.Cout && t.T == p.T && t.stride == p.stride && t.S == S &&
+            t.transposed == p.transposed)
+            return &t;
+    return nullptr;
+}
+
 // Split-K factor.  Decided from the layer's PER-SAMPLE geometry at a nominal batch of 32 samples, never
-// from the actual batch, so that a sample's summation order (hence its bits) does not depend on the
-// batch it is computed in.  Splits deep-K layers whose 64x64-tile grid would leave the 256 CUs short of
-// workgroups (measured on MI355X, tools/layer_bench.py: v6 79 -> 118 TFLOP/s at 8 splits, v5 110 -> 121
-// at 4; layers with fewer than ~100 K tiles per split lose more to the extra prologues than they gain).
+// from the actual batch (see kTuned).  Splits deep-K layers whose 64x64-tile grid would leave the 256
+// CUs short of workgroups (tools/layer_bench.py: v6 79 -> 118 TFLOP/s at 8 splits, v5 110 -> 121 at 4;
+// layers with fewer than ~100 K tiles per split lose more to the extra prologues than they gain).
 int conv_pick_ksplit(const ConvParams& p, int /*tile_cfg*/) {
+    if (const Tuned* t = find_tuned(p)) return t->ksplit;
     const int chunks = p.Cin / GBK;
     const long S = (long)p.Nd * p.Nh * p.Nw;
     const long wg_nom = ((p.Cout + 63) / 64) * ((32 * S + 63) / 64) * (p.transposed ? 8 : 1);
@@ -391,17 +426,20 @@ int conv_pick_ksplit(const ConvParams& p, int /*tile_cfg*/) {
     return ks;
 }
 
-// Tile shape by workgroup count (measured, same tool): tiles 64 couts tall win on every layer of this
-// network — finer work units balance the 256 CUs better than 128-tall tiles save in operand traffic —
-// and the position extent shrinks (256 -> 128 -> 64) as the layer offers fewer workgroups.
+// Tile shape by workgroup count (same tool): narrow-M tiles win on every layer of this network — finer
+// work units balance the 256 CUs better than 128-tall tiles save in operand traffic — and the position
+// extent shrinks (256 -> 128 -> 64) as the layer offers fewer workgroups.
 int conv_pick_tile(const ConvParams& p) {
     const int classes = (p.transposed ? 8 : 1) * (p.ksplit > 1 ? p.ksplit : 1);
     auto wgs = [&](int cfg) {
         const long bm = kTileDims[cfg][0], bn = kTileDims[cfg][1];
         return ((p.Cout + bm - 1) / bm) * ((p.Ntotal + bn - 1) / bn) * classes;
     };
+    if (const Tuned* t = find_tuned(p))
+        if (wgs(t->tile) >= 512) return t->tile;      // tuned at batch 32; tiny batches use the rules
     if (p.Cout <= 32) return 2;
     if (p.Cout <= 64) return wgs(1) >= 2000 ? 1 : (wgs(7) >= 2000 ? 7 : 3);
+    if (wgs(2) >= 1500) return 2;
     return wgs(7) >= 1500 ? 7 : 3;
 }
 

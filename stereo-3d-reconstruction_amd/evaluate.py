@@ -1,0 +1,56 @@
+"""Eval driver of the path: what `runner.py --test` does after building the model
+(/root/reference/README.md:88-92) — forward over an eval list, thresholded IoU per sample, mean per
+threshold — with the forward on the HIP modules and the IoU reduced on the device, so that multi-GPU
+collation gathers a few scalars per sample instead of 32^3 grids.
+
+The reference's threshold list and IoU formula are not in the mount; this build evaluates
+IoU = |pred>t & gt| / |pred>t | gt| (binary ground truth) at t in THRESHOLDS (build-specified) and labels it so.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Optional, Sequence, Tuple
+
+import torch
+
+from . import collate
+from .modules import voxel_iou
+
+THRESHOLDS = (0.2, 0.3, 0.4, 0.5)
+
+
+def synthetic_eval_set(n: int, seed: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """n synthetic (left, right, ground-truth 32^3 occupancy) triples: there is no dataset in this
+    container (README.md:29 is a download link).  GT is a random axis-aligned box per sample."""
+    g = torch.Generator().manual_seed(seed)
+    left, right = torch.rand(n, 3, 224, 224, generator=g), torch.rand(n, 3, 224, 224, generator=g)
+    gt = torch.zeros(n, 32, 32, 32)
+    lo = torch.randint(0, 12, (n, 3), generator=g)
+    hi = lo + torch.randint(8, 20, (n, 3), generator=g)
+    for i in range(n):
+        gt[i, lo[i, 0]:hi[i, 0], lo[i, 1]:hi[i, 1], lo[i, 2]:hi[i, 2]] = 1.0
+    return left, right, gt
+
+
+@torch.no_grad()
+def test_net(model, left: torch.Tensor, right: torch.Tensor, gt: torch.Tensor, batch: int = 32,
+             thresholds: Sequence[float] = THRESHOLDS, device="cuda", group=None) -> Dict[str, object]:
+    """Mean IoU per threshold over the eval list.  With torch.distributed initialised every rank
+    evaluates its shard_bounds slice and the per-sample IoUs are all-gathered (rank order = list order)."""
+    import torch.distributed as dist
+    dist_on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if dist_on else 1
+    rank = dist.get_rank(group) if dist_on else 0
+    total = left.shape[0]
+    b0, e0 = collate.shard_bounds(total, world, rank)
+    ious = torch.empty((e0 - b0, len(thresholds)), dtype=torch.float32, device=device)
+    for s in range(b0, e0, batch):
+        e = min(e0, s + batch)
+        l, r, g = left[s:e].to(device), right[s:e].to(device), gt[s:e].to(device)
+        pred = model(l, r)
+        for j, t in enumerate(thresholds):
+            # the device kernel thresholds both operands at t; GT is binary {0,1}, so gt > t == (gt == 1)
+            ious[s - b0:e - b0, j] = voxel_iou(pred, g, t)
+    if dist_on:
+        ious = collate.all_gather_ragged(ious, total, group)
+    mean = ious.mean(0).cpu().tolist() if total else [float("nan")] * len(thresholds)
+    return {"samples": total, "thresholds": list(thresholds), "mean_iou": mean, "per_sample": ious.cpu()}

@@ -351,6 +351,21 @@ def test_voxel_iou_exact(s3r, oracle):
     assert torch.equal(got, oracle.voxel_iou(a, b))
 
 
+def test_eval_driver_matches_oracle_iou(s3r, oracle, models):
+    """evaluate.test_net (device-side IoU per threshold) against the oracle's forward + IoU."""
+    hip, ref = models
+    left, right, gt = s3r.evaluate.synthetic_eval_set(5, 1)
+    res = s3r.evaluate.test_net(hip, left, right, gt, batch=2, device=DEV)
+    assert res["samples"] == 5 and res["per_sample"].shape == (5, 4)
+    with torch.no_grad():
+        pred = ref(left, right)
+    for j, t in enumerate(res["thresholds"]):
+        a, b = pred > t, gt > 0.5
+        want = (a & b).flatten(1).sum(1).float() / (a | b).flatten(1).sum(1).float().clamp(min=1)
+        assert (res["per_sample"][:, j] - want).abs().max().item() < 1e-3      # north_star: IoU within 1e-3
+        assert abs(res["mean_iou"][j] - want.mean().item()) < 1e-3
+
+
 # ------------------------------------------------------------------ error behaviour of the boundary
 def test_errors(s3r, models):
     hip, _ = models
