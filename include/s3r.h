@@ -123,9 +123,11 @@ int s3r_decoder_forward(const s3r_layer* layers, int n_layers, const float* volu
 int s3r_cost_volume_forward(const float* feat_left, const float* feat_right, float* volume, int batch, int channels,
                             int max_disp, int height, int width, int out_halo, void* stream);
 
-/* y[b][o] = act(sum_i x[b][i] w[o][i] + bias[o]); w in torch Linear layout (no packing) */
+/* y[b][o] = act(sum_i x[b][i] w[o][i] + bias[o]); w in torch Linear layout (no packing).  `scratch` holds the
+ * split-K partial sums (s3r_linear_scratch_elems floats; reduced in a fixed order: deterministic). */
+int64_t s3r_linear_scratch_elems(int batch, int cin, int cout);
 int s3r_linear_forward(const float* x, const float* w, const float* bias, float* y, int batch, int cin, int cout,
-                       int act, void* stream);
+                       int act, float* scratch, int64_t scratch_elems, void* stream);
 
 /* squared-L2 nearest neighbours both ways; p (B,N,3), q (B,M,3) */
 int s3r_chamfer_forward(const float* p, const float* q, float* dist1, float* dist2, int32_t* idx1, int32_t* idx2,

@@ -60,8 +60,9 @@ SIGNATURES = {
                                       C.c_int, C.c_void_p]),
     "s3r_cost_volume_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_void_p]),
+    "s3r_linear_scratch_elems": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "s3r_linear_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                     C.c_int, C.c_void_p]),
+                                     C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "s3r_chamfer_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "s3r_voxel_iou": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),

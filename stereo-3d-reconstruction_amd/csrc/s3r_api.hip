@@ -325,6 +325,7 @@ int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d) {
     int rc = geometry(d, &g);
     if (rc) return rc;
     if ((rc = route(d, &r))) return rc;
+    if (r == R_LINEAR) return s3r::linear_scratch_elems(d->batch, d->cin, d->cout);
     if (r != R_MFMA) return 0;
     s3r::ConvParams p = make_params(d, g);
     Launch L;
@@ -356,8 +357,12 @@ int s3r_conv_forward(const s3r_conv_desc* d, const float* x, const float* packed
             break;
         }
         case R_LINEAR: {
+            const int64_t need = s3r::linear_scratch_elems(d->batch, d->cin, d->cout);
+            if (!scratch || scratch_elems < need)
+                return fail(S3R_ERR_WORKSPACE, "linear layer needs %lld floats of scratch (s3r_conv_scratch_elems), got %lld",
+                            (long long)need, (long long)(scratch ? scratch_elems : 0));
             ProfScope ps(s, F_LINEAR, d->tag, g.flops, g.bytes);
-            e = s3r::launch_linear(x, packed_w, scale, shift, y, d->batch, d->cin, d->cout, d->act, s);
+            e = s3r::launch_linear(x, packed_w, scale, shift, y, d->batch, d->cin, d->cout, d->act, scratch, s);
             break;
         }
         case R_MFMA: {
@@ -465,13 +470,21 @@ int s3r_cost_volume_forward(const float* fl, const float* fr, float* vol, int ba
     return S3R_OK;
 }
 
+int64_t s3r_linear_scratch_elems(int batch, int cin, int cout) {
+    if (batch <= 0 || cin <= 0 || cout <= 0) return fail(S3R_ERR_INVALID, "linear dims must be positive");
+    return s3r::linear_scratch_elems(batch, cin, cout);
+}
+
 int s3r_linear_forward(const float* x, const float* w, const float* bias, float* y, int batch, int cin, int cout,
-                       int act, void* stream) {
+                       int act, float* scratch, int64_t scratch_elems, void* stream) {
     if (!x || !w || !y) return fail(S3R_ERR_INVALID, "null tensor pointer");
     if (batch <= 0 || cin <= 0 || cout <= 0) return fail(S3R_ERR_INVALID, "linear dims must be positive");
+    if (!scratch || scratch_elems < s3r::linear_scratch_elems(batch, cin, cout))
+        return fail(S3R_ERR_WORKSPACE, "linear needs %lld floats of scratch (s3r_linear_scratch_elems)",
+                    (long long)s3r::linear_scratch_elems(batch, cin, cout));
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(s, F_LINEAR, 0, 2.0 * batch * (double)cin * cout, 4.0 * ((double)cin * cout + (double)batch * (cin + cout)));
-    hipError_t e = s3r::launch_linear(x, w, nullptr, bias, y, batch, cin, cout, act, s);
+    hipError_t e = s3r::launch_linear(x, w, nullptr, bias, y, batch, cin, cout, act, scratch, s);
     if (e != hipSuccess) return hip_fail(e, "linear launch");
     return S3R_OK;
 }

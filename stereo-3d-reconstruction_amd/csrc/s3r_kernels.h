@@ -57,8 +57,10 @@ hipError_t launch_head(const float* x, const float* w, const float* scale, const
                        int64_t S, int act, hipStream_t s);
 hipError_t launch_chamfer(const float* p, const float* q, float* d1, float* d2, int* i1, int* i2,
                           int B, int N, int M, hipStream_t s);
+// scratch: linear_scratch_elems floats of split-K slabs
 hipError_t launch_linear(const float* x, const float* w, const float* scale, const float* bias, float* y, int B,
-                         int Cin, int Cout, int act, hipStream_t s);
+                         int Cin, int Cout, int act, float* scratch, hipStream_t s);
+int64_t linear_scratch_elems(int B, int Cin, int Cout);
 hipError_t launch_iou(const float* pred, const float* gt, float th, float* iou, int B, int64_t S, hipStream_t s);
 
 }  // namespace s3r

@@ -215,75 +215,134 @@ hipError_t launch_head(const float* x, const float* w, const float* scale, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// Point-head linear layer  y[b][o] = act(sum_i x[b][i] * w[o][i] + bias[o]),  weight-streaming bound
-// (p1 alone is 134 MB of fp32 weights for 2 GFLOP at B=32).  Split-K over blockIdx.y so that >=256
-// workgroups stream disjoint weight slabs; partial sums are combined with fp32 atomics into a
-// zeroed accumulator and finished (bias + activation) by a second tiny kernel.
-constexpr int LIN_TO = 32, LIN_TB = 32, LIN_TK = 64;
+// Point-head linear layer  y[b][o] = act(scale[o] * sum_i x[b][i] * w[o][i] + bias[o]).
+// HBM-bound weight streaming (p1 alone is 134 MB of fp32 weights for 2 GFLOP at B=32), so the design
+// goal is "every weight byte crosses HBM once, in whole 128-byte lines, with enough loads in flight":
+//   * one WAVE owns 32 output rows x one K slice x 32*TM batch rows and feeds the fp32 matrix core
+//     straight from registers: A = x (lane (i,h): batch row i), B = w (lane (j,h): output row j), both
+//     operands loaded as 4 x float4 per lane = 64 contiguous bytes of "their" row per 32-deep K step
+//     (the two lane halves take adjacent 64-byte halves of a 128-byte line), no LDS, no barrier;
+//   * v_mfma_f32_32x32x2_f32 at 16 MFMAs per 2 KiB of weights keeps the matrix pipe far below
+//     saturation (9.8 TB/s equivalent), so the kernel stays memory-bound;
+//   * split-K over waves for parallelism; partial slabs [kz][b][o] are reduced in kz order by
+//     linear_finish_kernel (deterministic: no atomics).
+typedef float f32x16_l __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void linear_partial_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             float* __restrict__ acc_out, int B, int Cin, int Cout,
-                                                             int kper) {
-    __shared__ float xs[LIN_TB][LIN_TK + 1];
-    __shared__ float ws[LIN_TO][LIN_TK + 1];
-    const int o0 = blockIdx.x * LIN_TO, b0 = blockIdx.z * LIN_TB;
-    const int k_begin = blockIdx.y * kper;
-    const int k_end = min(Cin, k_begin + kper);
-    const int tid = threadIdx.x;
-    const int tb = tid >> 3, to = tid & 7;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = k_begin; k0 < k_end; k0 += LIN_TK) {
+template <int TM>
+__global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          float* __restrict__ part, int B, int Cin, int Cout, int kper,
+                                                          int ksplit) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int o0 = blockIdx.x * 32;
+    const int kz = blockIdx.y * 4 + wave;
+    const int b0 = blockIdx.z * 32 * TM;
+    if (kz >= ksplit) return;
+    const int kbeg = kz * kper;
+    const int kend = min(Cin, kbeg + kper);
+    const int niter = (kend - kbeg) >> 5;
+    const float* __restrict__ wp = w + (size_t)min(o0 + j, Cout - 1) * Cin + kbeg + 16 * h;
+    const float* __restrict__ xp[TM];
 #pragma unroll
-        for (int i = 0; i < (LIN_TB * LIN_TK) / 256; ++i) {
-            const int e = tid + i * 256;
-            const int r = e / LIN_TK, cidx = e % LIN_TK;
-            const int k = k0 + cidx;
-            xs[r][cidx] = (b0 + r < B && k < k_end) ? x[(size_t)(b0 + r) * Cin + k] : 0.f;
-            ws[r][cidx] = (o0 + r < Cout && k < k_end) ? w[(size_t)(o0 + r) * Cin + k] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll 16
-        for (int i = 0; i < LIN_TK; ++i) {
-            const float xv = xs[tb][i];
+    for (int tm = 0; tm < TM; ++tm) xp[tm] = x + (size_t)min(b0 + tm * 32 + j, B - 1) * Cin + kbeg + 16 * h;
+    f32x16_l acc[TM];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = fmaf(xv, ws[to + 8 * q][i], acc[q]);
-        }
-        __syncthreads();
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+    v4f wv[2][4], xv[2][TM][4];
+#define S3R_LIN_LOAD(S, IT)                                                                          \
+    {                                                                                                \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                              \
+            wv[S][q] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(wp + (IT) * 32 + q * 4)); \
+            _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                        \
+                xv[S][tm][q] = *reinterpret_cast<const v4f*>(xp[tm] + (IT) * 32 + q * 4);            \
+        }                                                                                            \
     }
-    const int b = b0 + tb;
-    if (b < B) {
+#define S3R_LIN_MMA(S)                                                                               \
+    {                                                                                                \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                            \
+                _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                    \
+                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[S][tm][q][e], wv[S][q][e], acc[tm], 0, 0, 0); \
+    }
+    if (niter > 0) S3R_LIN_LOAD(0, 0);
+    int it = 0;
+    for (; it + 2 <= niter; it += 2) {
+        S3R_LIN_LOAD(1, it + 1);
+        S3R_LIN_MMA(0);
+        if (it + 2 < niter) S3R_LIN_LOAD(0, it + 2);
+        S3R_LIN_MMA(1);
+    }
+    if (it < niter) S3R_LIN_MMA(0);
+#undef S3R_LIN_LOAD
+#undef S3R_LIN_MMA
+    const int o = o0 + j;
+    if (o < Cout) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int o = o0 + to + 8 * q;
-            if (o < Cout) atomicAdd(acc_out + (size_t)b * Cout + o, acc[q]);
-        }
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = b0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (b < B) part[((size_t)kz * B + b) * Cout + o] = acc[tm][r];
+            }
     }
 }
 
-__global__ void linear_finish_kernel(float* __restrict__ y, const float* __restrict__ scale,
-                                     const float* __restrict__ bias, int Cout, long long total, int act) {
+// generic (any Cin) partial kernel: one thread per (b, o) of a K slice; used when Cin % 32 != 0
+__global__ __launch_bounds__(256) void linear_naive_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           float* __restrict__ part, int B, int Cin, int Cout) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * Cout) return;
+    const int b = (int)(i / Cout), o = (int)(i % Cout);
+    float s = 0.f;
+    for (int k = 0; k < Cin; ++k) s = fmaf(x[(size_t)b * Cin + k], w[(size_t)o * Cin + k], s);
+    part[i] = s;
+}
+
+__global__ void linear_finish_kernel(const float* __restrict__ part, float* __restrict__ y,
+                                     const float* __restrict__ scale, const float* __restrict__ bias, int Cout,
+                                     long long total, int ksplit, int act) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) {
         const int o = (int)(i % Cout);
-        y[i] = apply_act(fmaf(y[i], scale ? scale[o] : 1.f, bias ? bias[o] : 0.f), act);
+        float s = part[i];
+        for (int z = 1; z < ksplit; ++z) s += part[(size_t)z * total + i];     // fixed order: deterministic
+        y[i] = apply_act(fmaf(s, scale ? scale[o] : 1.f, bias ? bias[o] : 0.f), act);
     }
 }
 
+// split of the K axis: enough waves to cover HBM latency on 256 CUs, K slices of >= 128, multiples of 32
+static void linear_split(int B, int Cin, int Cout, int* ksplit, int* kper) {
+    if (Cin % 32 != 0) { *ksplit = 1; *kper = Cin; return; }
+    const int otiles = (Cout + 31) / 32, btiles = (B + 31) / 32;
+    int ks = 1;
+    while (otiles * btiles * ks < 2048 && Cin / (2 * ks) >= 128 && (Cin / (2 * ks)) % 32 == 0) ks *= 2;
+    *ksplit = ks;
+    *kper = Cin / ks;
+}
+
+int64_t linear_scratch_elems(int B, int Cin, int Cout) {
+    int ks, kper;
+    linear_split(B, Cin, Cout, &ks, &kper);
+    return (int64_t)ks * B * Cout;
+}
+
 hipError_t launch_linear(const float* x, const float* w, const float* scale, const float* bias, float* y, int B,
-                         int Cin, int Cout, int act, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(y, 0, (size_t)B * Cout * sizeof(float), s);
-    if (e != hipSuccess) return e;
-    const int otiles = (Cout + LIN_TO - 1) / LIN_TO, btiles = (B + LIN_TB - 1) / LIN_TB;
-    int ksplit = 1;
-    while (otiles * btiles * ksplit < 512 && Cin / (ksplit * 2) >= 4 * LIN_TK) ksplit *= 2;
-    int kper = (Cin + ksplit - 1) / ksplit;
-    kper = (kper + LIN_TK - 1) / LIN_TK * LIN_TK;
-    ksplit = (Cin + kper - 1) / kper;
-    hipLaunchKernelGGL(linear_partial_kernel, dim3(otiles, ksplit, btiles), dim3(256), 0, s, x, w, y, B, Cin, Cout,
-                       kper);
+                         int Cin, int Cout, int act, float* scratch, hipStream_t s) {
+    int ks, kper;
+    linear_split(B, Cin, Cout, &ks, &kper);
     const long long total = (long long)B * Cout;
-    hipLaunchKernelGGL(linear_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, y, scale, bias,
-                       Cout, total, act);
+    if (Cin % 32 != 0) {
+        hipLaunchKernelGGL(linear_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, scratch, B,
+                           Cin, Cout);
+    } else {
+        const dim3 grid((Cout + 31) / 32, (ks + 3) / 4, (B + 31) / 32);
+        hipLaunchKernelGGL(linear_mfma_kernel<1>, grid, dim3(256), 0, s, x, w, scratch, B, Cin, Cout, kper, ks);
+    }
+    hipLaunchKernelGGL(linear_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, scratch, y, scale,
+                       bias, Cout, total, ks, act);
     return hipGetLastError();
 }
 

@@ -321,6 +321,23 @@ def test_stereo2point_vs_oracle(s3r, oracle):
     assert rel_l2(got, want) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(32, 32768, 1024), (5, 1024, 6144), (33, 96, 40), (3, 50, 7), (70, 4096, 100)])
+def test_linear_layer(s3r, oracle, shape):
+    """Point-head linear kernel (fp32-MFMA weight streaming, deterministic split-K) incl. ragged batch /
+    cout and the Cin % 32 != 0 fallback."""
+    B, cin, cout = shape
+    L = s3r.arch_spec.Layer("t", "linear", cin, cout, 1, 1, 0, bn=False, act="relu")
+    ch = _single(s3r, L, 1)
+    blk = _oracle_block(oracle, L, ch.t.state_dict())
+    x = torch.randn(B, cin, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        want = blk(x)
+    ch.to(DEV)
+    got = ch._run(x.to(DEV))
+    assert rel_l2(got.cpu(), want) < 2e-6
+    assert torch.equal(ch._run(x.to(DEV)), got)
+
+
 @pytest.mark.parametrize("shape", [(2, 2048, 2048), (3, 100, 1500), (1, 1, 1), (2, 1025, 7)])
 def test_chamfer_exact(s3r, oracle, shape):
     B, N, M = shape
