@@ -22,6 +22,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (= fp32 vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -75,6 +76,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="stereo pairs per GPU per step")
     ap.add_argument("--variant", default="voxel", choices=["voxel", "point"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32: exact-fp32 MFMA path (the headline, BASELINE configs[1]); bf16: bf16 MFMA path, "
+                         "channels-last bf16 activations (configs[2], quoted at --batch 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--include-h2d", action="store_true",
@@ -103,7 +107,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B = args.batch
-    model = (s3r.Stereo2Voxel if args.variant == "voxel" else s3r.Stereo2Point)()
+    if args.dtype == "bf16" and args.variant != "voxel":
+        sys.exit("the bf16 path exists for Stereo2Voxel only")
+    model = s3r.Stereo2Voxel("bf16" if args.dtype == "bf16" else "fp32") if args.variant == "voxel" else s3r.Stereo2Point()
     s3r.seed_module(model, 0)
     model.to(dev)
     left, right = s3r.synthetic_pairs(B, seed=1000 + rank)      # random data (never zeros: DVFS, rule 25)
@@ -182,7 +188,8 @@ def main():
             log("conv_mfma per layer:   ms/launch   TFLOP/s   frac of fp32 MFMA peak")
             for tag, e in sorted(per_layer.items()):
                 tf = e["flops"] / e["ms"] / 1e9
-                log(f"  {names.get(tag, tag)!s:6s} {e['ms'] / e['n']:12.4f} {tf:9.2f} {tf / PEAK_FP32_MFMA_TFLOPS:8.3f}")
+                pk = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
+                log(f"  {names.get(tag, tag)!s:6s} {e['ms'] / e['n']:12.4f} {tf:9.2f} {tf / pk:8.3f}")
             c = fam.get("conv_mfma")
             if c and c["ms"] > 0:
                 # dominant kernel = conv_glds_kernel (one template, 16 launches per step): algorithmic FLOPs
@@ -196,24 +203,30 @@ def main():
                         traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")   # rocprofv3 PMC, per launch
                     except Exception:
                         traffic = None
-                roof = {"bound": "mfma", "kernel": "conv_glds_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv, "
-                                                   "LDS-DMA operand staging)",
-                        "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                bf = args.dtype == "bf16"
+                peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_FP32_MFMA_TFLOPS
+                if bf:
+                    traffic = None
+                roof = {"bound": "mfma",
+                        "kernel": "conv_bf16_kernel (v_mfma_f32_32x32x16_bf16 implicit-GEMM conv, channels-last, LDS-DMA)" if bf
+                        else "conv_glds_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv, LDS-DMA operand staging)",
+                        "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4), "traffic": traffic,
                         "launches_per_step": c["n"] // args.steps,
                         "algorithmic_gflop_per_launch": round(c["flops"] / c["n"] / 1e9, 3),
                         "avg_launch_ms": round(c["ms"] / c["n"], 5),
                         "algorithmic_gflop_per_step": round(c["flops"] / args.steps / 1e9, 3),
                         "kernel_ms_per_step": round(c["ms"] / args.steps, 4)}
         out = {
-            "metric": "stereo pairs/s forward (batch 32, 224x224 -> 32^3 voxel)" if args.variant == "voxel"
-                      else "stereo pairs/s forward (batch 32, 224x224 -> 2048-pt cloud)",
+            "metric": f"stereo pairs/s forward (batch {B}, 224x224 -> 32^3 voxel)" if args.variant == "voxel"
+                      else f"stereo pairs/s forward (batch {B}, 224x224 -> 2048-pt cloud)",
             "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic" + (" (host->device copy of every batch inside the step)" if args.include_h2d else ""),
             "config": {"workload": f"Stereo2{'Voxel' if args.variant == 'voxel' else 'Point'} forward, batch={B} per GPU, "
-                                   f"224x224 RGB stereo pair, fp32, random-init weights, build-specified arch_spec "
+                                   f"224x224 RGB stereo pair, {'bf16 MFMA path' if args.dtype == 'bf16' else 'fp32'}, "
+                                   f"random-init weights, build-specified arch_spec "
                                    f"({fl['total'] / 1e9:.2f} GFLOP/pair)",
                        "per_gpu_batch": B, "global_batch": world * B,
                        "parallelism": f"batch-sharded x{world}, all-gather of predictions" if world > 1 else "single GPU"},

@@ -49,6 +49,13 @@ typedef enum s3r_op {
     S3R_OP_LINEAR = 2         /* nn.Linear on the flattened input */
 } s3r_op;
 
+typedef enum s3r_dtype {
+    S3R_F32 = 0,              /* fp32 activations, NCHW / NCDHW, v_mfma_f32_32x32x2_f32 (exact fp32) */
+    S3R_BF16 = 1              /* bf16 activations, CHANNELS-LAST (B,[D,]H,W,C), v_mfma_f32_32x32x16_bf16, fp32
+                                 accumulate; the stem still reads fp32 NCHW renders and the occupancy head still
+                                 writes fp32 probabilities */
+} s3r_dtype;
+
 typedef enum s3r_act { S3R_ACT_NONE = 0, S3R_ACT_RELU = 1, S3R_ACT_SIGMOID = 2 } s3r_act;
 
 /* One layer's geometry.  Spatial sizes are cubic/square: `in_size` per axis, `ndim` axes.
@@ -72,13 +79,14 @@ typedef struct s3r_conv_desc {
     int32_t tile;      /* -1: library picks; >=0: force MFMA tile cfg + 16*gather_width (tuning) */
     int32_t in_halo;   /* zero halo of the input buffer  (elements per spatial axis side) */
     int32_t out_halo;  /* zero halo of the output buffer */
-    int32_t ksplit;    /* 0: library picks; >=1: force the split-K factor (must divide cin/16) */
+    int32_t ksplit;    /* 0: library picks; >=1: force the split-K factor (must divide cin/16; bf16: cin/32) */
+    int32_t dtype;     /* s3r_dtype: which path (layout + matrix instruction) the layer runs on */
 } s3r_conv_desc;
 
 /* One layer of a stage: geometry + its packed weights + folded epilogue vectors (device pointers). */
 typedef struct s3r_layer {
     s3r_conv_desc desc;
-    const float* packed_w;   /* from s3r_conv_pack_weights */
+    const void* packed_w;    /* from s3r_conv_pack_weights (fp32 or bf16 image, per desc.dtype) */
     const float* scale;      /* [cout] gamma/sqrt(var+eps)            (NULL = 1) */
     const float* shift;      /* [cout] beta + (bias-mean)*scale       (NULL = 0) */
 } s3r_layer;
@@ -88,17 +96,18 @@ const char* s3r_last_error(void);
 
 /* output edge of a layer: conv (n+2p-k)/s+1, deconv (n-1)s-2p+k, linear 1 */
 int s3r_conv_out_size(const s3r_conv_desc* d);
-/* elements of the packed weight buffer for a layer (>= the torch weight's numel: couts are padded) */
+/* size of the packed weight buffer for a layer IN 4-BYTE UNITS (>= the torch weight's numel on the fp32
+ * path: couts are padded; about half of it on the bf16 path) */
 int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems);
 /* repack a torch-layout weight (Conv: [cout][cin][k..]; ConvTranspose: [cin][cout][k..]; Linear:
  * [cout][cin]) into the kernel's K-major layout.  Device to device, on `stream`. */
-int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, float* packed, void* stream);
+int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, void* packed, void* stream);
 /* floats of split-K scratch s3r_conv_forward wants for this layer (0 when it does not split K) */
 int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d);
 /* y = act(conv(x) * scale + shift); dispatches to the stem / MFMA / head kernel by shape.  `scratch`
  * (may be NULL) holds split-K partial sums; without it a layer the library would split runs unsplit. */
-int s3r_conv_forward(const s3r_conv_desc* d, const float* x, const float* packed_w, const float* scale,
-                     const float* shift, float* y, float* scratch, int64_t scratch_elems, void* stream);
+int s3r_conv_forward(const s3r_conv_desc* d, const void* x, const void* packed_w, const float* scale,
+                     const float* shift, void* y, float* scratch, int64_t scratch_elems, void* stream);
 
 /* Run a chain of layers x -> y.  Every intermediate activation gets its own region of `ws`
  * (s3r_chain_workspace_elems floats; with 288 GB of HBM nothing is recycled), laid out with the halo
@@ -107,21 +116,25 @@ int s3r_conv_forward(const s3r_conv_desc* d, const float* x, const float* packed
  * `ws_fresh` != 0 makes the call zero the workspace first: pass 1 the first time a (chain, batch,
  * workspace) combination is used — or whenever anything else wrote to `ws` — and 0 afterwards. */
 int64_t s3r_chain_workspace_elems(const s3r_layer* layers, int n_layers);
-int s3r_chain_forward(const s3r_layer* layers, int n_layers, const float* x, float* y, float* ws, int64_t ws_elems,
+int s3r_chain_forward(const s3r_layer* layers, int n_layers, const void* x, void* y, float* ws, int64_t ws_elems,
                       int ws_fresh, void* stream);
 
 /* Stage entry points (thin, shape-checked views of s3r_chain_forward):
  *   encoder: images (N,3,224,224) -> features (N,C,28,28); N = 2B (left batch then right batch)
  *   decoder: cost volume (B,2C,D,H,W) -> occupancy (B,32,32,32)  */
-int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* images, float* features, float* ws,
+int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* images, void* features, float* ws,
                         int64_t ws_elems, int ws_fresh, void* stream);
-int s3r_decoder_forward(const s3r_layer* layers, int n_layers, const float* volume, float* occupancy, float* ws,
+int s3r_decoder_forward(const s3r_layer* layers, int n_layers, const void* volume, float* occupancy, float* ws,
                         int64_t ws_elems, int ws_fresh, void* stream);
 
 /* vol[b,c,d,h,w] = L[b,c,h,w]-R[b,c,h,w-d] (w>=d), vol[b,C+c,d,h,w] = R[b,c,h,w]-L[b,c,h,w+d] (w+d<W), else 0.
  * `out_halo` > 0 writes the interior of a (B,2C,D+2h,H+2h,W+2h) buffer whose halo the caller zeroed. */
 int s3r_cost_volume_forward(const float* feat_left, const float* feat_right, float* volume, int batch, int channels,
                             int max_disp, int height, int width, int out_halo, void* stream);
+
+/* the same on channels-last bf16 features (B,H,W,C) -> volume (B,D+2h,H+2h,W+2h,2C); channels % 8 == 0 */
+int s3r_cost_volume_forward_bf16(const void* feat_left, const void* feat_right, void* volume, int batch, int channels,
+                                 int max_disp, int height, int width, int out_halo, void* stream);
 
 /* y[b][o] = act(sum_i x[b][i] w[o][i] + bias[o]); w in torch Linear layout (no packing).  `scratch` holds the
  * split-K partial sums (s3r_linear_scratch_elems floats; reduced in a fixed order: deterministic). */

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libs3r_hip.so")
 
 OP_CONV, OP_DECONV, OP_LINEAR = 0, 1, 2
+DTYPE = {"fp32": 0, "bf16": 1}
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}
 FAMILY = {0: "conv_mfma", 1: "stem", 2: "head", 3: "cost_volume", 4: "linear", 5: "chamfer", 6: "iou", 7: "pack",
           8: "pad_copy"}
@@ -22,7 +23,7 @@ ABI_VERSION = 2
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("op", "ndim", "batch", "cin", "cout", "in_size", "k", "stride", "pad", "act", "tag", "tile",
-                 "in_halo", "out_halo", "ksplit")]
+                 "in_halo", "out_halo", "ksplit", "dtype")]
 
 
 class Layer(C.Structure):
@@ -60,6 +61,8 @@ SIGNATURES = {
                                       C.c_int, C.c_void_p]),
     "s3r_cost_volume_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_void_p]),
+    "s3r_cost_volume_forward_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_int, C.c_int, C.c_void_p]),
     "s3r_linear_scratch_elems": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "s3r_linear_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -104,12 +107,12 @@ def check(rc, what=""):
     return rc
 
 
-def make_desc(layer, batch, in_size, tag=0, tile=-1, in_halo=0, out_halo=0, ksplit=0):
+def make_desc(layer, batch, in_size, tag=0, tile=-1, in_halo=0, out_halo=0, ksplit=0, dtype=0):
     """arch_spec.Layer -> ConvDesc."""
     op = {"conv2d": OP_CONV, "conv3d": OP_CONV, "deconv3d": OP_DECONV, "linear": OP_LINEAR}[layer.op]
     nd = {"conv2d": 2, "conv3d": 3, "deconv3d": 3, "linear": 0}[layer.op]
     return ConvDesc(op, nd, batch, layer.cin, layer.cout, in_size, layer.k, layer.s, layer.p, ACT[layer.act], tag,
-                    tile, in_halo, out_halo, ksplit)
+                    tile, in_halo, out_halo, ksplit, dtype)
 
 
 def profile_enable(max_records):

@@ -73,6 +73,7 @@ struct Geo {
     int in_p, out_p;   // edge sizes of the halo-padded buffers
     int64_t in_sp, out_sp;         // logical voxels per channel
     int64_t x_elems, y_elems;      // elements of the (padded) buffers
+    int64_t x_store, y_store;      // their storage in 4-byte units (bf16 buffers take half)
     int64_t w_elems;
     double flops, bytes;           // algorithmic (unpadded) work of the layer
 };
@@ -88,14 +89,17 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
     if (d->batch <= 0 || d->cin <= 0 || d->cout <= 0) return fail(S3R_ERR_INVALID, "batch/cin/cout must be positive");
     if (d->in_halo < 0 || d->out_halo < 0 || d->in_halo > 8 || d->out_halo > 8)
         return fail(S3R_ERR_INVALID, "halo must be in [0, 8]");
+    if (d->dtype != S3R_F32 && d->dtype != S3R_BF16) return fail(S3R_ERR_INVALID, "unknown dtype %d", d->dtype);
     if (d->op == S3R_OP_LINEAR) {
         if (d->in_halo || d->out_halo) return fail(S3R_ERR_INVALID, "linear layers take no halo");
         g->nd = 0; g->in = g->out = g->in_p = g->out_p = 1; g->in_sp = 1; g->out_sp = 1;
         g->x_elems = (int64_t)d->batch * d->cin;
         g->y_elems = (int64_t)d->batch * d->cout;
         g->w_elems = (int64_t)d->cin * d->cout;
+        g->x_store = g->x_elems; g->y_store = g->y_elems;
         g->flops = 2.0 * d->batch * (double)d->cin * d->cout;
         g->bytes = 4.0 * (g->x_elems + g->y_elems + g->w_elems);
+        if (d->dtype != S3R_F32) return fail(S3R_ERR_INVALID, "linear layers exist on the fp32 path only");
         return S3R_OK;
     }
     if (d->op != S3R_OP_CONV && d->op != S3R_OP_DECONV) return fail(S3R_ERR_INVALID, "unknown op %d", d->op);
@@ -118,7 +122,14 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
         g->flops = 2.0 * d->batch * (double)d->cin * g->in_sp * d->cout * ipow(d->k, g->nd);
     else
         g->flops = 2.0 * d->batch * (double)d->cout * g->out_sp * d->cin * ipow(d->k, g->nd);
-    g->bytes = 4.0 * ((double)d->batch * (d->cin * (double)g->in_sp + d->cout * (double)g->out_sp) + (double)g->w_elems);
+    // element sizes: the bf16 path reads fp32 renders in its stem and writes fp32 probabilities from its head
+    const bool bf = d->dtype == S3R_BF16;
+    const bool stem = d->ndim == 2 && d->cin == 3;
+    const bool head = d->cout == 1 && d->k == 1;
+    const int xs = (bf && !stem) ? 2 : 4, ys = (bf && !head) ? 2 : 4, wsz = bf && !stem && !head ? 2 : 4;
+    g->x_store = (g->x_elems * xs + 3) / 4;
+    g->y_store = (g->y_elems * ys + 3) / 4;
+    g->bytes = (double)d->batch * (xs * d->cin * (double)g->in_sp + ys * d->cout * (double)g->out_sp) + wsz * (double)g->w_elems;
     if (g->x_elems >= kMaxElems || g->y_elems >= kMaxElems || g->x_elems * 4 >= kMaxBytes || g->y_elems * 4 >= kMaxBytes)
         return fail(S3R_ERR_INVALID, "tensor too large for one call (>= 2^31 elements / 4 GiB): split the batch");
     return S3R_OK;
@@ -133,7 +144,7 @@ int route(const s3r_conv_desc* d, Route* r) {
         d->pad == 1 && d->act == S3R_ACT_RELU) { *r = R_STEM; return S3R_OK; }
     if (d->op == S3R_OP_CONV && d->cout == 1 && d->k == 1 && d->stride == 1 && d->pad == 0 &&
         (ipow(d->in_size, d->ndim) % 4) == 0) { *r = R_HEAD; return S3R_OK; }
-    if (d->cin % 16 == 0) { *r = R_MFMA; return S3R_OK; }
+    if (d->dtype == S3R_BF16 ? d->cin % 32 == 0 : d->cin % 16 == 0) { *r = R_MFMA; return S3R_OK; }
     return fail(S3R_ERR_INVALID, "no kernel for this layer shape (cin=%d cout=%d k=%d s=%d p=%d ndim=%d): the MFMA path "
                 "needs cin %% 16 == 0", d->cin, d->cout, d->k, d->stride, d->pad, d->ndim);
 }
@@ -155,6 +166,53 @@ int check_halos(const s3r_conv_desc* d, Route r) {
 }
 
 int cout_pad(int cout) { return (cout + 127) / 128 * 128; }
+int cout_pad_h(int cout) { return (cout + 63) / 64 * 64; }
+
+// bf16 channels-last twin of make_params: strides are in elements of (B, Dp, Hp, Wp, C)
+s3r::ConvParamsH make_params_h(const s3r_conv_desc* d, const Geo& g) {
+    s3r::ConvParamsH p;
+    memset(&p, 0, sizeof(p));
+    const bool is3 = d->ndim == 3;
+    p.B = d->batch; p.Cin = d->cin; p.Cout = d->cout; p.CoutPad = cout_pad_h(d->cout);
+    p.act = d->act;
+    p.x_ws = d->cin; p.x_hs = g.in_p * d->cin; p.x_ds = is3 ? g.in_p * g.in_p * d->cin : 0;
+    p.x_bs = (int)ipow(g.in_p, g.nd) * d->cin;
+    p.y_ws = d->cout; p.y_hs = g.out_p * d->cout; p.y_ds = is3 ? g.out_p * g.out_p * d->cout : 0;
+    p.y_bs = (int)ipow(g.out_p, g.nd) * d->cout;
+    p.y_org = d->out_halo * (p.y_ds + p.y_hs + p.y_ws);
+    p.x_bytes = (unsigned)(g.x_elems * 2);
+    if (d->op == S3R_OP_DECONV) {
+        p.transposed = 1;
+        p.Nd = g.in; p.Nh = g.in; p.Nw = g.in;
+        p.kd = p.kh = p.kw = 2; p.T = 8;
+        p.stride = 1;
+        p.x_org = d->in_halo * (p.x_ds + p.x_hs + p.x_ws);
+    } else {
+        p.transposed = 0;
+        p.Nd = is3 ? g.out : 1; p.Nh = g.out; p.Nw = g.out;
+        p.kd = is3 ? d->k : 1; p.kh = d->k; p.kw = d->k; p.T = p.kd * p.kh * p.kw;
+        p.stride = d->stride;
+        p.x_org = (d->in_halo - d->pad) * (p.x_ds + p.x_hs + p.x_ws);
+    }
+    p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
+    p.ksplit = 1;
+    return p;
+}
+
+// (position-tile multiplier TM, split-K) of a bf16 MFMA layer
+struct LaunchH { int tm, ksplit; };
+
+int resolve_launch_h(const s3r_conv_desc* d, s3r::ConvParamsH* p, LaunchH* L) {
+    const int chunks = d->cin / 32;
+    if (d->ksplit < 0 || (d->ksplit > 0 && chunks % d->ksplit != 0))
+        return fail(S3R_ERR_INVALID, "ksplit=%d must divide cin/32=%d", d->ksplit, chunks);
+    L->ksplit = d->ksplit > 0 ? d->ksplit : s3r::conv_bf16_pick_ksplit(*p);
+    p->ksplit = L->ksplit;
+    if (d->tile >= 0 && d->tile != 1 && d->tile != 2 && d->tile != 4)
+        return fail(S3R_ERR_INVALID, "bf16 path: tile must be -1 (auto), 1, 2 or 4 (x128 positions)");
+    L->tm = d->tile >= 0 ? d->tile : s3r::conv_bf16_pick_tm(*p);
+    return S3R_OK;
+}
 
 s3r::ConvParams make_params(const s3r_conv_desc* d, const Geo& g) {
     s3r::ConvParams p;
@@ -237,6 +295,7 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
         int rc = geometry(&pl->d[i], &pl->g[i]);
         if (rc) return rc;
         if ((rc = check_halos(&pl->d[i], pl->r[i]))) return rc;
+        if (pl->d[i].dtype != pl->d[0].dtype) return fail(S3R_ERR_INVALID, "all layers of a chain must share one dtype");
         if (i > 0) {   // shapes must chain
             const s3r_conv_desc& a = pl->d[i - 1];
             const int64_t prev_out = (int64_t)a.cout * pl->g[i - 1].out_sp, cur_in = (int64_t)pl->d[i].cin * pl->g[i].in_sp;
@@ -252,11 +311,11 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
         if (user_in_halo != 0) return fail(S3R_ERR_INVALID, "chain input halo %d is smaller than the %d its first layer needs",
                                            user_in_halo, need0);
         pl->pad_off = 0;
-        off = align_up(pl->g[0].x_elems, 256);
+        off = align_up(pl->g[0].x_store, 256);
     }
     for (int i = 0; i + 1 < n; ++i) {
         pl->off[i] = off;
-        off = align_up(off + pl->g[i].y_elems, 256);
+        off = align_up(off + pl->g[i].y_store, 256);
     }
     for (int i = 0; i < n; ++i) {
         const int64_t sc = s3r_conv_scratch_elems(&pl->d[i]);
@@ -291,14 +350,16 @@ int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems) {
         case R_LINEAR: *elems = g.w_elems; break;
         case R_MFMA: {
             const int64_t taps = d->op == S3R_OP_DECONV ? 64 : ipow(d->k, g.nd);
-            *elems = taps * d->cin * cout_pad(d->cout);
+            if (d->dtype == S3R_BF16) *elems = (taps * d->cin * cout_pad_h(d->cout) + 1) / 2;   // bf16, in float units
+            else *elems = taps * d->cin * cout_pad(d->cout);
             break;
         }
     }
     return S3R_OK;
 }
 
-int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, float* packed, void* stream) {
+int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, void* packedv, void* stream) {
+    float* packed = static_cast<float*>(packedv);
     Geo g; Route r;
     int rc = geometry(d, &g);
     if (rc) return rc;
@@ -312,8 +373,12 @@ int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, float* packed,
         case R_HEAD: e = hipMemcpyAsync(packed, w, sizeof(float) * d->cin, hipMemcpyDeviceToDevice, s); break;
         case R_LINEAR: e = hipMemcpyAsync(packed, w, sizeof(float) * g.w_elems, hipMemcpyDeviceToDevice, s); break;
         case R_MFMA:
-            e = s3r::launch_pack_conv(w, packed, d->cin, d->cout, cout_pad(d->cout),
-                                      d->op == S3R_OP_DECONV ? 8 : (int)ipow(d->k, g.nd), d->op == S3R_OP_DECONV, s);
+            if (d->dtype == S3R_BF16)
+                e = s3r::launch_pack_bf16(w, packed, d->cin, d->cout, cout_pad_h(d->cout),
+                                          d->op == S3R_OP_DECONV ? 8 : (int)ipow(d->k, g.nd), d->op == S3R_OP_DECONV, s);
+            else
+                e = s3r::launch_pack_conv(w, packed, d->cin, d->cout, cout_pad(d->cout),
+                                          d->op == S3R_OP_DECONV ? 8 : (int)ipow(d->k, g.nd), d->op == S3R_OP_DECONV, s);
             break;
     }
     if (e != hipSuccess) return hip_fail(e, "pack weights");
@@ -327,14 +392,23 @@ int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d) {
     if ((rc = route(d, &r))) return rc;
     if (r == R_LINEAR) return s3r::linear_scratch_elems(d->batch, d->cin, d->cout);
     if (r != R_MFMA) return 0;
+    if (d->dtype == S3R_BF16) {
+        s3r::ConvParamsH ph = make_params_h(d, g);
+        LaunchH Lh;
+        if ((rc = resolve_launch_h(d, &ph, &Lh))) return rc;
+        return s3r::conv_bf16_scratch_elems(ph, Lh.tm);
+    }
     s3r::ConvParams p = make_params(d, g);
     Launch L;
     if ((rc = resolve_launch(d, &p, &L))) return rc;
     return s3r::conv_scratch_elems(p, L.cfg);
 }
 
-int s3r_conv_forward(const s3r_conv_desc* d, const float* x, const float* packed_w, const float* scale,
-                     const float* shift, float* y, float* scratch, int64_t scratch_elems, void* stream) {
+int s3r_conv_forward(const s3r_conv_desc* d, const void* xv, const void* packed_wv, const float* scale,
+                     const float* shift, void* yv, float* scratch, int64_t scratch_elems, void* stream) {
+    const float* x = static_cast<const float*>(xv);
+    const float* packed_w = static_cast<const float*>(packed_wv);
+    float* y = static_cast<float*>(yv);
     Geo g; Route r;
     int rc = geometry(d, &g);
     if (rc) return rc;
@@ -343,6 +417,44 @@ int s3r_conv_forward(const s3r_conv_desc* d, const float* x, const float* packed
     if (!x || !packed_w || !y) return fail(S3R_ERR_INVALID, "null tensor pointer");
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipSuccess;
+    if (d->dtype == S3R_BF16) {
+        if (g.x_elems * 2 >= ((int64_t)1 << 31) || g.y_elems * 2 >= ((int64_t)1 << 31))
+            return fail(S3R_ERR_INVALID, "bf16 path: tensors must be < 2 GiB per call: split the batch");
+        switch (r) {
+            case R_STEM: {
+                if (!scale || !shift) return fail(S3R_ERR_INVALID, "stem needs scale and shift");
+                ProfScope ps(s, F_STEM, d->tag, g.flops, g.bytes);
+                e = s3r::launch_stem_bf16(x, packed_w, scale, shift, yv, d->batch, g.in, g.in, g.out, g.out,
+                                          g.out_p * g.out_p * 32, g.out_p * 32, d->out_halo * (g.out_p + 1) * 32, s);
+                break;
+            }
+            case R_HEAD: {
+                ProfScope ps(s, F_HEAD, d->tag, g.flops, g.bytes);
+                e = s3r::launch_head_bf16(xv, packed_w, scale, shift, y, d->cin, (int64_t)d->batch * g.in_sp, d->act, s);
+                break;
+            }
+            case R_MFMA: {
+                s3r::ConvParamsH p = make_params_h(d, g);
+                p.x = xv; p.w = packed_wv; p.scale = scale; p.shift = shift; p.y = yv;
+                LaunchH L;
+                if ((rc = resolve_launch_h(d, &p, &L))) return rc;
+                if (L.ksplit > 1) {
+                    const int64_t need = s3r::conv_bf16_scratch_elems(p, L.tm);
+                    if (scratch && scratch_elems >= need) p.part = scratch;
+                    else if (d->ksplit > 0)
+                        return fail(S3R_ERR_WORKSPACE, "ksplit=%d needs %lld floats of scratch, got %lld", L.ksplit,
+                                    (long long)need, (long long)(scratch ? scratch_elems : 0));
+                    else p.ksplit = L.ksplit = 1;
+                }
+                ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
+                e = s3r::launch_conv_bf16(p, L.tm, s);
+                break;
+            }
+            default: return fail(S3R_ERR_INVALID, "layer not available on the bf16 path");
+        }
+        if (e != hipSuccess) return hip_fail(e, "conv forward launch (bf16)");
+        return S3R_OK;
+    }
     switch (r) {
         case R_STEM: {
             if (!scale || !shift) return fail(S3R_ERR_INVALID, "stem needs scale and shift");
@@ -394,7 +506,7 @@ int64_t s3r_chain_workspace_elems(const s3r_layer* layers, int n_layers) {
     return pl.total;
 }
 
-int s3r_chain_forward(const s3r_layer* layers, int n_layers, const float* x, float* y, float* ws, int64_t ws_elems,
+int s3r_chain_forward(const s3r_layer* layers, int n_layers, const void* x, void* y, float* ws, int64_t ws_elems,
                       int ws_fresh, void* stream) {
     Plan pl;
     int rc = plan_chain(layers, n_layers, &pl);
@@ -408,19 +520,27 @@ int s3r_chain_forward(const s3r_layer* layers, int n_layers, const float* x, flo
         hipError_t e = hipMemsetAsync(ws, 0, (size_t)pl.total * sizeof(float), s);
         if (e != hipSuccess) return hip_fail(e, "workspace memset");
     }
-    const float* cur = x;
+    const void* cur = x;
     if (pl.pad_input) {
         const s3r_conv_desc& d0 = pl.d[0];
         const int hl = d0.in_halo, is3 = d0.ndim == 3;
         ProfScope ps(s, F_PAD, d0.tag, 0.0, 8.0 * d0.batch * d0.cin * (double)pl.g[0].in_sp);
-        hipError_t e = s3r::launch_pad_copy(x, ws + pl.pad_off, (int64_t)d0.batch * d0.cin, is3 ? d0.in_size : 1, d0.in_size,
-                                            d0.in_size, is3 ? hl : 0, hl, hl, s);
+        hipError_t e;
+        if (d0.dtype == S3R_BF16) {
+            // channels-last bf16 (B, [D,] H, W, C): rows of W*C bf16 = W*C/2 floats, planes = samples
+            const int wc = d0.in_size * d0.cin / 2, hwc = hl * d0.cin / 2;
+            e = s3r::launch_pad_copy(static_cast<const float*>(x), ws + pl.pad_off, d0.batch, is3 ? d0.in_size : 1,
+                                     d0.in_size, wc, is3 ? hl : 0, hl, hwc, s);
+        } else {
+            e = s3r::launch_pad_copy(static_cast<const float*>(x), ws + pl.pad_off, (int64_t)d0.batch * d0.cin,
+                                     is3 ? d0.in_size : 1, d0.in_size, d0.in_size, is3 ? hl : 0, hl, hl, s);
+        }
         if (e != hipSuccess) return hip_fail(e, "pad copy launch");
         cur = ws + pl.pad_off;
     }
     for (int i = 0; i < n_layers; ++i) {
         const s3r_layer& L = layers[i];
-        float* out = (i == n_layers - 1) ? y : ws + pl.off[i];
+        void* out = (i == n_layers - 1) ? y : static_cast<void*>(ws + pl.off[i]);
         rc = s3r_conv_forward(&pl.d[i], cur, L.packed_w, L.scale, L.shift, out,
                               pl.scratch_elems ? ws + pl.scratch_off : nullptr, pl.scratch_elems, stream);
         if (rc) return rc;
@@ -429,7 +549,7 @@ int s3r_chain_forward(const s3r_layer* layers, int n_layers, const float* x, flo
     return S3R_OK;
 }
 
-int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* images, float* features, float* ws,
+int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* images, void* features, float* ws,
                         int64_t ws_elems, int ws_fresh, void* stream) {
     if (!layers || n_layers <= 0) return fail(S3R_ERR_INVALID, "empty encoder");
     const s3r_conv_desc& f = layers[0].desc;
@@ -441,7 +561,7 @@ int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* imag
     return s3r_chain_forward(layers, n_layers, images, features, ws, ws_elems, ws_fresh, stream);
 }
 
-int s3r_decoder_forward(const s3r_layer* layers, int n_layers, const float* volume, float* occupancy, float* ws,
+int s3r_decoder_forward(const s3r_layer* layers, int n_layers, const void* volume, float* occupancy, float* ws,
                         int64_t ws_elems, int ws_fresh, void* stream) {
     if (!layers || n_layers <= 0) return fail(S3R_ERR_INVALID, "empty decoder");
     for (int i = 0; i < n_layers; ++i)
@@ -467,6 +587,25 @@ int s3r_cost_volume_forward(const float* fl, const float* fr, float* vol, int ba
     ProfScope ps(s, F_COSTVOL, 0, (double)out, bytes);
     hipError_t e = s3r::launch_cost_volume(fl, fr, vol, batch, channels, max_disp, height, width, out_halo, s);
     if (e != hipSuccess) return hip_fail(e, "cost volume launch");
+    return S3R_OK;
+}
+
+int s3r_cost_volume_forward_bf16(const void* fl, const void* fr, void* vol, int batch, int channels, int max_disp,
+                                 int height, int width, int out_halo, void* stream) {
+    if (!fl || !fr || !vol) return fail(S3R_ERR_INVALID, "null tensor pointer");
+    if (batch <= 0 || channels <= 0 || max_disp <= 0 || height <= 0 || width <= 0)
+        return fail(S3R_ERR_INVALID, "cost volume dims must be positive");
+    if (channels % 8 != 0) return fail(S3R_ERR_INVALID, "bf16 cost volume needs channels %% 8 == 0");
+    if (out_halo < 0 || out_halo > 8) return fail(S3R_ERR_INVALID, "halo must be in [0, 8]");
+    const int64_t hw = (int64_t)height * width;
+    const int64_t out = (int64_t)batch * 2 * channels * max_disp * hw;
+    const int64_t out_p = (int64_t)batch * 2 * channels * (max_disp + 2 * out_halo) * (height + 2 * out_halo) *
+                          (width + 2 * out_halo);
+    if (out_p >= kMaxElems) return fail(S3R_ERR_INVALID, "cost volume too large for one call: split the batch");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(s, F_COSTVOL, 0, (double)out, 2.0 * (2.0 * batch * channels * hw + (double)out));
+    hipError_t e = s3r::launch_cost_volume_bf16(fl, fr, vol, batch, channels, max_disp, height, width, out_halo, s);
+    if (e != hipSuccess) return hip_fail(e, "cost volume launch (bf16)");
     return S3R_OK;
 }
 

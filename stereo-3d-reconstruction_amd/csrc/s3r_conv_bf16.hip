@@ -1,0 +1,368 @@
+// bf16 MFMA path (BASELINE.json configs[2]): 2D/3D convolution and transposed convolution as an implicit
+// GEMM on v_mfma_f32_32x32x16_bf16, bf16 activations in CHANNELS-LAST layout with a zero halo, fp32
+// accumulation, folded-BN affine + activation + bf16 rounding fused into the epilogue.
+//
+//   D[pos][cout] = sum_{chunk, tap, c} X[b(pos)][in(pos) + tap][chunk*32 + c] * Wp[(chunk*T + tap)][cout][c]
+//
+//   GEMM M = B*Nd*Nh*Nw positions (A operand: gathered activations), N = Cout (B operand: weights),
+//   K = Cin*T in K tiles of ONE tap x 32 channels = 64 contiguous bytes per position.
+//
+// Why channels-last here when the fp32 path is NCHW: the bf16 MFMA takes 8 consecutive k per lane
+// (A: lane (r,h) holds A[row r][k = 8h..8h+7]), i.e. 16 contiguous BYTES of one position's channel
+// vector — one ds_read_b128 — whereas the fp32 MFMA takes one k per lane and wants position-contiguous
+// rows.  The output falls out channels-last as well: D has the cout on the LANE and the position in the
+// registers, so a register row is 32 lanes x consecutive couts = one contiguous run per position.
+//
+// LDS images (per K tile): As[pos][4 slots x 16 B], Bs[cout row][4 slots x 16 B], slot = kgroup ^
+// ((row >> 2) & 3).  With 64-byte rows a plain image makes every ds_read_b128 lane group hit the same
+// 16-byte column of four rows; the XOR spreads the four rows of each bank-row residue over the four
+// slots (conflict-free for the b128 lane groups {0-3,12-15,20-27}, ...).  Both operands arrive by
+// LDS-DMA (16 B per lane, lane-linear destination), so the swizzle is applied on the SOURCE side: a lane
+// fetches channel group slot ^ f(row) of its position; weights are stored pre-swizzled by the pack kernel.
+//
+// Workgroup: 4 waves along M, each 32*TM positions x 64 couts (TN = 2 MFMA tiles, couts interleaved
+// 2c+tn so that a lane packs its two bf16 results into ONE dword store: 128 contiguous bytes per 32
+// lanes).  Per-position input / output offsets are decoded once per workgroup into LDS.
+#include "s3r_kernels.h"
+
+namespace s3r {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define S3R_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    const bf16x2 v = {(__bf16)lo, (__bf16)hi};      // one v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, v);
+}
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, S3R_LDS_PTR(lds_dst), 16, voffset, soffset, 0, 0);
+}
+
+constexpr int HKC = 32;    // channels per K tile
+constexpr int HBN = 64;    // couts per workgroup
+
+constexpr int min_waves_h(int tm) { return tm >= 4 ? 2 : 4; }
+
+template <int TM>
+__global__ __launch_bounds__(256, min_waves_h(TM)) void conv_bf16_kernel(const ConvParamsH p) {
+    constexpr int BM = 128 * TM;
+    constexpr int NPA = BM / 64;           // A pieces (16 positions x 64 B) per wave per K tile
+    constexpr int A_BYTES = BM * 64, B_BYTES = HBN * 64;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                               // [2][BM][64 B]
+    char* Bs = smem + 2 * A_BYTES;                 // [2][64][64 B]
+    int* xoff = reinterpret_cast<int*>(smem + 2 * A_BYTES + 2 * B_BYTES);   // [BM] input byte offsets
+    int* yoff = xoff + BM;                                                   // [BM] output element offsets, -1 = none
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int n_tile = bid % p.n_tiles;            // cout tile (fastest: neighbours share the gathered input)
+    const int m_tile = bid / p.n_tiles;
+    const int m0 = m_tile * BM, n0 = n_tile * HBN;
+    const int cls = blockIdx.y;
+    const int rd = (cls >> 2) & 1, rh = (cls >> 1) & 1, rw = cls & 1;
+    const int kz = blockIdx.z;
+
+    const int S = p.Nd * p.Nh * p.Nw;
+    const int T = p.T;
+    const int chunks = (p.Cin / HKC) / p.ksplit;
+    const int nkt = T * chunks;
+
+    // ---- decode this tile's positions once: input corner (bytes) and output offset (elements)
+    for (int t = tid; t < BM; t += 256) {
+        const int n = m0 + t;
+        const bool ok = n < p.Ntotal;
+        const int nn = ok ? n : p.Ntotal - 1;
+        const int b = nn / S;
+        int rem = nn - b * S;
+        const int pd = rem / (p.Nh * p.Nw);
+        rem -= pd * p.Nh * p.Nw;
+        const int ph = rem / p.Nw;
+        const int pw = rem - ph * p.Nw;
+        int xe = b * p.x_bs + p.x_org + (pd * p.x_ds + ph * p.x_hs + pw * p.x_ws) * p.stride;
+        const int ostep = p.transposed ? 2 : 1;
+        int ye = b * p.y_bs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw * p.y_ws) * ostep;
+        if (p.transposed) {
+            xe += (rd - 1) * p.x_ds + (rh - 1) * p.x_hs + (rw - 1) * p.x_ws;
+            ye += rd * p.y_ds + rh * p.y_hs + rw * p.y_ws;
+        }
+        xoff[t] = xe * 2;
+        yoff[t] = ok ? ye : -1;
+    }
+    __syncthreads();
+
+    // ---- loop-invariant DMA offsets
+    int avoff[NPA];
+#pragma unroll
+    for (int q = 0; q < NPA; ++q) {
+        const int pl = (wave + 4 * q) * 16 + (lane >> 2);          // position inside the tile
+        const int kg = (lane & 3) ^ ((pl >> 2) & 3);               // swizzle on the source side
+        avoff[q] = xoff[pl] + kg * 16;
+    }
+    const int bvoff = lane * 16;                                    // weights are stored pre-swizzled
+
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    // packed weights: [cls][kt][cout tile][64 rows][64 B]
+    const size_t w_cls = (size_t)cls * T * (p.Cin / HKC) * p.n_tiles * B_BYTES;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.w) + w_cls), 0,
+        (int)((unsigned)T * (unsigned)(p.Cin / HKC) * (unsigned)p.n_tiles * (unsigned)B_BYTES), 0x00020000);
+
+    int c_td = 0, c_th = 0, c_tw = 0, c_tap = 0, c_cc = kz * chunks, c_kt = kz * nkt;
+
+    auto issue = [&](int buf) {
+        char* sb = Bs + buf * B_BYTES + wave * 1024;
+        dma16(wrsrc, sb, bvoff, (c_kt * p.n_tiles + n_tile) * B_BYTES + wave * 1024);
+        char* sa = As + buf * A_BYTES + wave * 1024;
+        const int a_base = (c_cc * HKC + (c_td * p.x_ds + c_th * p.x_hs + c_tw * p.x_ws)) * 2;
+#pragma unroll
+        for (int q = 0; q < NPA; ++q)
+            dma16(xrsrc, sa + q * 4096, avoff[q], a_base);
+        ++c_kt;
+        if (++c_tw == p.kw) { c_tw = 0; if (++c_th == p.kh) { c_th = 0; ++c_td; } }
+        if (++c_tap == T) { c_tap = 0; c_td = 0; c_th = 0; c_tw = 0; ++c_cc; }
+    };
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // fragment byte offsets inside a K tile image: row*64 + ((h + 2q) ^ f(row))*16; q toggles bit 5
+    int a_off[TM], b_off[2];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int row = wave * 32 * TM + tm * 32 + c;
+        a_off[tm] = row * 64 + ((h ^ ((row >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int row = tn * 32 + c;
+        b_off[tn] = row * 64 + ((h ^ ((row >> 2) & 3)) << 4);
+    }
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) issue(cur ^ 1);
+        const char* a = As + cur * A_BYTES;
+        const char* b = Bs + cur * B_BYTES;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            bf16x8 av[TM], bv[2];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) av[tm] = *reinterpret_cast<const bf16x8*>(a + (a_off[tm] ^ (q << 5)));
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) bv[tn] = *reinterpret_cast<const bf16x8*>(b + (b_off[tn] ^ (q << 5)));
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue.  Lane c owns couts n0 + 2c (tn 0) and n0 + 2c + 1 (tn 1); register r of MFMA tile tm is
+    // position row wave*32*TM + tm*32 + (r&3) + 8*(r>>2) + 4h.
+    const int co = n0 + 2 * c;
+    if (p.ksplit > 1) {
+        // split-K: fp32 partial sums [cls][kz][position][CoutPad]; conv_finish_bf16 reduces in kz order
+        const int mpad = p.m_tiles * BM;
+        float* __restrict__ slab = p.part + ((size_t)(cls * p.ksplit + kz) * mpad + m0) * p.CoutPad + co;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float2 t = {acc[tm][0][r], acc[tm][1][r]};
+                *reinterpret_cast<float2*>(slab + (size_t)row * p.CoutPad) = t;
+            }
+        return;
+    }
+    const bool c0 = co < p.Cout, c1 = co + 1 < p.Cout;
+    const float sc0 = (c0 && p.scale) ? p.scale[co] : 1.f, sf0 = (c0 && p.shift) ? p.shift[co] : 0.f;
+    const float sc1 = (c1 && p.scale) ? p.scale[co + 1] : 1.f, sf1 = (c1 && p.shift) ? p.shift[co + 1] : 0.f;
+    unsigned short* __restrict__ y = reinterpret_cast<unsigned short*>(p.y);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int ye = yoff[row];
+            if (ye < 0 || !c0) continue;
+            float v0 = fmaf(acc[tm][0][r], sc0, sf0), v1 = fmaf(acc[tm][1][r], sc1, sf1);
+            if (p.act == ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            else if (p.act == ACT_SIGMOID) { v0 = 1.f / (1.f + __expf(-v0)); v1 = 1.f / (1.f + __expf(-v1)); }
+            const unsigned pk = pack_bf16(v0, v1);
+            if (c1) *reinterpret_cast<unsigned*>(y + (size_t)ye + co) = pk;
+            else y[(size_t)ye + co] = (unsigned short)(pk & 0xffffu);
+        }
+}
+
+// split-K finish: y[pos][cout] = bf16(act(scale * sum_kz slab + shift)); one thread per (position, cout pair)
+__global__ __launch_bounds__(256) void conv_finish_bf16_kernel(const ConvParamsH p, int mpad) {
+    const int S = p.Nd * p.Nh * p.Nw;
+    const int cls = blockIdx.y;
+    const int rd = (cls >> 2) & 1, rh = (cls >> 1) & 1, rw = cls & 1;
+    const int half = p.CoutPad >> 1;
+    const long long total = (long long)p.Ntotal * half;
+    const int ostep = p.transposed ? 2 : 1;
+    unsigned short* __restrict__ y = reinterpret_cast<unsigned short*>(p.y);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int n = (int)(i / half);
+        const int co = (int)(i - (long long)n * half) * 2;
+        if (co >= p.Cout) continue;
+        const float* __restrict__ src = p.part + ((size_t)cls * p.ksplit * mpad + n) * p.CoutPad + co;
+        float2 s = *reinterpret_cast<const float2*>(src);
+        for (int z = 1; z < p.ksplit; ++z) {
+            const float2 t = *reinterpret_cast<const float2*>(src + (size_t)z * mpad * p.CoutPad);
+            s.x += t.x; s.y += t.y;
+        }
+        const int b = n / S;
+        int rem = n - b * S;
+        const int pd = rem / (p.Nh * p.Nw);
+        rem -= pd * p.Nh * p.Nw;
+        const int ph = rem / p.Nw;
+        const int pw = rem - ph * p.Nw;
+        int ye = b * p.y_bs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw * p.y_ws) * ostep;
+        if (p.transposed) ye += rd * p.y_ds + rh * p.y_hs + rw * p.y_ws;
+        const bool c1 = co + 1 < p.Cout;
+        float v0 = fmaf(s.x, p.scale ? p.scale[co] : 1.f, p.shift ? p.shift[co] : 0.f);
+        float v1 = c1 ? fmaf(s.y, p.scale ? p.scale[co + 1] : 1.f, p.shift ? p.shift[co + 1] : 0.f) : 0.f;
+        if (p.act == ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        else if (p.act == ACT_SIGMOID) { v0 = 1.f / (1.f + __expf(-v0)); v1 = 1.f / (1.f + __expf(-v1)); }
+        const unsigned pk = pack_bf16(v0, v1);
+        if (c1) *reinterpret_cast<unsigned*>(y + (size_t)ye + co) = pk;
+        else y[(size_t)ye + co] = (unsigned short)(pk & 0xffffu);
+    }
+}
+
+int conv_bf16_pick_tm(const ConvParamsH& p) {
+    const long classes = (p.transposed ? 8 : 1) * (long)p.ksplit;
+    const long n_tiles = p.CoutPad / HBN;
+    auto wgs = [&](int tm) { return ((p.Ntotal + 128 * tm - 1) / (128 * tm)) * n_tiles * classes; };
+    if (wgs(2) >= 1024) return 2;
+    return 1;
+}
+
+int conv_bf16_pick_ksplit(const ConvParamsH& p) {
+    // per-sample geometry at a nominal batch of 32 (batch-invariant, as in the fp32 path)
+    const int chunks = p.Cin / HKC;
+    const long S = (long)p.Nd * p.Nh * p.Nw;
+    const long wg_nom = ((32 * S + 127) / 128) * (p.CoutPad / HBN) * (p.transposed ? 8 : 1);
+    int ks = 1;
+    while (wg_nom * ks < 1024 && chunks % (2 * ks) == 0 && (chunks / (2 * ks)) * p.T >= 64) ks *= 2;
+    return ks;
+}
+
+int64_t conv_bf16_scratch_elems(const ConvParamsH& p, int tm) {
+    if (p.ksplit <= 1) return 0;
+    const int bm = 128 * tm;
+    const int64_t mpad = (int64_t)((p.Ntotal + bm - 1) / bm) * bm;
+    return (int64_t)(p.transposed ? 8 : 1) * p.ksplit * mpad * p.CoutPad;
+}
+
+template <int TM>
+static hipError_t launch_tm(ConvParamsH p, hipStream_t stream) {
+    constexpr int BM = 128 * TM;
+    p.m_tiles = (p.Ntotal + BM - 1) / BM;
+    p.n_tiles = p.CoutPad / HBN;
+    const size_t lds = (size_t)2 * BM * 64 + 2 * HBN * 64 + 2 * BM * sizeof(int);
+    if (lds > 48 * 1024) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<TM>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr != hipSuccess) return attr;
+    }
+    dim3 grid(p.m_tiles * p.n_tiles, p.transposed ? 8 : 1, p.ksplit);
+    hipLaunchKernelGGL((conv_bf16_kernel<TM>), grid, dim3(256), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && p.ksplit > 1) {
+        const long long total = (long long)p.Ntotal * (p.CoutPad >> 1);
+        const long long blocks = (total + 255) / 256;
+        hipLaunchKernelGGL(conv_finish_bf16_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096), p.transposed ? 8 : 1),
+                           dim3(256), 0, stream, p, p.m_tiles * BM);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+hipError_t launch_conv_bf16(const ConvParamsH& p, int tm, hipStream_t stream) {
+    if (p.Cin % HKC != 0 || p.CoutPad % HBN != 0 || p.ksplit < 1 || (p.Cin / HKC) % p.ksplit != 0 ||
+        (p.ksplit > 1 && !p.part))
+        return hipErrorInvalidValue;
+    switch (tm) {
+        case 1: return launch_tm<1>(p, stream);
+        case 2: return launch_tm<2>(p, stream);
+        case 4: return launch_tm<4>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing for the bf16 kernel (fp32 torch layout -> bf16, K-tile major, pre-swizzled):
+//   wp[cls][kt = chunk*T + tap][cout tile][row = tn*32 + c][slot][8]   (64 B per row)
+//     cout = tile*64 + 2c + tn,   slot holds channel group kg = slot ^ ((row >> 2) & 3),  cin = chunk*32 + kg*8 + e
+__global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout,
+                                 int CoutPad, int T, int transposed) {
+    const size_t per_cls = (size_t)T * Cin * CoutPad;
+    const size_t total = (transposed ? 8 : 1) * per_cls;
+    const int n_tiles = CoutPad / 64;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cls = (int)(i / per_cls);
+        size_t r = i % per_cls;
+        const int e = (int)(r & 7); r >>= 3;
+        const int slot = (int)(r & 3); r >>= 2;
+        const int row = (int)(r & 63); r >>= 6;
+        const int tile = (int)(r % n_tiles); r /= n_tiles;
+        const int tap = (int)(r % T);
+        const int cc = (int)(r / T);
+        const int tn = row >> 5, c = row & 31;
+        const int co = tile * 64 + 2 * c + tn;
+        const int kg = slot ^ ((row >> 2) & 3);
+        const int cin = cc * 32 + kg * 8 + e;
+        float v = 0.f;
+        if (co < Cout) {
+            if (!transposed) {
+                v = w[((size_t)co * Cin + cin) * T + tap];
+            } else {
+                const int rd = (cls >> 2) & 1, rh = (cls >> 1) & 1, rw = cls & 1;
+                const int td = (tap >> 2) & 1, th = (tap >> 1) & 1, tw = tap & 1;
+                const int kd = 3 - rd - 2 * td, kh = 3 - rh - 2 * th, kw = 3 - rw - 2 * tw;
+                v = w[((size_t)cin * Cout + co) * 64 + (kd * 4 + kh) * 4 + kw];
+            }
+        }
+        wp[i] = __builtin_bit_cast(unsigned short, (__bf16)v);
+    }
+}
+
+hipError_t launch_pack_bf16(const float* w, void* wp, int Cin, int Cout, int CoutPad, int T, int transposed,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(1024), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wp), Cin, Cout,
+                       CoutPad, T, transposed);
+    return hipGetLastError();
+}
+
+}  // namespace s3r

@@ -33,6 +33,28 @@ struct ConvParams {
     float* part;          // split-K scratch: [cls][ksplit][Cout][n_tiles*BN]
 };
 
+// bf16 channels-last path: activations (B, [D,] H, W, C) bf16 with a zero halo, fp32 accumulate
+struct ConvParamsH {
+    const void* x;        // bf16 (B, Dp, Hp, Wp, Cin)
+    const void* w;        // bf16 packed weights, see pack_bf16_kernel
+    const float* scale;
+    const float* shift;
+    void* y;              // bf16 (B, Dp', Hp', Wp', Cout)
+    float* part;          // split-K scratch [cls][ksplit][m_tiles*BM][CoutPad] fp32
+    int B, Cin, Cout, CoutPad;            // CoutPad % 64 == 0
+    int Nd, Nh, Nw;
+    int kd, kh, kw, T;
+    int stride;
+    int x_bs, x_ds, x_hs, x_ws;           // input element strides: batch, depth, row, position (= Cin)
+    int x_org;
+    int y_bs, y_ds, y_hs, y_ws;           // output element strides (y_ws = Cout)
+    int y_org;
+    unsigned x_bytes;
+    int transposed, act, Ntotal;
+    int m_tiles, n_tiles;                 // position tiles, 64-cout tiles
+    int ksplit;
+};
+
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
 
 // launchers (defined in the .hip files); every launcher enqueues on `stream` and returns hipGetLastError()
@@ -61,6 +83,18 @@ hipError_t launch_chamfer(const float* p, const float* q, float* d1, float* d2, 
 hipError_t launch_linear(const float* x, const float* w, const float* scale, const float* bias, float* y, int B,
                          int Cin, int Cout, int act, float* scratch, hipStream_t s);
 int64_t linear_scratch_elems(int B, int Cin, int Cout);
+// ---- bf16 channels-last path
+hipError_t launch_conv_bf16(const ConvParamsH& p, int tm, hipStream_t stream);
+int conv_bf16_pick_tm(const ConvParamsH& p);
+int conv_bf16_pick_ksplit(const ConvParamsH& p);
+int64_t conv_bf16_scratch_elems(const ConvParamsH& p, int tm);
+hipError_t launch_pack_bf16(const float* w, void* wp, int Cin, int Cout, int CoutPad, int T, int transposed, hipStream_t s);
+hipError_t launch_stem_bf16(const float* x, const float* wt, const float* scale, const float* shift, void* y, int N,
+                            int Hi, int Wi, int Ho, int Wo, int y_bs, int y_hs, int y_org, hipStream_t s);
+hipError_t launch_cost_volume_bf16(const void* fl, const void* fr, void* vol, int B, int C, int D, int H, int W, int halo,
+                                   hipStream_t s);
+hipError_t launch_head_bf16(const void* x, const float* w, const float* scale, const float* shift, float* y, int C,
+                            int64_t voxels, int act, hipStream_t s);
 hipError_t launch_iou(const float* pred, const float* gt, float th, float* iou, int B, int64_t S, hipStream_t s);
 
 }  // namespace s3r

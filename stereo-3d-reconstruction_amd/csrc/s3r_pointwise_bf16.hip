@@ -1,0 +1,160 @@
+// Bandwidth-bound kernels of the bf16 channels-last path (BASELINE.json configs[2]): the Cin=3 stem
+// (fp32 NCHW renders -> bf16 NHWC features), the fused bidirectional cost volume on channels-last bf16
+// features, and the 1x1x1 occupancy head (bf16 NDHWC -> fp32 (B,32,32,32) probabilities).
+#include "s3r_kernels.h"
+
+namespace s3r {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v4u_u __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// ------------------------------------------------------------------------------------------------
+// Stem: Conv2d(3 -> 32, k3, s2, p1) + affine + ReLU, fp32 NCHW in, bf16 NHWC (halo-padded) out.
+// One thread per output pixel, 32 couts in registers -> ONE 64-byte contiguous store per thread.
+__global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        unsigned short* __restrict__ y, int N, int Hi, int Wi, int Ho, int Wo,
+                                                        int y_bs, int y_hs, int y_org) {
+    const int HWo = Ho * Wo;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)N * HWo) return;
+    const int n = (int)(gid / HWo);
+    const int sp = (int)(gid - (long long)n * HWo);
+    const int oh = sp / Wo, ow = sp - oh * Wo;
+    const int ih0 = oh * 2 - 1, iw0 = ow * 2 - 1;
+    const float* __restrict__ xn = x + (size_t)n * 3 * Hi * Wi;
+    float acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = ih0 + kh;
+            const bool vh = (unsigned)ih < (unsigned)Hi;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = iw0 + kw;
+                const bool v = vh && ((unsigned)iw < (unsigned)Wi);
+                const float xv = v ? xn[((size_t)ci * Hi + ih) * Wi + iw] : 0.f;
+                const float* __restrict__ wk = wt + ((ci * 3 + kh) * 3 + kw) * 32;
+#pragma unroll
+                for (int c = 0; c < 32; ++c) acc[c] = fmaf(xv, wk[c], acc[c]);
+            }
+        }
+    unsigned* __restrict__ yo = reinterpret_cast<unsigned*>(y + (size_t)n * y_bs + y_org + ((size_t)oh * y_hs + (size_t)ow * 32));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        v4u t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = q * 8 + k * 2;
+            t[k] = pack2(fmaxf(fmaf(acc[c], scale[c], shift[c]), 0.f), fmaxf(fmaf(acc[c + 1], scale[c + 1], shift[c + 1]), 0.f));
+        }
+        *reinterpret_cast<v4u*>(yo + q * 4) = t;       // 64-byte rows: 16-byte aligned
+    }
+}
+
+hipError_t launch_stem_bf16(const float* x, const float* wt, const float* scale, const float* shift, void* y, int N,
+                            int Hi, int Wi, int Ho, int Wo, int y_bs, int y_hs, int y_org, hipStream_t s) {
+    const long long total = (long long)N * Ho * Wo;
+    hipLaunchKernelGGL(stem_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, wt, scale, shift,
+                       reinterpret_cast<unsigned short*>(y), N, Hi, Wi, Ho, Wo, y_bs, y_hs, y_org);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cost volume on channels-last bf16: fl, fr (B,H,W,C) -> vol (B, D+2h, H+2h, W+2h, 2C), interior only:
+//   vol[b,d,h,w, c]     = L[b,h,w,c] - R[b,h,w-d,c]   (0 where w-d < 0)
+//   vol[b,d,h,w, C + c] = R[b,h,w,c] - L[b,h,w+d,c]   (0 where w+d >= W)
+// One thread per (b,d,h,w, 8-channel group of the 2C outputs): two 16-byte loads, one 16-byte store,
+// every access contiguous across the lanes of a position.  The differences are formed in fp32 and rounded
+// to bf16 once.  Re-reads of the (tiny) feature maps across d are L2 hits; HBM sees them once.
+__global__ __launch_bounds__(256) void cost_volume_bf16_kernel(const unsigned short* __restrict__ fl,
+                                                               const unsigned short* __restrict__ fr,
+                                                               unsigned short* __restrict__ vol, int B, int C, int D,
+                                                               int H, int W, int halo) {
+    const int G = (2 * C) >> 3;                       // 16-byte groups per output position
+    const long long total = (long long)B * D * H * W * G;
+    const int Wp = W + 2 * halo, Hp = H + 2 * halo, Dp = D + 2 * halo;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % G);
+        long long r = i / G;
+        const int w = (int)(r % W); r /= W;
+        const int hh = (int)(r % H); r /= H;
+        const int d = (int)(r % D);
+        const int b = (int)(r / D);
+        const bool right_ref = g >= (G >> 1);
+        const int cg = (right_ref ? g - (G >> 1) : g) * 8;
+        const int ws = right_ref ? w + d : w - d;     // the shifted operand's column
+        v4u out = {0u, 0u, 0u, 0u};
+        if (ws >= 0 && ws < W) {
+            const unsigned short* pa = (right_ref ? fr : fl) + (((size_t)b * H + hh) * W + w) * C + cg;
+            const unsigned short* pb = (right_ref ? fl : fr) + (((size_t)b * H + hh) * W + ws) * C + cg;
+            const v4u a = *reinterpret_cast<const v4u*>(pa), s = *reinterpret_cast<const v4u*>(pb);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[k] = pack2(bf_lo(a[k]) - bf_lo(s[k]), bf_hi(a[k]) - bf_hi(s[k]));
+        }
+        unsigned short* po = vol + ((((size_t)b * Dp + d + halo) * Hp + hh + halo) * Wp + w + halo) * (2 * C) + g * 8;
+        *reinterpret_cast<v4u*>(po) = out;
+    }
+}
+
+hipError_t launch_cost_volume_bf16(const void* fl, const void* fr, void* vol, int B, int C, int D, int H, int W, int halo,
+                                   hipStream_t s) {
+    const long long total = (long long)B * D * H * W * ((2 * C) >> 3);
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(cost_volume_bf16_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s,
+                       reinterpret_cast<const unsigned short*>(fl), reinterpret_cast<const unsigned short*>(fr),
+                       reinterpret_cast<unsigned short*>(vol), B, C, D, H, W, halo);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Occupancy head: Conv3d(C -> 1, k=1) + bias + activation, bf16 (B,S,C) channels-last in, fp32 (B,S) out.
+// Eight lanes share a voxel (16 bytes = 8 channels each for C = 64), reduce with wavefront shuffles.
+__global__ __launch_bounds__(256) void head_bf16_kernel(const unsigned short* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        float* __restrict__ y, int C, long long voxels, int act) {
+    const int lanes_per = C >> 3;                      // lanes per voxel (C % 8 == 0, C <= 512)
+    const int per_wave = 64 / lanes_per;
+    const long long wave_id = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % lanes_per;
+    const long long v = wave_id * per_wave + lane / lanes_per;
+    float s = 0.f;
+    if (v < voxels) {
+        const v4u a = *reinterpret_cast<const v4u*>(x + (size_t)v * C + sub * 8);
+        const float* __restrict__ wk = w + sub * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s = fmaf(bf_hi(a[k]), wk[2 * k + 1], fmaf(bf_lo(a[k]), wk[2 * k], s));
+    }
+    for (int o = lanes_per >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (sub == 0 && v < voxels) {
+        float t = fmaf(s, scale ? scale[0] : 1.f, shift ? shift[0] : 0.f);
+        if (act == ACT_RELU) t = fmaxf(t, 0.f);
+        else if (act == ACT_SIGMOID) t = 1.f / (1.f + __expf(-t));
+        y[v] = t;
+    }
+}
+
+hipError_t launch_head_bf16(const void* x, const float* w, const float* scale, const float* shift, float* y, int C,
+                            int64_t voxels, int act, hipStream_t s) {
+    const int lanes_per = C >> 3;
+    if (C % 8 != 0 || lanes_per > 64 || (lanes_per & (lanes_per - 1)) != 0) return hipErrorInvalidValue;
+    const long long waves = (voxels + 64 / lanes_per - 1) / (64 / lanes_per);
+    hipLaunchKernelGGL(head_bf16_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s,
+                       reinterpret_cast<const unsigned short*>(x), w, scale, shift, y, C, (long long)voxels, act);
+    return hipGetLastError();
+}
+
+}  // namespace s3r

@@ -23,17 +23,29 @@ from . import arch_spec as spec
 MAX_CHUNK = 256      # pairs per C-ABI call: keeps every activation < 2^31 elements / 4 GiB
 
 
+def _to_channels_last_physical(x: torch.Tensor) -> torch.Tensor:
+    """logical (B,C,...) tensor -> contiguous physical (B,...,C) tensor (no copy if already channels-last)."""
+    nd = x.dim()
+    return x.permute(0, *range(2, nd), 1).contiguous()
+
+
+def _to_logical(x: torch.Tensor) -> torch.Tensor:
+    """physical channels-last (B,...,C) -> logical (B,C,...) view (torch's channels_last convention)."""
+    nd = x.dim()
+    return x.permute(0, nd - 1, *range(1, nd - 1))
+
+
 def _stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def _check_input(x: torch.Tensor, name: str, shape_tail: Sequence[int]):
+def _check_input(x: torch.Tensor, name: str, shape_tail: Sequence[int], dtype=torch.float32):
     if not isinstance(x, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
     if not x.is_cuda:
         raise RuntimeError(f"{name} must live on a HIP device (got {x.device}); this path has no CPU fallback")
-    if x.dtype != torch.float32:
-        raise RuntimeError(f"{name} must be float32 (got {x.dtype})")
+    if x.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype} (got {x.dtype})")
     if tuple(x.shape[1:]) != tuple(shape_tail):
         raise RuntimeError(f"{name} must have shape (B, {', '.join(map(str, shape_tail))}), got {tuple(x.shape)}")
     return x.contiguous()
@@ -100,8 +112,12 @@ class _HipChain(nn.Module):
 
     _entry = "s3r_chain_forward"
 
-    def __init__(self, layers: Sequence[spec.Layer], in_size: int, tag_base: int = 0):
+    def __init__(self, layers: Sequence[spec.Layer], in_size: int, tag_base: int = 0, precision: str = "fp32"):
         super().__init__()
+        if precision not in _lib.DTYPE:
+            raise ValueError(f"precision must be one of {list(_lib.DTYPE)}")
+        self.precision = precision
+        self._dtype = _lib.DTYPE[precision]
         self._layers = tuple(layers)
         self._in_size = in_size
         self._tag_base = tag_base
@@ -122,7 +138,7 @@ class _HipChain(nn.Module):
 
     # -- weight packing cache ------------------------------------------------------------------
     def _cache_key(self, device):
-        items = [str(device)]
+        items = [str(device), self.precision]
         for t in list(self.parameters()) + list(self.buffers()):
             items.append((id(t), t._version, t.device.type))
         return tuple(items)
@@ -149,7 +165,7 @@ class _HipChain(nn.Module):
             if w.device != device:
                 raise RuntimeError(f"{l.name}: parameters are on {w.device}, input on {device}; call .to(device) first")
             w = w.float().contiguous()
-            desc = _lib.make_desc(l, 1, n_in)
+            desc = _lib.make_desc(l, 1, n_in, dtype=self._dtype)
             n = C.c_int64(0)
             _lib.check(lib.s3r_conv_packed_elems(C.byref(desc), C.byref(n)), f"{l.name}: packed_elems")
             pw = torch.empty(n.value, dtype=torch.float32, device=device)
@@ -171,7 +187,8 @@ class _HipChain(nn.Module):
             # only the chain's own input / output halos are the caller's to state (the output is always
             # a plain contiguous tensor); the library plans the intermediates
             arr[i].desc = _lib.make_desc(l, batch, n_in, tag=self._tag_base + i, tile=tile,
-                                         in_halo=in_halo if i == 0 else 0, out_halo=0, ksplit=ksplit)
+                                         in_halo=in_halo if i == 0 else 0, out_halo=0, ksplit=ksplit,
+                                         dtype=self._dtype)
             arr[i].packed_w = pw.data_ptr()
             arr[i].scale = scale.data_ptr() if scale is not None else None
             arr[i].shift = shift.data_ptr() if shift is not None else None
@@ -183,6 +200,10 @@ class _HipChain(nn.Module):
         nd = spec.ndim(l)
         return (batch, l.cout) + (m,) * nd
 
+    def _out_is_bf16(self, n_layers: int) -> bool:
+        l = self._layers[n_layers - 1]
+        return self.precision == "bf16" and not (l.cout == 1 and l.k == 1)      # the occupancy head writes fp32
+
     @torch.no_grad()
     def _run(self, x: torch.Tensor, upto: Optional[str] = None, in_halo: int = 0) -> torch.Tensor:
         """x: the chain input; with in_halo > 0 it is a halo-padded buffer (B, C, n+2h, ...) whose border
@@ -192,13 +213,17 @@ class _HipChain(nn.Module):
         if batch == 0:
             return x.new_empty(self._out_shape(0, len(self._layers) if upto is None else self.names.index(upto) + 1))
         arr, n = self._layer_array(batch, device, upto, in_halo)
-        y = torch.empty(self._out_shape(batch, n), dtype=torch.float32, device=device)
+        shape = self._out_shape(batch, n)
+        if self._out_is_bf16(n):      # physical channels-last (B,...,C) bf16; handed back as a logical (B,C,...) view
+            y = torch.empty((shape[0],) + shape[2:] + (shape[1],), dtype=torch.bfloat16, device=device)
+        else:
+            y = torch.empty(shape, dtype=torch.float32, device=device)
         need = _lib.check(lib.s3r_chain_workspace_elems(arr, n), "workspace query")
         ws, fresh = self._ws.get(device, need, (batch, n, in_halo))
         entry = getattr(lib, self._entry if upto is None else "s3r_chain_forward")
         _lib.check(entry(arr, n, x.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), fresh, _stream_ptr(device)),
                    type(self).__name__)
-        return y
+        return _to_logical(y) if self._out_is_bf16(n) else y
 
 
     # -- measured per-layer configuration ----------------------------------------------------------
@@ -257,10 +282,11 @@ class Encoder(_HipChain):
     """
     _entry = "s3r_encoder_forward"
 
-    def __init__(self):
-        super().__init__(spec.ENCODER, spec.IMG_HW, tag_base=100)
+    def __init__(self, precision: str = "fp32"):
+        super().__init__(spec.ENCODER, spec.IMG_HW, tag_base=100, precision=precision)
 
     def forward(self, images: torch.Tensor) -> torch.Tensor:
+        """fp32: (N,32,28,28) contiguous.  bf16: (N,32,28,28) bfloat16 in channels_last memory format."""
         x = _check_input(images, "images", (3, spec.IMG_HW, spec.IMG_HW))
         return self._run(x)
 
@@ -268,16 +294,40 @@ class Encoder(_HipChain):
 class CostVolume(nn.Module):
     """Bidirectional shift-and-diff disparity cost volume, (B,C,H,W) x2 -> (B,2C,D,H,W)."""
 
-    def __init__(self, max_disp: int = spec.MAX_DISP):
+    def __init__(self, max_disp: int = spec.MAX_DISP, precision: str = "fp32"):
         super().__init__()
         self.max_disp = max_disp
+        self.precision = precision
         self._padded: Optional[torch.Tensor] = None      # resident halo-padded volume (internal hand-off)
+
+    def _bf16(self, feat_left, feat_right, halo, resident):
+        """bf16 path: logical (B,C,H,W) channels_last features -> physical (B,D+2h,H+2h,W+2h,2C) volume."""
+        if feat_left.shape != feat_right.shape or feat_left.dim() != 4:
+            raise RuntimeError("feature maps must both be (B,C,H,W)")
+        fl = _to_channels_last_physical(_check_input(feat_left, "feat_left", feat_left.shape[1:], torch.bfloat16))
+        fr = _to_channels_last_physical(_check_input(feat_right, "feat_right", feat_left.shape[1:], torch.bfloat16))
+        B, H, W, Cc = fl.shape
+        shape = (B, self.max_disp + 2 * halo, H + 2 * halo, W + 2 * halo, 2 * Cc)
+        if resident:
+            if self._padded is None or tuple(self._padded.shape) != shape or self._padded.device != fl.device \
+                    or self._padded.dtype != torch.bfloat16:
+                self._padded = torch.zeros(shape, dtype=torch.bfloat16, device=fl.device)
+            vol = self._padded
+        else:
+            vol = torch.empty(shape, dtype=torch.bfloat16, device=fl.device)
+        if B:
+            _lib.check(_lib.load().s3r_cost_volume_forward_bf16(fl.data_ptr(), fr.data_ptr(), vol.data_ptr(), B, Cc,
+                                                                self.max_disp, H, W, halo, _stream_ptr(fl.device)),
+                       "cost_volume (bf16)")
+        return vol
 
     @torch.no_grad()
     def forward_padded(self, feat_left: torch.Tensor, feat_right: torch.Tensor, halo: int = 1) -> torch.Tensor:
         """Internal hand-off to the decoder: the volume written straight into a resident
         (B,2C,D+2h,H+2h,W+2h) buffer whose zero halo the decoder's first 3D conv reads as its padding.
         The buffer is zeroed when (re)allocated; the kernel writes the interior only."""
+        if self.precision == "bf16":
+            return self._bf16(feat_left, feat_right, halo, resident=True)
         fl = _check_input(feat_left, "feat_left", feat_left.shape[1:])
         fr = _check_input(feat_right, "feat_right", feat_left.shape[1:])
         B, Cc, H, W = fl.shape
@@ -293,6 +343,8 @@ class CostVolume(nn.Module):
 
     @torch.no_grad()
     def forward(self, feat_left: torch.Tensor, feat_right: torch.Tensor) -> torch.Tensor:
+        if self.precision == "bf16":      # logical (B,2C,D,H,W) view of the channels-last volume
+            return _to_logical(self._bf16(feat_left, feat_right, 0, resident=False))
         if feat_left.shape != feat_right.shape or feat_left.dim() != 4:
             raise RuntimeError(f"feature maps must both be (B,C,H,W), got {tuple(feat_left.shape)} and "
                                f"{tuple(feat_right.shape)}")
@@ -311,18 +363,25 @@ class Decoder(_HipChain):
     """3D conv hourglass: cost volume (B,64,28,28,28) -> occupancy probabilities (B,32,32,32)."""
     _entry = "s3r_decoder_forward"
 
-    def __init__(self):
-        super().__init__(spec.DECODER, spec.MAX_DISP, tag_base=200)
+    def __init__(self, precision: str = "fp32"):
+        super().__init__(spec.DECODER, spec.MAX_DISP, tag_base=200, precision=precision)
 
     def forward(self, volume: torch.Tensor, upto: Optional[str] = None) -> torch.Tensor:
-        x = _check_input(volume, "volume", (2 * spec.FEAT_C, spec.MAX_DISP, spec.FEAT_HW, spec.FEAT_HW))
+        tail = (2 * spec.FEAT_C, spec.MAX_DISP, spec.FEAT_HW, spec.FEAT_HW)
+        if self.precision == "bf16":
+            x = _to_channels_last_physical(_check_input(volume, "volume", tail, torch.bfloat16))
+        else:
+            x = _check_input(volume, "volume", tail)
         y = self._run(x, upto)
         return y.squeeze(1) if upto is None or upto == self.names[-1] else y
 
     def forward_padded(self, volume_padded: torch.Tensor, halo: int = 1) -> torch.Tensor:
         """Decoder on the halo-padded volume CostVolume.forward_padded produced (no pad copy)."""
-        x = _check_input(volume_padded, "volume_padded", (2 * spec.FEAT_C, spec.MAX_DISP + 2 * halo,
-                                                           spec.FEAT_HW + 2 * halo, spec.FEAT_HW + 2 * halo))
+        n = (spec.MAX_DISP + 2 * halo, spec.FEAT_HW + 2 * halo, spec.FEAT_HW + 2 * halo)
+        if self.precision == "bf16":
+            x = _check_input(volume_padded, "volume_padded", n + (2 * spec.FEAT_C,), torch.bfloat16)
+        else:
+            x = _check_input(volume_padded, "volume_padded", (2 * spec.FEAT_C,) + n)
         return self._run(x, None, in_halo=halo).squeeze(1)
 
 
@@ -355,13 +414,18 @@ class PointHead(_HipChain):
 
 
 class Stereo2Voxel(nn.Module):
-    """left,right (B,3,224,224) -> (B,32,32,32) occupancy.  state_dict keys: encoder.*, decoder.*"""
+    """left,right (B,3,224,224) -> (B,32,32,32) occupancy.  state_dict keys: encoder.*, decoder.*
 
-    def __init__(self):
+    precision="fp32": exact-fp32 MFMA path, NCHW (BASELINE configs[1]).  precision="bf16": bf16 MFMA path,
+    channels-last bf16 activations with fp32 accumulation (BASELINE configs[2]); parameters stay fp32
+    nn.Parameters either way (same state_dict), the bf16 images of the weights are made at pack time."""
+
+    def __init__(self, precision: str = "fp32"):
         super().__init__()
-        self.encoder = Encoder()
-        self.cost_volume = CostVolume()
-        self.decoder = Decoder()
+        self.precision = precision
+        self.encoder = Encoder(precision)
+        self.cost_volume = CostVolume(precision=precision)
+        self.decoder = Decoder(precision)
         self.eval()
 
     def train(self, mode: bool = True):
