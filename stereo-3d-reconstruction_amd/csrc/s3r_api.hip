@@ -224,6 +224,7 @@ s3r::ConvParams make_params(const s3r_conv_desc* d, const Geo& g) {
     p.x_hs = g.in_p; p.x_ds = is3 ? g.in_p * g.in_p : 0; p.x_cs = (int)ipow(g.in_p, g.nd);
     p.y_hs = g.out_p; p.y_ds = is3 ? g.out_p * g.out_p : 0; p.y_cs = (int)ipow(g.out_p, g.nd);
     p.y_org = d->out_halo * (p.y_ds + p.y_hs + 1);
+    p.y_bs = d->cout * p.y_cs;
     p.x_bytes = (unsigned)(g.x_elems * 4);
     if (d->op == S3R_OP_DECONV) {
         p.transposed = 1;
@@ -269,6 +270,7 @@ struct Plan {
     std::vector<Route> r;
     std::vector<Geo> g;
     std::vector<int64_t> off;         // workspace offset of layer i's OUTPUT (-1: the caller's y)
+    std::vector<char> fuse_head;      // layer i is an MFMA conv whose epilogue also runs layer i+1 (1x1 head)
     bool pad_input = false;
     int64_t pad_off = 0;
     int64_t scratch_off = 0, scratch_elems = 0;   // split-K slabs, shared by all layers of the chain
@@ -279,7 +281,7 @@ int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
     if (!layers || n <= 0) return fail(S3R_ERR_INVALID, "empty chain");
-    pl->d.resize(n); pl->r.resize(n); pl->g.resize(n); pl->off.assign(n, -1);
+    pl->d.resize(n); pl->r.resize(n); pl->g.resize(n); pl->off.assign(n, -1); pl->fuse_head.assign(n, 0);
     for (int i = 0; i < n; ++i) {
         pl->d[i] = layers[i].desc;
         int rc = route(&pl->d[i], &pl->r[i]);
@@ -306,6 +308,16 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
                 return fail(S3R_ERR_INVALID, "layer %d needs a halo but reshapes layer %d's output", i, i - 1);
         }
     }
+    // conv -> pointwise head fusion (fp32 path): a <=64-cout MFMA conv that does not split K, followed by the
+    // 1x1 single-channel head, runs the head inside its epilogue; its own output is never materialised
+    for (int i = 0; i + 1 < n; ++i) {
+        if (pl->r[i] != R_MFMA || pl->r[i + 1] != R_HEAD || pl->d[i].dtype != S3R_F32 || pl->d[i].cout > 64) continue;
+        if (pl->d[i + 1].cin != pl->d[i].cout || pl->d[i].out_halo != 0) continue;
+        s3r::ConvParams p = make_params(&pl->d[i], pl->g[i]);
+        Launch L;
+        if (resolve_launch(&pl->d[i], &p, &L) != S3R_OK || L.ksplit != 1) continue;
+        pl->fuse_head[i] = 1;
+    }
     int64_t off = 0;
     if (pl->pad_input) {
         if (user_in_halo != 0) return fail(S3R_ERR_INVALID, "chain input halo %d is smaller than the %d its first layer needs",
@@ -315,7 +327,7 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
     }
     for (int i = 0; i + 1 < n; ++i) {
         pl->off[i] = off;
-        off = align_up(off + pl->g[i].y_store, 256);
+        if (!pl->fuse_head[i]) off = align_up(off + pl->g[i].y_store, 256);   // a fused conv's output does not exist
     }
     for (int i = 0; i < n; ++i) {
         const int64_t sc = s3r_conv_scratch_elems(&pl->d[i]);
@@ -325,6 +337,34 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
     pl->scratch_off = off;
     off = align_up(off + pl->scratch_elems, 256);
     pl->total = off;
+    return S3R_OK;
+}
+
+// MFMA conv with the following 1x1 single-channel head folded into its epilogue (plan_chain decides)
+int conv_head_fused(const s3r_conv_desc* d, const Geo& g, const s3r_conv_desc* hd, const Geo& hg, const float* x,
+                    const s3r_layer& L, const s3r_layer& H, float* out, hipStream_t s) {
+    s3r::ConvParams p = make_params(d, g);
+    p.x = x; p.w = static_cast<const float*>(L.packed_w); p.scale = L.scale; p.shift = L.shift; p.y = out;
+    // y_* now describe the head's (B, 1, n[, n], n) output
+    const bool is3 = hd->ndim == 3;
+    p.y_hs = hg.out_p; p.y_ds = is3 ? hg.out_p * hg.out_p : 0; p.y_cs = (int)ipow(hg.out_p, hg.nd);
+    p.y_bs = p.y_cs;
+    p.y_org = hd->out_halo * (p.y_ds + p.y_hs + 1);
+    p.head_w = static_cast<const float*>(H.packed_w); p.head_scale = H.scale; p.head_shift = H.shift; p.head_act = hd->act;
+    Launch Ln;
+    int rc = resolve_launch(d, &p, &Ln);
+    if (rc) return rc;
+    if (!(Ln.cfg == 1 || Ln.cfg == 2 || Ln.cfg == 5 || Ln.cfg == 7) || (Ln.cfg == 2 && d->cout > 32)) {
+        // the heuristic's tile splits the couts over waves: take the widest one-wave-tall tile that fills the chip
+        int bm, bn;
+        s3r::conv_tile_dims(1, &bm, &bn);
+        const long wg1 = (long)((p.Ntotal + bn - 1) / bn) * (p.transposed ? 8 : 1);
+        Ln.cfg = d->cout <= 32 ? 2 : (wg1 >= 2000 ? 1 : 7);
+    }
+    ProfScope ps(s, F_MFMA, d->tag, g.flops + hg.flops, g.bytes - 4.0 * d->batch * d->cout * (double)g.out_sp +
+                 4.0 * d->batch * (double)hg.out_sp);
+    hipError_t e = s3r::launch_conv_mfma(p, Ln.cfg + 16 * Ln.vec, s);
+    if (e != hipSuccess) return hip_fail(e, "fused conv+head launch");
     return S3R_OK;
 }
 
@@ -540,6 +580,16 @@ int s3r_chain_forward(const s3r_layer* layers, int n_layers, const void* x, void
     }
     for (int i = 0; i < n_layers; ++i) {
         const s3r_layer& L = layers[i];
+        if (pl.fuse_head[i]) {
+            const s3r_layer& H = layers[i + 1];
+            void* out = (i + 1 == n_layers - 1) ? y : static_cast<void*>(ws + pl.off[i + 1]);
+            rc = conv_head_fused(&pl.d[i], pl.g[i], &pl.d[i + 1], pl.g[i + 1], static_cast<const float*>(cur), L, H,
+                                 static_cast<float*>(out), s);
+            if (rc) return rc;
+            cur = out;
+            ++i;
+            continue;
+        }
         void* out = (i == n_layers - 1) ? y : static_cast<void*>(ws + pl.off[i]);
         rc = s3r_conv_forward(&pl.d[i], cur, L.packed_w, L.scale, L.shift, out,
                               pl.scratch_elems ? ws + pl.scratch_off : nullptr, pl.scratch_elems, stream);

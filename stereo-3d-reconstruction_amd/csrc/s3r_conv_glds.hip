@@ -34,6 +34,7 @@
 // 2x2x2-tap gather over the input grid with its own packed weight slab: output-stationary, no atomics,
 // no zero-stuffed taps.
 #include "s3r_kernels.h"
+#include <cstdlib>
 
 namespace s3r {
 
@@ -65,6 +66,13 @@ __device__ __forceinline__ void dma_to_lds(__amdgpu_buffer_rsrc_t rsrc, float* l
 }
 
 constexpr int GBK = 16;   // K tile depth: one tap x 16 input channels
+
+#ifdef S3R_ABLATE   // diagnostic builds only: S3R_ABL=1 no epilogue stores, 2 one K tile only, 3 no DMA in the loop
+static int abl_mode() { static const int m = getenv("S3R_ABL") ? atoi(getenv("S3R_ABL")) : 0; return m; }
+#define S3R_ABL(p, m) ((p).debug == (m))
+#else
+#define S3R_ABL(p, m) false
+#endif
 
 // waves per SIMD the register allocator must leave room for: 16*TM*TN accumulator registers + ~48
 constexpr int min_waves(int tm, int tn) { return tm * tn >= 8 ? 2 : (tm * tn >= 4 ? 4 : 5); }
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
     // split-K: blockIdx.z owns a contiguous range of 16-channel chunks (all taps of each)
     const int chunks = (p.Cin / BK) / p.ksplit;
     const int kz = blockIdx.z;
-    const int nkt = T * chunks;
+    const int nkt = S3R_ABL(p, 2) ? 1 : T * chunks;
 
     // ---- per-lane loop-invariant DMA offsets (bytes)
     int bvoff;     // B: this lane's VEC positions (+ its row inside a multi-row piece)
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nkt) issue(cur ^ 1);
+        if (kt + 1 < nkt && !S3R_ABL(p, 3)) issue(cur ^ 1);
         const float* a = As + cur * BK * BM + a_off;
         const float* b = Bs + cur * BK * BN + b_off;
 #pragma unroll
@@ -259,9 +267,45 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
         rem -= pd * p.Nh * p.Nw;
         const int ph = rem / p.Nw;
         const int pw = rem - ph * p.Nw;
-        int e = b * p.Cout * p.y_cs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw) * ostep;
+        int e = b * p.y_bs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw) * ostep;
         if (p.transposed) e += rd * p.y_ds + rh * p.y_hs + rw;
         yoff[tn] = e;
+    }
+    // ---- fused pointwise head (conv -> 1x1x1 conv to ONE channel + activation, e.g. d3 -> d4 + sigmoid): the
+    // workgroup's M tile holds every cout of its positions inside one wave (WM == 1), so the channel
+    // reduction is 16*TM in-lane FMAs + one exchange between the two lane halves; the conv's own output
+    // (the largest activation of the network) is never written to or re-read from HBM.
+    if (p.head_w) {
+        if constexpr (WM == 1) {
+            float part[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) part[tn] = 0.f;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = ((r & 3) + 8 * (r >> 2) + 4 * h) * TM + tm;
+                    if (m >= p.Cout) continue;
+                    const float sc = p.scale ? p.scale[m] : 1.f, sf = p.shift ? p.shift[m] : 0.f, hw = p.head_w[m];
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        float t = fmaf(acc[tm][tn][r], sc, sf);
+                        if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
+                        else if (p.act == ACT_SIGMOID) t = 1.f / (1.f + __expf(-t));
+                        part[tn] = fmaf(t, hw, part[tn]);
+                    }
+                }
+            const float hsc = p.head_scale ? p.head_scale[0] : 1.f, hsf = p.head_shift ? p.head_shift[0] : 0.f;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                float t = part[tn] + __shfl_xor(part[tn], 32, 64);       // the other 32 couts live in lane j+32
+                t = fmaf(t, hsc, hsf);
+                if (p.head_act == ACT_RELU) t = fmaxf(t, 0.f);
+                else if (p.head_act == ACT_SIGMOID) t = 1.f / (1.f + __expf(-t));
+                if (h == 0 && yok[tn]) p.y[yoff[tn]] = t;
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
@@ -280,6 +324,7 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
                 v[tn] = t;
             }
             float* __restrict__ yrow = p.y + (size_t)m * p.y_cs;
+            if (S3R_ABL(p, 1) && v[0] != 12345.f) continue;
             if (TN > 1 && vec_ok && yok[TN - 1]) {
                 // dword-aligned (not 16-B aligned) vector store: legal for global memory on gfx950
                 if constexpr (TN == 2) {
@@ -492,6 +537,15 @@ hipError_t launch_conv_mfma(const ConvParams& p, int code, hipStream_t stream) {
     if (vec > vmax) vec = vmax;
     if (p.Cin % GBK != 0 || p.Ntotal % vec != 0) return hipErrorInvalidValue;
     if (p.ksplit < 1 || (p.Cin / GBK) % p.ksplit != 0 || (p.ksplit > 1 && !p.part)) return hipErrorInvalidValue;
+    if (p.head_w) {   // fused head: one wave must hold all couts of its positions (WM == 1, BM >= Cout), no split-K
+        int bm, bn;
+        conv_tile_dims(cfg, &bm, &bn);
+        const bool wm1 = cfg == 1 || cfg == 2 || cfg == 5 || cfg == 7;
+        if (!wm1 || bm < p.Cout || p.ksplit != 1) return hipErrorInvalidValue;
+    }
+#ifdef S3R_ABLATE
+    const_cast<ConvParams&>(p).debug = abl_mode();
+#endif
     switch (cfg) {
         case 0: return launch_vec<2, 2, 2, 2>(p, vec, stream);
         case 1: return launch_vec<1, 4, 2, 2>(p, vec, stream);

@@ -23,6 +23,7 @@ struct ConvParams {
     int x_cs, x_ds, x_hs; // input element strides: channel, depth, row   (batch stride = Cin * x_cs)
     int x_org;            // element offset of tap (0,0,0) of position (0,0,0): (halo_in - pad) per axis
     int y_cs, y_ds, y_hs; // output element strides
+    int y_bs;             // output batch stride (Cout * y_cs; the fused head's single-channel output: y_cs)
     int y_org;            // element offset of output (0,0,0): halo_out per axis
     unsigned x_bytes;     // size of the input buffer (buffer descriptor range)
     int transposed;       // 0: convolution, 1: ConvTranspose3d(k=4,s=2,p=1) split into 8 parity classes
@@ -31,6 +32,13 @@ struct ConvParams {
     int n_tiles, m_tiles;
     int ksplit;           // split-K factor (divides Cin/16); > 1: partial slabs to `part`, then conv_finish
     float* part;          // split-K scratch: [cls][ksplit][Cout][n_tiles*BN]
+    int debug;            // diagnostic builds (-DS3R_ABLATE) only
+    // fused pointwise head (conv -> 1x1x1 conv to one channel + activation): when head_w != null, y / y_* describe
+    // the HEAD's output and the conv's own output is never materialised
+    const float* head_w;       // [Cout]
+    const float* head_scale;   // [1] or null
+    const float* head_shift;   // [1] or null
+    int head_act;
 };
 
 // bf16 channels-last path: activations (B, [D,] H, W, C) bf16 with a zero halo, fp32 accumulate
