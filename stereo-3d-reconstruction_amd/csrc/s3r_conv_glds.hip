@@ -221,7 +221,8 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(vget<TM>(av, tm), vget<TN>(bv, tn),
                                                                        acc[tm][tn], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of tile kt+1 have landed
+        if (!S3R_ABL(p, 5)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of tile kt+1 have landed
+        if (S3R_ABL(p, 5)) __builtin_amdgcn_s_barrier(); else
         __syncthreads();                                    // ... everyone's have, and buffer `cur` is free
     }
 

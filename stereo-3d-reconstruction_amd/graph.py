@@ -1,0 +1,84 @@
+"""HIP-graph replay of the forward path and host->device staging on a side stream.
+
+The forward is ~20 kernel launches with no host-side data dependence, so for a fixed batch shape it is
+captured ONCE into a HIP graph (torch.cuda.CUDAGraph is hipGraph on ROCm) and replayed: one launch per
+step instead of twenty, no per-launch host work, no inter-kernel launch gaps.  At the BASELINE batch the
+gaps are ~2 % of a step; at small batches (latency serving) they are most of it.
+
+`GraphedForward` owns static input buffers; `__call__(left, right)` copies into them (device->device, or
+host->device for pinned host tensors) and replays.  `PrefetchingLoader` double-buffers host batches through
+a copy stream so the PCIe transfer of batch i+1 overlaps the forward of batch i.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Iterator, Optional, Tuple
+
+import torch
+
+
+class GraphedForward:
+    """Capture `model(left, right)` for one batch shape and replay it.
+
+    The model's own resident buffers (activation arenas, packed weights, padded cost volume) are allocated
+    and initialised by the warm-up calls made before capture, so the captured region only launches kernels.
+    """
+
+    def __init__(self, model, batch: int, device, warmup: int = 2):
+        self.model, self.batch, self.device = model, batch, torch.device(device)
+        self.left = torch.zeros(batch, 3, 224, 224, device=self.device)
+        self.right = torch.zeros(batch, 3, 224, 224, device=self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):                 # warm-up on the capture stream: arenas, packing, fresh memsets
+            for _ in range(max(1, warmup)):
+                self.out = model(self.left, self.right)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self.out = model(self.left, self.right)
+
+    @torch.no_grad()
+    def __call__(self, left: Optional[torch.Tensor] = None, right: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Replay.  With tensors given they are copied into the static inputs first (shape must match); with
+        none given the static inputs are used as they are (fill `.left` / `.right` yourself).  The returned
+        tensor is the graph's static output: it is overwritten by the next replay."""
+        if left is not None:
+            if left.shape != self.left.shape or right is None or right.shape != self.right.shape:
+                raise RuntimeError(f"graph was captured for batch {self.batch}; got {tuple(left.shape)}")
+            self.left.copy_(left, non_blocking=True)
+            self.right.copy_(right, non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+
+class PrefetchingLoader:
+    """Iterate (left, right) device batches while the NEXT host batch crosses PCIe on a copy stream."""
+
+    def __init__(self, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], device):
+        self.batches, self.device = batches, torch.device(device)
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+
+    def _stage(self, pair):
+        with torch.cuda.stream(self.copy_stream):
+            out = tuple(t.pin_memory().to(self.device, non_blocking=True) if not t.is_cuda else t for t in pair)
+        ev = torch.cuda.Event()
+        ev.record(self.copy_stream)
+        return out, ev
+
+    def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+        it = iter(self.batches)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur, ev = nxt
+            try:
+                nxt = self._stage(next(it))
+            except StopIteration:
+                nxt = None
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            for t in cur:
+                t.record_stream(torch.cuda.current_stream(self.device))
+            yield cur

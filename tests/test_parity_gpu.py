@@ -411,3 +411,27 @@ def test_non_default_stream(s3r, models):
         got = hip(left, right)
     st.synchronize()
     assert torch.equal(got, want)
+
+
+def test_hip_graph_replay_matches_eager(s3r, models):
+    hip, _ = models
+    left, right = s3r.synthetic_pairs(3, seed=31)
+    left, right = left.to(DEV), right.to(DEV)
+    want = hip(left, right).clone()
+    g = s3r.GraphedForward(hip, 3, DEV)
+    got = g(left, right).clone()
+    assert torch.equal(got, want)
+    l2, r2 = s3r.synthetic_pairs(3, seed=32)
+    want2 = hip(l2.to(DEV), r2.to(DEV)).clone()
+    assert torch.equal(g(l2.to(DEV), r2.to(DEV)), want2)     # replay with new data in the static inputs
+    assert torch.equal(hip(left, right), want)                # eager calls still work after capture
+    with pytest.raises(RuntimeError):
+        g(left[:2], right[:2])
+
+
+def test_prefetching_loader_order_and_values(s3r, models):
+    hip, _ = models
+    batches = [s3r.synthetic_pairs(2, seed=40 + i) for i in range(3)]
+    outs = [hip(l, r).clone() for l, r in s3r.PrefetchingLoader(batches, DEV)]
+    for (l, r), o in zip(batches, outs):
+        assert torch.equal(o, hip(l.to(DEV), r.to(DEV)))
