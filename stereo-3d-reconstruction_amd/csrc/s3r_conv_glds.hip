@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
     }
     const int m_tile = bid % p.m_tiles;
     const int n_tile = bid / p.m_tiles;
-    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int m0 = m_tile * BM, n0 = p.n_begin + n_tile * BN;
     const int cls = blockIdx.y;                       // output parity class (transposed only)
     const int rd = (cls >> 2) & 1, rh = (cls >> 1) & 1, rw = cls & 1;
 
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
         if (B_WIDE) { col = (wave % PPR) * PB + lane * VEC; lrow = 0; }
         else        { col = (lane % LPR_B) * VEC;           lrow = lane / LPR_B; }
         int n = n0 + col;
-        if (n >= p.Ntotal) n = p.Ntotal - VEC;          // tail tile: fetch a valid group, never stored
+        if (n >= p.n_end) n = p.n_end - VEC;            // tail tile: fetch a valid group, never stored
         const int b = n / S;
         int rem = n - b * S;
         const int pd = rem / (p.Nh * p.Nw);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int n = nl + tn;
-        yok[tn] = n < p.Ntotal;
+        yok[tn] = n < p.n_end;
         const int nn = yok[tn] ? n : 0;
         const int b = nn / S;
         int rem = nn - b * S;
@@ -435,8 +435,8 @@ static const Tuned kTuned[] = {
     {64,  64,  9, 2,  3136, 0, 3, 1},   // e3  -> 56^2
     {64, 128,  9, 1,  3136, 0, 2, 1},   // e4
     {128, 128, 9, 2,   784, 0, 3, 1},   // e5  -> 28^2
-    {128, 256, 9, 1,   784, 0, 2, 1},   // e6
-    {256, 256, 9, 1,   784, 0, 2, 1},   // e7
+    {128, 256, 9, 1,   784, 0, 1, 1},   // e6  (64x256 bulk + 64x64 remainder, see plan_tail_cut)
+    {256, 256, 9, 1,   784, 0, 1, 1},   // e7
     {256, 32,  1, 1,   784, 0, 2, 1},   // e8
     {64,  64, 27, 1, 21952, 0, 1, 1},   // v1  28^3
     {64, 128, 27, 2,  2744, 0, 3, 1},   // v2  -> 14^3
@@ -503,7 +503,7 @@ static hipError_t launch_cfg(ConvParams p, hipStream_t stream) {
         return hipErrorInvalidValue;   // tile too narrow / too wide for this gather width
     } else {
         p.m_tiles = (p.Cout + BM - 1) / BM;
-        p.n_tiles = (p.Ntotal + BN - 1) / BN;
+        p.n_tiles = (p.n_end - p.n_begin + BN - 1) / BN;
         const size_t lds = (size_t)2 * GBK * (BM + BN) * sizeof(float);
         if (lds > 48 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation
             static const hipError_t attr = hipFuncSetAttribute(
@@ -528,11 +528,54 @@ static hipError_t launch_vec(const ConvParams& p, int vec, hipStream_t stream) {
     }
 }
 
+static hipError_t launch_tile(const ConvParams& p, int cfg, int vec, hipStream_t stream) {
+    switch (cfg) {
+        case 0: return launch_vec<2, 2, 2, 2>(p, vec, stream);
+        case 1: return launch_vec<1, 4, 2, 2>(p, vec, stream);
+        case 2: return launch_vec<1, 4, 1, 2>(p, vec, stream);
+        case 3: return launch_vec<2, 2, 1, 1>(p, vec, stream);
+        case 4: return launch_vec<2, 2, 2, 4>(p, vec, stream);
+        case 5: return launch_vec<1, 4, 2, 4>(p, vec, stream);
+        case 6: return launch_vec<2, 2, 2, 1>(p, vec, stream);
+        case 7: return launch_vec<1, 4, 2, 1>(p, vec, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// Workgroup-count quantisation.  The four waves of a workgroup sit on the four SIMDs of a CU, so a CU that
+// hosts n workgroups takes n workgroup-times: a launch of W equal workgroups costs ceil(W / 256) of them
+// (measured: tools/quant_exp.py — e7 with 128x128 tiles runs 135 TFLOP/s at W = 1018 and 104 at W = 1030).
+// When W is a little over a multiple of 256 the launch is cut in two along the position axis: the bulk —
+// a whole number of 256-workgroup rounds — keeps its tile, and the remainder is re-tiled 64 x 64 so that it
+// spreads over all CUs in a fraction of a round.  Any tile shape produces the same bits (the K order is
+// fixed), so the cut never changes a result.
+static bool plan_tail_cut(const ConvParams& p, int cfg, int* n_cut) {
+    if (p.ksplit != 1 || p.Cout <= 32 || cfg == 3) return false;
+    const int classes = p.transposed ? 8 : 1;
+    const long bm = kTileDims[cfg][0], bn = kTileDims[cfg][1];
+    const long m_tiles = (p.Cout + bm - 1) / bm, n_tiles = (p.Ntotal + bn - 1) / bn;
+    const long W = m_tiles * n_tiles * classes;
+    const long rounds = W / 256, rem = W % 256;
+    if (rounds < 1 || rounds >= 16 || rem == 0) return false;
+    const long n_main = (rounds * 256) / (m_tiles * classes);          // whole N tiles in the bulk
+    if (n_main < 1 || n_main >= n_tiles) return false;
+    const long pos_tail = p.Ntotal - n_main * bn;
+    const long W_tail = ((pos_tail + 63) / 64) * ((p.Cout + 63) / 64) * classes;
+    const double before = (double)((W + 255) / 256);
+    const double bulk = (double)((n_main * m_tiles * classes + 255) / 256);
+    const double after = bulk + (double)((W_tail + 255) / 256) * (64.0 * 64.0) / (double)(bm * bn) / 0.8;
+    if (after > 0.97 * before) return false;
+    *n_cut = (int)(n_main * bn);
+    return true;
+}
+
 // code = tile_cfg (15 = heuristic) + 16 * forced_vec (0 = widest legal)
-hipError_t launch_conv_mfma(const ConvParams& p, int code, hipStream_t stream) {
+hipError_t launch_conv_mfma(const ConvParams& pin, int code, hipStream_t stream) {
+    ConvParams p = pin;
     int cfg = code & 15;
     int vec = code >> 4;
     if (cfg == 15) cfg = conv_pick_tile(p);
+    if (cfg >= kNumTiles) return hipErrorInvalidValue;
     const int vmax = conv_pick_vec(p);
     if (vec != 1 && vec != 4) vec = vmax;
     if (vec > vmax) vec = vmax;
@@ -545,19 +588,21 @@ hipError_t launch_conv_mfma(const ConvParams& p, int code, hipStream_t stream) {
         if (!wm1 || bm < p.Cout || p.ksplit != 1) return hipErrorInvalidValue;
     }
 #ifdef S3R_ABLATE
-    const_cast<ConvParams&>(p).debug = abl_mode();
+    p.debug = abl_mode();
 #endif
-    switch (cfg) {
-        case 0: return launch_vec<2, 2, 2, 2>(p, vec, stream);
-        case 1: return launch_vec<1, 4, 2, 2>(p, vec, stream);
-        case 2: return launch_vec<1, 4, 1, 2>(p, vec, stream);
-        case 3: return launch_vec<2, 2, 1, 1>(p, vec, stream);
-        case 4: return launch_vec<2, 2, 2, 4>(p, vec, stream);
-        case 5: return launch_vec<1, 4, 2, 4>(p, vec, stream);
-        case 6: return launch_vec<2, 2, 2, 1>(p, vec, stream);
-        case 7: return launch_vec<1, 4, 2, 1>(p, vec, stream);
-        default: return hipErrorInvalidValue;
+    p.n_begin = 0;
+    p.n_end = p.Ntotal;
+    int n_cut = 0;
+    static const bool no_cut = getenv("S3R_NO_TAIL_CUT") != nullptr;      // tuning / A-B switch
+    if (!p.head_w && !no_cut && plan_tail_cut(p, cfg, &n_cut)) {
+        p.n_end = n_cut;
+        hipError_t e = launch_tile(p, cfg, vec, stream);
+        if (e != hipSuccess) return e;
+        p.n_begin = n_cut;
+        p.n_end = p.Ntotal;
+        return launch_tile(p, 3, vec, stream);
     }
+    return launch_tile(p, cfg, vec, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

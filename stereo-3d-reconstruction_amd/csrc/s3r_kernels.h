@@ -29,6 +29,7 @@ struct ConvParams {
     int transposed;       // 0: convolution, 1: ConvTranspose3d(k=4,s=2,p=1) split into 8 parity classes
     int act;              // 0 none, 1 relu, 2 sigmoid
     int Ntotal;           // B*Nd*Nh*Nw
+    int n_begin, n_end;   // position range [n_begin, n_end) this launch covers (a layer may be cut in two launches)
     int n_tiles, m_tiles;
     int ksplit;           // split-K factor (divides Cin/16); > 1: partial slabs to `part`, then conv_finish
     float* part;          // split-K scratch: [cls][ksplit][Cout][n_tiles*BN]
