@@ -208,8 +208,9 @@ int resolve_launch_h(const s3r_conv_desc* d, s3r::ConvParamsH* p, LaunchH* L) {
         return fail(S3R_ERR_INVALID, "ksplit=%d must divide cin/32=%d", d->ksplit, chunks);
     L->ksplit = d->ksplit > 0 ? d->ksplit : s3r::conv_bf16_pick_ksplit(*p);
     p->ksplit = L->ksplit;
-    if (d->tile >= 0 && d->tile != 1 && d->tile != 2 && d->tile != 4)
-        return fail(S3R_ERR_INVALID, "bf16 path: tile must be -1 (auto), 1, 2 or 4 (x128 positions)");
+    if (d->tile >= 0 && d->tile != 1 && d->tile != 2 && d->tile != 4 && d->tile != 9 && d->tile != 10)
+        return fail(S3R_ERR_INVALID, "bf16 path: tile must be -1 (auto), 1, 2, 4 (x128 positions, per-tap gather) or "
+                    "9, 10 (x128 positions = 1, 2 with the row-reuse gather)");
     L->tm = d->tile >= 0 ? d->tile : s3r::conv_bf16_pick_tm(*p);
     return S3R_OK;
 }
@@ -311,11 +312,17 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
     // conv -> pointwise head fusion (fp32 path): a <=64-cout MFMA conv that does not split K, followed by the
     // 1x1 single-channel head, runs the head inside its epilogue; its own output is never materialised
     for (int i = 0; i + 1 < n; ++i) {
-        if (pl->r[i] != R_MFMA || pl->r[i + 1] != R_HEAD || pl->d[i].dtype != S3R_F32 || pl->d[i].cout > 64) continue;
+        if (pl->r[i] != R_MFMA || pl->r[i + 1] != R_HEAD || pl->d[i].cout > 64) continue;
         if (pl->d[i + 1].cin != pl->d[i].cout || pl->d[i].out_halo != 0) continue;
-        s3r::ConvParams p = make_params(&pl->d[i], pl->g[i]);
-        Launch L;
-        if (resolve_launch(&pl->d[i], &p, &L) != S3R_OK || L.ksplit != 1) continue;
+        if (pl->d[i].dtype == S3R_BF16) {
+            s3r::ConvParamsH ph = make_params_h(&pl->d[i], pl->g[i]);
+            LaunchH Lh;
+            if (resolve_launch_h(&pl->d[i], &ph, &Lh) != S3R_OK || Lh.ksplit != 1) continue;
+        } else {
+            s3r::ConvParams p = make_params(&pl->d[i], pl->g[i]);
+            Launch L;
+            if (resolve_launch(&pl->d[i], &p, &L) != S3R_OK || L.ksplit != 1) continue;
+        }
         pl->fuse_head[i] = 1;
     }
     int64_t off = 0;
@@ -365,6 +372,25 @@ int conv_head_fused(const s3r_conv_desc* d, const Geo& g, const s3r_conv_desc* h
                  4.0 * d->batch * (double)hg.out_sp);
     hipError_t e = s3r::launch_conv_mfma(p, Ln.cfg + 16 * Ln.vec, s);
     if (e != hipSuccess) return hip_fail(e, "fused conv+head launch");
+    return S3R_OK;
+}
+
+// the same on the bf16 channels-last path: the conv's 64-cout tile is the whole channel axis of its positions
+int conv_head_fused_h(const s3r_conv_desc* d, const Geo& g, const s3r_conv_desc* hd, const Geo& hg, const void* x,
+                      const s3r_layer& L, const s3r_layer& H, float* out, hipStream_t s) {
+    s3r::ConvParamsH p = make_params_h(d, g);
+    p.x = x; p.w = L.packed_w; p.scale = L.scale; p.shift = L.shift; p.y = out;
+    const bool is3 = hd->ndim == 3;
+    p.y_ws = 1; p.y_hs = hg.out_p; p.y_ds = is3 ? hg.out_p * hg.out_p : 0; p.y_bs = (int)ipow(hg.out_p, hg.nd);
+    p.y_org = hd->out_halo * (p.y_ds + p.y_hs + 1);
+    p.head_w = static_cast<const float*>(H.packed_w); p.head_scale = H.scale; p.head_shift = H.shift; p.head_act = hd->act;
+    LaunchH Ln;
+    int rc = resolve_launch_h(d, &p, &Ln);
+    if (rc) return rc;
+    ProfScope ps(s, F_MFMA, d->tag, g.flops + hg.flops, g.bytes - 2.0 * d->batch * d->cout * (double)g.out_sp +
+                 4.0 * d->batch * (double)hg.out_sp);
+    hipError_t e = s3r::launch_conv_bf16(p, Ln.tm, s);
+    if (e != hipSuccess) return hip_fail(e, "fused conv+head launch (bf16)");
     return S3R_OK;
 }
 
@@ -583,8 +609,11 @@ int s3r_chain_forward(const s3r_layer* layers, int n_layers, const void* x, void
         if (pl.fuse_head[i]) {
             const s3r_layer& H = layers[i + 1];
             void* out = (i + 1 == n_layers - 1) ? y : static_cast<void*>(ws + pl.off[i + 1]);
-            rc = conv_head_fused(&pl.d[i], pl.g[i], &pl.d[i + 1], pl.g[i + 1], static_cast<const float*>(cur), L, H,
-                                 static_cast<float*>(out), s);
+            if (pl.d[i].dtype == S3R_BF16)
+                rc = conv_head_fused_h(&pl.d[i], pl.g[i], &pl.d[i + 1], pl.g[i + 1], cur, L, H, static_cast<float*>(out), s);
+            else
+                rc = conv_head_fused(&pl.d[i], pl.g[i], &pl.d[i + 1], pl.g[i + 1], static_cast<const float*>(cur), L, H,
+                                     static_cast<float*>(out), s);
             if (rc) return rc;
             cur = out;
             ++i;

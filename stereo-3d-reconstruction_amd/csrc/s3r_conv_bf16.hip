@@ -24,8 +24,16 @@
 // 2c+tn so that a lane packs its two bf16 results into ONE dword store: 128 contiguous bytes per 32
 // lanes).  Per-position input / output offsets are decoded once per workgroup into LDS.
 #include "s3r_kernels.h"
+#include <cstdlib>
 
 namespace s3r {
+
+#ifdef S3R_ABLATE   // diagnostic builds only: S3R_ABL=1 no epilogue stores, 2 one K tile only, 3 no DMA in the loop
+static int abl_mode_h() { static const int m = getenv("S3R_ABL") ? atoi(getenv("S3R_ABL")) : 0; return m; }
+#define S3R_ABLH(p, m) ((p).debug == (m))
+#else
+#define S3R_ABLH(p, m) false
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -44,6 +52,76 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst
 
 constexpr int HKC = 32;    // channels per K tile
 constexpr int HBN = 64;    // couts per workgroup
+
+// Epilogue shared by both bf16 kernels.  Lane c owns couts n0 + 2c (tn 0) and n0 + 2c + 1 (tn 1); register r of
+// MFMA tile tm is position row wave*32*TM + tm*32 + (r&3) + 8*(r>>2) + 4h of the tile; yoff[row] is that
+// position's output element offset (-1: past the end).
+template <int TM>
+__device__ __forceinline__ void epilogue_h(const ConvParamsH& p, f32x16 (&acc)[TM][2], const int* yoff, int wave, int c,
+                                           int h, int m0, int n0, int cls, int kz, int bm) {
+    const int co = n0 + 2 * c;
+    if (p.ksplit > 1) {
+        // split-K: fp32 partial sums [cls][kz][position][CoutPad]; conv_finish_bf16 reduces in kz order
+        const int mpad = p.m_tiles * bm;
+        float* __restrict__ slab = p.part + ((size_t)(cls * p.ksplit + kz) * mpad + m0) * p.CoutPad + co;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float2 t = {acc[tm][0][r], acc[tm][1][r]};
+                *reinterpret_cast<float2*>(slab + (size_t)row * p.CoutPad) = t;
+            }
+        return;
+    }
+    const bool c0 = co < p.Cout, c1 = co + 1 < p.Cout;
+    const float sc0 = (c0 && p.scale) ? p.scale[co] : 1.f, sf0 = (c0 && p.shift) ? p.shift[co] : 0.f;
+    const float sc1 = (c1 && p.scale) ? p.scale[co + 1] : 1.f, sf1 = (c1 && p.shift) ? p.shift[co + 1] : 0.f;
+    if (p.head_w) {
+        // fused pointwise head (conv -> 1x1x1 conv to ONE channel + activation; the workgroup's 64-cout tile
+        // is the whole channel axis): per position, 2 FMAs in the lane, a 32-lane butterfly over the couts, one
+        // fp32 store.  The conv's own bf16 output — the largest activation of the network — is never written.
+        const float hw0 = c0 ? p.head_w[co] : 0.f, hw1 = c1 ? p.head_w[co + 1] : 0.f;
+        const float hsc = p.head_scale ? p.head_scale[0] : 1.f, hsf = p.head_shift ? p.head_shift[0] : 0.f;
+        float* __restrict__ y = reinterpret_cast<float*>(p.y);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v0 = fmaf(acc[tm][0][r], sc0, sf0), v1 = fmaf(acc[tm][1][r], sc1, sf1);
+                if (p.act == ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                else if (p.act == ACT_SIGMOID) { v0 = 1.f / (1.f + __expf(-v0)); v1 = 1.f / (1.f + __expf(-v1)); }
+                float t = fmaf(v1, hw1, v0 * hw0);
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);      // over the 32 lanes of this half
+                const int row = wave * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int ye = yoff[row];
+                if (c == 0 && ye >= 0) {
+                    t = fmaf(t, hsc, hsf);
+                    if (p.head_act == ACT_RELU) t = fmaxf(t, 0.f);
+                    else if (p.head_act == ACT_SIGMOID) t = 1.f / (1.f + __expf(-t));
+                    y[ye] = t;
+                }
+            }
+        return;
+    }
+    unsigned short* __restrict__ y = reinterpret_cast<unsigned short*>(p.y);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int ye = yoff[row];
+            if (ye < 0 || !c0) continue;
+            float v0 = fmaf(acc[tm][0][r], sc0, sf0), v1 = fmaf(acc[tm][1][r], sc1, sf1);
+            if (S3R_ABLH(p, 1) && v0 != 12345.f) continue;
+            if (p.act == ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            else if (p.act == ACT_SIGMOID) { v0 = 1.f / (1.f + __expf(-v0)); v1 = 1.f / (1.f + __expf(-v1)); }
+            const unsigned pk = pack_bf16(v0, v1);
+            if (c1) *reinterpret_cast<unsigned*>(y + (size_t)ye + co) = pk;
+            else y[(size_t)ye + co] = (unsigned short)(pk & 0xffffu);
+        }
+}
 
 constexpr int min_waves_h(int tm) { return tm >= 4 ? 2 : 4; }
 
@@ -80,7 +158,7 @@ __global__ __launch_bounds__(256, min_waves_h(TM)) void conv_bf16_kernel(const C
     const int S = p.Nd * p.Nh * p.Nw;
     const int T = p.T;
     const int chunks = (p.Cin / HKC) / p.ksplit;
-    const int nkt = T * chunks;
+    const int nkt = S3R_ABLH(p, 2) ? 1 : T * chunks;
 
     // ---- decode this tile's positions once: input corner (bytes) and output offset (elements)
     for (int t = tid; t < BM; t += 256) {
@@ -165,7 +243,7 @@ __global__ __launch_bounds__(256, min_waves_h(TM)) void conv_bf16_kernel(const C
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nkt) issue(cur ^ 1);
+        if (kt + 1 < nkt && !S3R_ABLH(p, 3)) issue(cur ^ 1);
         const char* a = As + cur * A_BYTES;
         const char* b = Bs + cur * B_BYTES;
 #pragma unroll
@@ -185,41 +263,185 @@ __global__ __launch_bounds__(256, min_waves_h(TM)) void conv_bf16_kernel(const C
         __syncthreads();
     }
 
-    // ---- epilogue.  Lane c owns couts n0 + 2c (tn 0) and n0 + 2c + 1 (tn 1); register r of MFMA tile tm is
-    // position row wave*32*TM + tm*32 + (r&3) + 8*(r>>2) + 4h.
-    const int co = n0 + 2 * c;
-    if (p.ksplit > 1) {
-        // split-K: fp32 partial sums [cls][kz][position][CoutPad]; conv_finish_bf16 reduces in kz order
-        const int mpad = p.m_tiles * BM;
-        float* __restrict__ slab = p.part + ((size_t)(cls * p.ksplit + kz) * mpad + m0) * p.CoutPad + co;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wave * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                float2 t = {acc[tm][0][r], acc[tm][1][r]};
-                *reinterpret_cast<float2*>(slab + (size_t)row * p.CoutPad) = t;
-            }
-        return;
+    epilogue_h<TM>(p, acc, yoff, wave, c, h, m0, n0, cls, kz, BM);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-reuse variant (the default): the kw taps of one (chunk, td, th) group read the SAME gathered input
+// rows shifted by one position, so the A operand is fetched ONCE per group instead of once per tap.
+//
+// LDS A image = the input positions the tile needs for a fixed (td, th), in input order: for every run of
+// tile positions inside one output row, a segment of stride*(run-1)+kw consecutive input positions
+// (64 B = 32 channels each); MFMA row r reads LDS row lrow[r] + tw for tap tw.  No position is computed that
+// is not stored (the halo columns sit in LDS but no MFMA row maps to them), the gather is kw (x stride)
+// times smaller, and it is CONTIGUOUS in HBM (whole runs of positions) instead of 64-byte pieces.
+// The weights of the group's kw taps (kw x 4 KiB, consecutive in the packed image) ride along, so there
+// is one barrier per GROUP: kw*2*TM*2 MFMAs per wave between barriers.
+constexpr int NPA_MAX = 10;    // 16-position A pieces per wave per group, upper bound (registers)
+
+template <int TM>
+__global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p, int r_max) {
+    constexpr int BM = 128 * TM;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int kw = p.kw;
+    const int a_bytes = r_max * 64, stage_bytes = a_bytes + kw * 4096;
+    int* yoff = reinterpret_cast<int*>(smem + 2 * stage_bytes);     // [BM] output element offsets, -1 = none
+    int* lrow = yoff + BM;                                            // [BM] LDS row of each tile position (tap tw = 0)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    const bool c0 = co < p.Cout, c1 = co + 1 < p.Cout;
-    const float sc0 = (c0 && p.scale) ? p.scale[co] : 1.f, sf0 = (c0 && p.shift) ? p.shift[co] : 0.f;
-    const float sc1 = (c1 && p.scale) ? p.scale[co + 1] : 1.f, sf1 = (c1 && p.shift) ? p.shift[co + 1] : 0.f;
-    unsigned short* __restrict__ y = reinterpret_cast<unsigned short*>(p.y);
+    const int n_tile = bid % p.n_tiles;
+    const int m_tile = bid / p.n_tiles;
+    const int m0 = m_tile * BM, n0 = n_tile * HBN;
+    const int cls = blockIdx.y;
+    const int rd = (cls >> 2) & 1, rh = (cls >> 1) & 1, rw = cls & 1;
+    const int kz = blockIdx.z;
+
+    const int S = p.Nd * p.Nh * p.Nw;
+    const int T = p.T;
+    const int chunks = (p.Cin / HKC) / p.ksplit;
+    const int ngroups = S3R_ABLH(p, 2) ? 1 : chunks * p.kd * p.kh;
+    const int cls_x = p.transposed ? (rd - 1) * p.x_ds + (rh - 1) * p.x_hs + (rw - 1) * p.x_ws : 0;
+
+    // ---- geometry of the tile's first position (wave-uniform): its output row and column
+    int rowid0, pw0;
+    {
+        const int b = m0 / S;
+        int rem = m0 - b * S;
+        const int pd = rem / (p.Nh * p.Nw);
+        rem -= pd * p.Nh * p.Nw;
+        const int ph = rem / p.Nw;
+        pw0 = rem - ph * p.Nw;
+        rowid0 = (b * p.Nd + pd) * p.Nh + ph;
+    }
+    const int seg0 = p.stride * (p.Nw - pw0 - 1) + kw;       // LDS rows of the first (partial) run
+    const int segw = p.stride * (p.Nw - 1) + kw;             // LDS rows of a full output row
+    const int last_row = p.B * p.Nd * p.Nh - 1;
+
+    for (int t = tid; t < BM; t += 256) {
+        const int n = m0 + t;
+        const bool ok = n < p.Ntotal;
+        const int nn = ok ? n : p.Ntotal - 1;
+        const int b = nn / S;
+        int rem = nn - b * S;
+        const int pd = rem / (p.Nh * p.Nw);
+        rem -= pd * p.Nh * p.Nw;
+        const int ph = rem / p.Nw;
+        const int pw = rem - ph * p.Nw;
+        const int ostep = p.transposed ? 2 : 1;
+        int ye = b * p.y_bs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw * p.y_ws) * ostep;
+        if (p.transposed) ye += rd * p.y_ds + rh * p.y_hs + rw * p.y_ws;
+        yoff[t] = ok ? ye : -1;
+        const int k = (b * p.Nd + pd) * p.Nh + ph - rowid0;
+        lrow[t] = k == 0 ? p.stride * (pw - pw0) : seg0 + (k - 1) * segw + p.stride * pw;
+    }
+
+    // ---- loop-invariant DMA source offsets: LDS row q of the A image <- input position src(q)
+    const int npa = r_max >> 6;                               // pieces per wave (r_max % 64 == 0)
+    int avoff[NPA_MAX];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+    for (int q = 0; q < NPA_MAX; ++q) {
+        const int lr = ((wave + 4 * q) << 4) + (lane >> 2);   // LDS row this lane fills in its q-th piece
+        int k, off;
+        if (lr < seg0) { k = 0; off = lr + p.stride * pw0; }
+        else { k = 1 + (lr - seg0) / segw; off = (lr - seg0) - (k - 1) * segw; }
+        int rowid = rowid0 + k;
+        if (rowid > last_row) rowid = last_row;              // past the tensor: any valid address, never read
+        const int b = rowid / (p.Nd * p.Nh);
+        int rem = rowid - b * (p.Nd * p.Nh);
+        const int pd = rem / p.Nh;
+        const int ph = rem - pd * p.Nh;
+        const int e = b * p.x_bs + p.x_org + (pd * p.x_ds + ph * p.x_hs) * p.stride + off * p.x_ws + cls_x;
+        const int kg = (lane & 3) ^ ((lr >> 2) & 3);          // swizzle on the source side
+        avoff[q] = e * 2 + kg * 16;
+    }
+    const int bvoff = lane * 16;
+
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const size_t w_cls = (size_t)cls * T * (p.Cin / HKC) * p.n_tiles * 4096;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.w) + w_cls), 0,
+        (int)((unsigned)T * (unsigned)(p.Cin / HKC) * (unsigned)p.n_tiles * 4096u), 0x00020000);
+
+    int c_td = 0, c_th = 0, c_cc = kz * chunks, c_kt = kz * chunks * T;      // cursor of the NEXT group to fetch
+
+    auto issue = [&](int buf) {
+        char* st = smem + buf * stage_bytes;
+        for (int tw = 0; tw < kw; ++tw)                                      // the group's kw weight tiles
+            dma16(wrsrc, st + a_bytes + tw * 4096 + wave * 1024, bvoff,
+                  ((c_kt + tw) * p.n_tiles + n_tile) * 4096 + wave * 1024);
+        const int a_base = (c_cc * HKC + c_td * p.x_ds + c_th * p.x_hs) * 2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wave * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int ye = yoff[row];
-            if (ye < 0 || !c0) continue;
-            float v0 = fmaf(acc[tm][0][r], sc0, sf0), v1 = fmaf(acc[tm][1][r], sc1, sf1);
-            if (p.act == ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-            else if (p.act == ACT_SIGMOID) { v0 = 1.f / (1.f + __expf(-v0)); v1 = 1.f / (1.f + __expf(-v1)); }
-            const unsigned pk = pack_bf16(v0, v1);
-            if (c1) *reinterpret_cast<unsigned*>(y + (size_t)ye + co) = pk;
-            else y[(size_t)ye + co] = (unsigned short)(pk & 0xffffu);
+        for (int q = 0; q < NPA_MAX; ++q)
+            if (q < npa) dma16(xrsrc, st + ((wave + 4 * q) << 10), avoff[q], a_base);
+        c_kt += kw;
+        if (++c_th == p.kh) { c_th = 0; if (++c_td == p.kd) { c_td = 0; ++c_cc; } }
+    };
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                          // also publishes yoff / lrow
+
+    int lr[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) lr[tm] = lrow[wave * 32 * TM + tm * 32 + c];
+    int b_off[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int row = tn * 32 + c;
+        b_off[tn] = row * 64 + ((h ^ ((row >> 2) & 3)) << 4);
+    }
+
+    for (int g = 0; g < ngroups; ++g) {
+        const int cur = g & 1;
+        if (g + 1 < ngroups && !S3R_ABLH(p, 3)) issue(cur ^ 1);
+        const char* a = smem + cur * stage_bytes;
+        const char* b = a + a_bytes;
+        for (int tw = 0; tw < kw; ++tw) {
+            int a_off[TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int row = lr[tm] + tw;
+                a_off[tm] = (row << 6) + (((h ^ (row >> 2)) & 3) << 4);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                bf16x8 av[TM], bv[2];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) av[tm] = *reinterpret_cast<const bf16x8*>(a + (a_off[tm] ^ (q << 5)));
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    bv[tn] = *reinterpret_cast<const bf16x8*>(b + tw * 4096 + (b_off[tn] ^ (q << 5)));
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+            }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    epilogue_h<TM>(p, acc, yoff, wave, c, h, m0, n0, cls, kz, BM);
 }
 
 // split-K finish: y[pos][cout] = bf16(act(scale * sum_kz slab + shift)); one thread per (position, cout pair)
@@ -260,11 +482,21 @@ __global__ __launch_bounds__(256) void conv_finish_bf16_kernel(const ConvParamsH
     }
 }
 
+static int rowreuse_rows(const ConvParamsH& p, int bm);
+
+// Tile / gather choice (tools/layer_bench.py --dtype bf16, B = 256, MI355X):
+//   * stride-1 layers with >= 3 taps along w and a deep K (v1, v3, v5, e7, v6) gain 10-25 % from the row-reuse
+//     gather (codes 9 / 10 = 128 / 256 positions);
+//   * the shallow-K 2D layers and the big-output layers (e2-e5, d3) sit near their HBM floor: they want the
+//     small-LDS per-tap kernel with 128-position tiles (more workgroups per CU to overlap loads and stores);
+//   * stride-2 layers would need a 2x larger LDS image for the reuse: per-tap kernel.
 int conv_bf16_pick_tm(const ConvParamsH& p) {
     const long classes = (p.transposed ? 8 : 1) * (long)p.ksplit;
     const long n_tiles = p.CoutPad / HBN;
     auto wgs = [&](int tm) { return ((p.Ntotal + 128 * tm - 1) / (128 * tm)) * n_tiles * classes; };
-    if (wgs(2) >= 1024) return 2;
+    const bool reuse = p.stride == 1 && p.kw >= 3 && !p.transposed && (long)p.Cin * p.T >= 64 * 27 &&
+                       rowreuse_rows(p, 128) <= 64 * NPA_MAX;
+    if (reuse) return (wgs(2) >= 1024 && rowreuse_rows(p, 256) <= 64 * NPA_MAX) ? 10 : 9;
     return 1;
 }
 
@@ -280,9 +512,41 @@ int conv_bf16_pick_ksplit(const ConvParamsH& p) {
 
 int64_t conv_bf16_scratch_elems(const ConvParamsH& p, int tm) {
     if (p.ksplit <= 1) return 0;
-    const int bm = 128 * tm;
+    const int bm = 128 * (tm >= 9 ? tm - 8 : tm);
     const int64_t mpad = (int64_t)((p.Ntotal + bm - 1) / bm) * bm;
     return (int64_t)(p.transposed ? 8 : 1) * p.ksplit * mpad * p.CoutPad;
+}
+
+// LDS rows (64 B each) the row-reuse kernel's A image needs for a BM-position tile, rounded to whole pieces per wave
+static int rowreuse_rows(const ConvParamsH& p, int bm) {
+    const int nrows = (bm + p.Nw - 2) / p.Nw + 1;
+    const int r = p.stride * bm + nrows * p.kw;
+    return (r + 63) / 64 * 64;
+}
+
+template <int TM>
+static hipError_t launch_tm_rowreuse(ConvParamsH p, hipStream_t stream) {
+    constexpr int BM = 128 * TM;
+    p.m_tiles = (p.Ntotal + BM - 1) / BM;
+    p.n_tiles = p.CoutPad / HBN;
+    const int r_max = rowreuse_rows(p, BM);
+    if (r_max > 64 * NPA_MAX) return hipErrorInvalidValue;
+    const size_t lds = (size_t)2 * (r_max * 64 + p.kw * 4096) + 2 * BM * sizeof(int);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16r_kernel<TM>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return attr;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    dim3 grid(p.m_tiles * p.n_tiles, p.transposed ? 8 : 1, p.ksplit);
+    hipLaunchKernelGGL((conv_bf16r_kernel<TM>), grid, dim3(256), lds, stream, p, r_max);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && p.ksplit > 1) {
+        const long long total = (long long)p.Ntotal * (p.CoutPad >> 1);
+        const long long blocks = (total + 255) / 256;
+        hipLaunchKernelGGL(conv_finish_bf16_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096), p.transposed ? 8 : 1),
+                           dim3(256), 0, stream, p, p.m_tiles * BM);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 template <int TM>
@@ -309,14 +573,21 @@ static hipError_t launch_tm(ConvParamsH p, hipStream_t stream) {
     return e;
 }
 
-hipError_t launch_conv_bf16(const ConvParamsH& p, int tm, hipStream_t stream) {
+hipError_t launch_conv_bf16(const ConvParamsH& pin, int tm, hipStream_t stream) {
+    ConvParamsH p = pin;
+#ifdef S3R_ABLATE
+    p.debug = abl_mode_h();
+#endif
     if (p.Cin % HKC != 0 || p.CoutPad % HBN != 0 || p.ksplit < 1 || (p.Cin / HKC) % p.ksplit != 0 ||
         (p.ksplit > 1 && !p.part))
         return hipErrorInvalidValue;
+    // tm = 1, 2, 4: per-tap gather (conv_bf16_kernel); tm = 9, 10: row-reuse gather (conv_bf16r_kernel) with TM 1, 2
     switch (tm) {
         case 1: return launch_tm<1>(p, stream);
         case 2: return launch_tm<2>(p, stream);
         case 4: return launch_tm<4>(p, stream);
+        case 9: return launch_tm_rowreuse<1>(p, stream);
+        case 10: return launch_tm_rowreuse<2>(p, stream);
         default: return hipErrorInvalidValue;
     }
 }

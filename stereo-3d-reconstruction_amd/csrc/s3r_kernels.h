@@ -62,6 +62,12 @@ struct ConvParamsH {
     int transposed, act, Ntotal;
     int m_tiles, n_tiles;                 // position tiles, 64-cout tiles
     int ksplit;
+    int debug;                            // diagnostic builds (-DS3R_ABLATE) only
+    // fused pointwise head: when head_w != null, y / y_* describe the head's fp32 single-channel output
+    const float* head_w;
+    const float* head_scale;
+    const float* head_shift;
+    int head_act;
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };

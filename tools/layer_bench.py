@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import s3r  # noqa: E402
 
-PEAK = 157.3
+PEAK = 157.3   # fp32; bf16 runs are shown against the same number for convenience
 
 
 def main():
@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--ksplits", default="0", help="split-K factors to try (0 = library heuristic)")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     args = ap.parse_args()
     spec = s3r.arch_spec
     dev = torch.device("cuda:0")
@@ -50,10 +51,12 @@ def main():
     except AttributeError:
         pass
     for l, n_in, B in cases:
-        ch = s3r.modules._HipChain([l], n_in)
+        ch = s3r.modules._HipChain([l], n_in, precision=args.dtype)
         s3r.seed_module(ch, 1)
         ch.to(dev)
         x = torch.randn((B, l.cin) + (n_in,) * spec.ndim(l), device=dev)
+        if args.dtype == "bf16":
+            x = x.to(torch.bfloat16).permute(0, *range(2, x.dim()), 1).contiguous()
         flops = 2.0 * spec.layer_macs(l, n_in) * B
         res = {}
         clk = {}
@@ -77,7 +80,7 @@ def main():
                     if rnd == 0:
                         if ref is None:
                             ref = y.clone()
-                        elif not torch.allclose(y, ref, rtol=1e-4, atol=1e-4):
+                        elif not torch.allclose(y.float(), ref.float(), rtol=1e-4, atol=1e-4):
                             print(f"!! {l.name} tile {t} variant {v}: output differs from first config "
                                   f"(max {float((y - ref).abs().max()):.3e})")
                         continue
