@@ -158,6 +158,7 @@ typedef struct s3r_prof_record {
     int32_t family;
     int32_t tag;
     float ms;
+    int32_t launches;   /* kernel launches bracketed by this record (a conv layer may be 1-3 launches) */
     double flops;
     double bytes;
 } s3r_prof_record;

@@ -31,8 +31,8 @@ class Layer(C.Structure):
 
 
 class ProfRecord(C.Structure):
-    _fields_ = [("family", C.c_int32), ("tag", C.c_int32), ("ms", C.c_float), ("flops", C.c_double),
-                ("bytes", C.c_double)]
+    _fields_ = [("family", C.c_int32), ("tag", C.c_int32), ("ms", C.c_float), ("launches", C.c_int32),
+                ("flops", C.c_double), ("bytes", C.c_double)]
 
 
 class S3RError(RuntimeError):
@@ -126,5 +126,5 @@ def profile_reset():
 def profile_read(max_records=4096):
     buf = (ProfRecord * max_records)()
     n = check(load().s3r_profile_read(buf, max_records), "profile_read")
-    return [dict(family=FAMILY.get(r.family, str(r.family)), tag=r.tag, ms=r.ms, flops=r.flops, bytes=r.bytes)
-            for r in buf[:n]]
+    return [dict(family=FAMILY.get(r.family, str(r.family)), tag=r.tag, ms=r.ms, launches=r.launches, flops=r.flops,
+                 bytes=r.bytes) for r in buf[:n]]

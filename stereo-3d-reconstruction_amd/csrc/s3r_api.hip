@@ -49,6 +49,7 @@ struct Prof {
 struct ProfScope {
     bool active = false;
     int slot = -1;
+    int launches = 1;     // kernel launches inside the scope (a conv may be cut into bulk + remainder, + split-K finish)
     hipStream_t stream;
     ProfScope(hipStream_t s, int family, int tag, double flops, double bytes) : stream(s) {
         if (!g_prof.on) return;
@@ -56,13 +57,16 @@ struct ProfScope {
         if (!g_prof.on || (int)g_prof.rec.size() >= g_prof.cap) return;
         slot = (int)g_prof.rec.size();
         s3r_prof_record r;
-        r.family = family; r.tag = tag; r.ms = 0.f; r.flops = flops; r.bytes = bytes;
+        r.family = family; r.tag = tag; r.ms = 0.f; r.flops = flops; r.bytes = bytes; r.launches = 1;
         g_prof.rec.push_back(r);
         active = true;
         (void)hipEventRecord(g_prof.ev[2 * slot], stream);
     }
     ~ProfScope() {
-        if (active) (void)hipEventRecord(g_prof.ev[2 * slot + 1], stream);
+        if (!active) return;
+        (void)hipEventRecord(g_prof.ev[2 * slot + 1], stream);
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        if (slot < (int)g_prof.rec.size()) g_prof.rec[slot].launches = launches;
     }
 };
 
@@ -371,6 +375,7 @@ int conv_head_fused(const s3r_conv_desc* d, const Geo& g, const s3r_conv_desc* h
     ProfScope ps(s, F_MFMA, d->tag, g.flops + hg.flops, g.bytes - 4.0 * d->batch * d->cout * (double)g.out_sp +
                  4.0 * d->batch * (double)hg.out_sp);
     hipError_t e = s3r::launch_conv_mfma(p, Ln.cfg + 16 * Ln.vec, s);
+    ps.launches = s3r::conv_last_launch_count();
     if (e != hipSuccess) return hip_fail(e, "fused conv+head launch");
     return S3R_OK;
 }
@@ -514,6 +519,7 @@ int s3r_conv_forward(const s3r_conv_desc* d, const void* xv, const void* packed_
                 }
                 ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
                 e = s3r::launch_conv_bf16(p, L.tm, s);
+                ps.launches = L.ksplit > 1 ? 2 : 1;
                 break;
             }
             default: return fail(S3R_ERR_INVALID, "layer not available on the bf16 path");
@@ -558,6 +564,7 @@ int s3r_conv_forward(const s3r_conv_desc* d, const void* xv, const void* packed_
             }
             ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
             e = s3r::launch_conv_mfma(p, L.cfg + 16 * L.vec, s);
+            ps.launches = s3r::conv_last_launch_count();
             break;
         }
     }

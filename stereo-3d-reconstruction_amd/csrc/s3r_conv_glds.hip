@@ -528,7 +528,11 @@ static hipError_t launch_vec(const ConvParams& p, int vec, hipStream_t stream) {
     }
 }
 
+static thread_local int g_launch_count = 0;
+int conv_last_launch_count() { return g_launch_count; }
+
 static hipError_t launch_tile(const ConvParams& p, int cfg, int vec, hipStream_t stream) {
+    g_launch_count += p.ksplit > 1 ? 2 : 1;
     switch (cfg) {
         case 0: return launch_vec<2, 2, 2, 2>(p, vec, stream);
         case 1: return launch_vec<1, 4, 2, 2>(p, vec, stream);
@@ -572,6 +576,7 @@ static bool plan_tail_cut(const ConvParams& p, int cfg, int* n_cut) {
 // code = tile_cfg (15 = heuristic) + 16 * forced_vec (0 = widest legal)
 hipError_t launch_conv_mfma(const ConvParams& pin, int code, hipStream_t stream) {
     ConvParams p = pin;
+    g_launch_count = 0;
     int cfg = code & 15;
     int vec = code >> 4;
     if (cfg == 15) cfg = conv_pick_tile(p);

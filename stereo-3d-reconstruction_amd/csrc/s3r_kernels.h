@@ -79,6 +79,7 @@ int conv_pick_vec(const ConvParams& p);
 int conv_pick_ksplit(const ConvParams& p, int tile_cfg);
 int64_t conv_scratch_elems(const ConvParams& p, int tile_cfg);
 int conv_num_tiles();
+int conv_last_launch_count();     // kernel launches the calling thread's last launch_conv_mfma made
 void conv_tile_dims(int tile_cfg, int* bm, int* bn);
 hipError_t launch_pack_conv(const float* w, float* wp, int Cin, int Cout, int CoutPad, int T, int transposed,
                             hipStream_t s);

@@ -32,7 +32,7 @@ def test_header_symbols_all_exported(s3r, lib):
 def test_struct_layouts_match_header(s3r):
     assert C.sizeof(s3r._lib.ConvDesc) == 16 * 4
     assert C.sizeof(s3r._lib.Layer) == 16 * 4 + 3 * 8
-    assert C.sizeof(s3r._lib.ProfRecord) == 32
+    assert C.sizeof(s3r._lib.ProfRecord) == 32      # 4 x 4 bytes + 2 doubles
 
 
 def _desc(s3r, layer, batch, n):

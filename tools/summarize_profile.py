@@ -75,8 +75,8 @@ def main():
         w.writerow(["kernel", "occurrence"] + names)
         for (k, i), v in sorted(per.items()):
             w.writerow([k, i] + [v.get(c, "") for c in names])
-    # ---- traffic per bench step (profile.sh's PMC passes run 1 warm-up + 3 timed steps = 4 identical steps)
-    steps = 4
+    # ---- traffic per forward pass; the PMC passes' forward count = number of stem_kernel dispatches
+    steps = max(1, sum(1 for (k, _), v in per.items() if k.startswith("stem_kernel") and "FETCH_SIZE" in v))
     fam = [v for (k, _), v in per.items() if k.startswith(FAMILY)]
     launches = len(fam)
     fetch = sum(v.get("FETCH_SIZE", 0) for v in fam) * 1024
