@@ -153,6 +153,8 @@ def main():
             dist.all_gather_into_tensor(gathered, y)      # eval collation over xGMI (RCCL)
         return y
 
+    if world > 1:          # build the RCCL communicator outside the timed region even when --warmup 0
+        dist.all_gather_into_tensor(gathered, torch.zeros(out_shape, dtype=torch.float32, device=dev))
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

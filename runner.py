@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--weights", default=None, help="checkpoint (.pth) to load")
     ap.add_argument("--keymap", default=None, help="JSON: reference state_dict key -> this build's key")
     ap.add_argument("--data", default=None, help=".npz with left, right, volume; default: synthetic")
+    ap.add_argument("--dataset-root", default=None,
+                    help="StereoShapeNet root (ShapeNetStereoRendering/ + ShapeNetVox32/, README.md:73-77)")
     ap.add_argument("--samples", type=int, default=64, help="synthetic eval list length")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--seed", type=int, default=0)
@@ -58,17 +60,22 @@ def main():
         s3r.seed_module(model, args.seed)
     model.to(dev)
 
-    if args.data:
+    if args.dataset_root:
+        ds = s3r.data.StereoShapeNet(args.dataset_root)
+        res = s3r.evaluate.test_dataset(model, ds, batch=args.batch, device=dev)
+        left = None
+    elif args.data:
         z = np.load(args.data)
         left, right, gt = (torch.from_numpy(z[k]).float() for k in ("left", "right", "volume"))
     else:
         left, right, gt = s3r.evaluate.synthetic_eval_set(args.samples, args.seed)
-    res = s3r.evaluate.test_net(model, left, right, gt, batch=args.batch, device=dev)
+    if left is not None:
+        res = s3r.evaluate.test_net(model, left, right, gt, batch=args.batch, device=dev)
     if rank == 0:
         print(json.dumps({"samples": res["samples"], "n_gpus": world, "thresholds": res["thresholds"],
                           "mean_iou": [round(x, 6) for x in res["mean_iou"]],
                           "weights": args.weights or f"seeded random init (seed {args.seed})",
-                          "data": args.data or "synthetic"}))
+                          "data": args.dataset_root or args.data or "synthetic"}))
     if world > 1:
         dist.destroy_process_group()
 

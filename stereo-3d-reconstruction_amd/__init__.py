@@ -8,7 +8,7 @@ reference's model code is not in the mount (/root/reference/README.md:5).
 Importing this package never touches the GPU and never loads the oracle; the HIP library
 (csrc/libs3r_hip.so) is loaded on first use and its absence is a hard error.
 """
-from . import arch_spec, checkpoint, collate, evaluate
+from . import arch_spec, checkpoint, collate, data, evaluate
 from .graph import GraphedForward, PrefetchingLoader
 from ._lib import S3RError, LIB_PATH, load as load_library, profile_enable, profile_read, profile_reset
 from .init import seed_module, seeded_state_dict, synthetic_pairs
@@ -16,7 +16,7 @@ from .modules import (ChamferDistance, CostVolume, Decoder, Encoder, PointHead, 
                       VolumeEncoder, chamfer_distance, cost_volume, decoder, encoder, voxel_iou)
 
 __all__ = [
-    "GraphedForward", "PrefetchingLoader", "arch_spec", "checkpoint", "collate", "evaluate", "S3RError", "LIB_PATH", "load_library", "profile_enable", "profile_read", "profile_reset",
+    "GraphedForward", "PrefetchingLoader", "arch_spec", "checkpoint", "collate", "data", "evaluate", "S3RError", "LIB_PATH", "load_library", "profile_enable", "profile_read", "profile_reset",
     "seed_module", "seeded_state_dict", "synthetic_pairs",
     "Encoder", "CostVolume", "Decoder", "VolumeEncoder", "PointHead", "Stereo2Voxel", "Stereo2Point",
     "ChamferDistance", "chamfer_distance", "voxel_iou", "encoder", "cost_volume", "decoder",

@@ -1,0 +1,96 @@
+"""Input pipeline of the path: StereoShapeNet files -> (left, right, volume) batches.
+
+File layout as the reference's config documents it (/root/reference/README.md:73-77):
+    LEFT_RENDERING_PATH   <root>/ShapeNetStereoRendering/<taxonomy>/<model>/render_%02d_l.png
+    RIGHT_RENDERING_PATH  <root>/ShapeNetStereoRendering/<taxonomy>/<model>/render_%02d_r.png
+    LEFT/RIGHT_DISP_PATH  .../disp_%02d_{l,r}.exr          (ground-truth disparity: NOT read here — EXR needs
+                                                            pyexr/OpenEXR, absent from this image, and the
+                                                            forward path does not consume it)
+    VOLUME_PATH           <root>/ShapeNetVox32/<taxonomy>/<model>.mat
+
+The reference's own transforms (crop / background / normalisation constants) are on unmounted branches
+(SURVEY.md §0), so the ones here are build-specified and stated: RGBA renders are composited over a white
+background, scaled to [0,1], resized to 224x224 (bilinear) when they are not already.  Decoding is host
+work; batches are handed to the GPU through graph.PrefetchingLoader so the copy overlaps the forward.
+"""
+from __future__ import annotations
+
+import os
+import re
+from typing import Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+IMG = 224
+RENDER_DIR, VOLUME_DIR = "ShapeNetStereoRendering", "ShapeNetVox32"
+_VIEW = re.compile(r"render_(\d+)_l\.png$")
+
+
+def _load_png(path: str) -> np.ndarray:
+    try:
+        from PIL import Image
+    except ImportError as e:                              # pragma: no cover
+        raise RuntimeError("decoding PNG renders needs Pillow") from e
+    with Image.open(path) as im:
+        im = im.convert("RGBA")
+        if im.size != (IMG, IMG):
+            im = im.resize((IMG, IMG), Image.BILINEAR)
+        a = np.asarray(im, dtype=np.float32) / 255.0
+    rgb, alpha = a[..., :3], a[..., 3:4]
+    return (rgb * alpha + (1.0 - alpha)).transpose(2, 0, 1).copy()          # white background, CHW
+
+
+def _load_volume(path: str) -> np.ndarray:
+    from scipy.io import loadmat
+    m = loadmat(path)
+    for k, v in m.items():
+        if not k.startswith("__") and isinstance(v, np.ndarray) and v.ndim == 3:
+            if v.shape != (32, 32, 32):
+                raise RuntimeError(f"{path}: volume {k} has shape {v.shape}, expected 32^3")
+            return (v > 0).astype(np.float32)
+    raise RuntimeError(f"{path}: no 3D array found")
+
+
+class StereoShapeNet(torch.utils.data.Dataset):
+    """One item per (taxonomy, model, view): left, right (3,224,224) float32 in [0,1], volume (32,32,32) {0,1}."""
+
+    def __init__(self, root: str, taxonomies: Optional[Sequence[str]] = None, views: Optional[Sequence[int]] = None):
+        rdir = os.path.join(root, RENDER_DIR)
+        if not os.path.isdir(rdir):
+            raise FileNotFoundError(f"{rdir} not found (expected the layout of README.md:73-77 under {root})")
+        self.root, self.items = root, []
+        for tax in sorted(os.listdir(rdir)):
+            if taxonomies is not None and tax not in taxonomies:
+                continue
+            tdir = os.path.join(rdir, tax)
+            if not os.path.isdir(tdir):
+                continue
+            for model in sorted(os.listdir(tdir)):
+                mdir = os.path.join(tdir, model)
+                vol = os.path.join(root, VOLUME_DIR, tax, model + ".mat")
+                if not os.path.isdir(mdir) or not os.path.exists(vol):
+                    continue
+                for f in sorted(os.listdir(mdir)):
+                    m = _VIEW.match(f)
+                    if m and (views is None or int(m.group(1)) in views) and \
+                            os.path.exists(os.path.join(mdir, f.replace("_l.png", "_r.png"))):
+                        self.items.append((tax, model, int(m.group(1))))
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        tax, model, view = self.items[i]
+        mdir = os.path.join(self.root, RENDER_DIR, tax, model)
+        left = _load_png(os.path.join(mdir, "render_%02d_l.png" % view))
+        right = _load_png(os.path.join(mdir, "render_%02d_r.png" % view))
+        vol = _load_volume(os.path.join(self.root, VOLUME_DIR, tax, model + ".mat"))
+        return torch.from_numpy(left), torch.from_numpy(right), torch.from_numpy(vol)
+
+
+def batches(ds: StereoShapeNet, batch: int, indices: Optional[Sequence[int]] = None, workers: int = 0
+            ) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+    """Sequential (left, right, volume) host batches over `indices` (default: the whole set)."""
+    sub = ds if indices is None else torch.utils.data.Subset(ds, list(indices))
+    yield from torch.utils.data.DataLoader(sub, batch_size=batch, shuffle=False, num_workers=workers, pin_memory=False)

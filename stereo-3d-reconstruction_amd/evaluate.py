@@ -32,6 +32,34 @@ def synthetic_eval_set(n: int, seed: int = 0) -> Tuple[torch.Tensor, torch.Tenso
 
 
 @torch.no_grad()
+def test_dataset(model, ds, batch: int = 32, thresholds: Sequence[float] = THRESHOLDS, device="cuda", group=None,
+                 workers: int = 0) -> Dict[str, object]:
+    """test_net over a data.StereoShapeNet: each rank decodes and evaluates only its shard_bounds slice of the item
+    list, host batches cross PCIe on a copy stream while the previous batch runs (graph.PrefetchingLoader), and the
+    per-sample IoUs are all-gathered in list order."""
+    import torch.distributed as dist
+    from . import data as _data
+    from .graph import PrefetchingLoader
+    dist_on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if dist_on else 1
+    rank = dist.get_rank(group) if dist_on else 0
+    total = len(ds)
+    b0, e0 = collate.shard_bounds(total, world, rank)
+    ious = torch.empty((e0 - b0, len(thresholds)), dtype=torch.float32, device=device)
+    host = _data.batches(ds, batch, range(b0, e0), workers)
+    done = 0
+    for l, r, g in PrefetchingLoader(host, device):
+        pred = model(l, r)
+        for j, t in enumerate(thresholds):
+            ious[done:done + l.shape[0], j] = voxel_iou(pred, g, t)
+        done += l.shape[0]
+    if dist_on:
+        ious = collate.all_gather_ragged(ious, total, group)
+    mean = ious.mean(0).cpu().tolist() if total else [float("nan")] * len(thresholds)
+    return {"samples": total, "thresholds": list(thresholds), "mean_iou": mean, "per_sample": ious.cpu()}
+
+
+@torch.no_grad()
 def test_net(model, left: torch.Tensor, right: torch.Tensor, gt: torch.Tensor, batch: int = 32,
              thresholds: Sequence[float] = THRESHOLDS, device="cuda", group=None) -> Dict[str, object]:
     """Mean IoU per threshold over the eval list.  With torch.distributed initialised every rank

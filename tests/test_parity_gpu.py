@@ -435,3 +435,17 @@ def test_prefetching_loader_order_and_values(s3r, models):
     outs = [hip(l, r).clone() for l, r in s3r.PrefetchingLoader(batches, DEV)]
     for (l, r), o in zip(batches, outs):
         assert torch.equal(o, hip(l.to(DEV), r.to(DEV)))
+
+
+def test_dataset_eval_matches_tensor_eval(s3r, models, tmp_path):
+    """evaluate.test_dataset (PNG/MAT decode -> PrefetchingLoader -> HIP forward -> device IoU) equals
+    evaluate.test_net on the same decoded tensors."""
+    from tests.test_data_cpu import _make_tree
+    hip, _ = models
+    _make_tree(str(tmp_path), n_models=3, views=(0,), size=224)
+    ds = s3r.data.StereoShapeNet(str(tmp_path))
+    a = s3r.evaluate.test_dataset(hip, ds, batch=2, device=DEV)
+    items = [ds[i] for i in range(len(ds))]
+    left, right, gt = (torch.stack([it[k] for it in items]) for k in range(3))
+    b = s3r.evaluate.test_net(hip, left, right, gt, batch=2, device=DEV)
+    assert a["samples"] == 3 and torch.equal(a["per_sample"], b["per_sample"])
