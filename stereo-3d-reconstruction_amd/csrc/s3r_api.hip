@@ -317,7 +317,7 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
     // 1x1 single-channel head, runs the head inside its epilogue; its own output is never materialised
     for (int i = 0; i + 1 < n; ++i) {
         if (pl->r[i] != R_MFMA || pl->r[i + 1] != R_HEAD || pl->d[i].cout > 64) continue;
-        if (pl->d[i + 1].cin != pl->d[i].cout || pl->d[i].out_halo != 0) continue;
+        if (pl->d[i + 1].cin != pl->d[i].cout || pl->d[i].out_halo != 0 || pl->d[i].act == S3R_ACT_SIGMOID) continue;
         if (pl->d[i].dtype == S3R_BF16) {
             s3r::ConvParamsH ph = make_params_h(&pl->d[i], pl->g[i]);
             LaunchH Lh;

@@ -35,6 +35,7 @@
 // no zero-stuffed taps.
 #include "s3r_kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace s3r {
 
@@ -67,6 +68,20 @@ __device__ __forceinline__ void dma_to_lds(__amdgpu_buffer_rsrc_t rsrc, float* l
 
 constexpr int GBK = 16;   // K tile depth: one tap x 16 input channels
 
+// activation with the kind resolved at compile time: the epilogue is instantiated once per kind and entered
+// through ONE wave-uniform switch, instead of branching on p.act for every output element (the branchy form
+// was 3800 instructions and 20-25 % of a workgroup's lifetime: tools/timeline.py)
+template <int ACT>
+__device__ __forceinline__ float act_fn(float t) {
+    if constexpr (ACT == ACT_RELU) return fmaxf(t, 0.f);
+    else if constexpr (ACT == ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.f + __expf(-t));
+    else return t;
+}
+
+#ifdef S3R_ABLATE
+// S3R_ABL=7: per-workgroup timeline stamps (s_memrealtime, 100 MHz): [cu key, start, loop start, loop end, end]
+__device__ unsigned long long s3r_timeline[6 * 65536];
+#endif
 #ifdef S3R_ABLATE   // diagnostic builds only: S3R_ABL=1 no epilogue stores, 2 one K tile only, 3 no DMA in the loop
 static int abl_mode() { static const int m = getenv("S3R_ABL") ? atoi(getenv("S3R_ABL")) : 0; return m; }
 #define S3R_ABL(p, m) ((p).debug == (m))
@@ -108,6 +123,10 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int j = lane & 31, h = lane >> 5;
+#ifdef S3R_ABLATE
+    unsigned long long tl0 = 0, tl1 = 0, tl2 = 0;
+    if (p.debug == 7) tl0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a
     // contiguous run of tiles so neighbouring N tiles find their shared input rows in that XCD's L2.
@@ -200,6 +219,9 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+#ifdef S3R_ABLATE
+    if (p.debug == 7) tl1 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int a_off = h * BM + wm * TM * 32 + j * TM;
     const int b_off = h * BN + wn * TN * 32 + j * TN;
     typedef typename FVec<TM>::type AV;
@@ -226,6 +248,25 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
         __syncthreads();                                    // ... everyone's have, and buffer `cur` is free
     }
 
+#ifdef S3R_ABLATE
+    if (p.debug == 7) tl2 = __builtin_amdgcn_s_memrealtime();
+    struct TlGuard {
+        const ConvParams& p; unsigned long long a, b, c; int tid;
+        __device__ ~TlGuard() {
+            if (p.debug == 7 && tid == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 65536) {
+                const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
+                unsigned xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                unsigned long long* t = s3r_timeline + 6 * (size_t)blockIdx.x;
+                t[5] = t_issued;
+                t[0] = ((unsigned long long)(xcc & 15u) << 8) | ((hw >> 8) & 0xffu);
+                t[1] = a; t[2] = b; t[3] = c; t[4] = __builtin_amdgcn_s_memrealtime();
+            }
+        }
+    } tl_guard{p, tl0, tl1, tl2, tid};
+#endif
     // ---- split-K: raw partial sums to the scratch slab [cls][kz][cout][n] (n = GEMM position index,
     // padded to whole N tiles so no lane needs a bounds check); s3r::launch_conv_finish reduces the slabs
     // in kz order and applies the epilogue.
@@ -249,6 +290,20 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
         }
         return;
     }
+
+    // ---- per-cout epilogue constants through LDS.  vmcnt retires in issue order and counts stores, so a
+    // scale/shift load issued between two stores would wait for every earlier store to LAND (measured with
+    // tools/timeline.py: the epilogue took 100 us of a 470 us workgroup on v1 that way).  LDS reads wait on lgkmcnt.
+    float* ep_sc = smem;            // [BM]
+    float* ep_sf = smem + BM;       // [BM]
+    float* ep_hw = smem + 2 * BM;   // [BM] fused-head weights (0 for padded couts)
+    if (tid < BM) {
+        const int m = m0 + tid;
+        ep_sc[tid] = (p.scale && m < p.Cout) ? p.scale[m] : 1.f;
+        ep_sf[tid] = (p.shift && m < p.Cout) ? p.shift[m] : 0.f;
+        ep_hw[tid] = (p.head_w && m < p.Cout) ? p.head_w[m] : 0.f;
+    }
+    __syncthreads();
 
     // ---- epilogue: y = act(acc * scale[cout] + shift[cout]) into the (halo-padded) NC(D)HW output;
     // a lane's TN positions are consecutive in one output row when Nw % TN == 0 (convolutions).
@@ -278,70 +333,84 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
     // (the largest activation of the network) is never written to or re-read from HBM.
     if (p.head_w) {
         if constexpr (WM == 1) {
-            float part[TN];
+            {   // (the planner fuses only ReLU / identity convs: one copy of this loop)
+                const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+                float part[TN];
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) part[tn] = 0.f;
+                for (int tn = 0; tn < TN; ++tn) part[tn] = 0.f;
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+                for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = ((r & 3) + 8 * (r >> 2) + 4 * h) * TM + tm;
-                    if (m >= p.Cout) continue;
-                    const float sc = p.scale ? p.scale[m] : 1.f, sf = p.shift ? p.shift[m] : 0.f, hw = p.head_w[m];
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = ((r & 3) + 8 * (r >> 2) + 4 * h) * TM + tm;
+                        const float hw = ep_hw[m];                            // 0 for padded couts
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) {
-                        float t = fmaf(acc[tm][tn][r], sc, sf);
-                        if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
-                        else if (p.act == ACT_SIGMOID) t = 1.f / (1.f + __expf(-t));
-                        part[tn] = fmaf(t, hw, part[tn]);
-                    }
+                        for (int tn = 0; tn < TN; ++tn) {
+                            const float t = fmaf(acc[tm][tn][r], ep_sc[m], ep_sf[m]);
+                            part[tn] = fmaf(fmaxf(t, lo), hw, part[tn]);
+                        }
+                        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads of later rows from
+                    }                                                          // being hoisted (and spilled) up front
+                const float hsc = p.head_scale ? p.head_scale[0] : 1.f, hsf = p.head_shift ? p.head_shift[0] : 0.f;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    float t = part[tn] + __shfl_xor(part[tn], 32, 64);       // the other 32 couts live in lane j+32
+                    t = fmaf(t, hsc, hsf);
+                    if (p.head_act == ACT_RELU) t = fmaxf(t, 0.f);
+                    else if (p.head_act == ACT_SIGMOID) t = __builtin_amdgcn_rcpf(1.f + __expf(-t));
+                    if (h == 0 && yok[tn]) p.y[yoff[tn]] = t;
                 }
-            const float hsc = p.head_scale ? p.head_scale[0] : 1.f, hsf = p.head_shift ? p.head_shift[0] : 0.f;
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                float t = part[tn] + __shfl_xor(part[tn], 32, 64);       // the other 32 couts live in lane j+32
-                t = fmaf(t, hsc, hsf);
-                if (p.head_act == ACT_RELU) t = fmaxf(t, 0.f);
-                else if (p.head_act == ACT_SIGMOID) t = 1.f / (1.f + __expf(-t));
-                if (h == 0 && yok[tn]) p.y[yoff[tn]] = t;
             }
         }
         return;
     }
+
+    // ---- stores.  The per-element work is branch-free: ReLU / identity is one v_max against a wave-uniform
+    // floor (0 or -inf); the (rare) sigmoid layers take a separate copy of the loop chosen by ONE wave-uniform
+    // branch.  The branchy form (3-way p.act test + IEEE divide per element) was 3800 instructions and 20-25 %
+    // of a workgroup's lifetime (tools/timeline.py).
+#if defined(S3R_ABLATE) && defined(__HIP_DEVICE_COMPILE__)
+    if (S3R_ABL(p, 1)) {       // timing-only build: no stores, accumulators kept live
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * TM * 32 + ((r & 3) + 8 * (r >> 2) + 4 * h) * TM + tm;
-            if (m >= p.Cout) continue;
-            const float sc = p.scale ? p.scale[m] : 1.f;
-            const float sf = p.shift ? p.shift[m] : 0.f;
-            float v[TN];
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                float t = fmaf(acc[tm][tn][r], sc, sf);
-                if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
-                else if (p.act == ACT_SIGMOID) t = 1.f / (1.f + __expf(-t));
-                v[tn] = t;
-            }
-            float* __restrict__ yrow = p.y + (size_t)m * p.y_cs;
-            if (S3R_ABL(p, 1) && v[0] != 12345.f) continue;
-            if (TN > 1 && vec_ok && yok[TN - 1]) {
-                // dword-aligned (not 16-B aligned) vector store: legal for global memory on gfx950
-                if constexpr (TN == 2) {
-                    const v2f t = {v[0], v[1]};
-                    *reinterpret_cast<v2f_u*>(yrow + yoff[0]) = t;
-                } else if constexpr (TN == 4) {
-                    const v4f t = {v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<v4f_u*>(yrow + yoff[0]) = t;
-                }
-            } else {
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    if (yok[tn]) yrow[yoff[tn]] = v[tn];
-            }
-        }
+            for (int tn = 0; tn < TN; ++tn) asm volatile("" ::"v"(acc[tm][tn]));
+        return;
     }
+#endif
+    const bool lane_vec = TN > 1 && vec_ok && yok[TN - 1];
+    const int mbase = wm * TM * 32 + 4 * h * TM;
+    const int mlimit = p.Cout - (m0 + mbase);                  // rows dm >= mlimit are padding
+    float* __restrict__ ybase = p.y + (size_t)(m0 + mbase) * p.y_cs;
+    auto rows = [&](auto sig_tag) {
+        constexpr bool SIG = decltype(sig_tag)::value;
+        const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dm = ((r & 3) + 8 * (r >> 2)) * TM + tm;              // compile-time row offset
+                if (dm >= mlimit) continue;
+                const float sc = ep_sc[mbase + dm], sf = ep_sf[mbase + dm];
+                float v[TN];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const float t = fmaf(acc[tm][tn][r], sc, sf);
+                    v[tn] = SIG ? act_fn<ACT_SIGMOID>(t) : fmaxf(t, lo);
+                }
+                float* __restrict__ yrow = ybase + (size_t)dm * p.y_cs;
+                if (lane_vec) {                    // dword-aligned (not 16-B aligned) vector store: legal on gfx950
+                    if constexpr (TN == 2) { const v2f t = {v[0], v[1]}; *reinterpret_cast<v2f_u*>(yrow + yoff[0]) = t; }
+                    else if constexpr (TN == 4) { const v4f t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<v4f_u*>(yrow + yoff[0]) = t; }
+                } else {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        if (yok[tn]) yrow[yoff[tn]] = v[tn];
+                }
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+    if (p.act == ACT_SIGMOID) rows(std::true_type{}); else rows(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -590,7 +659,7 @@ hipError_t launch_conv_mfma(const ConvParams& pin, int code, hipStream_t stream)
         int bm, bn;
         conv_tile_dims(cfg, &bm, &bn);
         const bool wm1 = cfg == 1 || cfg == 2 || cfg == 5 || cfg == 7;
-        if (!wm1 || bm < p.Cout || p.ksplit != 1) return hipErrorInvalidValue;
+        if (!wm1 || bm < p.Cout || p.ksplit != 1 || p.act == ACT_SIGMOID) return hipErrorInvalidValue;
     }
 #ifdef S3R_ABLATE
     p.debug = abl_mode();
@@ -651,4 +720,12 @@ hipError_t launch_pack_conv(const float* w, float* wp, int Cin, int Cout, int Co
     return hipGetLastError();
 }
 
+#ifdef S3R_ABLATE
+}  // namespace s3r
+extern "C" int s3r_debug_read_timeline(unsigned long long* out, int nblocks) {
+    if (nblocks > 65536) nblocks = 65536;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(s3r::s3r_timeline), sizeof(unsigned long long) * 6 * (size_t)nblocks) == hipSuccess ? nblocks : -1;
+}
+namespace s3r {
+#endif
 }  // namespace s3r
