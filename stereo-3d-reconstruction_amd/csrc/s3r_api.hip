@@ -231,6 +231,7 @@ s3r::ConvParams make_params(const s3r_conv_desc* d, const Geo& g) {
     p.y_org = d->out_halo * (p.y_ds + p.y_hs + 1);
     p.y_bs = d->cout * p.y_cs;
     p.x_bytes = (unsigned)(g.x_elems * 4);
+    p.y_bytes = (unsigned)(g.y_elems * 4);
     if (d->op == S3R_OP_DECONV) {
         p.transposed = 1;
         p.Nd = g.in; p.Nh = g.in; p.Nw = g.in;
@@ -361,6 +362,7 @@ int conv_head_fused(const s3r_conv_desc* d, const Geo& g, const s3r_conv_desc* h
     p.y_hs = hg.out_p; p.y_ds = is3 ? hg.out_p * hg.out_p : 0; p.y_cs = (int)ipow(hg.out_p, hg.nd);
     p.y_bs = p.y_cs;
     p.y_org = hd->out_halo * (p.y_ds + p.y_hs + 1);
+    p.y_bytes = (unsigned)(hg.y_elems * 4);
     p.head_w = static_cast<const float*>(H.packed_w); p.head_scale = H.scale; p.head_shift = H.shift; p.head_act = hd->act;
     Launch Ln;
     int rc = resolve_launch(d, &p, &Ln);

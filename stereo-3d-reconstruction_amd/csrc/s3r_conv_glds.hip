@@ -44,6 +44,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned vector access
 typedef float v2f_u __attribute__((ext_vector_type(2), aligned(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 #define S3R_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -381,7 +383,13 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
     const bool lane_vec = TN > 1 && vec_ok && yok[TN - 1];
     const int mbase = wm * TM * 32 + 4 * h * TM;
     const int mlimit = p.Cout - (m0 + mbase);                  // rows dm >= mlimit are padding
-    float* __restrict__ ybase = p.y + (size_t)(m0 + mbase) * p.y_cs;
+    // buffer stores: per-lane 32-bit byte offset in a VGPR (computed once), the row's cout offset in the SGPR
+    // soffset -> no per-row address VALU and no 64-bit row pointers to keep (or spill) across the loop
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
+    int yvo[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) yvo[tn] = (yoff[tn] + (m0 + mbase) * p.y_cs) * 4;
+    const int row_bytes = p.y_cs * 4;
     auto rows = [&](auto sig_tag) {
         constexpr bool SIG = decltype(sig_tag)::value;
         const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
@@ -398,14 +406,19 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
                     const float t = fmaf(acc[tm][tn][r], sc, sf);
                     v[tn] = SIG ? act_fn<ACT_SIGMOID>(t) : fmaxf(t, lo);
                 }
-                float* __restrict__ yrow = ybase + (size_t)dm * p.y_cs;
+                const int so = dm * row_bytes;
                 if (lane_vec) {                    // dword-aligned (not 16-B aligned) vector store: legal on gfx950
-                    if constexpr (TN == 2) { const v2f t = {v[0], v[1]}; *reinterpret_cast<v2f_u*>(yrow + yoff[0]) = t; }
-                    else if constexpr (TN == 4) { const v4f t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<v4f_u*>(yrow + yoff[0]) = t; }
+                    if constexpr (TN == 2) {
+                        const v2f t = {v[0], v[1]};
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, t), yrsrc, yvo[0], so, 0);
+                    } else if constexpr (TN == 4) {
+                        const v4f t = {v[0], v[1], v[2], v[3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), yrsrc, yvo[0], so, 0);
+                    }
                 } else {
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        if (yok[tn]) yrow[yoff[tn]] = v[tn];
+                        if (yok[tn]) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[tn]), yrsrc, yvo[tn], so, 0);
                 }
                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }

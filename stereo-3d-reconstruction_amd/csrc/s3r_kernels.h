@@ -26,6 +26,7 @@ struct ConvParams {
     int y_bs;             // output batch stride (Cout * y_cs; the fused head's single-channel output: y_cs)
     int y_org;            // element offset of output (0,0,0): halo_out per axis
     unsigned x_bytes;     // size of the input buffer (buffer descriptor range)
+    unsigned y_bytes;     // size of the output buffer
     int transposed;       // 0: convolution, 1: ConvTranspose3d(k=4,s=2,p=1) split into 8 parity classes
     int act;              // 0 none, 1 relu, 2 sigmoid
     int Ntotal;           // B*Nd*Nh*Nw
