@@ -199,6 +199,11 @@ s3r::ConvParamsH make_params_h(const s3r_conv_desc* d, const Geo& g) {
         p.x_org = (d->in_halo - d->pad) * (p.x_ds + p.x_hs + p.x_ws);
     }
     p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
+    p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
+    p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
+    p.dW = s3r::FastDiv((unsigned)p.Nw);
+    p.dDH = s3r::FastDiv((unsigned)(p.Nd * p.Nh));
+    p.dH = s3r::FastDiv((unsigned)p.Nh);
     p.ksplit = 1;
     return p;
 }
@@ -246,6 +251,9 @@ s3r::ConvParams make_params(const s3r_conv_desc* d, const Geo& g) {
         p.x_org = (d->in_halo - d->pad) * (p.x_ds + p.x_hs + 1);
     }
     p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
+    p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
+    p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
+    p.dW = s3r::FastDiv((unsigned)p.Nw);
     p.ksplit = 1;
     return p;
 }

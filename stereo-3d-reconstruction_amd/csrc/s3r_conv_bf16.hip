@@ -77,6 +77,9 @@ __device__ __forceinline__ void epilogue_h(const ConvParamsH& p, f32x16 (&acc)[T
     const bool c0 = co < p.Cout, c1 = co + 1 < p.Cout;
     const float sc0 = (c0 && p.scale) ? p.scale[co] : 1.f, sf0 = (c0 && p.shift) ? p.shift[co] : 0.f;
     const float sc1 = (c1 && p.scale) ? p.scale[co + 1] : 1.f, sf1 = (c1 && p.shift) ? p.shift[co + 1] : 0.f;
+    // ReLU / identity as ONE v_max against a wave-uniform floor; sigmoid (rare) behind a wave-uniform flag
+    const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+    const bool sig = p.act == ACT_SIGMOID;
     if (p.head_w) {
         // fused pointwise head (conv -> 1x1x1 conv to ONE channel + activation; the workgroup's 64-cout tile
         // is the whole channel axis): per position, 2 FMAs in the lane, a 32-lane butterfly over the couts, one
@@ -88,9 +91,7 @@ __device__ __forceinline__ void epilogue_h(const ConvParamsH& p, f32x16 (&acc)[T
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v0 = fmaf(acc[tm][0][r], sc0, sf0), v1 = fmaf(acc[tm][1][r], sc1, sf1);
-                if (p.act == ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                else if (p.act == ACT_SIGMOID) { v0 = 1.f / (1.f + __expf(-v0)); v1 = 1.f / (1.f + __expf(-v1)); }
+                float v0 = fmaxf(fmaf(acc[tm][0][r], sc0, sf0), lo), v1 = fmaxf(fmaf(acc[tm][1][r], sc1, sf1), lo);
                 float t = fmaf(v1, hw1, v0 * hw0);
 #pragma unroll
                 for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);      // over the 32 lanes of this half
@@ -115,8 +116,8 @@ __device__ __forceinline__ void epilogue_h(const ConvParamsH& p, f32x16 (&acc)[T
             if (ye < 0 || !c0) continue;
             float v0 = fmaf(acc[tm][0][r], sc0, sf0), v1 = fmaf(acc[tm][1][r], sc1, sf1);
             if (S3R_ABLH(p, 1) && v0 != 12345.f) continue;
-            if (p.act == ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-            else if (p.act == ACT_SIGMOID) { v0 = 1.f / (1.f + __expf(-v0)); v1 = 1.f / (1.f + __expf(-v1)); }
+            if (sig) { v0 = __builtin_amdgcn_rcpf(1.f + __expf(-v0)); v1 = __builtin_amdgcn_rcpf(1.f + __expf(-v1)); }
+            else { v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); }
             const unsigned pk = pack_bf16(v0, v1);
             if (c1) *reinterpret_cast<unsigned*>(y + (size_t)ye + co) = pk;
             else y[(size_t)ye + co] = (unsigned short)(pk & 0xffffu);
@@ -165,11 +166,11 @@ __global__ __launch_bounds__(256, min_waves_h(TM)) void conv_bf16_kernel(const C
         const int n = m0 + t;
         const bool ok = n < p.Ntotal;
         const int nn = ok ? n : p.Ntotal - 1;
-        const int b = nn / S;
+        const int b = p.dS.div(nn);
         int rem = nn - b * S;
-        const int pd = rem / (p.Nh * p.Nw);
+        const int pd = p.dHW.div(rem);
         rem -= pd * p.Nh * p.Nw;
-        const int ph = rem / p.Nw;
+        const int ph = p.dW.div(rem);
         const int pw = rem - ph * p.Nw;
         int xe = b * p.x_bs + p.x_org + (pd * p.x_ds + ph * p.x_hs + pw * p.x_ws) * p.stride;
         const int ostep = p.transposed ? 2 : 1;
@@ -315,11 +316,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p,
     // ---- geometry of the tile's first position (wave-uniform): its output row and column
     int rowid0, pw0;
     {
-        const int b = m0 / S;
+        const int b = p.dS.div(m0);
         int rem = m0 - b * S;
-        const int pd = rem / (p.Nh * p.Nw);
+        const int pd = p.dHW.div(rem);
         rem -= pd * p.Nh * p.Nw;
-        const int ph = rem / p.Nw;
+        const int ph = p.dW.div(rem);
         pw0 = rem - ph * p.Nw;
         rowid0 = (b * p.Nd + pd) * p.Nh + ph;
     }
@@ -331,11 +332,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p,
         const int n = m0 + t;
         const bool ok = n < p.Ntotal;
         const int nn = ok ? n : p.Ntotal - 1;
-        const int b = nn / S;
+        const int b = p.dS.div(nn);
         int rem = nn - b * S;
-        const int pd = rem / (p.Nh * p.Nw);
+        const int pd = p.dHW.div(rem);
         rem -= pd * p.Nh * p.Nw;
-        const int ph = rem / p.Nw;
+        const int ph = p.dW.div(rem);
         const int pw = rem - ph * p.Nw;
         const int ostep = p.transposed ? 2 : 1;
         int ye = b * p.y_bs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw * p.y_ws) * ostep;
@@ -353,12 +354,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p,
         const int lr = ((wave + 4 * q) << 4) + (lane >> 2);   // LDS row this lane fills in its q-th piece
         int k, off;
         if (lr < seg0) { k = 0; off = lr + p.stride * pw0; }
-        else { k = 1 + (lr - seg0) / segw; off = (lr - seg0) - (k - 1) * segw; }
+        else { k = 1 + (lr - seg0) / segw; off = (lr - seg0) - (k - 1) * segw; }      // (segw depends on kw: plain divide)
         int rowid = rowid0 + k;
         if (rowid > last_row) rowid = last_row;              // past the tensor: any valid address, never read
-        const int b = rowid / (p.Nd * p.Nh);
+        const int b = p.dDH.div(rowid);
         int rem = rowid - b * (p.Nd * p.Nh);
-        const int pd = rem / p.Nh;
+        const int pd = p.dH.div(rem);
         const int ph = rem - pd * p.Nh;
         const int e = b * p.x_bs + p.x_org + (pd * p.x_ds + ph * p.x_hs) * p.stride + off * p.x_ws + cls_x;
         const int kg = (lane & 3) ^ ((lr >> 2) & 3);          // swizzle on the source side
@@ -463,11 +464,11 @@ __global__ __launch_bounds__(256) void conv_finish_bf16_kernel(const ConvParamsH
             const float2 t = *reinterpret_cast<const float2*>(src + (size_t)z * mpad * p.CoutPad);
             s.x += t.x; s.y += t.y;
         }
-        const int b = n / S;
+        const int b = p.dS.div(n);
         int rem = n - b * S;
-        const int pd = rem / (p.Nh * p.Nw);
+        const int pd = p.dHW.div(rem);
         rem -= pd * p.Nh * p.Nw;
-        const int ph = rem / p.Nw;
+        const int ph = p.dW.div(rem);
         const int pw = rem - ph * p.Nw;
         int ye = b * p.y_bs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw * p.y_ws) * ostep;
         if (p.transposed) ye += rd * p.y_ds + rh * p.y_hs + rw * p.y_ws;

@@ -159,11 +159,11 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
         else        { col = (lane % LPR_B) * VEC;           lrow = lane / LPR_B; }
         int n = n0 + col;
         if (n >= p.n_end) n = p.n_end - VEC;            // tail tile: fetch a valid group, never stored
-        const int b = n / S;
+        const int b = p.dS.div(n);
         int rem = n - b * S;
-        const int pd = rem / (p.Nh * p.Nw);
+        const int pd = p.dHW.div(rem);
         rem -= pd * p.Nh * p.Nw;
-        const int ph = rem / p.Nw;
+        const int ph = p.dW.div(rem);
         const int pw = rem - ph * p.Nw;
         int e = b * p.Cin * p.x_cs + p.x_org + (pd * p.x_ds + ph * p.x_hs + pw) * p.stride + lrow * p.x_cs;
         if (p.transposed) e += (rd - 1) * p.x_ds + (rh - 1) * p.x_hs + (rw - 1);
@@ -319,11 +319,11 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
         const int n = nl + tn;
         yok[tn] = n < p.n_end;
         const int nn = yok[tn] ? n : 0;
-        const int b = nn / S;
+        const int b = p.dS.div(nn);
         int rem = nn - b * S;
-        const int pd = rem / (p.Nh * p.Nw);
+        const int pd = p.dHW.div(rem);
         rem -= pd * p.Nh * p.Nw;
-        const int ph = rem / p.Nw;
+        const int ph = p.dW.div(rem);
         const int pw = rem - ph * p.Nw;
         int e = b * p.y_bs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw) * ostep;
         if (p.transposed) e += rd * p.y_ds + rh * p.y_hs + rw;
@@ -452,11 +452,11 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(const ConvParams p, in
         for (int k = 0; k < 4; ++k) {
             const int nn = n + k;
             if (nn >= p.Ntotal) break;
-            const int b = nn / S;
+            const int b = p.dS.div(nn);
             int rem = nn - b * S;
-            const int pd = rem / (p.Nh * p.Nw);
+            const int pd = p.dHW.div(rem);
             rem -= pd * p.Nh * p.Nw;
-            const int ph = rem / p.Nw;
+            const int ph = p.dW.div(rem);
             const int pw = rem - ph * p.Nw;
             int e = b * p.Cout * p.y_cs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw) * ostep;
             if (p.transposed) e += rd * p.y_ds + rh * p.y_hs + rw;

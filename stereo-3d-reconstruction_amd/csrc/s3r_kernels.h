@@ -6,6 +6,21 @@
 
 namespace s3r {
 
+// Division of a non-negative int (< 2^31) by a launch-invariant divisor, as mulhi + add + shift (Granlund &
+// Montgomery): the position decodes of the conv kernels did ~10 integer divisions per thread, ~40 instructions each.
+struct FastDiv {
+    unsigned mul, shr;
+    FastDiv() : mul(1), shr(0) {}
+    explicit FastDiv(unsigned d) {
+        shr = 0;
+        while ((1ull << shr) < d) ++shr;
+        mul = (unsigned)((((1ull << shr) - d) << 32) / d + 1);
+    }
+#if defined(__HIPCC__)
+    __device__ __forceinline__ int div(int n) const { return (int)((__umulhi((unsigned)n, mul) + (unsigned)n) >> shr); }
+#endif
+};
+
 // Kernel-side view of one convolution launch.  All tensors are fp32 NC(D)HW; activations may carry a
 // zero halo of `halo` elements on every spatial axis (padded edge = edge + 2*halo), described here
 // purely by element strides and origin offsets.
@@ -18,6 +33,7 @@ struct ConvParams {
     int B, Cin, Cout, CoutPad;
     int Nd, Nh, Nw;       // per-sample position grid walked by the GEMM N index
                           //   conv: output grid; transposed conv: input grid (one parity class per blockIdx.y)
+    FastDiv dS, dHW, dW;  // fast division by Nd*Nh*Nw, Nh*Nw, Nw
     int kd, kh, kw, T;    // taps per axis and in total (transposed k4s2p1: 2,2,2 per parity class)
     int stride;           // input step per position (transposed: 1)
     int x_cs, x_ds, x_hs; // input element strides: channel, depth, row   (batch stride = Cin * x_cs)
@@ -53,6 +69,7 @@ struct ConvParamsH {
     float* part;          // split-K scratch [cls][ksplit][m_tiles*BM][CoutPad] fp32
     int B, Cin, Cout, CoutPad;            // CoutPad % 64 == 0
     int Nd, Nh, Nw;
+    FastDiv dS, dHW, dW, dDH, dH;         // fast division by Nd*Nh*Nw, Nh*Nw, Nw, Nd*Nh, Nh
     int kd, kh, kw, T;
     int stride;
     int x_bs, x_ds, x_hs, x_ws;           // input element strides: batch, depth, row, position (= Cin)
