@@ -375,7 +375,7 @@ int conv_head_fused(const s3r_conv_desc* d, const Geo& g, const s3r_conv_desc* h
     Launch Ln;
     int rc = resolve_launch(d, &p, &Ln);
     if (rc) return rc;
-    if (!(Ln.cfg == 1 || Ln.cfg == 2 || Ln.cfg == 5 || Ln.cfg == 7) || (Ln.cfg == 2 && d->cout > 32)) {
+    if (!(Ln.cfg == 1 || Ln.cfg == 2 || Ln.cfg == 7) || (Ln.cfg == 2 && d->cout > 32)) {
         // the heuristic's tile splits the couts over waves: take the widest one-wave-tall tile that fills the chip
         int bm, bn;
         s3r::conv_tile_dims(1, &bm, &bn);
@@ -529,7 +529,7 @@ int s3r_conv_forward(const s3r_conv_desc* d, const void* xv, const void* packed_
                 }
                 ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
                 e = s3r::launch_conv_bf16(p, L.tm, s);
-                ps.launches = L.ksplit > 1 ? 2 : 1;
+                ps.launches = 1;
                 break;
             }
             default: return fail(S3R_ERR_INVALID, "layer not available on the bf16 path");

@@ -94,8 +94,9 @@ static int abl_mode() { static const int m = getenv("S3R_ABL") ? atoi(getenv("S3
 // waves per SIMD the register allocator must leave room for: 16*TM*TN accumulator registers + ~48
 constexpr int min_waves(int tm, int tn) { return tm * tn >= 8 ? 2 : (tm * tn >= 4 ? 4 : 5); }
 
-template <int WM, int WN, int TM, int TN, int VEC>
-__global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const ConvParams p) {
+// HEAD: the fused pointwise-head epilogue (its own instantiation: the two epilogues never share registers)
+template <int WM, int WN, int TM, int TN, int VEC, bool HEAD = false>
+__global__ __launch_bounds__(256, min_waves(TM, TN) - (HEAD ? 1 : 0)) void conv_glds_kernel(const ConvParams p) {
     constexpr int BM = 32 * WM * TM;
     constexpr int BN = 32 * WN * TN;
     constexpr int BK = GBK;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
     // ---- split-K: raw partial sums to the scratch slab [cls][kz][cout][n] (n = GEMM position index,
     // padded to whole N tiles so no lane needs a bounds check); s3r::launch_conv_finish reduces the slabs
     // in kz order and applies the epilogue.
-    if (p.ksplit > 1) {
+    if (!HEAD && p.ksplit > 1) {
         const int npad = p.n_tiles * BN;
         float* __restrict__ slab = p.part + ((size_t)(cls * p.ksplit + kz) * p.Cout) * npad + n0 + wn * TN * 32 + j * TN;
 #pragma unroll
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_kernel(const
     // workgroup's M tile holds every cout of its positions inside one wave (WM == 1), so the channel
     // reduction is 16*TM in-lane FMAs + one exchange between the two lane halves; the conv's own output
     // (the largest activation of the network) is never written to or re-read from HBM.
-    if (p.head_w) {
+    if constexpr (HEAD) {
         if constexpr (WM == 1) {
             {   // (the planner fuses only ReLU / identity convs: one copy of this loop)
                 const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
@@ -578,7 +579,7 @@ int conv_pick_vec(const ConvParams& p) {
     return (p.Nw % 4 == 0) ? 4 : 1;   // (there is no 8-byte LDS-DMA)
 }
 
-template <int WM, int WN, int TM, int TN, int VEC>
+template <int WM, int WN, int TM, int TN, int VEC, bool HEAD>
 static hipError_t launch_cfg(ConvParams p, hipStream_t stream) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     if constexpr (GBK * BN % (256 * VEC) != 0 || BN > 256 * VEC) {
@@ -589,12 +590,12 @@ static hipError_t launch_cfg(ConvParams p, hipStream_t stream) {
         const size_t lds = (size_t)2 * GBK * (BM + BN) * sizeof(float);
         if (lds > 48 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation
             static const hipError_t attr = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(&conv_glds_kernel<WM, WN, TM, TN, VEC>),
+                reinterpret_cast<const void*>(&conv_glds_kernel<WM, WN, TM, TN, VEC, HEAD>),
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (attr != hipSuccess) return attr;
         }
         dim3 grid(p.m_tiles * p.n_tiles, p.transposed ? 8 : 1, p.ksplit);
-        hipLaunchKernelGGL((conv_glds_kernel<WM, WN, TM, TN, VEC>), grid, dim3(256), lds, stream, p);
+        hipLaunchKernelGGL((conv_glds_kernel<WM, WN, TM, TN, VEC, HEAD>), grid, dim3(256), lds, stream, p);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess && p.ksplit > 1) e = launch_conv_finish(p, p.n_tiles * BN, stream);
         return e;
@@ -603,9 +604,20 @@ static hipError_t launch_cfg(ConvParams p, hipStream_t stream) {
 
 template <int WM, int WN, int TM, int TN>
 static hipError_t launch_vec(const ConvParams& p, int vec, hipStream_t stream) {
+    if constexpr (WM == 1 && TM * TN <= 4) {      // the head epilogue exists for the one-wave-tall tiles it can use
+        if (p.head_w) {
+            switch (vec) {
+                case 4: return launch_cfg<WM, WN, TM, TN, 4, true>(p, stream);
+                case 1: return launch_cfg<WM, WN, TM, TN, 1, true>(p, stream);
+                default: return hipErrorInvalidValue;
+            }
+        }
+    } else if (p.head_w) {
+        return hipErrorInvalidValue;
+    }
     switch (vec) {
-        case 4: return launch_cfg<WM, WN, TM, TN, 4>(p, stream);
-        case 1: return launch_cfg<WM, WN, TM, TN, 1>(p, stream);
+        case 4: return launch_cfg<WM, WN, TM, TN, 4, false>(p, stream);
+        case 1: return launch_cfg<WM, WN, TM, TN, 1, false>(p, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -614,7 +626,7 @@ static thread_local int g_launch_count = 0;
 int conv_last_launch_count() { return g_launch_count; }
 
 static hipError_t launch_tile(const ConvParams& p, int cfg, int vec, hipStream_t stream) {
-    g_launch_count += p.ksplit > 1 ? 2 : 1;
+    g_launch_count += 1;      // launches of THIS kernel (the split-K finish kernel is not counted)
     switch (cfg) {
         case 0: return launch_vec<2, 2, 2, 2>(p, vec, stream);
         case 1: return launch_vec<1, 4, 2, 2>(p, vec, stream);
@@ -671,7 +683,7 @@ hipError_t launch_conv_mfma(const ConvParams& pin, int code, hipStream_t stream)
     if (p.head_w) {   // fused head: one wave must hold all couts of its positions (WM == 1, BM >= Cout), no split-K
         int bm, bn;
         conv_tile_dims(cfg, &bm, &bn);
-        const bool wm1 = cfg == 1 || cfg == 2 || cfg == 5 || cfg == 7;
+        const bool wm1 = cfg == 1 || cfg == 2 || cfg == 7;
         if (!wm1 || bm < p.Cout || p.ksplit != 1 || p.act == ACT_SIGMOID) return hipErrorInvalidValue;
     }
 #ifdef S3R_ABLATE
