@@ -144,11 +144,18 @@ def main():
             graphed = None
             torch.cuda.synchronize()
 
+    gt_cloud = None
+    if args.variant == "point":       # BASELINE configs[3]: Stereo2Point forward + the Chamfer-distance kernel
+        g = torch.Generator().manual_seed(77 + rank)
+        gt_cloud = torch.rand(B, spec.N_POINTS, 3, generator=g).to(dev)
+
     def step():
         if host_l is not None:
             (graphed.left if graphed else left).copy_(host_l, non_blocking=True)
             (graphed.right if graphed else right).copy_(host_r, non_blocking=True)
         y = graphed() if graphed else model(left, right)
+        if gt_cloud is not None:
+            s3r.chamfer_distance(y, gt_cloud)
         if world > 1:
             dist.all_gather_into_tensor(gathered, y)      # eval collation over xGMI (RCCL)
         return y
@@ -182,7 +189,9 @@ def main():
         if graphed is not None:      # per-kernel HIP events: the same K steps again, launched eagerly (untimed)
             s3r.profile_enable(64 * args.steps + 64)
             for _ in range(args.steps):
-                model(left, right)
+                yy = model(left, right)
+                if gt_cloud is not None:
+                    s3r.chamfer_distance(yy, gt_cloud)
             torch.cuda.synchronize()
         records = s3r.profile_read(64 * args.steps + 64)
         s3r.profile_enable(0)
