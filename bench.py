@@ -85,6 +85,10 @@ def main():
                     help="launch the ~20 kernels of a step eagerly instead of replaying the captured HIP graph")
     ap.add_argument("--include-h2d", action="store_true",
                     help="PCIe-inclusive variant: every step copies its batch host->device first (never the headline)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to exercise the N>1 code on one GPU)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="testing only: every rank uses cuda:0 (with --backend gloo) so the N>1 path runs on a 1-GPU box")
     ap.add_argument("--autotune", action="store_true",
                     help="time tile / split-K candidates per layer in warm-up instead of using the library's table")
     args = ap.parse_args()
@@ -101,12 +105,17 @@ def main():
             f"(WORLD_SIZE={world})")
         sys.exit(2)
     dist = None
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     B = args.batch
     if args.dtype == "bf16" and args.variant != "voxel":

@@ -148,3 +148,18 @@ def test_bf16_and_fp32_modules_share_a_state_dict(s3r):
     a, b = s3r.Stereo2Voxel(), s3r.Stereo2Voxel(precision="bf16")
     assert a.state_dict().keys() == b.state_dict().keys()
     assert all(v.dtype in (torch.float32, torch.int64) for v in b.state_dict().values())
+
+
+def test_bf16_eval_metric_within_1e3_of_fp32_path(s3r):
+    """north_star's criterion for this path, literally: the evaluation metric (mean voxel IoU against ground truth,
+    per threshold) computed with the bf16 path differs from the fp32 path's by < 1e-3 (same weights, same data)."""
+    a, b = s3r.Stereo2Voxel(), s3r.Stereo2Voxel(precision="bf16")
+    s3r.seed_module(a, 0)
+    b.load_state_dict(a.state_dict())
+    a.to(DEV), b.to(DEV)
+    left, right, gt = s3r.evaluate.synthetic_eval_set(16, 3)
+    ra = s3r.evaluate.test_net(a, left, right, gt, batch=8, device=DEV)
+    rb = s3r.evaluate.test_net(b, left, right, gt, batch=8, device=DEV)
+    for t, x, y in zip(ra["thresholds"], ra["mean_iou"], rb["mean_iou"]):
+        print(f"threshold {t}: mean IoU fp32 path {x:.5f}  bf16 path {y:.5f}  |diff| {abs(x - y):.2e}")
+        assert abs(x - y) < 1e-3

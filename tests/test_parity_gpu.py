@@ -449,3 +449,23 @@ def test_dataset_eval_matches_tensor_eval(s3r, models, tmp_path):
     left, right, gt = (torch.stack([it[k] for it in items]) for k in range(3))
     b = s3r.evaluate.test_net(hip, left, right, gt, batch=2, device=DEV)
     assert a["samples"] == 3 and torch.equal(a["per_sample"], b["per_sample"])
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N>1 path (sharded batch, all-gather collation, barrier, max-over-ranks timing, rank-0 JSON) run
+    with two ranks sharing cuda:0 over gloo — the RCCL run itself needs a multi-GPU node."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--batch", "4", "--backend", "gloo", "--same-device", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # exactly one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak"
+    assert d["value"] > 0 and "cpu_baseline" not in d
