@@ -469,3 +469,23 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak"
     assert d["value"] > 0 and "cpu_baseline" not in d
+
+
+def test_maximum_sizes_chunking_and_limits(s3r, models):
+    """Above MAX_CHUNK pairs the modules split the batch (every tensor of one C-ABI call must stay below 2^31
+    elements / 4 GiB); a single chain call over the limit is refused, not silently wrapped."""
+    hip, _ = models
+    B = s3r.modules.MAX_CHUNK + 2
+    g = torch.Generator().manual_seed(5)
+    base_l, base_r = torch.rand(6, 3, 224, 224, generator=g).to(DEV), torch.rand(6, 3, 224, 224, generator=g).to(DEV)
+    reps = -(-B // 6)
+    left, right = base_l.repeat(reps, 1, 1, 1)[:B].contiguous(), base_r.repeat(reps, 1, 1, 1)[:B].contiguous()
+    out = hip(left, right)
+    assert out.shape == (B, 32, 32, 32)
+    small = hip(base_l, base_r)
+    for i in (0, 5, 255, 256, B - 1):                      # both sides of the chunk boundary
+        assert torch.equal(out[i], small[i % 6])
+    del out, left, right
+    torch.cuda.empty_cache()
+    with pytest.raises(s3r.S3RError, match="split the batch"):
+        hip.encoder._run(torch.zeros(1500, 3, 224, 224, device=DEV))      # e2's 1500x64x114x114 output > 4 GiB
