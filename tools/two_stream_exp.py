@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Experiment: does running two half-batches on two HIP streams (tails of one kernel overlapping the body of
-another) beat one full-batch stream?  python tools/two_stream_exp.py [--batch 32]"""
+"""Experiment: do two INDEPENDENT batches in flight on two HIP streams (tails of one kernel overlapping the body
+of another) beat running them back to back?  python tools/two_stream_exp.py [--batch 32] [--half]
+--half: split ONE batch over the two streams instead (each kernel half-size)."""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,49 +10,51 @@ import s3r
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32)
-ap.add_argument("--splits", type=int, default=2)
+ap.add_argument("--streams", type=int, default=2)
 ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--half", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
-B, S = a.batch, a.splits
-models = [s3r.Stereo2Voxel() for _ in range(S + 1)]
+B, S = a.batch, a.streams
+per = B // S if a.half else B
+models = [s3r.Stereo2Voxel() for _ in range(S)]
 s3r.seed_module(models[0], 0)
 for m in models[1:]:
     m.load_state_dict(models[0].state_dict())
 for m in models:
     m.to(dev)
-left, right = s3r.synthetic_pairs(B, seed=1000)
-left, right = left.to(dev), right.to(dev)
+data = [tuple(t.to(dev) for t in s3r.synthetic_pairs(per, seed=1000 + i)) for i in range(S)]
 streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-h = B // S
+graphs = [s3r.GraphedForward(m, per, dev) for m in models]
+for g, (l, r) in zip(graphs, data):
+    g.left.copy_(l); g.right.copy_(r)
 
 
-def one():
-    return models[S](left, right)
+def sequential():
+    for g in graphs:
+        g()
 
 
-def multi():
+def concurrent():
     cur = torch.cuda.current_stream(dev)
-    outs = []
-    for i, st in enumerate(streams):
+    for g, st in zip(graphs, streams):
         st.wait_stream(cur)
         with torch.cuda.stream(st):
-            outs.append(models[i](left[i * h:(i + 1) * h], right[i * h:(i + 1) * h]))
+            g()
     for st in streams:
         cur.wait_stream(st)
-    return torch.cat(outs, 0)
 
 
-for fn in (one, multi):
+for fn in (sequential, concurrent):
     for _ in range(3):
-        y = fn()
+        fn()
 torch.cuda.synchronize()
-assert torch.equal(one(), multi())
-for name, fn in (("one stream", one), (f"{S} streams", multi), ("one stream", one), (f"{S} streams", multi)):
+pairs = per * S
+for name, fn in (("back to back", sequential), ("concurrent", concurrent), ("back to back", sequential), ("concurrent", concurrent)):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         fn()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-    print(f"{name:12s}: {dt * 1e3:7.3f} ms/step  {B / dt:8.1f} pairs/s")
+    print(f"{name:13s}: {dt * 1e3:7.3f} ms per {pairs} pairs  {pairs / dt:8.1f} pairs/s")
