@@ -37,6 +37,14 @@ class GraphedForward:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=side):
             self.out = model(self.left, self.right)
+        # the graph now holds raw addresses of the model's resident buffers: pin them, so that a later call with
+        # another batch shape or new parameters raises instead of re-allocating memory the graph still uses
+        for m in model.modules():
+            ws = getattr(m, "_ws", None)
+            if ws is not None and hasattr(ws, "pinned"):
+                ws.pinned = True
+            if hasattr(m, "_padded"):
+                m._pinned = True
 
     @torch.no_grad()
     def __call__(self, left: Optional[torch.Tensor] = None, right: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -60,9 +60,14 @@ class _Workspace:
     def __init__(self):
         self.buf: Optional[torch.Tensor] = None
         self.layout = None
+        self.pinned = False      # a captured HIP graph holds this buffer's address and layout
 
     def get(self, device, elems: int, layout):
         fresh = 0
+        if self.buf is None or self.buf.device != device or self.buf.numel() < elems or self.layout != layout:
+            if self.pinned:
+                raise RuntimeError("this module's activation arena is captured in a HIP graph (GraphedForward) for "
+                                   f"layout {self.layout}; run other batch shapes on another module instance")
         if self.buf is None or self.buf.device != device or self.buf.numel() < elems:
             self.buf = torch.empty(max(elems, 1), dtype=torch.float32, device=device)
             fresh = 1
@@ -156,6 +161,9 @@ class _HipChain(nn.Module):
         key = self._cache_key(device)
         if self._packed is not None and self._packed[0] == key:
             return self._packed[1]
+        if self._ws.pinned:
+            raise RuntimeError("parameters changed after this module was captured in a HIP graph (GraphedForward): "
+                               "re-capture (build a new GraphedForward) after load_state_dict / .to()")
         lib = _lib.load()
         packed = []
         stream = _stream_ptr(device)
@@ -311,6 +319,8 @@ class CostVolume(nn.Module):
         if resident:
             if self._padded is None or tuple(self._padded.shape) != shape or self._padded.device != fl.device \
                     or self._padded.dtype != torch.bfloat16:
+                if getattr(self, "_pinned", False):
+                    raise RuntimeError("the padded cost volume of this module is captured in a HIP graph for another shape")
                 self._padded = torch.zeros(shape, dtype=torch.bfloat16, device=fl.device)
             vol = self._padded
         else:
@@ -333,6 +343,8 @@ class CostVolume(nn.Module):
         B, Cc, H, W = fl.shape
         shape = (B, 2 * Cc, self.max_disp + 2 * halo, H + 2 * halo, W + 2 * halo)
         if self._padded is None or tuple(self._padded.shape) != shape or self._padded.device != fl.device:
+            if getattr(self, "_pinned", False):
+                raise RuntimeError("the padded cost volume of this module is captured in a HIP graph for another shape")
             self._padded = torch.zeros(shape, dtype=torch.float32, device=fl.device)
         if B == 0:
             return self._padded

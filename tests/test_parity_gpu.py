@@ -413,8 +413,10 @@ def test_non_default_stream(s3r, models):
     assert torch.equal(got, want)
 
 
-def test_hip_graph_replay_matches_eager(s3r, models):
-    hip, _ = models
+def test_hip_graph_replay_matches_eager(s3r):
+    hip = s3r.Stereo2Voxel()          # own instance: capture pins the module's buffers to one batch shape
+    s3r.seed_module(hip, 0)
+    hip.to(DEV)
     left, right = s3r.synthetic_pairs(3, seed=31)
     left, right = left.to(DEV), right.to(DEV)
     want = hip(left, right).clone()
@@ -424,9 +426,17 @@ def test_hip_graph_replay_matches_eager(s3r, models):
     l2, r2 = s3r.synthetic_pairs(3, seed=32)
     want2 = hip(l2.to(DEV), r2.to(DEV)).clone()
     assert torch.equal(g(l2.to(DEV), r2.to(DEV)), want2)     # replay with new data in the static inputs
-    assert torch.equal(hip(left, right), want)                # eager calls still work after capture
+    assert torch.equal(hip(left, right), want)                # eager calls of the captured shape still work
     with pytest.raises(RuntimeError):
         g(left[:2], right[:2])
+    # the graph holds the module's resident buffers: other shapes / new weights on the same module must raise
+    with pytest.raises(RuntimeError, match="HIP graph"):
+        hip(left[:2], right[:2])
+    other = s3r.Stereo2Voxel()
+    s3r.seed_module(other, 9)
+    with pytest.raises(RuntimeError, match="HIP graph"):
+        hip.load_state_dict(other.state_dict())
+        hip(left, right)
 
 
 def test_prefetching_loader_order_and_values(s3r, models):
