@@ -36,20 +36,24 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     float acc[32];
 #pragma unroll
     for (int c = 0; c < 32; ++c) acc[c] = 0.f;
-#pragma unroll
+    // The (channel, row) loops stay ROLLED: fully unrolled, all 864 weights become live scalar loads at once, do not
+    // fit the SGPR file, and were spilled through v_writelane / v_readlane (1536 extra instructions per thread).
+    // Rolled, one iteration holds the 96 weights of its three taps.
+#pragma unroll 1
     for (int ci = 0; ci < 3; ++ci) {
-#pragma unroll
+#pragma unroll 1
         for (int kh = 0; kh < 3; ++kh) {
             const int ih = ih0 + kh;
             const bool vh = (unsigned)ih < (unsigned)Hi;
+            const float* __restrict__ xrow = xn + ((size_t)ci * Hi + ih) * Wi;
+            const float* __restrict__ wrow = wt + (ci * 3 + kh) * 96;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int iw = iw0 + kw;
                 const bool v = vh && ((unsigned)iw < (unsigned)Wi);
-                const float xv = v ? xn[((size_t)ci * Hi + ih) * Wi + iw] : 0.f;
-                const float* __restrict__ wk = wt + ((ci * 3 + kh) * 3 + kw) * 32;
+                const float xv = v ? xrow[iw] : 0.f;
 #pragma unroll
-                for (int c = 0; c < 32; ++c) acc[c] = fmaf(xv, wk[c], acc[c]);
+                for (int c = 0; c < 32; ++c) acc[c] = fmaf(xv, wrow[kw * 32 + c], acc[c]);
             }
         }
     }

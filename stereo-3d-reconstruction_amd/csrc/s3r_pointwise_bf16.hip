@@ -35,20 +35,22 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
     float acc[32];
 #pragma unroll
     for (int c = 0; c < 32; ++c) acc[c] = 0.f;
-#pragma unroll
+    // (channel, row) loops rolled: see stem_kernel — unrolled, the 864 scalar weight loads overflow the SGPR file
+#pragma unroll 1
     for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
+#pragma unroll 1
         for (int kh = 0; kh < 3; ++kh) {
             const int ih = ih0 + kh;
             const bool vh = (unsigned)ih < (unsigned)Hi;
+            const float* __restrict__ xrow = xn + ((size_t)ci * Hi + ih) * Wi;
+            const float* __restrict__ wrow = wt + (ci * 3 + kh) * 96;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int iw = iw0 + kw;
                 const bool v = vh && ((unsigned)iw < (unsigned)Wi);
-                const float xv = v ? xn[((size_t)ci * Hi + ih) * Wi + iw] : 0.f;
-                const float* __restrict__ wk = wt + ((ci * 3 + kh) * 3 + kw) * 32;
+                const float xv = v ? xrow[iw] : 0.f;
 #pragma unroll
-                for (int c = 0; c < 32; ++c) acc[c] = fmaf(xv, wk[c], acc[c]);
+                for (int c = 0; c < 32; ++c) acc[c] = fmaf(xv, wrow[kw * 32 + c], acc[c]);
             }
         }
     unsigned* __restrict__ yo = reinterpret_cast<unsigned*>(y + (size_t)n * y_bs + y_org + ((size_t)oh * y_hs + (size_t)ow * 32));
