@@ -10,7 +10,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libs3r_hip.so")
+# S3R_LIB: another build of the SAME library (tools/ab_bench.sh times two builds on one device); never a fallback
+LIB_PATH = os.environ.get("S3R_LIB") or os.path.join(_HERE, "csrc", "libs3r_hip.so")
 
 OP_CONV, OP_DECONV, OP_LINEAR = 0, 1, 2
 DTYPE = {"fp32": 0, "bf16": 1}

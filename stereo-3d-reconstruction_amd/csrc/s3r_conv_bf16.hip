@@ -20,9 +20,10 @@
 // LDS-DMA (16 B per lane, lane-linear destination), so the swizzle is applied on the SOURCE side: a lane
 // fetches channel group slot ^ f(row) of its position; weights are stored pre-swizzled by the pack kernel.
 //
-// Workgroup: 4 waves along M, each 32*TM positions x 64 couts (TN = 2 MFMA tiles, couts interleaved
-// 2c+tn so that a lane packs its two bf16 results into ONE dword store: 128 contiguous bytes per 32
-// lanes).  Per-position input / output offsets are decoded once per workgroup into LDS.
+// Workgroup: 4 waves along M, each 32*TM positions x 64 couts (TN = 2 MFMA tiles).  The MFMA is issued
+// with the weights as its A operand, so D = [cout][position]: a lane owns ONE position and 16 consecutive
+// couts per MFMA tile (32 contiguous bytes of the channels-last output: two 16-byte stores).
+// Per-position input / output offsets are decoded once per workgroup into LDS.
 #include "s3r_kernels.h"
 #include <cstdlib>
 
@@ -36,6 +37,7 @@ static int abl_mode_h() { static const int m = getenv("S3R_ABL") ? atoi(getenv("
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
@@ -53,90 +55,181 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst
 constexpr int HKC = 32;    // channels per K tile
 constexpr int HBN = 64;    // couts per workgroup
 
-// Epilogue shared by both bf16 kernels.  Lane c owns couts n0 + 2c (tn 0) and n0 + 2c + 1 (tn 1); register r of
-// MFMA tile tm is position row wave*32*TM + tm*32 + (r&3) + 8*(r>>2) + 4h of the tile; yoff[row] is that
+// Epilogue shared by both bf16 kernels.  The MFMA runs with the WEIGHTS as its A operand, so D is [cout][position]:
+// lane c owns position row wave*32*TM + tm*32 + c of the tile, and its 16 registers of MFMA tile tn are the 16
+// CONSECUTIVE couts n0 + tn*32 + 16h + r (the pack kernel permutes the weight rows to make them consecutive).
+// A lane therefore stores 32 contiguous bytes per MFMA tile (two 16-byte stores), needs one output offset per
+// position, and the fused head's reduction over the couts stays inside the lane (one cross-half exchange).
+// ep = LDS [3][64]: folded-BN scale, shift and head weight of the workgroup's 64 couts; yoff[row] = the
 // position's output element offset (-1: past the end).
-template <int TM>
-__device__ __forceinline__ void epilogue_h(const ConvParamsH& p, f32x16 (&acc)[TM][2], const int* yoff, int wave, int c,
-                                           int h, int m0, int n0, int cls, int kz, int bm) {
-    const int co = n0 + 2 * c;
+constexpr int EP_BYTES = 3 * 64 * 4;
+constexpr int ST_ROW = 144;     // staging row: 128 payload bytes + 16 (rows 9 sixteen-byte slots apart: conflict-free b128 writes)
+
+__device__ __forceinline__ void fill_ep(const ConvParamsH& p, float* ep, int tid, int n0) {
+    if (tid < 64) {
+        const int co = n0 + tid;
+        const bool ok = co < p.Cout;
+        ep[tid] = (ok && p.scale) ? p.scale[co] : 1.f;
+        ep[64 + tid] = (ok && p.shift) ? p.shift[co] : 0.f;
+        ep[128 + tid] = (ok && p.head_w) ? p.head_w[co] : 0.f;
+    }
+}
+
+template <int TM, bool HEAD>
+__device__ __forceinline__ void epilogue_h(const ConvParamsH& p, f32x16 (&acc)[TM][2], const int* yoff, const float* ep,
+                                           char* stage, int wave, int c, int h, int m0, int n0, int cls, int kz, int bm) {
+    // `stage`: this wave's 32 x ST_ROW bytes of the (now idle) operand buffers.  A lane holds 32 B (bf16) /
+    // 64 B (fp32 slab) of ONE position; stored as they stand, a wave instruction would touch 32 rows with
+    // 16-byte pieces.  Staged through LDS, lanes 8r..8r+7 write the 128 contiguous bytes of row r: every store
+    // instruction covers eight whole 128-byte lines.
+    const int lane = c + 32 * h;
+    const int srow = lane >> 3, spiece = lane & 7;
     if (p.ksplit > 1) {
         // split-K: fp32 partial sums [cls][kz][position][CoutPad]; conv_finish_bf16 reduces in kz order
         const int mpad = p.m_tiles * bm;
-        float* __restrict__ slab = p.part + ((size_t)(cls * p.ksplit + kz) * mpad + m0) * p.CoutPad + co;
+        float* __restrict__ slab = p.part + ((size_t)(cls * p.ksplit + kz) * mpad + m0) * p.CoutPad + n0 + 4 * spiece;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wave * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                float2 t = {acc[tm][0][r], acc[tm][1][r]};
-                *reinterpret_cast<float2*>(slab + (size_t)row * p.CoutPad) = t;
-            }
-        return;
-    }
-    const bool c0 = co < p.Cout, c1 = co + 1 < p.Cout;
-    const float sc0 = (c0 && p.scale) ? p.scale[co] : 1.f, sf0 = (c0 && p.shift) ? p.shift[co] : 0.f;
-    const float sc1 = (c1 && p.scale) ? p.scale[co + 1] : 1.f, sf1 = (c1 && p.shift) ? p.shift[co + 1] : 0.f;
-    // ReLU / identity as ONE v_max against a wave-uniform floor; sigmoid (rare) behind a wave-uniform flag
-    const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
-    const bool sig = p.act == ACT_SIGMOID;
-    if (p.head_w) {
-        // fused pointwise head (conv -> 1x1x1 conv to ONE channel + activation; the workgroup's 64-cout tile
-        // is the whole channel axis): per position, 2 FMAs in the lane, a 32-lane butterfly over the couts, one
-        // fp32 store.  The conv's own bf16 output — the largest activation of the network — is never written.
-        const float hw0 = c0 ? p.head_w[co] : 0.f, hw1 = c1 ? p.head_w[co + 1] : 0.f;
-        const float hsc = p.head_scale ? p.head_scale[0] : 1.f, hsf = p.head_shift ? p.head_shift[0] : 0.f;
-        float* __restrict__ y = reinterpret_cast<float*>(p.y);
+            for (int tn = 0; tn < 2; ++tn) {       // one MFMA tile = 32 positions x 32 couts fp32 = 128-byte rows
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 t = {acc[tm][tn][4 * j], acc[tm][tn][4 * j + 1], acc[tm][tn][4 * j + 2],
+                                     acc[tm][tn][4 * j + 3]};
+                    *reinterpret_cast<f32x4*>(stage + c * ST_ROW + h * 64 + j * 16) = t;
+                }
+                if (S3R_ABLH(p, 1)) continue;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v0 = fmaxf(fmaf(acc[tm][0][r], sc0, sf0), lo), v1 = fmaxf(fmaf(acc[tm][1][r], sc1, sf1), lo);
-                float t = fmaf(v1, hw1, v0 * hw0);
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);      // over the 32 lanes of this half
-                const int row = wave * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int ye = yoff[row];
-                if (c == 0 && ye >= 0) {
-                    t = fmaf(t, hsc, hsf);
-                    if (p.head_act == ACT_RELU) t = fmaxf(t, 0.f);
-                    else if (p.head_act == ACT_SIGMOID) t = 1.f / (1.f + __expf(-t));
-                    y[ye] = t;
+                for (int i = 0; i < 4; ++i) {
+                    const int r = i * 8 + srow;
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(stage + r * ST_ROW + spiece * 16);
+                    *reinterpret_cast<f32x4*>(slab + (size_t)(wave * 32 * TM + tm * 32 + r) * p.CoutPad + tn * 32) = t;
                 }
             }
         return;
     }
-    unsigned short* __restrict__ y = reinterpret_cast<unsigned short*>(p.y);
+    // ReLU / identity as ONE v_max against a wave-uniform floor; sigmoid (rare) behind a wave-uniform flag
+    const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+    const bool sig = p.act == ACT_SIGMOID;
+    if constexpr (HEAD) {
+        int ye[TM];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm) ye[tm] = yoff[wave * 32 * TM + tm * 32 + c];
+        // fused pointwise head (conv -> 1x1x1 conv to ONE channel + activation; the workgroup's 64-cout tile
+        // is the whole channel axis): 32 FMAs in the lane, one exchange with the other half, one fp32 store per
+        // position.  The conv's own bf16 output — the largest activation of the network — is never written.
+        float t[TM];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wave * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int ye = yoff[row];
-            if (ye < 0 || !c0) continue;
-            float v0 = fmaf(acc[tm][0][r], sc0, sf0), v1 = fmaf(acc[tm][1][r], sc1, sf1);
-            if (S3R_ABLH(p, 1) && v0 != 12345.f) continue;
-            if (sig) { v0 = __builtin_amdgcn_rcpf(1.f + __expf(-v0)); v1 = __builtin_amdgcn_rcpf(1.f + __expf(-v1)); }
-            else { v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); }
-            const unsigned pk = pack_bf16(v0, v1);
-            if (c1) *reinterpret_cast<unsigned*>(y + (size_t)ye + co) = pk;
-            else y[(size_t)ye + co] = (unsigned short)(pk & 0xffffu);
+        for (int tm = 0; tm < TM; ++tm) t[tm] = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const float* e = ep + tn * 32 + 16 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(e + 4 * q);
+                const f32x4 sf = *reinterpret_cast<const f32x4*>(e + 64 + 4 * q);
+                const f32x4 hw = *reinterpret_cast<const f32x4*>(e + 128 + 4 * q);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    t[tm] = fmaf(fmaxf(fmaf(acc[tm][tn][4 * q + 0], sc.x, sf.x), lo), hw.x, t[tm]);
+                    t[tm] = fmaf(fmaxf(fmaf(acc[tm][tn][4 * q + 1], sc.y, sf.y), lo), hw.y, t[tm]);
+                    t[tm] = fmaf(fmaxf(fmaf(acc[tm][tn][4 * q + 2], sc.z, sf.z), lo), hw.z, t[tm]);
+                    t[tm] = fmaf(fmaxf(fmaf(acc[tm][tn][4 * q + 3], sc.w, sf.w), lo), hw.w, t[tm]);
+                }
+            }
         }
+        const float hsc = p.head_scale ? p.head_scale[0] : 1.f, hsf = p.head_shift ? p.head_shift[0] : 0.f;
+        float* __restrict__ y = reinterpret_cast<float*>(p.y);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            float v = t[tm] + __shfl_xor(t[tm], 32, 64);
+            if (h == 0 && ye[tm] >= 0) {
+                v = fmaf(v, hsc, hsf);
+                if (p.head_act == ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.head_act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+                y[ye[tm]] = v;
+            }
+        }
+        return;
+    }
+    unsigned short* __restrict__ y = reinterpret_cast<unsigned short*>(p.y);
+    const bool wide = (p.Cout & 7) == 0;          // 16-byte stores need the channel axis in whole groups of 8
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int cl = tn * 32 + 16 * h + 8 * g;          // (tile-local) cout of register 8g
+                const f32x4 sc0 = *reinterpret_cast<const f32x4*>(ep + cl);
+                const f32x4 sc1 = *reinterpret_cast<const f32x4*>(ep + cl + 4);
+                const f32x4 sf0 = *reinterpret_cast<const f32x4*>(ep + 64 + cl);
+                const f32x4 sf1 = *reinterpret_cast<const f32x4*>(ep + 64 + cl + 4);
+                const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+                const float sf[8] = {sf0.x, sf0.y, sf0.z, sf0.w, sf1.x, sf1.y, sf1.z, sf1.w};
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    v[r] = fmaf(acc[tm][tn][8 * g + r], sc[r], sf[r]);
+                    v[r] = sig ? __builtin_amdgcn_rcpf(1.f + __expf(-v[r])) : fmaxf(v[r], lo);
+                }
+                const uint4 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]),
+                                  pack_bf16(v[6], v[7])};
+                *reinterpret_cast<uint4*>(stage + c * ST_ROW + cl * 2) = pk;
+            }
+        if (S3R_ABLH(p, 1)) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 8 + srow;
+            const int ye = yoff[wave * 32 * TM + tm * 32 + r];
+            const int co = n0 + 8 * spiece;
+            const uint4 pk = *reinterpret_cast<const uint4*>(stage + r * ST_ROW + spiece * 16);
+            if (ye < 0 || co >= p.Cout) continue;
+            unsigned short* dst = y + (size_t)ye + co;
+            if (wide) {
+                *reinterpret_cast<uint4*>(dst) = pk;
+            } else {
+                const unsigned w[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (co + e < p.Cout) dst[e] = (unsigned short)((w[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+            }
+        }
+    }
 }
 
-constexpr int min_waves_h(int tm) { return tm >= 4 ? 2 : 4; }
+// (the fused-head epilogue keeps 3 constants per cout live: its own instantiation, one workgroup fewer per CU,
+// so that the plain kernel stays free of scratch; KC = 64 doubles the LDS per workgroup)
+constexpr int min_waves_h(int tm, int kc, bool head) {
+    return kc == 64 ? (tm == 1 ? 3 : 1) : (tm >= 4 ? 2 : (head ? 3 : 4));
+}
 
-template <int TM>
-__global__ __launch_bounds__(256, min_waves_h(TM)) void conv_bf16_kernel(const ConvParamsH p) {
+// LDS rows are KC channels = KC*2 bytes = KC/8 sixteen-byte slots; slot = kgroup ^ swz(row) keeps every
+// ds_read_b128 lane group on 16 distinct (bank half, slot) pairs:  64-byte rows: (row >> 2) & 3,
+// 128-byte rows: (row >> 1) & 7  (the b128 lane groups are {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...).
+template <int KC>
+__device__ __forceinline__ int swz(int row) { return KC == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
+
+// Per-tap kernel.  K tile = ONE tap x KC channels.  KC = 64 (Cin % 64 == 0) makes every gathered piece a WHOLE
+// 128-byte line of the channels-last input (KC = 32 fetches half of each line, and the other half again one
+// chunk later: the operand path of these layers is L2 -> LDS bound) and halves the barriers per FLOP.
+// The packed weights stay in the 32-channel layout for both: with KC = 64 a lane's 16 bytes come from chunk
+// 2j or 2j+1 by a per-lane source offset (LDS-DMA destinations are lane-linear, sources are free).
+template <int TM, int KC, bool HEAD>
+__global__ __launch_bounds__(256, min_waves_h(TM, KC, HEAD)) void conv_bf16_kernel(const ConvParamsH p) {
     constexpr int BM = 128 * TM;
-    constexpr int NPA = BM / 64;           // A pieces (16 positions x 64 B) per wave per K tile
-    constexpr int A_BYTES = BM * 64, B_BYTES = HBN * 64;
+    constexpr int ROWB = KC * 2;                   // bytes per LDS row
+    constexpr int LPR = ROWB / 16;                 // lanes (16-byte slots) per row
+    constexpr int RPP = 64 / LPR;                  // rows per 1 KiB LDS-DMA piece
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = HBN * ROWB;
+    constexpr int NPA = A_BYTES / 4096, NPB = B_BYTES / 4096;     // pieces per wave per K tile
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;                               // [2][BM][64 B]
-    char* Bs = smem + 2 * A_BYTES;                 // [2][64][64 B]
+    char* As = smem;                               // [2][BM][ROWB]
+    char* Bs = smem + 2 * A_BYTES;                 // [2][64][ROWB]
     int* xoff = reinterpret_cast<int*>(smem + 2 * A_BYTES + 2 * B_BYTES);   // [BM] input byte offsets
     int* yoff = xoff + BM;                                                   // [BM] output element offsets, -1 = none
+    float* ep = reinterpret_cast<float*>(yoff + BM);                         // [3][64] scale / shift / head weight
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -158,9 +251,10 @@ __global__ __launch_bounds__(256, min_waves_h(TM)) void conv_bf16_kernel(const C
 
     const int S = p.Nd * p.Nh * p.Nw;
     const int T = p.T;
-    const int chunks = (p.Cin / HKC) / p.ksplit;
+    const int chunks = (p.Cin / KC) / p.ksplit;
     const int nkt = S3R_ABLH(p, 2) ? 1 : T * chunks;
 
+    fill_ep(p, ep, tid, n0);
     // ---- decode this tile's positions once: input corner (bytes) and output offset (elements)
     for (int t = tid; t < BM; t += 256) {
         const int n = m0 + t;
@@ -184,35 +278,45 @@ __global__ __launch_bounds__(256, min_waves_h(TM)) void conv_bf16_kernel(const C
     }
     __syncthreads();
 
-    // ---- loop-invariant DMA offsets
-    int avoff[NPA];
+    // ---- loop-invariant DMA source offsets (the swizzle is applied on the source side)
+    const int w_tile = p.n_tiles * 4096;           // bytes between consecutive 32-channel weight tiles (kt32 + 1)
+    int avoff[NPA], bvoff[NPB];
 #pragma unroll
     for (int q = 0; q < NPA; ++q) {
-        const int pl = (wave + 4 * q) * 16 + (lane >> 2);          // position inside the tile
-        const int kg = (lane & 3) ^ ((pl >> 2) & 3);               // swizzle on the source side
+        const int pl = (wave + 4 * q) * RPP + lane / LPR;          // position inside the tile
+        const int kg = (lane % LPR) ^ swz<KC>(pl);
         avoff[q] = xoff[pl] + kg * 16;
     }
-    const int bvoff = lane * 16;                                    // weights are stored pre-swizzled
+#pragma unroll
+    for (int q = 0; q < NPB; ++q) {
+        if constexpr (KC == 32) {
+            bvoff[q] = (wave + 4 * q) * 1024 + lane * 16;          // stored pre-swizzled for 64-byte rows
+        } else {
+            const int r = (wave + 4 * q) * RPP + lane / LPR;       // cout row
+            const int kg = (lane % LPR) ^ swz<64>(r);              // 16-byte channel group 0..7 of the 64
+            bvoff[q] = (kg >> 2) * (T * w_tile) + r * 64 + (((kg & 3) ^ swz<32>(r)) << 4);
+        }
+    }
 
     const __amdgpu_buffer_rsrc_t xrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
-    // packed weights: [cls][kt][cout tile][64 rows][64 B]
-    const size_t w_cls = (size_t)cls * T * (p.Cin / HKC) * p.n_tiles * B_BYTES;
+    // packed weights: [cls][kt32 = chunk32*T + tap][cout tile][64 rows][64 B]
+    const size_t w_cls = (size_t)cls * T * (p.Cin / HKC) * w_tile;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.w) + w_cls), 0,
-        (int)((unsigned)T * (unsigned)(p.Cin / HKC) * (unsigned)p.n_tiles * (unsigned)B_BYTES), 0x00020000);
+        (int)((unsigned)T * (unsigned)(p.Cin / HKC) * (unsigned)w_tile), 0x00020000);
 
-    int c_td = 0, c_th = 0, c_tw = 0, c_tap = 0, c_cc = kz * chunks, c_kt = kz * nkt;
+    int c_td = 0, c_th = 0, c_tw = 0, c_tap = 0, c_cc = kz * chunks;
 
     auto issue = [&](int buf) {
-        char* sb = Bs + buf * B_BYTES + wave * 1024;
-        dma16(wrsrc, sb, bvoff, (c_kt * p.n_tiles + n_tile) * B_BYTES + wave * 1024);
-        char* sa = As + buf * A_BYTES + wave * 1024;
-        const int a_base = (c_cc * HKC + (c_td * p.x_ds + c_th * p.x_hs + c_tw * p.x_ws)) * 2;
+        const int b_base = ((c_cc * (KC / 32) * T + c_tap) * p.n_tiles + n_tile) * 4096;
+#pragma unroll
+        for (int q = 0; q < NPB; ++q)
+            dma16(wrsrc, Bs + buf * B_BYTES + (wave + 4 * q) * 1024, bvoff[q], b_base);
+        const int a_base = (c_cc * KC + (c_td * p.x_ds + c_th * p.x_hs + c_tw * p.x_ws)) * 2;
 #pragma unroll
         for (int q = 0; q < NPA; ++q)
-            dma16(xrsrc, sa + q * 4096, avoff[q], a_base);
-        ++c_kt;
+            dma16(xrsrc, As + buf * A_BYTES + (wave + 4 * q) * 1024, avoff[q], a_base);
         if (++c_tw == p.kw) { c_tw = 0; if (++c_th == p.kh) { c_th = 0; ++c_td; } }
         if (++c_tap == T) { c_tap = 0; c_td = 0; c_th = 0; c_tw = 0; ++c_cc; }
     };
@@ -229,17 +333,17 @@ __global__ __launch_bounds__(256, min_waves_h(TM)) void conv_bf16_kernel(const C
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // fragment byte offsets inside a K tile image: row*64 + ((h + 2q) ^ f(row))*16; q toggles bit 5
+    // fragment byte offsets inside a K tile image: row*ROWB + ((2q + h) ^ swz(row))*16; q toggles bits 5..
     int a_off[TM], b_off[2];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int row = wave * 32 * TM + tm * 32 + c;
-        a_off[tm] = row * 64 + ((h ^ ((row >> 2) & 3)) << 4);
+        a_off[tm] = row * ROWB + ((h ^ swz<KC>(row)) << 4);
     }
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         const int row = tn * 32 + c;
-        b_off[tn] = row * 64 + ((h ^ ((row >> 2) & 3)) << 4);
+        b_off[tn] = row * ROWB + ((h ^ swz<KC>(row)) << 4);
     }
 
     for (int kt = 0; kt < nkt; ++kt) {
@@ -248,7 +352,7 @@ __global__ __launch_bounds__(256, min_waves_h(TM)) void conv_bf16_kernel(const C
         const char* a = As + cur * A_BYTES;
         const char* b = Bs + cur * B_BYTES;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < KC / 16; ++q) {
             bf16x8 av[TM], bv[2];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) av[tm] = *reinterpret_cast<const bf16x8*>(a + (a_off[tm] ^ (q << 5)));
@@ -258,13 +362,13 @@ __global__ __launch_bounds__(256, min_waves_h(TM)) void conv_bf16_kernel(const C
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[tn], av[tm], acc[tm][tn], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
-    epilogue_h<TM>(p, acc, yoff, wave, c, h, m0, n0, cls, kz, BM);
+    epilogue_h<TM, HEAD>(p, acc, yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -288,6 +392,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p,
     const int a_bytes = r_max * 64, stage_bytes = a_bytes + kw * 4096;
     int* yoff = reinterpret_cast<int*>(smem + 2 * stage_bytes);     // [BM] output element offsets, -1 = none
     int* lrow = yoff + BM;                                            // [BM] LDS row of each tile position (tap tw = 0)
+    float* ep = reinterpret_cast<float*>(lrow + BM);                  // [3][64] scale / shift / head weight
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -328,6 +433,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p,
     const int segw = p.stride * (p.Nw - 1) + kw;             // LDS rows of a full output row
     const int last_row = p.B * p.Nd * p.Nh - 1;
 
+    fill_ep(p, ep, tid, n0);
     for (int t = tid; t < BM; t += 256) {
         const int n = m0 + t;
         const bool ok = n < p.Ntotal;
@@ -435,14 +541,242 @@ __global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p,
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[tn], av[tm], acc[tm][tn], 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
-    epilogue_h<TM>(p, acc, yoff, wave, c, h, m0, n0, cls, kz, BM);
+    if (p.head_w) epilogue_h<TM, true>(p, acc, yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
+    else epilogue_h<TM, false>(p, acc, yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Plane-reuse variant (stride-1 layers with Cin % 64 == 0): ALL kh*kw taps of one (64-channel chunk, td) group
+// read the same gathered input PLANE, shifted by th*in_p + tw positions, so the A operand is fetched once per
+// kh*kw taps (9 for a 3x3[x3] conv, 4 for a transposed-conv class) instead of once per tap / per kw taps.
+//
+// LDS A image = for every (batch, depth) plane the tile touches, the contiguous run of padded-input positions
+// u = ph*in_p + pw .. that its output positions need (128 B = 64 channels each, whole 128-byte lines), plus
+// HALO = (kh-1)*in_p + kw-1 trailing positions; MFMA row r reads LDS row lrow[r] + th*in_p + tw.  The image is
+// SINGLE-buffered (two workgroups per CU overlap one's reload with the other's MFMAs); the weights (8 KiB per
+// tap) stream through a 3-slot ring with one barrier per tap: 4*TM*2 MFMAs per wave between barriers.
+constexpr int NPA_PL = 15;     // 8-row A pieces per wave, upper bound (registers)
+constexpr int PL_NB = 3;       // weight ring slots
+
+template <int TM>
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_bf16p_kernel(const ConvParamsH p, int r_max) {
+    constexpr int BM = 128 * TM;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int a_bytes = r_max * 128;
+    char* Bs = smem + a_bytes;                                        // [PL_NB][64][128 B]
+    int* yoff = reinterpret_cast<int*>(Bs + PL_NB * 8192);            // [BM] output element offsets, -1 = none
+    int* lrow = yoff + BM;                                            // [BM] LDS row of each tile position (tap 0,0)
+    float* ep = reinterpret_cast<float*>(lrow + BM);                  // [3][64] scale / shift / head weight
+    int* asrc = reinterpret_cast<int*>(Bs + 2 * 8192);                // [r_max] source byte offset of each image row
+                                                                      // (prologue only: aliases ring slot 2)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int n_tile = bid % p.n_tiles;
+    const int m_tile = bid / p.n_tiles;
+    const int m0 = m_tile * BM, n0 = n_tile * HBN;
+    const int cls = blockIdx.y;
+    const int rd = (cls >> 2) & 1, rh = (cls >> 1) & 1, rw = cls & 1;
+    const int kz = blockIdx.z;
+
+    const int S = p.Nd * p.Nh * p.Nw, P = p.Nh * p.Nw;
+    const int T = p.T, kh = p.kh, kw = p.kw;
+    const int taps_g = kh * kw;
+    const int chunks = (p.Cin / 64) / p.ksplit;
+    const int ngroups = S3R_ABLH(p, 2) ? 1 : chunks * p.kd;
+    const int total = ngroups * taps_g;
+    const int cls_x = p.transposed ? (rd - 1) * p.x_ds + (rh - 1) * p.x_hs + (rw - 1) * p.x_ws : 0;
+    const int in_p = p.x_hs / p.x_ws;                        // padded input row length, in positions
+    const int halo = (kh - 1) * in_p + kw - 1;
+    const int umax = (p.Nh - 1) * in_p + p.Nw - 1;
+    const int LP = umax + 1 + halo;                          // image rows of a whole plane
+
+    // ---- geometry of the tile's first and last position (wave-uniform)
+    const int m1 = (m0 + BM < p.Ntotal ? m0 + BM : p.Ntotal) - 1;
+    int pl0, u0, pl1, u1;
+    {
+        pl0 = p.dHW.div(m0);
+        int nl = m0 - pl0 * P;
+        int ph = p.dW.div(nl);
+        u0 = ph * in_p + (nl - ph * p.Nw);
+        pl1 = p.dHW.div(m1);
+        nl = m1 - pl1 * P;
+        ph = p.dW.div(nl);
+        u1 = ph * in_p + (nl - ph * p.Nw);
+    }
+    const int nseg = pl1 - pl0 + 1;
+    const int len0 = (nseg > 1 ? umax : u1) - u0 + 1 + halo; // image rows of the first plane's segment
+
+    fill_ep(p, ep, tid, n0);
+    for (int t = tid; t < BM; t += 256) {
+        const int n = m0 + t;
+        const bool ok = n < p.Ntotal;
+        const int nn = ok ? n : p.Ntotal - 1;
+        const int b = p.dS.div(nn);
+        int rem = nn - b * S;
+        const int pd = p.dHW.div(rem);
+        rem -= pd * P;
+        const int ph = p.dW.div(rem);
+        const int pw = rem - ph * p.Nw;
+        const int ostep = p.transposed ? 2 : 1;
+        int ye = b * p.y_bs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw * p.y_ws) * ostep;
+        if (p.transposed) ye += rd * p.y_ds + rh * p.y_hs + rw * p.y_ws;
+        yoff[t] = ok ? ye : -1;
+        const int sgm = b * p.Nd + pd - pl0, u = ph * in_p + pw;
+        lrow[t] = sgm == 0 ? u - u0 : len0 + (sgm - 1) * LP + u;
+    }
+    // source of every image row: (plane, position inside the padded plane)
+    for (int j = tid; j < r_max; j += 256) {
+        int sgm, off;
+        if (j < len0) { sgm = 0; off = j + u0; }
+        else { sgm = 1 + (j - len0) / LP; off = (j - len0) - (sgm - 1) * LP; }
+        int pl = pl0 + sgm;
+        if (sgm >= nseg) { pl = pl1; off = 0; }              // past the image: any valid address, never read
+        const int b = p.dS.div(pl * P);
+        const int pd = pl - b * p.Nd;
+        asrc[j] = (b * p.x_bs + p.x_org + pd * p.x_ds + off * p.x_ws + cls_x) * 2;
+    }
+    __syncthreads();
+
+    // ---- loop-invariant DMA source offsets
+    const int npa = r_max >> 5;                               // A pieces per wave (r_max % 32 == 0)
+    int avoff[NPA_PL];
+#pragma unroll
+    for (int q = 0; q < NPA_PL; ++q) {
+        const int j = (wave + 4 * q) * 8 + (lane >> 3);
+        avoff[q] = (q < npa ? asrc[j] : 0) + (((lane & 7) ^ swz<64>(j)) << 4);
+    }
+    const int w_tile = p.n_tiles * 4096;
+    int bvoff[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = (wave + 4 * q) * 8 + (lane >> 3);
+        const int kg = (lane & 7) ^ swz<64>(r);
+        bvoff[q] = (kg >> 2) * (T * w_tile) + r * 64 + (((kg & 3) ^ swz<32>(r)) << 4);
+    }
+    int lr[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) lr[tm] = lrow[wave * 32 * TM + tm * 32 + c];
+    int b_off[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int row = tn * 32 + c;
+        b_off[tn] = row * 128 + ((h ^ swz<64>(row)) << 4);
+    }
+
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const size_t w_cls = (size_t)cls * T * (p.Cin / HKC) * w_tile;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.w) + w_cls), 0,
+        (int)((unsigned)T * (unsigned)(p.Cin / HKC) * (unsigned)w_tile), 0x00020000);
+
+    int a_cc = kz * chunks, a_td = 0;                         // cursor of the NEXT image to fetch
+    int b_cc = kz * chunks, b_tap = 0, b_slot = 0;            // cursor of the NEXT weight tile to fetch
+    auto issue_a = [&]() {
+        const int a_base = (a_cc * 64 + a_td * p.x_ds) * 2;
+#pragma unroll
+        for (int q = 0; q < NPA_PL; ++q)
+            if (q < npa) dma16(xrsrc, smem + ((wave + 4 * q) << 10), avoff[q], a_base);
+        if (++a_td == p.kd) { a_td = 0; ++a_cc; }
+    };
+    auto issue_b = [&]() {
+        const int b_base = ((b_cc * 2 * T + b_tap) * p.n_tiles + n_tile) * 4096;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) dma16(wrsrc, Bs + b_slot * 8192 + ((wave + 4 * q) << 10), bvoff[q], b_base);
+        if (++b_tap == T) { b_tap = 0; ++b_cc; }
+        if (++b_slot == PL_NB) b_slot = 0;
+    };
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    __syncthreads();                                          // asrc (ring slot 2) has been read by every wave
+    issue_a();
+    issue_b();
+    if (total > 1) issue_b();
+
+    int tt = 0, c_slot = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        int tapoff = 0, c_tw = 0;
+        for (int t = 0; t < taps_g; ++t, ++tt) {
+            // this tap's weights (and, at t == 0, the image) have landed; the next tap's may still be in flight.
+            // (s_barrier as inline asm: the compiler drains vmcnt before every barrier it knows about, which
+            // would cut the weight prefetch back to one tap)
+            if (t == 0 || tt + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");           // ... for every wave; ring slot (tt+2)%3 is free
+            if (tt + 2 < total && !S3R_ABLH(p, 3)) issue_b();
+            const char* b = Bs + c_slot * 8192;
+            int a_off[TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int row = lr[tm] + tapoff;
+                a_off[tm] = (row << 7) + (((h ^ (row >> 1)) & 7) << 4);
+            }
+            // fragments of k-step q+1 are requested before the MFMAs of k-step q
+            bf16x8 av[2][TM], bv[2][2];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) av[0][tm] = *reinterpret_cast<const bf16x8*>(smem + a_off[tm]);
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) bv[0][tn] = *reinterpret_cast<const bf16x8*>(b + b_off[tn]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < 3) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        av[(q + 1) & 1][tm] = *reinterpret_cast<const bf16x8*>(smem + (a_off[tm] ^ ((q + 1) << 5)));
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        bv[(q + 1) & 1][tn] = *reinterpret_cast<const bf16x8*>(b + (b_off[tn] ^ ((q + 1) << 5)));
+                }
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[q & 1][tn], av[q & 1][tm], acc[tm][tn], 0, 0, 0);
+            }
+            // pin the issue order (the scheduler otherwise reuses the fragment registers and serialises
+            // read -> wait -> MFMA): k-step 0's reads, then per k-step one read of the NEXT step behind each MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + 2, 0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int i = 0; i < 2 * TM; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i < TM + 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM, 0);
+            if (++c_slot == PL_NB) c_slot = 0;
+            ++tapoff;
+            if (++c_tw == kw) { c_tw = 0; tapoff += in_p - kw; }
+        }
+        asm volatile("s_barrier" ::: "memory");               // every wave is done with this image
+        if (g + 1 < ngroups && !S3R_ABLH(p, 3)) issue_a();
+    }
+
+    if (p.head_w) epilogue_h<TM, true>(p, acc, yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
+    else epilogue_h<TM, false>(p, acc, yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
 }
 
 // split-K finish: y[pos][cout] = bf16(act(scale * sum_kz slab + shift)); one thread per (position, cout pair)
@@ -484,29 +818,35 @@ __global__ __launch_bounds__(256) void conv_finish_bf16_kernel(const ConvParamsH
 }
 
 static int rowreuse_rows(const ConvParamsH& p, int bm);
+static int plane_rows(const ConvParamsH& p, int bm);
 
 // Tile / gather choice (tools/layer_bench.py --dtype bf16, B = 256, MI355X):
-//   * stride-1 layers with >= 3 taps along w and a deep K (v1, v3, v5, e7, v6) gain 10-25 % from the row-reuse
-//     gather (codes 9 / 10 = 128 / 256 positions);
-//   * the shallow-K 2D layers and the big-output layers (e2-e5, d3) sit near their HBM floor: they want the
-//     small-LDS per-tap kernel with 128-position tiles (more workgroups per CU to overlap loads and stores);
-//   * stride-2 layers would need a 2x larger LDS image for the reuse: per-tap kernel.
+//   * stride-1 layers with Cin % 64 == 0 whose 256-position plane image leaves room for two workgroups per CU
+//     (e6, e7, v1, v3, d2, d3) run the plane-reuse gather (code 6): 16-17 % faster than the row-reuse gather;
+//   * small planes (v5 7^3, d1 4^3: a tile spans many planes, each with its halo) and deep stride-1 layers that
+//     do not qualify keep the row-reuse gather (codes 9 / 10 = 128 / 256 positions);
+//   * everything else (stride 2, shallow K, Cin = 32) runs the per-tap kernel with 128-position tiles: more
+//     workgroups per CU to overlap loads and stores, 64-channel K tiles wherever Cin % 64 == 0.
 int conv_bf16_pick_tm(const ConvParamsH& p) {
     const long classes = (p.transposed ? 8 : 1) * (long)p.ksplit;
     const long n_tiles = p.CoutPad / HBN;
     auto wgs = [&](int tm) { return ((p.Ntotal + 128 * tm - 1) / (128 * tm)) * n_tiles * classes; };
-    // (transposed layers reuse 2 taps per group: worth it from Cin*T >= 2048 — d1 +7 %, d2 +9 %, d3 -5 %)
-    const bool deep = p.transposed ? (long)p.Cin * p.T >= 2048 : (p.kw >= 3 && (long)p.Cin * p.T >= 64 * 27);
+    const int pr = plane_rows(p, 256);
+    if (pr > 0 && pr <= 416 && (p.Cin / 64) % p.ksplit == 0 && (long)p.Cin * p.T >= 1024 && wgs(2) >= 512) return 6;
+    // row-reuse: 3+ taps along w over rows that are not tiny (v5 +7 %, v6 (4-wide rows) only with 128 positions);
+    // the transposed layers that miss the plane kernel (d1) are faster per tap with 64-channel K tiles
+    const bool deep = !p.transposed && p.kw >= 3 && (long)p.Cin * p.T >= 64 * 27;
     const bool reuse = p.stride == 1 && deep && rowreuse_rows(p, 128) <= 64 * NPA_MAX;
-    if (reuse) return (wgs(2) >= 1024 && rowreuse_rows(p, 256) <= 64 * NPA_MAX) ? 10 : 9;
+    if (reuse) return (wgs(2) >= 1024 && p.Nw >= 7 && rowreuse_rows(p, 256) <= 64 * NPA_MAX) ? 10 : 9;
     return 1;
 }
 
 int conv_bf16_pick_ksplit(const ConvParamsH& p) {
-    // per-sample geometry at a nominal batch of 32 (batch-invariant, as in the fp32 path)
+    // per-sample geometry at a nominal batch (batch-invariant, as in the fp32 path); 128 here: this path's
+    // named configuration is batch 256, where splitting v5 / v6 / d1 further costs 15-30 % of their time
     const int chunks = p.Cin / HKC;
     const long S = (long)p.Nd * p.Nh * p.Nw;
-    const long wg_nom = ((32 * S + 127) / 128) * (p.CoutPad / HBN) * (p.transposed ? 8 : 1);
+    const long wg_nom = ((128 * S + 127) / 128) * (p.CoutPad / HBN) * (p.transposed ? 8 : 1);
     int ks = 1;
     while (wg_nom * ks < 1024 && chunks % (2 * ks) == 0 && (chunks / (2 * ks)) * p.T >= 64) ks *= 2;
     return ks;
@@ -514,7 +854,7 @@ int conv_bf16_pick_ksplit(const ConvParamsH& p) {
 
 int64_t conv_bf16_scratch_elems(const ConvParamsH& p, int tm) {
     if (p.ksplit <= 1) return 0;
-    const int bm = 128 * (tm >= 9 ? tm - 8 : tm);
+    const int bm = 128 * (tm >= 16 ? tm - 16 : (tm >= 9 ? tm - 8 : (tm >= 5 ? tm - 4 : tm)));
     const int64_t mpad = (int64_t)((p.Ntotal + bm - 1) / bm) * bm;
     return (int64_t)(p.transposed ? 8 : 1) * p.ksplit * mpad * p.CoutPad;
 }
@@ -533,7 +873,7 @@ static hipError_t launch_tm_rowreuse(ConvParamsH p, hipStream_t stream) {
     p.n_tiles = p.CoutPad / HBN;
     const int r_max = rowreuse_rows(p, BM);
     if (r_max > 64 * NPA_MAX) return hipErrorInvalidValue;
-    const size_t lds = (size_t)2 * (r_max * 64 + p.kw * 4096) + 2 * BM * sizeof(int);
+    const size_t lds = (size_t)2 * (r_max * 64 + p.kw * 4096) + 2 * BM * sizeof(int) + EP_BYTES;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16r_kernel<TM>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return attr;
@@ -551,20 +891,68 @@ static hipError_t launch_tm_rowreuse(ConvParamsH p, hipStream_t stream) {
     return e;
 }
 
+// LDS rows (128 B each) of the plane-reuse kernel's A image for a BM-position tile: an upper bound over all
+// tiles (see conv_bf16p_kernel), in whole 32-row units (8-row pieces x 4 waves); 0 = layer not eligible
+static int plane_rows(const ConvParamsH& p, int bm) {
+    if (p.stride != 1 || p.Cin % 64 != 0 || p.x_hs % p.x_ws != 0) return 0;
+    const int in_p = p.x_hs / p.x_ws, P = p.Nh * p.Nw;
+    const int halo = (p.kh - 1) * in_p + p.kw - 1;
+    const int rows_touched = (bm + p.Nw - 2) / p.Nw + 1;
+    const int nseg = (bm + P - 2) / P + 1;
+    const int r = bm + (in_p - p.Nw) * rows_touched + nseg * halo;
+    return (r + 31) / 32 * 32;
+}
+
 template <int TM>
-static hipError_t launch_tm(ConvParamsH p, hipStream_t stream) {
+static hipError_t launch_tm_plane(ConvParamsH p, hipStream_t stream) {
     constexpr int BM = 128 * TM;
     p.m_tiles = (p.Ntotal + BM - 1) / BM;
     p.n_tiles = p.CoutPad / HBN;
-    const size_t lds = (size_t)2 * BM * 64 + 2 * HBN * 64 + 2 * BM * sizeof(int);
+    const int r_max = plane_rows(p, BM);
+    if (r_max == 0 || r_max > 32 * NPA_PL || (p.Cin / 64) % p.ksplit != 0) return hipErrorInvalidValue;
+    const size_t lds = (size_t)r_max * 128 + PL_NB * 8192 + 2 * BM * sizeof(int) + EP_BYTES;
+    if (lds > 160 * 1024 || (size_t)r_max * 4 > 8192) return hipErrorInvalidValue;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<TM>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return attr;
+    dim3 grid(p.m_tiles * p.n_tiles, p.transposed ? 8 : 1, p.ksplit);
+    hipLaunchKernelGGL((conv_bf16p_kernel<TM>), grid, dim3(256), lds, stream, p, r_max);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && p.ksplit > 1) {
+        const long long total = (long long)p.Ntotal * (p.CoutPad >> 1);
+        const long long blocks = (total + 255) / 256;
+        hipLaunchKernelGGL(conv_finish_bf16_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096), p.transposed ? 8 : 1),
+                           dim3(256), 0, stream, p, p.m_tiles * BM);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+template <int TM, int KC, bool HEAD>
+static hipError_t launch_tm_k(const ConvParamsH& p, dim3 grid, hipStream_t stream) {
+    constexpr int BM = 128 * TM;
+    constexpr size_t lds = (size_t)2 * BM * KC * 2 + 2 * HBN * KC * 2 + 2 * BM * sizeof(int) + EP_BYTES;
+    static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
     if (lds > 48 * 1024) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<TM>),
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<TM, KC, HEAD>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (attr != hipSuccess) return attr;
     }
+    hipLaunchKernelGGL((conv_bf16_kernel<TM, KC, HEAD>), grid, dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+// kc32: the caller forces 32-channel K tiles (tile code + 16); otherwise 64 wherever the layer allows it
+template <int TM>
+static hipError_t launch_tm(ConvParamsH p, bool kc32, hipStream_t stream) {
+    constexpr int BM = 128 * TM;
+    p.m_tiles = (p.Ntotal + BM - 1) / BM;
+    p.n_tiles = p.CoutPad / HBN;
     dim3 grid(p.m_tiles * p.n_tiles, p.transposed ? 8 : 1, p.ksplit);
-    hipLaunchKernelGGL((conv_bf16_kernel<TM>), grid, dim3(256), lds, stream, p);
-    hipError_t e = hipGetLastError();
+    const bool head = p.head_w && p.ksplit == 1;
+    const bool kc64 = !kc32 && p.Cin % 64 == 0 && (p.Cin / 64) % p.ksplit == 0;
+    hipError_t e = kc64 ? (head ? launch_tm_k<TM, 64, true>(p, grid, stream) : launch_tm_k<TM, 64, false>(p, grid, stream))
+                        : (head ? launch_tm_k<TM, 32, true>(p, grid, stream) : launch_tm_k<TM, 32, false>(p, grid, stream));
     if (e == hipSuccess && p.ksplit > 1) {
         const long long total = (long long)p.Ntotal * (p.CoutPad >> 1);
         const long long blocks = (total + 255) / 256;
@@ -583,11 +971,14 @@ hipError_t launch_conv_bf16(const ConvParamsH& pin, int tm, hipStream_t stream) 
     if (p.Cin % HKC != 0 || p.CoutPad % HBN != 0 || p.ksplit < 1 || (p.Cin / HKC) % p.ksplit != 0 ||
         (p.ksplit > 1 && !p.part))
         return hipErrorInvalidValue;
-    // tm = 1, 2, 4: per-tap gather (conv_bf16_kernel); tm = 9, 10: row-reuse gather (conv_bf16r_kernel) with TM 1, 2
+    // tm = 1, 2, 4: per-tap gather (conv_bf16_kernel; + 16: 32-channel K tiles even where 64 are possible);
+    // tm = 9, 10: row-reuse gather (conv_bf16r_kernel) with TM 1, 2
     switch (tm) {
-        case 1: return launch_tm<1>(p, stream);
-        case 2: return launch_tm<2>(p, stream);
-        case 4: return launch_tm<4>(p, stream);
+        case 1: case 17: return launch_tm<1>(p, tm > 16, stream);
+        case 2: case 18: return launch_tm<2>(p, tm > 16, stream);
+        case 4: case 20: return launch_tm<4>(p, tm > 16, stream);
+        case 5: return launch_tm_plane<1>(p, stream);
+        case 6: return launch_tm_plane<2>(p, stream);
         case 9: return launch_tm_rowreuse<1>(p, stream);
         case 10: return launch_tm_rowreuse<2>(p, stream);
         default: return hipErrorInvalidValue;
@@ -597,7 +988,8 @@ hipError_t launch_conv_bf16(const ConvParamsH& pin, int tm, hipStream_t stream) 
 // ------------------------------------------------------------------------------------------------
 // weight packing for the bf16 kernel (fp32 torch layout -> bf16, K-tile major, pre-swizzled):
 //   wp[cls][kt = chunk*T + tap][cout tile][row = tn*32 + c][slot][8]   (64 B per row)
-//     cout = tile*64 + 2c + tn,   slot holds channel group kg = slot ^ ((row >> 2) & 3),  cin = chunk*32 + kg*8 + e
+//     cout = tile*64 + tn*32 + 16*((c>>2)&1) + (c&3) + 4*(c>>3)  (MFMA output row c of half h = (c>>2)&1 is the
+//     lane-half's register r = (c&3) + 4*(c>>3): 16 consecutive couts per lane),   slot holds channel group kg = slot ^ ((row >> 2) & 3),  cin = chunk*32 + kg*8 + e
 __global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout,
                                  int CoutPad, int T, int transposed) {
     const size_t per_cls = (size_t)T * Cin * CoutPad;
@@ -613,7 +1005,7 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __
         const int tap = (int)(r % T);
         const int cc = (int)(r / T);
         const int tn = row >> 5, c = row & 31;
-        const int co = tile * 64 + 2 * c + tn;
+        const int co = tile * 64 + tn * 32 + 16 * ((c >> 2) & 1) + (c & 3) + 4 * (c >> 3);
         const int kg = slot ^ ((row >> 2) & 3);
         const int cin = cc * 32 + kg * 8 + e;
         float v = 0.f;

@@ -67,9 +67,12 @@ def test_each_layer_bf16_vs_oracle(s3r, oracle, idx):
     assert (err <= 2.0 ** -7 * want.abs() + 1e-3 * want.abs().max()).all(), layer.name
 
 
-@pytest.mark.parametrize("tm", [1, 2, 4, 9, 10])      # 9, 10: the row-reuse gather with 128 / 256-position tiles
+# 1, 2, 4: per-tap gather (64-channel K tiles where Cin allows, +16 = 32-channel); 5, 6: plane-reuse gather;
+# 9, 10: row-reuse gather (x128 / x256 positions)
+@pytest.mark.parametrize("tm", [1, 2, 4, 5, 6, 9, 10, 17, 18])
 @pytest.mark.parametrize("kind", ["conv3d_s1", "conv3d_s2", "deconv", "conv2d_s2", "conv3d_k4_valid_ks2", "cout32",
-                                  "conv2d_s1_w28", "conv3d_s1_w14"])
+                                  "conv2d_s1_w28", "conv3d_s1_w14", "conv3d_s1_c64", "deconv_c64", "deconv_c128_w8",
+                                  "conv3d_k4_valid_c128_ks2", "conv2d_s1_c128_w9"])
 def test_bf16_tiles_and_split_k(s3r, oracle, tm, kind):
     Layer = s3r.arch_spec.Layer
     layer, n_in, B, ks = {
@@ -81,6 +84,11 @@ def test_bf16_tiles_and_split_k(s3r, oracle, tm, kind):
         "cout32": (Layer("t", "conv2d", 256, 32, 1, 1, 0), 9, 3, 4),
         "conv2d_s1_w28": (Layer("t", "conv2d", 64, 64, 3, 1, 1), 28, 3, 0),
         "conv3d_s1_w14": (Layer("t", "conv3d", 32, 64, 3, 1, 1), 14, 2, 0),
+        "conv3d_s1_c64": (Layer("t", "conv3d", 64, 96, 3, 1, 1), 7, 3, 0),
+        "deconv_c64": (Layer("t", "deconv3d", 64, 48, 4, 2, 1), 5, 3, 0),
+        "deconv_c128_w8": (Layer("t", "deconv3d", 128, 64, 4, 2, 1), 8, 2, 0),
+        "conv3d_k4_valid_c128_ks2": (Layer("t", "conv3d", 128, 40, 4, 1, 0), 7, 2, 2),
+        "conv2d_s1_c128_w9": (Layer("t", "conv2d", 128, 64, 3, 1, 1), 9, 21, 0),
     }[kind]
     ch = s3r.modules._HipChain([layer], n_in, precision="bf16")
     s3r.seed_module(ch, 7)
@@ -96,7 +104,12 @@ def test_bf16_tiles_and_split_k(s3r, oracle, tm, kind):
         want = blk(x)
     xin = x.to(DEV).to(torch.bfloat16)
     xin = xin.permute(0, *range(2, xin.dim()), 1).contiguous()
-    if tm == 10 and kind == "conv3d_s2":      # 5-wide rows at stride 2: the 256-position reuse image exceeds its LDS budget
+    plane_ok = (layer.s == 1 or layer.op == "deconv3d") and layer.cin % 64 == 0 and (ks == 0 or (layer.cin // 64) % ks == 0)
+    if tm == 6 and kind == "conv3d_k4_valid_c128_ks2":
+        plane_ok = False                       # 16-position planes: a 256-position tile spans 17 of them (+ halos)
+    if (tm == 10 and kind == "conv3d_s2") or (tm in (5, 6) and not plane_ok):
+        # 5-wide rows at stride 2: the 256-position reuse image exceeds its LDS budget; the plane-reuse gather
+        # needs stride 1 and whole 64-channel chunks per split
         with pytest.raises(s3r.S3RError):
             ch.to(DEV)._run(xin)
         return

@@ -67,6 +67,8 @@ def main():
                   for ks in ksplits:
                     v = (v0, ks)
                     code = (15 if t < 0 else t) + 16 * v0
+                    if args.dtype == "bf16":
+                        code = t            # -1 = library heuristic; 1, 2, 4 per-tap; 9, 10 row-reuse
                     ch.tile_override[l.name] = code
                     ch.ksplit_override[l.name] = ks
                     s3r.profile_enable(8)
