@@ -562,20 +562,29 @@ __global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p,
 // HALO = (kh-1)*in_p + kw-1 trailing positions; MFMA row r reads LDS row lrow[r] + th*in_p + tw.  The image is
 // SINGLE-buffered (two workgroups per CU overlap one's reload with the other's MFMAs); the weights (8 KiB per
 // tap) stream through a 3-slot ring with one barrier per tap: 4*TM*2 MFMAs per wave between barriers.
-constexpr int NPA_PL = 15;     // 8-row A pieces per wave, upper bound (registers)
+constexpr int NPA_PL = 15;     // 8-row A pieces per wave, upper bound (registers), 128-byte rows
+constexpr int NPA_PL32 = 12;   // 16-row pieces, 64-byte rows
 constexpr int PL_NB = 3;       // weight ring slots
 
-template <int TM>
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_bf16p_kernel(const ConvParamsH p, int r_max) {
+// KC = 64: 128-byte image rows (whole lines), two workgroups per CU; KC = 32: 64-byte rows, half the LDS, three
+// workgroups per CU (and the only form for Cin = 32).
+template <int TM, int KC>
+__global__ __launch_bounds__(256, KC == 64 ? 2 : 3) void conv_bf16p_kernel(const ConvParamsH p, int r_max) {
     constexpr int BM = 128 * TM;
+    constexpr int ROWB = KC * 2;                   // bytes per LDS row
+    constexpr int LPR = ROWB / 16;                 // lanes (16-byte slots) per row
+    constexpr int RPP = 64 / LPR;                  // rows per 1 KiB LDS-DMA piece
+    constexpr int B_BYTES = HBN * ROWB;            // one tap's weight tile
+    constexpr int NPB = B_BYTES / 4096;            // its pieces per wave
+    constexpr int NPA_CAP = KC == 64 ? NPA_PL : NPA_PL32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int a_bytes = r_max * 128;
-    char* Bs = smem + a_bytes;                                        // [PL_NB][64][128 B]
-    int* yoff = reinterpret_cast<int*>(Bs + PL_NB * 8192);            // [BM] output element offsets, -1 = none
+    const int a_bytes = r_max * ROWB;
+    char* Bs = smem + a_bytes;                                        // [PL_NB][64][ROWB]
+    int* yoff = reinterpret_cast<int*>(Bs + PL_NB * B_BYTES);         // [BM] output element offsets, -1 = none
     int* lrow = yoff + BM;                                            // [BM] LDS row of each tile position (tap 0,0)
     float* ep = reinterpret_cast<float*>(lrow + BM);                  // [3][64] scale / shift / head weight
-    int* asrc = reinterpret_cast<int*>(Bs + 2 * 8192);                // [r_max] source byte offset of each image row
-                                                                      // (prologue only: aliases ring slot 2)
+    int* asrc = reinterpret_cast<int*>(Bs + (PL_NB - 1) * B_BYTES);  // [r_max] source byte offset of each image row
+                                                                      // (prologue only: aliases the last ring slot)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -597,7 +606,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int S = p.Nd * p.Nh * p.Nw, P = p.Nh * p.Nw;
     const int T = p.T, kh = p.kh, kw = p.kw;
     const int taps_g = kh * kw;
-    const int chunks = (p.Cin / 64) / p.ksplit;
+    const int chunks = (p.Cin / KC) / p.ksplit;
     const int ngroups = S3R_ABLH(p, 2) ? 1 : chunks * p.kd;
     const int total = ngroups * taps_g;
     const int cls_x = p.transposed ? (rd - 1) * p.x_ds + (rh - 1) * p.x_hs + (rw - 1) * p.x_ws : 0;
@@ -654,20 +663,24 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     __syncthreads();
 
     // ---- loop-invariant DMA source offsets
-    const int npa = r_max >> 5;                               // A pieces per wave (r_max % 32 == 0)
-    int avoff[NPA_PL];
+    const int npa = r_max / (4 * RPP);                        // A pieces per wave (r_max % (4*RPP) == 0)
+    int avoff[NPA_CAP];
 #pragma unroll
-    for (int q = 0; q < NPA_PL; ++q) {
-        const int j = (wave + 4 * q) * 8 + (lane >> 3);
-        avoff[q] = (q < npa ? asrc[j] : 0) + (((lane & 7) ^ swz<64>(j)) << 4);
+    for (int q = 0; q < NPA_CAP; ++q) {
+        const int j = (wave + 4 * q) * RPP + lane / LPR;
+        avoff[q] = (q < npa ? asrc[j] : 0) + (((lane % LPR) ^ swz<KC>(j)) << 4);
     }
     const int w_tile = p.n_tiles * 4096;
-    int bvoff[2];
+    int bvoff[NPB];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int r = (wave + 4 * q) * 8 + (lane >> 3);
-        const int kg = (lane & 7) ^ swz<64>(r);
-        bvoff[q] = (kg >> 2) * (T * w_tile) + r * 64 + (((kg & 3) ^ swz<32>(r)) << 4);
+    for (int q = 0; q < NPB; ++q) {
+        if constexpr (KC == 32) {
+            bvoff[q] = (wave + 4 * q) * 1024 + lane * 16;     // stored pre-swizzled for 64-byte rows
+        } else {
+            const int r = (wave + 4 * q) * RPP + lane / LPR;
+            const int kg = (lane % LPR) ^ swz<64>(r);
+            bvoff[q] = (kg >> 2) * (T * w_tile) + r * 64 + (((kg & 3) ^ swz<32>(r)) << 4);
+        }
     }
     int lr[TM];
 #pragma unroll
@@ -676,7 +689,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         const int row = tn * 32 + c;
-        b_off[tn] = row * 128 + ((h ^ swz<64>(row)) << 4);
+        b_off[tn] = row * ROWB + ((h ^ swz<KC>(row)) << 4);
     }
 
     const __amdgpu_buffer_rsrc_t xrsrc =
@@ -689,16 +702,16 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     int a_cc = kz * chunks, a_td = 0;                         // cursor of the NEXT image to fetch
     int b_cc = kz * chunks, b_tap = 0, b_slot = 0;            // cursor of the NEXT weight tile to fetch
     auto issue_a = [&]() {
-        const int a_base = (a_cc * 64 + a_td * p.x_ds) * 2;
+        const int a_base = (a_cc * KC + a_td * p.x_ds) * 2;
 #pragma unroll
-        for (int q = 0; q < NPA_PL; ++q)
+        for (int q = 0; q < NPA_CAP; ++q)
             if (q < npa) dma16(xrsrc, smem + ((wave + 4 * q) << 10), avoff[q], a_base);
         if (++a_td == p.kd) { a_td = 0; ++a_cc; }
     };
     auto issue_b = [&]() {
-        const int b_base = ((b_cc * 2 * T + b_tap) * p.n_tiles + n_tile) * 4096;
+        const int b_base = ((b_cc * (KC / 32) * T + b_tap) * p.n_tiles + n_tile) * 4096;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) dma16(wrsrc, Bs + b_slot * 8192 + ((wave + 4 * q) << 10), bvoff[q], b_base);
+        for (int q = 0; q < NPB; ++q) dma16(wrsrc, Bs + b_slot * B_BYTES + ((wave + 4 * q) << 10), bvoff[q], b_base);
         if (++b_tap == T) { b_tap = 0; ++b_cc; }
         if (++b_slot == PL_NB) b_slot = 0;
     };
@@ -724,15 +737,16 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             // (s_barrier as inline asm: the compiler drains vmcnt before every barrier it knows about, which
             // would cut the weight prefetch back to one tap)
             if (t == 0 || tt + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (NPB == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");           // ... for every wave; ring slot (tt+2)%3 is free
             if (tt + 2 < total && !S3R_ABLH(p, 3)) issue_b();
-            const char* b = Bs + c_slot * 8192;
+            const char* b = Bs + c_slot * B_BYTES;
             int a_off[TM];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 const int row = lr[tm] + tapoff;
-                a_off[tm] = (row << 7) + (((h ^ (row >> 1)) & 7) << 4);
+                a_off[tm] = row * ROWB + ((h ^ swz<KC>(row)) << 4);
             }
             // fragments of k-step q+1 are requested before the MFMAs of k-step q
             bf16x8 av[2][TM], bv[2][2];
@@ -741,8 +755,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) bv[0][tn] = *reinterpret_cast<const bf16x8*>(b + b_off[tn]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q < 3) {
+            for (int q = 0; q < KC / 16; ++q) {
+                if (q < KC / 16 - 1) {
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
                         av[(q + 1) & 1][tm] = *reinterpret_cast<const bf16x8*>(smem + (a_off[tm] ^ ((q + 1) << 5)));
@@ -760,7 +774,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             // read -> wait -> MFMA): k-step 0's reads, then per k-step one read of the NEXT step behind each MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, TM + 2, 0);
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+            for (int q = 0; q < KC / 16 - 1; ++q)
 #pragma unroll
                 for (int i = 0; i < 2 * TM; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -818,27 +832,32 @@ __global__ __launch_bounds__(256) void conv_finish_bf16_kernel(const ConvParamsH
 }
 
 static int rowreuse_rows(const ConvParamsH& p, int bm);
-static int plane_rows(const ConvParamsH& p, int bm);
+static int plane_rows(const ConvParamsH& p, int bm, int kc);
 
 // Tile / gather choice (tools/layer_bench.py --dtype bf16, B = 256, MI355X):
-//   * stride-1 layers with Cin % 64 == 0 whose 256-position plane image leaves room for two workgroups per CU
-//     (e6, e7, v1, v3, d2, d3) run the plane-reuse gather (code 6): 16-17 % faster than the row-reuse gather;
-//   * small planes (v5 7^3, d1 4^3: a tile spans many planes, each with its halo) and deep stride-1 layers that
-//     do not qualify keep the row-reuse gather (codes 9 / 10 = 128 / 256 positions);
-//   * everything else (stride 2, shallow K, Cin = 32) runs the per-tap kernel with 128-position tiles: more
+//   * stride-1 layers from K = 512 up whose 256-position plane image leaves room for THREE workgroups per CU
+//     (e4, e6, e7, v1, v3, v5, d1, d2, d3) run the plane-reuse gather with 32-channel K tiles (code 22): 5-25 %
+//     faster than the per-tap / row-reuse kernels, and 2-7 % faster than its own 64-channel form (code 6, two
+//     workgroups per CU): overlapping one workgroup's image reload and stores with the others' MFMAs is worth
+//     more than whole-line gathers once the image is fetched only once per kh*kw taps;
+//   * deep stride-1 layers that do not qualify (v6: 16-position planes) keep the row-reuse gather (codes 9 / 10);
+//   * everything else (stride 2, shallow K, small batches) runs the per-tap kernel with 128-position tiles: more
 //     workgroups per CU to overlap loads and stores, 64-channel K tiles wherever Cin % 64 == 0.
 int conv_bf16_pick_tm(const ConvParamsH& p) {
     const long classes = (p.transposed ? 8 : 1) * (long)p.ksplit;
     const long n_tiles = p.CoutPad / HBN;
     auto wgs = [&](int tm) { return ((p.Ntotal + 128 * tm - 1) / (128 * tm)) * n_tiles * classes; };
-    const int pr = plane_rows(p, 256);
-    if (pr > 0 && pr <= 416 && (p.Cin / 64) % p.ksplit == 0 && (long)p.Cin * p.T >= 1024 && wgs(2) >= 512) return 6;
-    // row-reuse: 3+ taps along w over rows that are not tiny (v5 +7 %, v6 (4-wide rows) only with 128 positions);
-    // the transposed layers that miss the plane kernel (d1) are faster per tap with 64-channel K tiles
+    // The K summation order of a layer must not depend on the batch (a sample's result is batch-invariant): the
+    // plane / row-reuse kernels and the 32-channel per-tap kernel accumulate chunk32-major, the 64-channel per-tap
+    // kernel chunk64-major.  So the FAMILY is chosen from per-sample geometry, only the tile from the batch.
+    const int pr = plane_rows(p, 256, 32);
+    const bool plane_family = pr > 0 && pr <= 576 && (p.Cin / 32) % p.ksplit == 0 && (long)p.Cin * p.T >= 512;
+    if (plane_family && wgs(2) >= 512) return 22;
+    // row-reuse: 3+ taps along w over rows that are not tiny (v6 (4-wide rows) only with 128 positions)
     const bool deep = !p.transposed && p.kw >= 3 && (long)p.Cin * p.T >= 64 * 27;
     const bool reuse = p.stride == 1 && deep && rowreuse_rows(p, 128) <= 64 * NPA_MAX;
     if (reuse) return (wgs(2) >= 1024 && p.Nw >= 7 && rowreuse_rows(p, 256) <= 64 * NPA_MAX) ? 10 : 9;
-    return 1;
+    return plane_family ? 17 : 1;                  // (17: small batches of a plane-family layer)
 }
 
 int conv_bf16_pick_ksplit(const ConvParamsH& p) {
@@ -854,7 +873,7 @@ int conv_bf16_pick_ksplit(const ConvParamsH& p) {
 
 int64_t conv_bf16_scratch_elems(const ConvParamsH& p, int tm) {
     if (p.ksplit <= 1) return 0;
-    const int bm = 128 * (tm >= 16 ? tm - 16 : (tm >= 9 ? tm - 8 : (tm >= 5 ? tm - 4 : tm)));
+    const int bm = 128 * (tm >= 21 ? tm - 20 : (tm >= 16 ? tm - 16 : (tm >= 9 ? tm - 8 : (tm >= 5 ? tm - 4 : tm))));
     const int64_t mpad = (int64_t)((p.Ntotal + bm - 1) / bm) * bm;
     return (int64_t)(p.transposed ? 8 : 1) * p.ksplit * mpad * p.CoutPad;
 }
@@ -893,30 +912,32 @@ static hipError_t launch_tm_rowreuse(ConvParamsH p, hipStream_t stream) {
 
 // LDS rows (128 B each) of the plane-reuse kernel's A image for a BM-position tile: an upper bound over all
 // tiles (see conv_bf16p_kernel), in whole 32-row units (8-row pieces x 4 waves); 0 = layer not eligible
-static int plane_rows(const ConvParamsH& p, int bm) {
-    if (p.stride != 1 || p.Cin % 64 != 0 || p.x_hs % p.x_ws != 0) return 0;
+static int plane_rows(const ConvParamsH& p, int bm, int kc) {
+    if (p.stride != 1 || p.Cin % kc != 0 || p.x_hs % p.x_ws != 0) return 0;
     const int in_p = p.x_hs / p.x_ws, P = p.Nh * p.Nw;
     const int halo = (p.kh - 1) * in_p + p.kw - 1;
     const int rows_touched = (bm + p.Nw - 2) / p.Nw + 1;
     const int nseg = (bm + P - 2) / P + 1;
     const int r = bm + (in_p - p.Nw) * rows_touched + nseg * halo;
-    return (r + 31) / 32 * 32;
+    const int unit = kc == 64 ? 32 : 64;           // rows per (piece x 4 waves)
+    return (r + unit - 1) / unit * unit;
 }
 
-template <int TM>
+template <int TM, int KC>
 static hipError_t launch_tm_plane(ConvParamsH p, hipStream_t stream) {
     constexpr int BM = 128 * TM;
     p.m_tiles = (p.Ntotal + BM - 1) / BM;
     p.n_tiles = p.CoutPad / HBN;
-    const int r_max = plane_rows(p, BM);
-    if (r_max == 0 || r_max > 32 * NPA_PL || (p.Cin / 64) % p.ksplit != 0) return hipErrorInvalidValue;
-    const size_t lds = (size_t)r_max * 128 + PL_NB * 8192 + 2 * BM * sizeof(int) + EP_BYTES;
-    if (lds > 160 * 1024 || (size_t)r_max * 4 > 8192) return hipErrorInvalidValue;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<TM>),
+    const int r_max = plane_rows(p, BM, KC);
+    if (r_max == 0 || r_max > (KC == 64 ? 32 * NPA_PL : 64 * NPA_PL32) || (p.Cin / KC) % p.ksplit != 0)
+        return hipErrorInvalidValue;
+    const size_t lds = (size_t)r_max * KC * 2 + PL_NB * HBN * KC * 2 + 2 * BM * sizeof(int) + EP_BYTES;
+    if (lds > 160 * 1024 || r_max * 4 > HBN * KC * 2) return hipErrorInvalidValue;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<TM, KC>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return attr;
     dim3 grid(p.m_tiles * p.n_tiles, p.transposed ? 8 : 1, p.ksplit);
-    hipLaunchKernelGGL((conv_bf16p_kernel<TM>), grid, dim3(256), lds, stream, p, r_max);
+    hipLaunchKernelGGL((conv_bf16p_kernel<TM, KC>), grid, dim3(256), lds, stream, p, r_max);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && p.ksplit > 1) {
         const long long total = (long long)p.Ntotal * (p.CoutPad >> 1);
@@ -977,8 +998,10 @@ hipError_t launch_conv_bf16(const ConvParamsH& pin, int tm, hipStream_t stream) 
         case 1: case 17: return launch_tm<1>(p, tm > 16, stream);
         case 2: case 18: return launch_tm<2>(p, tm > 16, stream);
         case 4: case 20: return launch_tm<4>(p, tm > 16, stream);
-        case 5: return launch_tm_plane<1>(p, stream);
-        case 6: return launch_tm_plane<2>(p, stream);
+        case 5: return launch_tm_plane<1, 64>(p, stream);
+        case 6: return launch_tm_plane<2, 64>(p, stream);
+        case 21: return launch_tm_plane<1, 32>(p, stream);
+        case 22: return launch_tm_plane<2, 32>(p, stream);
         case 9: return launch_tm_rowreuse<1>(p, stream);
         case 10: return launch_tm_rowreuse<2>(p, stream);
         default: return hipErrorInvalidValue;
