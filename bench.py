@@ -259,18 +259,17 @@ def main():
                 # recorded by the library on the stream it launches on)
                 achieved = c["flops"] / c["ms"] / 1e9            # TFLOP/s
                 traffic = None
-                tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+                bf = args.dtype == "bf16"
+                tpath = os.path.join(ROOT, "profiles", "traffic_r01_bf16.json" if bf else "traffic_r01.json")
                 if os.path.exists(tpath):
                     try:
                         traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")   # rocprofv3 PMC, per launch
                     except Exception:
                         traffic = None
-                bf = args.dtype == "bf16"
                 peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_FP32_MFMA_TFLOPS
-                if bf:
-                    traffic = None
                 roof = {"bound": "mfma",
-                        "kernel": "conv_bf16_kernel (v_mfma_f32_32x32x16_bf16 implicit-GEMM conv, channels-last, LDS-DMA)" if bf
+                        "kernel": "conv_bf16{,r,p}_kernel (v_mfma_f32_32x32x16_bf16 implicit-GEMM conv, channels-last, LDS-DMA; "
+                                  "per-tap / row-reuse / plane-reuse gathers)" if bf
                         else "conv_glds_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv, LDS-DMA operand staging)",
                         "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(achieved / peak, 4), "traffic": traffic,

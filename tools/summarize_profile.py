@@ -16,7 +16,7 @@ import sys
 from collections import defaultdict
 
 
-FAMILY = "conv_glds_kernel"
+FAMILY = "conv_glds_kernel"     # third argument overrides it (bf16 path: "conv_bf16", matching all three kernels)
 
 
 def rows(path):
@@ -30,7 +30,10 @@ def short(name):
 
 
 def main():
+    global FAMILY
     src, tag = sys.argv[1], sys.argv[2]
+    if len(sys.argv) > 3:
+        FAMILY = sys.argv[3]
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(out, exist_ok=True)
     # ---- --stats summary
@@ -76,7 +79,7 @@ def main():
         for (k, i), v in sorted(per.items()):
             w.writerow([k, i] + [v.get(c, "") for c in names])
     # ---- traffic per forward pass; the PMC passes' forward count = number of stem_kernel dispatches
-    steps = max(1, sum(1 for (k, _), v in per.items() if k.startswith("stem_kernel") and "FETCH_SIZE" in v))
+    steps = max(1, sum(1 for (k, _), v in per.items() if k.startswith("stem_") and "FETCH_SIZE" in v))
     fam = [v for (k, _), v in per.items() if k.startswith(FAMILY)]
     launches = len(fam)
     fetch = sum(v.get("FETCH_SIZE", 0) for v in fam) * 1024
