@@ -15,6 +15,8 @@
  *   s3r_chamfer_forward                     extensions/chamfer_dist (the reference's one native op,
  *                                           built by `python setup.py install`)         (README.md:64-65)
  *   s3r_voxel_iou                           the IoU metric of `runner.py --test`        (README.md:88-92)
+ *   s3r_disparity_wta, s3r_disparity_epe    predicted left / right disparity and its end-point error
+ *                                           against the disp_%02d_{l,r}.exr ground truth (README.md:75-76)
  *
  * Conventions
  *   - every tensor is fp32, contiguous, NCHW / NCDHW, resident in device memory owned by the caller;
@@ -150,9 +152,22 @@ int s3r_chamfer_forward(const float* p, const float* q, float* dist1, float* dis
 int s3r_voxel_iou(const float* pred, const float* gt, float threshold, float* iou, int batch, int64_t voxels,
                   void* stream);
 
+/* Disparity read-out: winner-take-all over the shift-and-diff costs of the cost volume (same features, same
+ * |L - R shifted| costs, volume never materialised).  feat_* (B,C,H,W) fp32; disp_* (B,H,W) fp32, integer-valued,
+ * in feature-resolution pixels:
+ *   disp_l[b,h,w] = first argmin_{d in [0, min(max_disp-1, w)]}     sum_c |L[b,c,h,w] - R[b,c,h,w-d]|
+ *   disp_r[b,h,w] = first argmin_{d in [0, min(max_disp-1, W-1-w)]} sum_c |R[b,c,h,w] - L[b,c,h,w+d]|   */
+int s3r_disparity_wta(const float* feat_l, const float* feat_r, float* disp_l, float* disp_r, int batch, int channels,
+                      int height, int width, int max_disp, void* stream);
+
+/* per-sample end-point error mean|pred - gt| over the pixels with a valid ground truth (finite, >= 0), and that
+ * pixel count; epe = 0 where no pixel is valid */
+int s3r_disparity_epe(const float* pred, const float* gt, float* epe, int32_t* count, int batch, int64_t pixels,
+                      void* stream);
+
 /* Kernel-level profiler: when enabled, every kernel the library launches is bracketed by HIP events
  * on the launch stream.  s3r_profile_read synchronises those events and returns, per launch, the
- * kernel family (0 mfma conv, 1 stem, 2 head, 3 cost volume, 4 linear, 5 chamfer, 6 iou, 7 pack, 8 pad copy),
+ * kernel family (0 mfma conv, 1 stem, 2 head, 3 cost volume, 4 linear, 5 chamfer, 6 iou, 7 pack, 8 pad copy, 9 disparity read-out / epe),
  * the caller's tag, milliseconds, and the algorithmic flops / bytes of that launch. */
 typedef struct s3r_prof_record {
     int32_t family;

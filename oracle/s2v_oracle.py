@@ -178,6 +178,42 @@ def chamfer_loss(p, q):
     return d1.mean() + d2.mean()
 
 
+def disparity_wta(feat_l: torch.Tensor, feat_r: torch.Tensor, max_disp: int = spec.MAX_DISP):
+    """Winner-take-all disparity from the cost volume's own costs (README.md:75-76 documents the
+    ground truth this is scored against).  (B,C,H,W) x2 -> disp_l, disp_r (B,H,W) fp32, integer-valued:
+        disp_l[b,h,w] = first argmin_{d <= min(max_disp-1, w)}     sum_c |L[b,c,h,w] - R[b,c,h,w-d]|
+        disp_r[b,h,w] = first argmin_{d <= min(max_disp-1, W-1-w)} sum_c |R[b,c,h,w] - L[b,c,h,w+d]|
+    The channel sum is accumulated c = 0..C-1 one channel at a time in fp32 (not torch.sum, whose order is
+    unspecified), so near-ties resolve the same way in every implementation of this definition."""
+    B, C, H, W = feat_l.shape
+    inf = torch.full((B, H, W), float("inf"))
+    best_l, best_r = inf.clone(), inf.clone()
+    arg_l, arg_r = torch.zeros(B, H, W), torch.zeros(B, H, W)
+    for d in range(min(max_disp, W)):
+        cl = torch.zeros(B, H, W - d)
+        cr = torch.zeros(B, H, W - d)
+        for c in range(C):
+            diff = (feat_l[:, c, :, d:] - feat_r[:, c, :, : W - d]).abs()      # |L(w) - R(w-d)| == |R(w') - L(w'+d)|
+            cl = cl + diff
+            cr = cr + diff
+        full_l, full_r = inf.clone(), inf.clone()
+        full_l[:, :, d:] = cl
+        full_r[:, :, : W - d] = cr
+        upd_l, upd_r = full_l < best_l, full_r < best_r
+        best_l, best_r = torch.where(upd_l, full_l, best_l), torch.where(upd_r, full_r, best_r)
+        arg_l, arg_r = torch.where(upd_l, torch.full_like(arg_l, d), arg_l), torch.where(upd_r, torch.full_like(arg_r, d), arg_r)
+    return arg_l, arg_r
+
+
+def disparity_epe(pred: torch.Tensor, gt: torch.Tensor):
+    """Per-sample end-point error over the valid ground-truth pixels (finite, >= 0) and their count."""
+    valid = torch.isfinite(gt) & (gt >= 0)
+    err = torch.where(valid, (pred - torch.where(valid, gt, torch.zeros_like(gt))).abs(), torch.zeros_like(gt)).double()
+    n = valid.flatten(1).sum(1)
+    s = err.flatten(1).sum(1)
+    return torch.where(n > 0, s / n.clamp(min=1), torch.zeros_like(s)).float(), n.to(torch.int32)
+
+
 def voxel_iou(pred: torch.Tensor, gt: torch.Tensor, th: float = 0.5) -> torch.Tensor:
     """Per-sample IoU of thresholded occupancy grids: |pred>th & gt>th| / |pred>th | gt>th|."""
     a, b = pred > th, gt > th

@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--test", action="store_true", help="evaluate (the only mode this build implements)")
     ap.add_argument("--weights", default=None, help="checkpoint (.pth) to load")
     ap.add_argument("--keymap", default=None, help="JSON: reference state_dict key -> this build's key")
-    ap.add_argument("--data", default=None, help=".npz with left, right, volume; default: synthetic")
+    ap.add_argument("--data", default=None, help=".npz with left, right, volume [, disp_left, disp_right]; default: synthetic")
     ap.add_argument("--dataset-root", default=None,
                     help="StereoShapeNet root (ShapeNetStereoRendering/ + ShapeNetVox32/, README.md:73-77)")
     ap.add_argument("--samples", type=int, default=64, help="synthetic eval list length")
@@ -69,13 +69,21 @@ def main():
         left, right, gt = (torch.from_numpy(z[k]).float() for k in ("left", "right", "volume"))
     else:
         left, right, gt = s3r.evaluate.synthetic_eval_set(args.samples, args.seed)
+    disp = None
     if left is not None:
         res = s3r.evaluate.test_net(model, left, right, gt, batch=args.batch, device=dev)
+        if args.data and "disp_left" in z.files and "disp_right" in z.files:
+            # (N,28,28) ground-truth disparity at feature resolution, render pixels; inf / negative = invalid
+            disp = s3r.evaluate.test_disparity(model, left, right, torch.from_numpy(z["disp_left"]).float(),
+                                               torch.from_numpy(z["disp_right"]).float(), batch=args.batch, device=dev)
     if rank == 0:
-        print(json.dumps({"samples": res["samples"], "n_gpus": world, "thresholds": res["thresholds"],
-                          "mean_iou": [round(x, 6) for x in res["mean_iou"]],
-                          "weights": args.weights or f"seeded random init (seed {args.seed})",
-                          "data": args.dataset_root or args.data or "synthetic"}))
+        out = {"samples": res["samples"], "n_gpus": world, "thresholds": res["thresholds"],
+               "mean_iou": [round(x, 6) for x in res["mean_iou"]],
+               "weights": args.weights or f"seeded random init (seed {args.seed})",
+               "data": args.dataset_root or args.data or "synthetic"}
+        if disp is not None:
+            out.update({"disparity_epe_left_px": round(disp["epe_left"], 4), "disparity_epe_right_px": round(disp["epe_right"], 4)})
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 

@@ -17,7 +17,7 @@ OP_CONV, OP_DECONV, OP_LINEAR = 0, 1, 2
 DTYPE = {"fp32": 0, "bf16": 1}
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}
 FAMILY = {0: "conv_mfma", 1: "stem", 2: "head", 3: "cost_volume", 4: "linear", 5: "chamfer", 6: "iou", 7: "pack",
-          8: "pad_copy"}
+          8: "pad_copy", 9: "disparity"}
 ABI_VERSION = 2
 
 
@@ -70,6 +70,9 @@ SIGNATURES = {
     "s3r_chamfer_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "s3r_voxel_iou": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "s3r_disparity_wta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_void_p]),
+    "s3r_disparity_epe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "s3r_profile_enable": (C.c_int, [C.c_int]),
     "s3r_profile_reset": (C.c_int, []),
     "s3r_profile_read": (C.c_int, [C.POINTER(ProfRecord), C.c_int]),

@@ -36,7 +36,7 @@ constexpr int64_t kMaxElems = (int64_t)1 << 31;
 constexpr int64_t kMaxBytes = (int64_t)1 << 32;
 
 // ---------------------------------------------------------------- profiler
-enum Family { F_MFMA = 0, F_STEM = 1, F_HEAD = 2, F_COSTVOL = 3, F_LINEAR = 4, F_CHAMFER = 5, F_IOU = 6, F_PACK = 7, F_PAD = 8 };
+enum Family { F_MFMA = 0, F_STEM = 1, F_HEAD = 2, F_COSTVOL = 3, F_LINEAR = 4, F_CHAMFER = 5, F_IOU = 6, F_PACK = 7, F_PAD = 8, F_DISP = 9 };
 
 struct Prof {
     std::mutex mu;
@@ -746,6 +746,32 @@ int s3r_voxel_iou(const float* pred, const float* gt, float threshold, float* io
     ProfScope ps(s, F_IOU, 0, 0.0, 8.0 * batch * (double)voxels);
     hipError_t e = s3r::launch_iou(pred, gt, threshold, iou, batch, voxels, s);
     if (e != hipSuccess) return hip_fail(e, "iou launch");
+    return S3R_OK;
+}
+
+int s3r_disparity_wta(const float* feat_l, const float* feat_r, float* disp_l, float* disp_r, int batch, int channels,
+                      int height, int width, int max_disp, void* stream) {
+    if (!feat_l || !feat_r || !disp_l || !disp_r) return fail(S3R_ERR_INVALID, "null tensor pointer");
+    if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || max_disp <= 0)
+        return fail(S3R_ERR_INVALID, "disparity dims must be positive");
+    if ((size_t)2 * channels * width * sizeof(float) > 64 * 1024)
+        return fail(S3R_ERR_INVALID, "disparity read-out: a feature row pair (2*C*W floats) must fit 64 KiB of LDS");
+    hipStream_t s = (hipStream_t)stream;
+    const double px = (double)batch * height * width;
+    ProfScope ps(s, F_DISP, 0, 0.0, 4.0 * px * (2.0 * channels + 2.0));
+    hipError_t e = s3r::launch_disparity_wta(feat_l, feat_r, disp_l, disp_r, batch, channels, max_disp, height, width, s);
+    if (e != hipSuccess) return hip_fail(e, "disparity read-out launch");
+    return S3R_OK;
+}
+
+int s3r_disparity_epe(const float* pred, const float* gt, float* epe, int32_t* count, int batch, int64_t pixels,
+                      void* stream) {
+    if (!pred || !gt || !epe || !count) return fail(S3R_ERR_INVALID, "null tensor pointer");
+    if (batch <= 0 || pixels <= 0) return fail(S3R_ERR_INVALID, "epe dims must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(s, F_DISP, 1, 0.0, 8.0 * batch * (double)pixels);
+    hipError_t e = s3r::launch_disparity_epe(pred, gt, epe, count, batch, pixels, s);
+    if (e != hipSuccess) return hip_fail(e, "epe launch");
     return S3R_OK;
 }
 

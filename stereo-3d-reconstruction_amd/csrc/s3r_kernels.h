@@ -130,5 +130,9 @@ hipError_t launch_cost_volume_bf16(const void* fl, const void* fr, void* vol, in
 hipError_t launch_head_bf16(const void* x, const float* w, const float* scale, const float* shift, float* y, int C,
                             int64_t voxels, int act, hipStream_t s);
 hipError_t launch_iou(const float* pred, const float* gt, float th, float* iou, int B, int64_t S, hipStream_t s);
+hipError_t launch_disparity_wta(const float* fl, const float* fr, float* dl, float* dr, int B, int C, int D, int H, int W,
+                                hipStream_t s);
+hipError_t launch_disparity_epe(const float* pred, const float* gt, float* epe, int* count, int B, int64_t S,
+                                hipStream_t s);
 
 }  // namespace s3r

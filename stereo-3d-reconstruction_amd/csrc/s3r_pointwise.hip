@@ -387,4 +387,92 @@ hipError_t launch_iou(const float* pred, const float* gt, float th, float* iou, 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Disparity read-out: winner-take-all over the SAME shift-and-diff costs the cost volume
+// holds, without materialising the volume:
+//   disp_l[b,h,w] = first argmin_{d in [0, min(D-1, w)]}     sum_c |L[b,c,h,w] - R[b,c,h,w-d]|
+//   disp_r[b,h,w] = first argmin_{d in [0, min(D-1, W-1-w)]} sum_c |R[b,c,h,w] - L[b,c,h,w+d]|
+// The channel sum runs c = 0..C-1 sequentially in fp32 (no FMA: |a-b| then add), which is what the oracle
+// does, so ties and near-ties resolve identically: the result is bit-exact.  One workgroup per (b, h) row, both
+// feature rows staged in LDS ([C][W] each); HBM-bound on 2*C*H*W*4 bytes per sample (25 KB at 28x28x32).
+__global__ __launch_bounds__(256) void disparity_wta_kernel(const float* __restrict__ fl, const float* __restrict__ fr,
+                                                            float* __restrict__ dl, float* __restrict__ dr, int C, int D,
+                                                            int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float dw_smem[];
+    float* sl = dw_smem;
+    float* sr = dw_smem + C * W;
+    const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
+    const size_t plane = (size_t)H * W;
+    const float* __restrict__ pl = fl + (size_t)b * C * plane + (size_t)hh * W;
+    const float* __restrict__ pr = fr + (size_t)b * C * plane + (size_t)hh * W;
+    for (int i = threadIdx.x; i < C * W; i += 256) {
+        const int c = i / W, w = i - c * W;
+        sl[i] = pl[(size_t)c * plane + w];
+        sr[i] = pr[(size_t)c * plane + w];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 2 * W; o += 256) {
+        const bool right = o >= W;
+        const int w = right ? o - W : o;
+        const float* a = right ? sr : sl;          // reference view
+        const float* m = right ? sl : sr;          // matched view, shifted by -d (left-referenced) / +d
+        const int dmax = right ? (W - 1 - w) : w;
+        const int nd = (dmax < D - 1 ? dmax : D - 1) + 1;
+        const int step = right ? 1 : -1;
+        float best = __builtin_inff();
+        int arg = 0;
+        for (int d = 0; d < nd; ++d) {
+            float cost = 0.f;
+            const int wm = w + step * d;
+            for (int c = 0; c < C; ++c) cost = cost + fabsf(a[c * W + w] - m[c * W + wm]);
+            if (cost < best) { best = cost; arg = d; }
+        }
+        (right ? dr : dl)[(size_t)b * plane + (size_t)hh * W + w] = (float)arg;
+    }
+}
+
+hipError_t launch_disparity_wta(const float* fl, const float* fr, float* dl, float* dr, int B, int C, int D, int H, int W,
+                                hipStream_t s) {
+    const size_t lds = (size_t)2 * C * W * sizeof(float);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(disparity_wta_kernel, dim3(B * H), dim3(256), lds, s, fl, fr, dl, dr, C, D, H, W);
+    return hipGetLastError();
+}
+
+// End-point error per sample: mean |pred - gt| over the pixels whose ground truth is valid (finite and >= 0: EXR
+// disparity maps mark background with inf / negative values), plus the valid count so a caller can pool samples
+// exactly.  fp64 accumulation in a fixed order (thread-strided partials, wave butterfly, 4 wave partials).
+__global__ __launch_bounds__(256) void disparity_epe_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                            float* __restrict__ epe, int* __restrict__ count, long long S) {
+    __shared__ double psum[4];
+    __shared__ unsigned pcnt[4];
+    const float* __restrict__ p = pred + (size_t)blockIdx.x * S;
+    const float* __restrict__ g = gt + (size_t)blockIdx.x * S;
+    double sum = 0.0;
+    unsigned n = 0;
+    for (long long i = threadIdx.x; i < S; i += 256) {
+        const float t = g[i];
+        const bool ok = (t >= 0.f) && (t < __builtin_inff());       // false for NaN as well
+        if (ok) { sum += (double)fabsf(p[i] - t); ++n; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    n = wave_sum(n);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { psum[wave] = sum; pcnt[wave] = n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double s4 = ((psum[0] + psum[1]) + psum[2]) + psum[3];
+        const unsigned n4 = pcnt[0] + pcnt[1] + pcnt[2] + pcnt[3];
+        epe[blockIdx.x] = n4 ? (float)(s4 / (double)n4) : 0.f;
+        count[blockIdx.x] = (int)n4;
+    }
+}
+
+hipError_t launch_disparity_epe(const float* pred, const float* gt, float* epe, int* count, int B, int64_t S,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(disparity_epe_kernel, dim3(B), dim3(256), 0, s, pred, gt, epe, count, (long long)S);
+    return hipGetLastError();
+}
+
 }  // namespace s3r

@@ -13,7 +13,7 @@ from typing import Dict, Iterable, Optional, Sequence, Tuple
 import torch
 
 from . import collate
-from .modules import voxel_iou
+from .modules import disparity_epe, voxel_iou
 
 THRESHOLDS = (0.2, 0.3, 0.4, 0.5)
 
@@ -57,6 +57,37 @@ def test_dataset(model, ds, batch: int = 32, thresholds: Sequence[float] = THRES
         ious = collate.all_gather_ragged(ious, total, group)
     mean = ious.mean(0).cpu().tolist() if total else [float("nan")] * len(thresholds)
     return {"samples": total, "thresholds": list(thresholds), "mean_iou": mean, "per_sample": ious.cpu()}
+
+
+@torch.no_grad()
+def test_disparity(model, left: torch.Tensor, right: torch.Tensor, disp_l_gt: torch.Tensor, disp_r_gt: torch.Tensor,
+                   batch: int = 32, device="cuda", group=None) -> Dict[str, object]:
+    """End-point error of the model's predicted left / right disparity (Stereo2Voxel.disparity, render pixels) against
+    (N,28,28) ground-truth maps at feature resolution in render pixels (the dataset's
+    disp_%02d_{l,r}.exr, /root/reference/README.md:75-76, downsampled by the caller; invalid pixels: inf / negative).
+    EPE is pooled over all valid pixels of the list: per-sample (sum, count) pairs are reduced on the device and, with
+    torch.distributed initialised, all-gathered (rank order = list order)."""
+    import torch.distributed as dist
+    dist_on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if dist_on else 1
+    rank = dist.get_rank(group) if dist_on else 0
+    total = left.shape[0]
+    b0, e0 = collate.shard_bounds(total, world, rank)
+    rows = torch.zeros((e0 - b0, 4), dtype=torch.float64, device=device)        # epe_l, n_l, epe_r, n_r
+    for s in range(b0, e0, batch):
+        e = min(e0, s + batch)
+        dl, dr = model.disparity(left[s:e].to(device), right[s:e].to(device))
+        el, nl = disparity_epe(dl, disp_l_gt[s:e].to(device))
+        er, nr = disparity_epe(dr, disp_r_gt[s:e].to(device))
+        rows[s - b0:e - b0] = torch.stack([el.double(), nl.double(), er.double(), nr.double()], 1)
+    if dist_on:
+        rows = collate.all_gather_ragged(rows, total, group)
+    rows = rows.cpu()
+    nl, nr = rows[:, 1].sum().item(), rows[:, 3].sum().item()
+    epe_l = (rows[:, 0] * rows[:, 1]).sum().item() / nl if nl else float("nan")
+    epe_r = (rows[:, 2] * rows[:, 3]).sum().item() / nr if nr else float("nan")
+    return {"samples": total, "epe_left": epe_l, "epe_right": epe_r, "valid_left": int(nl), "valid_right": int(nr),
+            "per_sample": rows}
 
 
 @torch.no_grad()

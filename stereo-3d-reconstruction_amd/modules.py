@@ -461,6 +461,27 @@ class Stereo2Voxel(nn.Module):
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
     @torch.no_grad()
+    def disparity(self, left: torch.Tensor, right: torch.Tensor, in_pixels: bool = True):
+        """Predicted (left, right) disparity maps, (B,28,28) each: the winner-take-all read-out of the cost volume's
+        shift-and-diff costs on this model's encoder features (`disparity_wta`).  in_pixels scales feature-resolution
+        disparities to 224x224 render pixels (x8), the unit of the dataset's EXR ground truth."""
+        left = _check_input(left, "left", (3, spec.IMG_HW, spec.IMG_HW))
+        right = _check_input(right, "right", (3, spec.IMG_HW, spec.IMG_HW))
+        if left.shape[0] != right.shape[0]:
+            raise RuntimeError("left and right batch sizes differ")
+        dls, drs = [], []
+        for s in range(0, max(left.shape[0], 1), MAX_CHUNK):
+            l, r = left[s:s + MAX_CHUNK], right[s:s + MAX_CHUNK]
+            b = l.shape[0]
+            feats = self.encoder(torch.cat([l, r], 0)).float().contiguous()     # (bf16 path: back to fp32 NCHW)
+            dl, dr = disparity_wta(feats[:b], feats[b:], self.cost_volume.max_disp)
+            dls.append(dl), drs.append(dr)
+        dl = dls[0] if len(dls) == 1 else torch.cat(dls, 0)
+        dr = drs[0] if len(drs) == 1 else torch.cat(drs, 0)
+        scale = float(spec.IMG_HW // spec.FEAT_HW) if in_pixels else 1.0
+        return dl * scale, dr * scale
+
+    @torch.no_grad()
     def autotune(self, left: torch.Tensor, right: torch.Tensor, rounds: int = 3, log=None):
         """Measure-and-pick the per-layer kernel configuration on a representative batch (see
         _HipChain.autotune).  Returns {layer: {tile, ksplit, ms}}."""
@@ -549,6 +570,43 @@ def voxel_iou(pred: torch.Tensor, gt: torch.Tensor, threshold: float = 0.5) -> t
         _lib.check(_lib.load().s3r_voxel_iou(pred.data_ptr(), gt.data_ptr(), float(threshold), out.data_ptr(), B,
                                              pred[0].numel(), _stream_ptr(pred.device)), "voxel_iou")
     return out
+
+
+@torch.no_grad()
+def disparity_wta(feat_l: torch.Tensor, feat_r: torch.Tensor, max_disp: int = spec.MAX_DISP):
+    """Predicted left / right disparity maps (ground truth: disp_%02d_{l,r}.exr,
+    /root/reference/README.md:75-76): winner-take-all over the shift-and-diff costs the cost volume holds, read
+    straight from the two feature maps.  (B,C,H,W) x2 fp32 -> two (B,H,W) fp32 maps, integer-valued, in
+    feature-resolution pixels; disp_l[b,h,w] = first argmin_d sum_c |L[b,c,h,w] - R[b,c,h,w-d]|, disp_r mirrored."""
+    if feat_l.shape != feat_r.shape or feat_l.dim() != 4:
+        raise RuntimeError("feat_l / feat_r must be two (B,C,H,W) tensors of one shape")
+    feat_l = _check_input(feat_l.float(), "feat_l", feat_l.shape[1:])
+    feat_r = _check_input(feat_r.float(), "feat_r", feat_r.shape[1:])
+    B, Cc, H, W = feat_l.shape
+    dl = torch.empty((B, H, W), dtype=torch.float32, device=feat_l.device)
+    dr = torch.empty_like(dl)
+    if B:
+        _lib.check(_lib.load().s3r_disparity_wta(feat_l.data_ptr(), feat_r.data_ptr(), dl.data_ptr(), dr.data_ptr(), B,
+                                                 Cc, H, W, int(max_disp), _stream_ptr(feat_l.device)), "disparity_wta")
+    return dl, dr
+
+
+@torch.no_grad()
+def disparity_epe(pred: torch.Tensor, gt: torch.Tensor):
+    """Per-sample end-point error mean|pred - gt| over the pixels whose ground truth is valid (finite and >= 0 — EXR
+    disparity maps mark background with inf / negative values), reduced on the device: (B,...) x2 ->
+    (epe (B,) fp32, valid pixel count (B,) int32)."""
+    if pred.shape != gt.shape:
+        raise RuntimeError("pred and gt shapes differ")
+    pred = _check_input(pred, "pred", pred.shape[1:])
+    gt = _check_input(gt, "gt", gt.shape[1:])
+    B = pred.shape[0]
+    epe = torch.empty((B,), dtype=torch.float32, device=pred.device)
+    cnt = torch.empty((B,), dtype=torch.int32, device=pred.device)
+    if B:
+        _lib.check(_lib.load().s3r_disparity_epe(pred.data_ptr(), gt.data_ptr(), epe.data_ptr(), cnt.data_ptr(), B,
+                                                 pred[0].numel(), _stream_ptr(pred.device)), "disparity_epe")
+    return epe, cnt
 
 
 # the names BASELINE.json's north_star uses for the module API

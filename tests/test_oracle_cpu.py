@@ -163,6 +163,35 @@ def test_voxel_iou_oracle(oracle):
     assert oracle.voxel_iou(a, b).tolist() == [pytest.approx(1 / 3), 0.0, 1.0]
 
 
+def test_disparity_wta_oracle_recovers_a_known_shift(oracle):
+    """R(w) = L(w + d0): every left pixel with w >= d0 matches at disparity d0 with zero cost; the right view mirrors
+    it.  Ties resolve to the first minimum (constant features -> 0), and max_disp beyond the width is harmless."""
+    g = torch.Generator().manual_seed(0)
+    fl = torch.randn(2, 8, 5, 12, generator=g)
+    d0 = 3
+    fr = torch.zeros_like(fl)
+    fr[..., : 12 - d0] = fl[..., d0:]
+    dl, dr = oracle.disparity_wta(fl, fr, 8)
+    assert (dl[..., d0:] == d0).all() and (dr[..., : 12 - d0] == d0).all()
+    assert (dl[..., :d0] <= torch.arange(d0)).all()                     # d never exceeds w
+    cl, cr = oracle.disparity_wta(torch.ones(1, 4, 3, 6), torch.ones(1, 4, 3, 6), 40)
+    assert cl.abs().max() == 0 and cr.abs().max() == 0
+    # the winner is the minimiser of the cost volume's own |.| costs
+    vol = oracle.cost_volume(fl, fr, 8)                                  # (B,2C,D,H,W)
+    cost_l = vol[:, :8].abs().sum(1)                                      # (B,D,H,W); zero-filled where w < d
+    w = torch.arange(12).view(1, 1, 1, 12)
+    d = torch.arange(8).view(1, 8, 1, 1)
+    cost_l = torch.where(w >= d, cost_l, torch.full_like(cost_l, float("inf")))
+    assert ((cost_l.min(1).values - cost_l.gather(1, dl.long().unsqueeze(1)).squeeze(1)).abs() < 1e-5).all()
+
+
+def test_disparity_epe_oracle(oracle):
+    pred = torch.tensor([[[1.0, 2.0], [3.0, 4.0]], [[0.0, 0.0], [0.0, 0.0]]])
+    gt = torch.tensor([[[2.0, float("inf")], [-1.0, 1.0]], [[float("nan"), -5.0], [float("inf"), -0.5]]])
+    epe, n = oracle.disparity_epe(pred, gt)
+    assert n.tolist() == [2, 0] and epe.tolist() == [2.0, 0.0]           # (|1-2| + |4-1|) / 2; no valid pixel -> 0
+
+
 # ------------------------------------------------------------------ product modules vs oracle: same keys, same init
 def test_state_dict_keys_match_oracle(s3r, oracle):
     for hip_cls, ref_cls in ((s3r.Stereo2Voxel, oracle.OracleStereo2Voxel), (s3r.Stereo2Point, oracle.OracleStereo2Point)):

@@ -368,6 +368,60 @@ def test_voxel_iou_exact(s3r, oracle):
     assert torch.equal(got, oracle.voxel_iou(a, b))
 
 
+@pytest.mark.parametrize("shape", [(3, 32, 28, 28, 28), (2, 5, 7, 13, 40), (1, 64, 9, 57, 16), (4, 3, 1, 1, 4)])
+def test_disparity_wta_bit_exact(s3r, oracle, shape):
+    """Winner-take-all disparity read-out vs the oracle: integer results, bit-exact, including
+    max_disp > width, a single-pixel map, exact ties (first minimum) and a planted shift."""
+    B, Cc, H, W, D = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    fl, fr = torch.randn(B, Cc, H, W, generator=g), torch.randn(B, Cc, H, W, generator=g)
+    if W > 6:
+        fr[0, :, :, : W - 5] = fl[0, :, :, 5:]            # sample 0: a true disparity of 5
+    fl[-1, :, :, : W // 2] = 1.0                          # last sample: constant patches -> ties
+    fr[-1, :, :, : W // 2] = 1.0
+    want_l, want_r = oracle.disparity_wta(fl, fr, D)
+    got_l, got_r = s3r.disparity_wta(fl.to(DEV), fr.to(DEV), D)
+    assert got_l.shape == (B, H, W) and got_l.dtype == torch.float32
+    assert torch.equal(got_l.cpu(), want_l) and torch.equal(got_r.cpu(), want_r)
+    if W > 6 and D > 5 and B > 1:                        # (B == 1: sample 0 also carries the constant patch)
+        assert (got_l[0, :, 5:] == 5).all()
+
+
+def test_disparity_epe_exact(s3r, oracle):
+    g = torch.Generator().manual_seed(21)
+    pred = torch.randint(0, 28, (6, 28, 28), generator=g).float() * 8
+    gt = torch.rand(6, 28, 28, generator=g) * 200
+    gt[0, :5] = float("inf")                              # background as EXR marks it
+    gt[1, 3] = -1.0
+    gt[2, 0, 0] = float("nan")
+    gt[5] = float("inf")                                  # no valid pixel at all
+    epe, n = s3r.disparity_epe(pred.to(DEV), gt.to(DEV))
+    want_e, want_n = oracle.disparity_epe(pred, gt)
+    assert torch.equal(n.cpu(), want_n) and n.dtype == torch.int32
+    assert (epe.cpu() - want_e).abs().max().item() <= 1e-6 * want_e.abs().max().item()    # fp64 sums, fp32 result
+    assert epe[5].item() == 0.0
+
+
+def test_model_disparity_and_eval_driver(s3r, oracle, models):
+    """Stereo2Voxel.disparity = read-out of the model's own encoder features (x8 to render pixels); the eval driver
+    pools EPE over valid pixels exactly as the oracle does."""
+    hip, _ = models
+    left, right, _ = s3r.evaluate.synthetic_eval_set(5, 4)
+    dl, dr = hip.disparity(left.to(DEV), right.to(DEV))
+    feats = hip.encoder(torch.cat([left, right], 0).to(DEV)).cpu()
+    wl, wr = oracle.disparity_wta(feats[:5], feats[5:], s3r.arch_spec.MAX_DISP)
+    assert torch.equal(dl.cpu(), wl * 8) and torch.equal(dr.cpu(), wr * 8)
+    g = torch.Generator().manual_seed(9)
+    gl, gr = torch.rand(5, 28, 28, generator=g) * 220, torch.rand(5, 28, 28, generator=g) * 220
+    gl[0, :10] = float("inf")
+    res = s3r.evaluate.test_disparity(hip, left, right, gl, gr, batch=2, device=DEV)
+    el, nl = oracle.disparity_epe(wl * 8, gl)
+    er, nr = oracle.disparity_epe(wr * 8, gr)
+    assert res["valid_left"] == int(nl.sum()) and res["valid_right"] == int(nr.sum())
+    assert abs(res["epe_left"] - float((el.double() * nl).sum() / nl.sum())) < 1e-4
+    assert abs(res["epe_right"] - float((er.double() * nr).sum() / nr.sum())) < 1e-4
+
+
 def test_eval_driver_matches_oracle_iou(s3r, oracle, models):
     """evaluate.test_net (device-side IoU per threshold) against the oracle's forward + IoU."""
     hip, ref = models
