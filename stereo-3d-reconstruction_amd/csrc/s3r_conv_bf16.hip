@@ -65,14 +65,29 @@ constexpr int HBN = 64;    // couts per workgroup
 constexpr int EP_BYTES = 3 * 64 * 4;
 constexpr int ST_ROW = 144;     // staging row: 128 payload bytes + 16 (rows 9 sixteen-byte slots apart: conflict-free b128 writes)
 
-__device__ __forceinline__ void fill_ep(const ConvParamsH& p, float* ep, int tid, int n0) {
+// The per-cout constants are LOADED first thing in the kernel (their latency hides behind the first operand
+// fetch) and only written to LDS after the main loop: nothing before the epilogue waits for them.
+struct EpRegs { float sc, sf, hw; };
+
+__device__ __forceinline__ EpRegs load_ep(const ConvParamsH& p, int tid, int n0) {
+    EpRegs e = {1.f, 0.f, 0.f};
     if (tid < 64) {
         const int co = n0 + tid;
         const bool ok = co < p.Cout;
-        ep[tid] = (ok && p.scale) ? p.scale[co] : 1.f;
-        ep[64 + tid] = (ok && p.shift) ? p.shift[co] : 0.f;
-        ep[128 + tid] = (ok && p.head_w) ? p.head_w[co] : 0.f;
+        e.sc = (ok && p.scale) ? p.scale[co] : 1.f;
+        e.sf = (ok && p.shift) ? p.shift[co] : 0.f;
+        e.hw = (ok && p.head_w) ? p.head_w[co] : 0.f;
     }
+    return e;
+}
+
+__device__ __forceinline__ void store_ep(const EpRegs& e, float* ep, int tid) {
+    if (tid < 64) {
+        ep[tid] = e.sc;
+        ep[64 + tid] = e.sf;
+        ep[128 + tid] = e.hw;
+    }
+    __syncthreads();
 }
 
 template <int TM, bool HEAD>
@@ -254,7 +269,7 @@ __global__ __launch_bounds__(256, min_waves_h(TM, KC, HEAD)) void conv_bf16_kern
     const int chunks = (p.Cin / KC) / p.ksplit;
     const int nkt = S3R_ABLH(p, 2) ? 1 : T * chunks;
 
-    fill_ep(p, ep, tid, n0);
+    const EpRegs epr = load_ep(p, tid, n0);
     // ---- decode this tile's positions once: input corner (bytes) and output offset (elements)
     for (int t = tid; t < BM; t += 256) {
         const int n = m0 + t;
@@ -368,6 +383,7 @@ __global__ __launch_bounds__(256, min_waves_h(TM, KC, HEAD)) void conv_bf16_kern
         __syncthreads();
     }
 
+    store_ep(epr, ep, tid);
     epilogue_h<TM, HEAD>(p, acc, yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
 }
 
@@ -433,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p,
     const int segw = p.stride * (p.Nw - 1) + kw;             // LDS rows of a full output row
     const int last_row = p.B * p.Nd * p.Nh - 1;
 
-    fill_ep(p, ep, tid, n0);
+    const EpRegs epr = load_ep(p, tid, n0);
     for (int t = tid; t < BM; t += 256) {
         const int n = m0 + t;
         const bool ok = n < p.Ntotal;
@@ -548,6 +564,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p,
         __syncthreads();
     }
 
+    store_ep(epr, ep, tid);
     if (p.head_w) epilogue_h<TM, true>(p, acc, yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
     else epilogue_h<TM, false>(p, acc, yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
 }
@@ -631,7 +648,36 @@ __global__ __launch_bounds__(256, KC == 64 ? 2 : 3) void conv_bf16p_kernel(const
     const int nseg = pl1 - pl0 + 1;
     const int len0 = (nseg > 1 ? umax : u1) - u0 + 1 + halo; // image rows of the first plane's segment
 
-    fill_ep(p, ep, tid, n0);
+    const EpRegs epr = load_ep(p, tid, n0);
+
+    // ---- the first two taps' weights depend on nothing the prologue computes: fetch them before it
+    const int w_tile = p.n_tiles * 4096;
+    int bvoff[NPB];
+#pragma unroll
+    for (int q = 0; q < NPB; ++q) {
+        if constexpr (KC == 32) {
+            bvoff[q] = (wave + 4 * q) * 1024 + lane * 16;     // stored pre-swizzled for 64-byte rows
+        } else {
+            const int r = (wave + 4 * q) * RPP + lane / LPR;
+            const int kg = (lane % LPR) ^ swz<64>(r);
+            bvoff[q] = (kg >> 2) * (T * w_tile) + r * 64 + (((kg & 3) ^ swz<32>(r)) << 4);
+        }
+    }
+    const size_t w_cls = (size_t)cls * T * (p.Cin / HKC) * w_tile;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.w) + w_cls), 0,
+        (int)((unsigned)T * (unsigned)(p.Cin / HKC) * (unsigned)w_tile), 0x00020000);
+    int b_cc = kz * chunks, b_tap = 0, b_slot = 0;            // cursor of the NEXT weight tile to fetch
+    auto issue_b = [&]() {
+        const int b_base = ((b_cc * (KC / 32) * T + b_tap) * p.n_tiles + n_tile) * 4096;
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) dma16(wrsrc, Bs + b_slot * B_BYTES + ((wave + 4 * q) << 10), bvoff[q], b_base);
+        if (++b_tap == T) { b_tap = 0; ++b_cc; }
+        if (++b_slot == PL_NB) b_slot = 0;
+    };
+    issue_b();
+    if (total > 1) issue_b();
+
     for (int t = tid; t < BM; t += 256) {
         const int n = m0 + t;
         const bool ok = n < p.Ntotal;
@@ -670,18 +716,6 @@ __global__ __launch_bounds__(256, KC == 64 ? 2 : 3) void conv_bf16p_kernel(const
         const int j = (wave + 4 * q) * RPP + lane / LPR;
         avoff[q] = (q < npa ? asrc[j] : 0) + (((lane % LPR) ^ swz<KC>(j)) << 4);
     }
-    const int w_tile = p.n_tiles * 4096;
-    int bvoff[NPB];
-#pragma unroll
-    for (int q = 0; q < NPB; ++q) {
-        if constexpr (KC == 32) {
-            bvoff[q] = (wave + 4 * q) * 1024 + lane * 16;     // stored pre-swizzled for 64-byte rows
-        } else {
-            const int r = (wave + 4 * q) * RPP + lane / LPR;
-            const int kg = (lane % LPR) ^ swz<64>(r);
-            bvoff[q] = (kg >> 2) * (T * w_tile) + r * 64 + (((kg & 3) ^ swz<32>(r)) << 4);
-        }
-    }
     int lr[TM];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) lr[tm] = lrow[wave * 32 * TM + tm * 32 + c];
@@ -694,13 +728,7 @@ __global__ __launch_bounds__(256, KC == 64 ? 2 : 3) void conv_bf16p_kernel(const
 
     const __amdgpu_buffer_rsrc_t xrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
-    const size_t w_cls = (size_t)cls * T * (p.Cin / HKC) * w_tile;
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(p.w) + w_cls), 0,
-        (int)((unsigned)T * (unsigned)(p.Cin / HKC) * (unsigned)w_tile), 0x00020000);
-
     int a_cc = kz * chunks, a_td = 0;                         // cursor of the NEXT image to fetch
-    int b_cc = kz * chunks, b_tap = 0, b_slot = 0;            // cursor of the NEXT weight tile to fetch
     auto issue_a = [&]() {
         const int a_base = (a_cc * KC + a_td * p.x_ds) * 2;
 #pragma unroll
@@ -708,14 +736,6 @@ __global__ __launch_bounds__(256, KC == 64 ? 2 : 3) void conv_bf16p_kernel(const
             if (q < npa) dma16(xrsrc, smem + ((wave + 4 * q) << 10), avoff[q], a_base);
         if (++a_td == p.kd) { a_td = 0; ++a_cc; }
     };
-    auto issue_b = [&]() {
-        const int b_base = ((b_cc * (KC / 32) * T + b_tap) * p.n_tiles + n_tile) * 4096;
-#pragma unroll
-        for (int q = 0; q < NPB; ++q) dma16(wrsrc, Bs + b_slot * B_BYTES + ((wave + 4 * q) << 10), bvoff[q], b_base);
-        if (++b_tap == T) { b_tap = 0; ++b_cc; }
-        if (++b_slot == PL_NB) b_slot = 0;
-    };
-
     f32x16 acc[TM][2];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -724,10 +744,8 @@ __global__ __launch_bounds__(256, KC == 64 ? 2 : 3) void conv_bf16p_kernel(const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    __syncthreads();                                          // asrc (ring slot 2) has been read by every wave
-    issue_a();
-    issue_b();
-    if (total > 1) issue_b();
+    issue_a();                                                // (asrc aliases the LAST ring slot, first filled
+                                                              //  behind the loop's first barrier)
 
     int tt = 0, c_slot = 0;
     for (int g = 0; g < ngroups; ++g) {
@@ -789,6 +807,7 @@ __global__ __launch_bounds__(256, KC == 64 ? 2 : 3) void conv_bf16p_kernel(const
         if (g + 1 < ngroups && !S3R_ABLH(p, 3)) issue_a();
     }
 
+    store_ep(epr, ep, tid);
     if (p.head_w) epilogue_h<TM, true>(p, acc, yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
     else epilogue_h<TM, false>(p, acc, yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
 }

@@ -4,7 +4,7 @@
 #   bash tools/ab_bench.sh <outdir> [layer_bench args...]
 OUT=$1; shift
 mkdir -p $OUT
-for i in 1 2; do
+for i in 1 2 3; do
   S3R_LIB=$PWD/tools/alt/base.so python tools/layer_bench.py "$@" > $OUT/base$i.log 2>&1
   python tools/layer_bench.py "$@" > $OUT/new$i.log 2>&1
 done
