@@ -258,12 +258,14 @@ def main():
                 # per launch / average launch duration, both over the timed region's launches (HIP events
                 # recorded by the library on the stream it launches on)
                 achieved = c["flops"] / c["ms"] / 1e9            # TFLOP/s
-                traffic = None
+                traffic = pmc_util = pmc_clock = None
                 bf = args.dtype == "bf16"
                 tpath = os.path.join(ROOT, "profiles", "traffic_r01_bf16.json" if bf else "traffic_r01.json")
                 if os.path.exists(tpath):
                     try:
-                        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")   # rocprofv3 PMC, per launch
+                        tj = json.load(open(tpath))
+                        traffic = tj.get("hbm_bytes_per_launch")                         # rocprofv3 PMC, per launch
+                        pmc_util, pmc_clock = tj.get("mfma_utilisation_pmc"), tj.get("shader_clock_ghz_pmc")
                     except Exception:
                         traffic = None
                 peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_FP32_MFMA_TFLOPS
@@ -273,6 +275,10 @@ def main():
                         else "conv_glds_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv, LDS-DMA operand staging)",
                         "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                        # from the committed rocprofv3 SQ pass of this command (profiles/traffic_*.json): MFMA pipe
+                        # cycles / (1024 SIMDs x elapsed shader cycles), and the shader clock the chip held
+                        "mfma_utilisation_pmc": round(pmc_util, 4) if pmc_util else None,
+                        "shader_clock_ghz_pmc": round(pmc_clock, 3) if pmc_clock else None,
                         "layers_per_step": c["n"] // args.steps,
                         "launches_per_step": c["launches"] // args.steps,
                         "algorithmic_gflop_per_launch": round(c["flops"] / c["launches"] / 1e9, 3),

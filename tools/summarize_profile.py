@@ -86,6 +86,11 @@ def main():
     write = sum(v.get("WRITE_SIZE", 0) for v in fam) * 1024
     busy = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for v in fam)
     gui = sum(v.get("GRBM_GUI_ACTIVE", 0) for v in fam)
+    sq_ns = sum(v.get("ns", 0) for v in fam)                  # durations of the SQ-counter pass
+    # SQ_VALU_MFMA_BUSY_CYCLES = MFMA pipe cycles summed over the 1024 SIMDs (64 per v_mfma_f32_32x32x2_f32, 32 per
+    # v_mfma_f32_32x32x16_bf16: it reproduces the algorithmic MFMA count); GRBM_GUI_ACTIVE sums the 8 XCDs' active
+    # cycles.  utilisation = busy / (1024 x elapsed shader cycles); the clock held = elapsed cycles / elapsed time.
+    cycles = gui / 8.0
     info = {
         "source": src, "steps_profiled": steps, "kernel": FAMILY, "launches_profiled": launches,
         "fetch_bytes_per_step_raw": fetch / steps,
@@ -97,6 +102,8 @@ def main():
         "note": "FETCH_SIZE is in KiB and is doubled per MI355X_MICROARCH.md §HBM (gfx950 reports 1/2 of a wide "
                 "coalesced stream; this kernel's loads are 16-byte-per-lane LDS-DMA on most layers); WRITE_SIZE as read",
         "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": gui,
+        "mfma_utilisation_pmc": busy / (1024.0 * cycles) if cycles else None,
+        "shader_clock_ghz_pmc": cycles / sq_ns if sq_ns else None,
     }
     with open(os.path.join(out, f"traffic_{tag}.json"), "w") as f:
         json.dump(info, f, indent=1)
