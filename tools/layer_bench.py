@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--zeros", action="store_true", help="all-zero inputs and weights (how much of the rate is power: the\n"
+                    "chip holds a higher clock on zeros, MI355X_MICROARCH.md DVFS notes)")
     args = ap.parse_args()
     spec = s3r.arch_spec
     dev = torch.device("cuda:0")
@@ -55,6 +57,11 @@ def main():
         s3r.seed_module(ch, 1)
         ch.to(dev)
         x = torch.randn((B, l.cin) + (n_in,) * spec.ndim(l), device=dev)
+        if args.zeros:
+            x.zero_()
+            with torch.no_grad():
+                for prm in ch.parameters():
+                    prm.zero_()
         if args.dtype == "bf16":
             x = x.to(torch.bfloat16).permute(0, *range(2, x.dim()), 1).contiguous()
         flops = 2.0 * spec.layer_macs(l, n_in) * B
