@@ -69,9 +69,9 @@ constexpr int ST_ROW = 144;     // staging row: 128 payload bytes + 16 (rows 9 s
 // fetch) and only written to LDS after the main loop: nothing before the epilogue waits for them.
 struct EpRegs { float sc, sf, hw; };
 
-__device__ __forceinline__ EpRegs load_ep(const ConvParamsH& p, int tid, int n0) {
+__device__ __forceinline__ EpRegs load_ep(const ConvParamsH& p, int tid, int n0, int nco = 64) {
     EpRegs e = {1.f, 0.f, 0.f};
-    if (tid < 64) {
+    if (tid < nco) {
         const int co = n0 + tid;
         const bool ok = co < p.Cout;
         e.sc = (ok && p.scale) ? p.scale[co] : 1.f;
@@ -81,11 +81,12 @@ __device__ __forceinline__ EpRegs load_ep(const ConvParamsH& p, int tid, int n0)
     return e;
 }
 
-__device__ __forceinline__ void store_ep(const EpRegs& e, float* ep, int tid) {
-    if (tid < 64) {
-        ep[tid] = e.sc;
-        ep[64 + tid] = e.sf;
-        ep[128 + tid] = e.hw;
+__device__ __forceinline__ void store_ep(const EpRegs& e, float* ep, int tid, int nco = 64) {
+    if (tid < nco) {                               // [64-cout half][scale | shift | head weight][64]
+        float* q = ep + (tid >> 6) * 192 + (tid & 63);
+        q[0] = e.sc;
+        q[64] = e.sf;
+        q[128] = e.hw;
     }
     __syncthreads();
 }
@@ -230,21 +231,26 @@ __device__ __forceinline__ int swz(int row) { return KC == 64 ? (row >> 1) & 7 :
 // chunk later: the operand path of these layers is L2 -> LDS bound) and halves the barriers per FLOP.
 // The packed weights stay in the 32-channel layout for both: with KC = 64 a lane's 16 bytes come from chunk
 // 2j or 2j+1 by a per-lane source offset (LDS-DMA destinations are lane-linear, sources are free).
-template <int TM, int KC, bool HEAD>
-__global__ __launch_bounds__(256, min_waves_h(TM, KC, HEAD)) void conv_bf16_kernel(const ConvParamsH p) {
+// NH = 64-cout halves per workgroup: 2 (a 128 x 128 tile; Cout % 128 == 0) gathers the activations once for twice
+// the couts — 1.5x the FLOPs per byte brought into LDS, for the layers this kernel keeps (stride 2), which are
+// bound by exactly that.
+template <int TM, int KC, bool HEAD, int NH>
+__global__ __launch_bounds__(256, NH == 2 ? (KC == 64 ? 2 : 3) : min_waves_h(TM, KC, HEAD)) void conv_bf16_kernel(const ConvParamsH p) {
+    static_assert(NH == 1 || !HEAD, "the fused head needs the whole channel axis in one 64-cout tile");
     constexpr int BM = 128 * TM;
+    constexpr int BNW = HBN * NH;                  // couts per workgroup
     constexpr int ROWB = KC * 2;                   // bytes per LDS row
     constexpr int LPR = ROWB / 16;                 // lanes (16-byte slots) per row
     constexpr int RPP = 64 / LPR;                  // rows per 1 KiB LDS-DMA piece
-    constexpr int A_BYTES = BM * ROWB, B_BYTES = HBN * ROWB;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BNW * ROWB;
     constexpr int NPA = A_BYTES / 4096, NPB = B_BYTES / 4096;     // pieces per wave per K tile
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                               // [2][BM][ROWB]
-    char* Bs = smem + 2 * A_BYTES;                 // [2][64][ROWB]
+    char* Bs = smem + 2 * A_BYTES;                 // [2][BNW][ROWB]
     int* xoff = reinterpret_cast<int*>(smem + 2 * A_BYTES + 2 * B_BYTES);   // [BM] input byte offsets
     int* yoff = xoff + BM;                                                   // [BM] output element offsets, -1 = none
-    float* ep = reinterpret_cast<float*>(yoff + BM);                         // [3][64] scale / shift / head weight
+    float* ep = reinterpret_cast<float*>(yoff + BM);                         // [NH][3][64] scale / shift / head weight
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -257,8 +263,9 @@ __global__ __launch_bounds__(256, min_waves_h(TM, KC, HEAD)) void conv_bf16_kern
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    const int n_tile = bid % p.n_tiles;            // cout tile (fastest: neighbours share the gathered input)
-    const int m_tile = bid / p.n_tiles;
+    const int n_tiles_w = p.n_tiles / NH;          // workgroup cout tiles
+    const int n_tile = (bid % n_tiles_w) * NH;     // first 64-cout tile (fastest: neighbours share the gathered input)
+    const int m_tile = bid / n_tiles_w;
     const int m0 = m_tile * BM, n0 = n_tile * HBN;
     const int cls = blockIdx.y;
     const int rd = (cls >> 2) & 1, rh = (cls >> 1) & 1, rw = cls & 1;
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(256, min_waves_h(TM, KC, HEAD)) void conv_bf16_kern
     const int chunks = (p.Cin / KC) / p.ksplit;
     const int nkt = S3R_ABLH(p, 2) ? 1 : T * chunks;
 
-    const EpRegs epr = load_ep(p, tid, n0);
+    const EpRegs epr = load_ep(p, tid, n0, BNW);
     // ---- decode this tile's positions once: input corner (bytes) and output offset (elements)
     for (int t = tid; t < BM; t += 256) {
         const int n = m0 + t;
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256, min_waves_h(TM, KC, HEAD)) void conv_bf16_kern
         if constexpr (KC == 32) {
             bvoff[q] = (wave + 4 * q) * 1024 + lane * 16;          // stored pre-swizzled for 64-byte rows
         } else {
-            const int r = (wave + 4 * q) * RPP + lane / LPR;       // cout row
+            const int r = (wave + 4 * q) * RPP + lane / LPR;       // cout row (consecutive 64-cout tiles are 4 KiB apart)
             const int kg = (lane % LPR) ^ swz<64>(r);              // 16-byte channel group 0..7 of the 64
             bvoff[q] = (kg >> 2) * (T * w_tile) + r * 64 + (((kg & 3) ^ swz<32>(r)) << 4);
         }
@@ -336,27 +343,29 @@ __global__ __launch_bounds__(256, min_waves_h(TM, KC, HEAD)) void conv_bf16_kern
         if (++c_tap == T) { c_tap = 0; c_td = 0; c_th = 0; c_tw = 0; ++c_cc; }
     };
 
-    f32x16 acc[TM][2];
+    f32x16 acc[NH][TM][2];
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+    for (int nh = 0; nh < NH; ++nh)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nh][a][b][r] = 0.f;
 
     issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // fragment byte offsets inside a K tile image: row*ROWB + ((2q + h) ^ swz(row))*16; q toggles bits 5..
-    int a_off[TM], b_off[2];
+    int a_off[TM], b_off[2 * NH];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int row = wave * 32 * TM + tm * 32 + c;
         a_off[tm] = row * ROWB + ((h ^ swz<KC>(row)) << 4);
     }
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
+    for (int tn = 0; tn < 2 * NH; ++tn) {
         const int row = tn * 32 + c;
         b_off[tn] = row * ROWB + ((h ^ swz<KC>(row)) << 4);
     }
@@ -368,23 +377,27 @@ __global__ __launch_bounds__(256, min_waves_h(TM, KC, HEAD)) void conv_bf16_kern
         const char* b = Bs + cur * B_BYTES;
 #pragma unroll
         for (int q = 0; q < KC / 16; ++q) {
-            bf16x8 av[TM], bv[2];
+            bf16x8 av[TM], bv[2 * NH];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) av[tm] = *reinterpret_cast<const bf16x8*>(a + (a_off[tm] ^ (q << 5)));
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) bv[tn] = *reinterpret_cast<const bf16x8*>(b + (b_off[tn] ^ (q << 5)));
+            for (int tn = 0; tn < 2 * NH; ++tn) bv[tn] = *reinterpret_cast<const bf16x8*>(b + (b_off[tn] ^ (q << 5)));
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[tn], av[tm], acc[tm][tn], 0, 0, 0);
+                for (int tn = 0; tn < 2 * NH; ++tn)
+                    acc[tn >> 1][tm][tn & 1] =
+                        __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[tn], av[tm], acc[tn >> 1][tm][tn & 1], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
-    store_ep(epr, ep, tid);
-    epilogue_h<TM, HEAD>(p, acc, yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
+    store_ep(epr, ep, tid, BNW);
+#pragma unroll
+    for (int nh = 0; nh < NH; ++nh)
+        epilogue_h<TM, HEAD>(p, acc[nh], yoff, ep + nh * 192, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0 + nh * HBN, cls,
+                             kz, BM);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -859,9 +872,10 @@ static int plane_rows(const ConvParamsH& p, int bm, int kc);
 //     faster than the per-tap / row-reuse kernels, and 2-7 % faster than its own 64-channel form (code 6, two
 //     workgroups per CU): overlapping one workgroup's image reload and stores with the others' MFMAs is worth
 //     more than whole-line gathers once the image is fetched only once per kh*kw taps;
-//   * deep stride-1 layers that do not qualify (v6: 16-position planes) keep the row-reuse gather (codes 9 / 10);
-//   * everything else (stride 2, shallow K, small batches) runs the per-tap kernel with 128-position tiles: more
-//     workgroups per CU to overlap loads and stores, 64-channel K tiles wherever Cin % 64 == 0.
+//   * everything else (stride 2, shallow K, v6's 16-position planes) runs the per-tap kernel with 128-position
+//     tiles — more workgroups per CU to overlap loads and stores, 64-channel K tiles wherever Cin % 64 == 0 — and
+//     128-cout workgroup tiles (code 3) where Cout % 128 == 0: these layers are bound by L2 -> LDS delivery;
+//   * the row-reuse gather (codes 9 / 10) remains for deep stride-1 layers with an odd number of 64-cout tiles.
 int conv_bf16_pick_tm(const ConvParamsH& p) {
     const long classes = (p.transposed ? 8 : 1) * (long)p.ksplit;
     const long n_tiles = p.CoutPad / HBN;
@@ -872,11 +886,15 @@ int conv_bf16_pick_tm(const ConvParamsH& p) {
     const int pr = plane_rows(p, 256, 32);
     const bool plane_family = pr > 0 && pr <= 576 && (p.Cin / 32) % p.ksplit == 0 && (long)p.Cin * p.T >= 512;
     if (plane_family && wgs(2) >= 512) return 22;
-    // row-reuse: 3+ taps along w over rows that are not tiny (v6 (4-wide rows) only with 128 positions)
+    // row-reuse (32-channel K order, like the plane kernel): small batches of deep plane-family layers (v5 at B = 32)
     const bool deep = !p.transposed && p.kw >= 3 && (long)p.Cin * p.T >= 64 * 27;
     const bool reuse = p.stride == 1 && deep && rowreuse_rows(p, 128) <= 64 * NPA_MAX;
+    if (plane_family) return reuse ? 9 : 17;
+    // the per-tap family (64-channel K tiles where Cin allows): 128 x 128-cout tiles when the channel axis has an even
+    // number of 64-cout tiles and the grid stays full (e5 -9 %, v2 -14 %, v4 -11 %, v6 -21 % vs the row-reuse gather)
+    if (n_tiles % 2 == 0 && !p.head_w) return wgs(1) / 2 >= 1024 ? 3 : 1;
     if (reuse) return (wgs(2) >= 1024 && p.Nw >= 7 && rowreuse_rows(p, 256) <= 64 * NPA_MAX) ? 10 : 9;
-    return plane_family ? 17 : 1;                  // (17: small batches of a plane-family layer)
+    return 1;
 }
 
 int conv_bf16_pick_ksplit(const ConvParamsH& p) {
@@ -892,7 +910,8 @@ int conv_bf16_pick_ksplit(const ConvParamsH& p) {
 
 int64_t conv_bf16_scratch_elems(const ConvParamsH& p, int tm) {
     if (p.ksplit <= 1) return 0;
-    const int bm = 128 * (tm >= 21 ? tm - 20 : (tm >= 16 ? tm - 16 : (tm >= 9 ? tm - 8 : (tm >= 5 ? tm - 4 : tm))));
+    const int t0 = tm >= 21 ? tm - 20 : (tm >= 16 ? tm - 16 : (tm >= 9 ? tm - 8 : (tm >= 5 ? tm - 4 : tm)));
+    const int bm = 128 * (t0 == 3 ? 1 : t0);
     const int64_t mpad = (int64_t)((p.Ntotal + bm - 1) / bm) * bm;
     return (int64_t)(p.transposed ? 8 : 1) * p.ksplit * mpad * p.CoutPad;
 }
@@ -968,31 +987,38 @@ static hipError_t launch_tm_plane(ConvParamsH p, hipStream_t stream) {
     return e;
 }
 
-template <int TM, int KC, bool HEAD>
-static hipError_t launch_tm_k(const ConvParamsH& p, dim3 grid, hipStream_t stream) {
+template <int TM, int KC, bool HEAD, int NH>
+static hipError_t launch_tm_k(const ConvParamsH& p, hipStream_t stream) {
     constexpr int BM = 128 * TM;
-    constexpr size_t lds = (size_t)2 * BM * KC * 2 + 2 * HBN * KC * 2 + 2 * BM * sizeof(int) + EP_BYTES;
+    constexpr size_t lds = (size_t)2 * BM * KC * 2 + 2 * HBN * NH * KC * 2 + 2 * BM * sizeof(int) + EP_BYTES * NH;
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
     if (lds > 48 * 1024) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<TM, KC, HEAD>),
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<TM, KC, HEAD, NH>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (attr != hipSuccess) return attr;
     }
-    hipLaunchKernelGGL((conv_bf16_kernel<TM, KC, HEAD>), grid, dim3(256), lds, stream, p);
+    dim3 grid(p.m_tiles * (p.n_tiles / NH), p.transposed ? 8 : 1, p.ksplit);
+    hipLaunchKernelGGL((conv_bf16_kernel<TM, KC, HEAD, NH>), grid, dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
-// kc32: the caller forces 32-channel K tiles (tile code + 16); otherwise 64 wherever the layer allows it
-template <int TM>
+// kc32: the caller forces 32-channel K tiles (tile code + 16); otherwise 64 wherever the layer allows it.
+// NH = 2: 128-cout workgroup tiles (Cout % 128 == 0, no fused head).
+template <int TM, int NH>
 static hipError_t launch_tm(ConvParamsH p, bool kc32, hipStream_t stream) {
     constexpr int BM = 128 * TM;
     p.m_tiles = (p.Ntotal + BM - 1) / BM;
     p.n_tiles = p.CoutPad / HBN;
-    dim3 grid(p.m_tiles * p.n_tiles, p.transposed ? 8 : 1, p.ksplit);
     const bool head = p.head_w && p.ksplit == 1;
+    if (NH == 2 && (p.n_tiles % 2 != 0 || head)) return hipErrorInvalidValue;
     const bool kc64 = !kc32 && p.Cin % 64 == 0 && (p.Cin / 64) % p.ksplit == 0;
-    hipError_t e = kc64 ? (head ? launch_tm_k<TM, 64, true>(p, grid, stream) : launch_tm_k<TM, 64, false>(p, grid, stream))
-                        : (head ? launch_tm_k<TM, 32, true>(p, grid, stream) : launch_tm_k<TM, 32, false>(p, grid, stream));
+    hipError_t e;
+    if constexpr (NH == 2) {
+        e = kc64 ? launch_tm_k<TM, 64, false, 2>(p, stream) : launch_tm_k<TM, 32, false, 2>(p, stream);
+    } else {
+        e = kc64 ? (head ? launch_tm_k<TM, 64, true, 1>(p, stream) : launch_tm_k<TM, 64, false, 1>(p, stream))
+                 : (head ? launch_tm_k<TM, 32, true, 1>(p, stream) : launch_tm_k<TM, 32, false, 1>(p, stream));
+    }
     if (e == hipSuccess && p.ksplit > 1) {
         const long long total = (long long)p.Ntotal * (p.CoutPad >> 1);
         const long long blocks = (total + 255) / 256;
@@ -1014,9 +1040,10 @@ hipError_t launch_conv_bf16(const ConvParamsH& pin, int tm, hipStream_t stream) 
     // tm = 1, 2, 4: per-tap gather (conv_bf16_kernel; + 16: 32-channel K tiles even where 64 are possible);
     // tm = 9, 10: row-reuse gather (conv_bf16r_kernel) with TM 1, 2
     switch (tm) {
-        case 1: case 17: return launch_tm<1>(p, tm > 16, stream);
-        case 2: case 18: return launch_tm<2>(p, tm > 16, stream);
-        case 4: case 20: return launch_tm<4>(p, tm > 16, stream);
+        case 1: case 17: return launch_tm<1, 1>(p, tm > 16, stream);
+        case 2: case 18: return launch_tm<2, 1>(p, tm > 16, stream);
+        case 4: case 20: return launch_tm<4, 1>(p, tm > 16, stream);
+        case 3: case 19: return launch_tm<1, 2>(p, tm > 16, stream);      // 128 positions x 128 couts
         case 5: return launch_tm_plane<1, 64>(p, stream);
         case 6: return launch_tm_plane<2, 64>(p, stream);
         case 21: return launch_tm_plane<1, 32>(p, stream);
