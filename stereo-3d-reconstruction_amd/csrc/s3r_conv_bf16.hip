@@ -598,13 +598,15 @@ constexpr int PL_NB = 3;       // weight ring slots
 
 // KC = 64: 128-byte image rows (whole lines), two workgroups per CU; KC = 32: 64-byte rows, half the LDS, three
 // workgroups per CU (and the only form for Cin = 32).
-template <int TM, int KC>
-__global__ __launch_bounds__(256, KC == 64 ? 2 : 3) void conv_bf16p_kernel(const ConvParamsH p, int r_max) {
+// NH = 64-cout halves per workgroup (2: a 256 x 128 tile, the image serves twice the couts; two workgroups per CU).
+template <int TM, int KC, int NH>
+__global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p_kernel(const ConvParamsH p, int r_max) {
     constexpr int BM = 128 * TM;
+    constexpr int BNW = HBN * NH;                  // couts per workgroup
     constexpr int ROWB = KC * 2;                   // bytes per LDS row
     constexpr int LPR = ROWB / 16;                 // lanes (16-byte slots) per row
     constexpr int RPP = 64 / LPR;                  // rows per 1 KiB LDS-DMA piece
-    constexpr int B_BYTES = HBN * ROWB;            // one tap's weight tile
+    constexpr int B_BYTES = BNW * ROWB;            // one tap's weight tile
     constexpr int NPB = B_BYTES / 4096;            // its pieces per wave
     constexpr int NPA_CAP = KC == 64 ? NPA_PL : NPA_PL32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -626,8 +628,9 @@ __global__ __launch_bounds__(256, KC == 64 ? 2 : 3) void conv_bf16p_kernel(const
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    const int n_tile = bid % p.n_tiles;
-    const int m_tile = bid / p.n_tiles;
+    const int n_tiles_w = p.n_tiles / NH;
+    const int n_tile = (bid % n_tiles_w) * NH;     // first 64-cout tile of this workgroup
+    const int m_tile = bid / n_tiles_w;
     const int m0 = m_tile * BM, n0 = n_tile * HBN;
     const int cls = blockIdx.y;
     const int rd = (cls >> 2) & 1, rh = (cls >> 1) & 1, rw = cls & 1;
@@ -661,7 +664,7 @@ __global__ __launch_bounds__(256, KC == 64 ? 2 : 3) void conv_bf16p_kernel(const
     const int nseg = pl1 - pl0 + 1;
     const int len0 = (nseg > 1 ? umax : u1) - u0 + 1 + halo; // image rows of the first plane's segment
 
-    const EpRegs epr = load_ep(p, tid, n0);
+    const EpRegs epr = load_ep(p, tid, n0, BNW);
 
     // ---- the first two taps' weights depend on nothing the prologue computes: fetch them before it
     const int w_tile = p.n_tiles * 4096;
@@ -732,9 +735,9 @@ __global__ __launch_bounds__(256, KC == 64 ? 2 : 3) void conv_bf16p_kernel(const
     int lr[TM];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) lr[tm] = lrow[wave * 32 * TM + tm * 32 + c];
-    int b_off[2];
+    int b_off[2 * NH];
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
+    for (int tn = 0; tn < 2 * NH; ++tn) {
         const int row = tn * 32 + c;
         b_off[tn] = row * ROWB + ((h ^ swz<KC>(row)) << 4);
     }
@@ -749,13 +752,15 @@ __global__ __launch_bounds__(256, KC == 64 ? 2 : 3) void conv_bf16p_kernel(const
             if (q < npa) dma16(xrsrc, smem + ((wave + 4 * q) << 10), avoff[q], a_base);
         if (++a_td == p.kd) { a_td = 0; ++a_cc; }
     };
-    f32x16 acc[TM][2];
+    f32x16 acc[NH][TM][2];
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+    for (int nh = 0; nh < NH; ++nh)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nh][a][b][r] = 0.f;
 
     issue_a();                                                // (asrc aliases the LAST ring slot, first filled
                                                               //  behind the loop's first barrier)
@@ -780,11 +785,11 @@ __global__ __launch_bounds__(256, KC == 64 ? 2 : 3) void conv_bf16p_kernel(const
                 a_off[tm] = row * ROWB + ((h ^ swz<KC>(row)) << 4);
             }
             // fragments of k-step q+1 are requested before the MFMAs of k-step q
-            bf16x8 av[2][TM], bv[2][2];
+            bf16x8 av[2][TM], bv[2][2 * NH];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) av[0][tm] = *reinterpret_cast<const bf16x8*>(smem + a_off[tm]);
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) bv[0][tn] = *reinterpret_cast<const bf16x8*>(b + b_off[tn]);
+            for (int tn = 0; tn < 2 * NH; ++tn) bv[0][tn] = *reinterpret_cast<const bf16x8*>(b + b_off[tn]);
 #pragma unroll
             for (int q = 0; q < KC / 16; ++q) {
                 if (q < KC / 16 - 1) {
@@ -792,26 +797,27 @@ __global__ __launch_bounds__(256, KC == 64 ? 2 : 3) void conv_bf16p_kernel(const
                     for (int tm = 0; tm < TM; ++tm)
                         av[(q + 1) & 1][tm] = *reinterpret_cast<const bf16x8*>(smem + (a_off[tm] ^ ((q + 1) << 5)));
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
+                    for (int tn = 0; tn < 2 * NH; ++tn)
                         bv[(q + 1) & 1][tn] = *reinterpret_cast<const bf16x8*>(b + (b_off[tn] ^ ((q + 1) << 5)));
                 }
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[q & 1][tn], av[q & 1][tm], acc[tm][tn], 0, 0, 0);
+                    for (int tn = 0; tn < 2 * NH; ++tn)
+                        acc[tn >> 1][tm][tn & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            bv[q & 1][tn], av[q & 1][tm], acc[tn >> 1][tm][tn & 1], 0, 0, 0);
             }
             // pin the issue order (the scheduler otherwise reuses the fragment registers and serialises
             // read -> wait -> MFMA): k-step 0's reads, then per k-step one read of the NEXT step behind each MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, TM + 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + 2 * NH, 0);
 #pragma unroll
             for (int q = 0; q < KC / 16 - 1; ++q)
 #pragma unroll
-                for (int i = 0; i < 2 * TM; ++i) {
+                for (int i = 0; i < 2 * NH * TM; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (i < TM + 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (i < TM + 2 * NH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NH * TM, 0);
             if (++c_slot == PL_NB) c_slot = 0;
             ++tapoff;
             if (++c_tw == kw) { c_tw = 0; tapoff += in_p - kw; }
@@ -820,9 +826,16 @@ __global__ __launch_bounds__(256, KC == 64 ? 2 : 3) void conv_bf16p_kernel(const
         if (g + 1 < ngroups && !S3R_ABLH(p, 3)) issue_a();
     }
 
-    store_ep(epr, ep, tid);
-    if (p.head_w) epilogue_h<TM, true>(p, acc, yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
-    else epilogue_h<TM, false>(p, acc, yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
+    store_ep(epr, ep, tid, BNW);
+    if constexpr (NH == 1) {
+        if (p.head_w) epilogue_h<TM, true>(p, acc[0], yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
+        else epilogue_h<TM, false>(p, acc[0], yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
+    } else {
+#pragma unroll
+        for (int nh = 0; nh < NH; ++nh)
+            epilogue_h<TM, false>(p, acc[nh], yoff, ep + nh * 192, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0 + nh * HBN,
+                                  cls, kz, BM);
+    }
 }
 
 // split-K finish: y[pos][cout] = bf16(act(scale * sum_kz slab + shift)); one thread per (position, cout pair)
@@ -885,7 +898,9 @@ int conv_bf16_pick_tm(const ConvParamsH& p) {
     // kernel chunk64-major.  So the FAMILY is chosen from per-sample geometry, only the tile from the batch.
     const int pr = plane_rows(p, 256, 32);
     const bool plane_family = pr > 0 && pr <= 576 && (p.Cin / 32) % p.ksplit == 0 && (long)p.Cin * p.T >= 512;
-    if (plane_family && wgs(2) >= 512) return 22;
+    // (transposed classes have only 4 taps per image: its 256 x 128-cout form, code 23, amortises the image over twice
+    //  the couts — d1 -10 %, d2 -6 %; the 9-tap layers are level or slower with it)
+    if (plane_family && wgs(2) >= 512) return (p.transposed && n_tiles % 2 == 0 && wgs(2) / 2 >= 512) ? 23 : 22;
     // row-reuse (32-channel K order, like the plane kernel): small batches of deep plane-family layers (v5 at B = 32)
     const bool deep = !p.transposed && p.kw >= 3 && (long)p.Cin * p.T >= 64 * 27;
     const bool reuse = p.stride == 1 && deep && rowreuse_rows(p, 128) <= 64 * NPA_MAX;
@@ -910,7 +925,7 @@ int conv_bf16_pick_ksplit(const ConvParamsH& p) {
 
 int64_t conv_bf16_scratch_elems(const ConvParamsH& p, int tm) {
     if (p.ksplit <= 1) return 0;
-    const int t0 = tm >= 21 ? tm - 20 : (tm >= 16 ? tm - 16 : (tm >= 9 ? tm - 8 : (tm >= 5 ? tm - 4 : tm)));
+    const int t0 = tm == 23 ? 2 : tm >= 21 ? tm - 20 : (tm >= 16 ? tm - 16 : (tm >= 9 ? tm - 8 : (tm >= 5 ? tm - 4 : tm)));
     const int bm = 128 * (t0 == 3 ? 1 : t0);
     const int64_t mpad = (int64_t)((p.Ntotal + bm - 1) / bm) * bm;
     return (int64_t)(p.transposed ? 8 : 1) * p.ksplit * mpad * p.CoutPad;
@@ -961,7 +976,7 @@ static int plane_rows(const ConvParamsH& p, int bm, int kc) {
     return (r + unit - 1) / unit * unit;
 }
 
-template <int TM, int KC>
+template <int TM, int KC, int NH = 1>
 static hipError_t launch_tm_plane(ConvParamsH p, hipStream_t stream) {
     constexpr int BM = 128 * TM;
     p.m_tiles = (p.Ntotal + BM - 1) / BM;
@@ -969,13 +984,14 @@ static hipError_t launch_tm_plane(ConvParamsH p, hipStream_t stream) {
     const int r_max = plane_rows(p, BM, KC);
     if (r_max == 0 || r_max > (KC == 64 ? 32 * NPA_PL : 64 * NPA_PL32) || (p.Cin / KC) % p.ksplit != 0)
         return hipErrorInvalidValue;
-    const size_t lds = (size_t)r_max * KC * 2 + PL_NB * HBN * KC * 2 + 2 * BM * sizeof(int) + EP_BYTES;
-    if (lds > 160 * 1024 || r_max * 4 > HBN * KC * 2) return hipErrorInvalidValue;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<TM, KC>),
+    if (NH == 2 && (p.n_tiles % 2 != 0 || p.head_w)) return hipErrorInvalidValue;
+    const size_t lds = (size_t)r_max * KC * 2 + PL_NB * HBN * NH * KC * 2 + 2 * BM * sizeof(int) + EP_BYTES * NH;
+    if (lds > 160 * 1024 || r_max * 4 > HBN * NH * KC * 2) return hipErrorInvalidValue;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<TM, KC, NH>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return attr;
-    dim3 grid(p.m_tiles * p.n_tiles, p.transposed ? 8 : 1, p.ksplit);
-    hipLaunchKernelGGL((conv_bf16p_kernel<TM, KC>), grid, dim3(256), lds, stream, p, r_max);
+    dim3 grid(p.m_tiles * (p.n_tiles / NH), p.transposed ? 8 : 1, p.ksplit);
+    hipLaunchKernelGGL((conv_bf16p_kernel<TM, KC, NH>), grid, dim3(256), lds, stream, p, r_max);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && p.ksplit > 1) {
         const long long total = (long long)p.Ntotal * (p.CoutPad >> 1);
@@ -1048,6 +1064,7 @@ hipError_t launch_conv_bf16(const ConvParamsH& pin, int tm, hipStream_t stream) 
         case 6: return launch_tm_plane<2, 64>(p, stream);
         case 21: return launch_tm_plane<1, 32>(p, stream);
         case 22: return launch_tm_plane<2, 32>(p, stream);
+        case 23: return launch_tm_plane<2, 32, 2>(p, stream);            // 256 positions x 128 couts
         case 9: return launch_tm_rowreuse<1>(p, stream);
         case 10: return launch_tm_rowreuse<2>(p, stream);
         default: return hipErrorInvalidValue;

@@ -68,9 +68,9 @@ def test_each_layer_bf16_vs_oracle(s3r, oracle, idx):
 
 
 # 1, 2, 4: per-tap gather (64-channel K tiles where Cin allows, +16 = 32-channel), 3: its 128 x 128-cout tile;
-# 5, 6 / 21, 22: plane-reuse gather;
+# 5, 6 / 21, 22: plane-reuse gather, 23: its 256 x 128-cout tile;
 # 9, 10: row-reuse gather (x128 / x256 positions)
-@pytest.mark.parametrize("tm", [1, 2, 3, 4, 5, 6, 9, 10, 17, 18, 19, 21, 22])
+@pytest.mark.parametrize("tm", [1, 2, 3, 4, 5, 6, 9, 10, 17, 18, 19, 21, 22, 23])
 @pytest.mark.parametrize("kind", ["conv3d_s1", "conv3d_s2", "deconv", "conv2d_s2", "conv3d_k4_valid_ks2", "cout32",
                                   "conv2d_s1_w28", "conv3d_s1_w14", "conv3d_s1_c64", "deconv_c64", "deconv_c128_w8",
                                   "conv3d_k4_valid_c128_ks2", "conv2d_s1_c128_w9"])
@@ -107,10 +107,11 @@ def test_bf16_tiles_and_split_k(s3r, oracle, tm, kind):
     xin = xin.permute(0, *range(2, xin.dim()), 1).contiguous()
     kc = 64 if tm in (5, 6) else 32            # plane-reuse gather: 5, 6 = 64-channel K tiles, 21, 22 = 32-channel
     plane_ok = (layer.s == 1 or layer.op == "deconv3d") and layer.cin % kc == 0 and (ks == 0 or (layer.cin // kc) % ks == 0)
-    if tm in (6, 22) and kind in ("conv3d_k4_valid_c128_ks2", "conv3d_k4_valid_ks2"):
+    if tm in (6, 22, 23) and kind in ("conv3d_k4_valid_c128_ks2", "conv3d_k4_valid_ks2"):
         plane_ok = False                       # 16-position planes: a 256-position tile spans 17 of them (+ halos)
     wide_ok = (-(-layer.cout // 64)) % 2 == 0          # 128-cout workgroup tiles need an even number of 64-cout tiles
-    if (tm == 10 and kind == "conv3d_s2") or (tm in (5, 6, 21, 22) and not plane_ok) or (tm in (3, 19) and not wide_ok):
+    if (tm == 10 and kind == "conv3d_s2") or (tm in (5, 6, 21, 22, 23) and not plane_ok) or \
+            (tm in (3, 19, 23) and not wide_ok):
         # 5-wide rows at stride 2: the 256-position reuse image exceeds its LDS budget; the plane-reuse gather
         # needs stride 1 and whole 64-channel chunks per split
         with pytest.raises(s3r.S3RError):
