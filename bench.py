@@ -261,7 +261,8 @@ def main():
                 traffic = pmc_util = pmc_clock = None
                 bf = args.dtype == "bf16"
                 tpath = os.path.join(ROOT, "profiles", "traffic_r01_bf16.json" if bf else "traffic_r01.json")
-                if os.path.exists(tpath):
+                # the committed counters are those of the default fp32 run (B=32) / the bf16 run at B=256 only
+                if os.path.exists(tpath) and args.variant == "voxel" and B == (256 if bf else 32):
                     try:
                         tj = json.load(open(tpath))
                         traffic = tj.get("hbm_bytes_per_launch")                         # rocprofv3 PMC, per launch
