@@ -218,8 +218,12 @@ class _HipChain(nn.Module):
         is zero (internal hand-off from the cost-volume kernel), otherwise a plain contiguous tensor."""
         lib = _lib.load()
         device, batch = x.device, x.shape[0]
-        if batch == 0:
-            return x.new_empty(self._out_shape(0, len(self._layers) if upto is None else self.names.index(upto) + 1))
+        if batch == 0:                 # same dtype / layout contract as a non-empty batch
+            n0 = len(self._layers) if upto is None else self.names.index(upto) + 1
+            shape = self._out_shape(0, n0)
+            if self._out_is_bf16(n0):
+                return _to_logical(torch.empty((0,) + shape[2:] + (shape[1],), dtype=torch.bfloat16, device=device))
+            return torch.empty(shape, dtype=torch.float32, device=device)
         arr, n = self._layer_array(batch, device, upto, in_halo)
         shape = self._out_shape(batch, n)
         if self._out_is_bf16(n):      # physical channels-last (B,...,C) bf16; handed back as a logical (B,C,...) view

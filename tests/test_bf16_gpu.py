@@ -161,6 +161,22 @@ def test_stereo2voxel_bf16_vs_fp32_oracle(s3r, oracle):
     assert torch.equal(one[0], got[2])
 
 
+def test_bf16_odd_empty_and_chunked_batches(s3r):
+    """Ragged sizes on the bf16 path: an odd batch equals its samples run one by one (bitwise), an empty batch is an
+    empty result, and the disparity read-out works from the bf16 encoder's features."""
+    hip = s3r.Stereo2Voxel(precision="bf16")
+    s3r.seed_module(hip, 3)
+    hip.to(DEV)
+    left, right = s3r.synthetic_pairs(5, seed=11)
+    got = hip(left.to(DEV), right.to(DEV))
+    for i in range(5):
+        assert torch.equal(hip(left[i:i + 1].to(DEV), right[i:i + 1].to(DEV))[0], got[i])
+    assert hip(left[:0].to(DEV), right[:0].to(DEV)).shape == (0, 32, 32, 32)
+    dl, dr = hip.disparity(left.to(DEV), right.to(DEV))
+    assert dl.shape == (5, 28, 28) and dr.shape == (5, 28, 28)
+    assert float(dl.min()) >= 0 and float(dl.max()) <= 8 * 27 and bool((dl % 8 == 0).all())
+
+
 def test_bf16_and_fp32_modules_share_a_state_dict(s3r):
     a, b = s3r.Stereo2Voxel(), s3r.Stereo2Voxel(precision="bf16")
     assert a.state_dict().keys() == b.state_dict().keys()
