@@ -1,0 +1,50 @@
+"""runner.py --test end to end (the reference's eval entry point, /root/reference/README.md:88-92): a checkpoint in a
+training-style container, an .npz eval list with ground-truth disparity, one JSON line out."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.mark.gpu
+def test_runner_test_mode_matches_in_process_eval(tmp_path):
+    import s3r
+    left, right, gt = s3r.evaluate.synthetic_eval_set(3, 5)
+    g = torch.Generator().manual_seed(2)
+    dl, dr = torch.rand(3, 28, 28, generator=g) * 200, torch.rand(3, 28, 28, generator=g) * 200
+    dl[0, :7] = float("inf")                                   # background, as the EXR maps mark it
+    data = tmp_path / "eval.npz"
+    np.savez(data, left=left.numpy(), right=right.numpy(), volume=gt.numpy(), disp_left=dl.numpy(), disp_right=dr.numpy())
+    model = s3r.Stereo2Voxel()
+    s3r.seed_module(model, 4)
+    ckpt = tmp_path / "ckpt.pth"                               # DataParallel-style keys inside a container
+    torch.save({"epoch": 7, "state_dict": {"module." + k: v for k, v in model.state_dict().items()}}, ckpt)
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "runner.py"), "--test", "--weights", str(ckpt), "--data", str(data),
+                        "--batch", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["samples"] == 3 and out["n_gpus"] == 1 and len(out["mean_iou"]) == len(out["thresholds"])
+
+    model.to("cuda:0")
+    want = s3r.evaluate.test_net(model, left, right, gt, batch=2, device="cuda:0")
+    assert out["mean_iou"] == [round(x, 6) for x in want["mean_iou"]]
+    wd = s3r.evaluate.test_disparity(model, left, right, dl, dr, batch=2, device="cuda:0")
+    assert out["disparity_epe_left_px"] == round(wd["epe_left"], 4)
+    assert out["disparity_epe_right_px"] == round(wd["epe_right"], 4)
+
+
+def test_runner_refuses_what_it_does_not_implement():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "runner.py")], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode != 0 and "only --test is implemented" in (r.stderr + r.stdout)
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "runner.py"), "--test"], capture_output=True, text=True,
+                           timeout=300, cwd=ROOT)
+        assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
