@@ -239,7 +239,8 @@ class _HipChain(nn.Module):
 
 
     # -- measured per-layer configuration ----------------------------------------------------------
-    _TUNE_TILES = (1, 2, 3, 7, 0)
+    _TUNE_TILES = (1, 2, 3, 7, 0)               # fp32 tile configurations (s3r_conv_glds.hip)
+    _TUNE_TILES_BF16 = (1, 3, 9, 17, 22, 23)    # bf16: per-tap (128 / 128x128 / 32-ch K), row-reuse, plane-reuse
     _TUNE_KSPLITS = (1, 2, 4, 8)
 
     def _mfma_layers(self):
@@ -255,12 +256,13 @@ class _HipChain(nn.Module):
         chosen = {}
         for l in self._mfma_layers():
             tag = self._tag_base + self.names.index(l.name)
-            chunks = l.cin // 16
+            bf16 = self.precision == "bf16"
+            chunks = l.cin // (32 if bf16 else 16)
             best = None
             for ks in self._TUNE_KSPLITS:
                 if chunks % ks:
                     continue
-                for t in self._TUNE_TILES:
+                for t in (self._TUNE_TILES_BF16 if bf16 else self._TUNE_TILES):
                     self.tile_override[l.name], self.ksplit_override[l.name] = t, ks
                     ms = []
                     try:
@@ -426,7 +428,7 @@ class PointHead(_HipChain):
 
     def forward(self, latent: torch.Tensor) -> torch.Tensor:
         x = _check_input(latent, "latent", (spec.LATENT_C, 4, 4, 4))
-        return self._run(x.view(x.shape[0], -1)).view(-1, spec.N_POINTS, 3)
+        return self._run(x.view(x.shape[0], spec.LATENT_C * 64)).view(x.shape[0], spec.N_POINTS, 3)   # (B may be 0)
 
 
 class Stereo2Voxel(nn.Module):

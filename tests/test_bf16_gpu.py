@@ -177,6 +177,35 @@ def test_bf16_odd_empty_and_chunked_batches(s3r):
     assert float(dl.min()) >= 0 and float(dl.max()) <= 8 * 27 and bool((dl % 8 == 0).all())
 
 
+def test_bf16_hip_graph_replay_matches_eager(s3r):
+    hip = s3r.Stereo2Voxel(precision="bf16")
+    s3r.seed_module(hip, 0)
+    hip.to(DEV)
+    left, right = s3r.synthetic_pairs(3, seed=31)
+    left, right = left.to(DEV), right.to(DEV)
+    want = hip(left, right).clone()
+    g = s3r.GraphedForward(hip, 3, DEV)
+    assert torch.equal(g(left, right), want)
+    l2, r2 = s3r.synthetic_pairs(3, seed=32)
+    want2 = hip(l2.to(DEV), r2.to(DEV)).clone()
+    assert torch.equal(g(l2.to(DEV), r2.to(DEV)), want2)
+
+
+def test_bf16_autotune_keeps_the_result_within_bf16_tolerance(s3r):
+    """Measured per-layer (tile, split-K) choices change summation orders, nothing else."""
+    hip = s3r.Stereo2Voxel(precision="bf16")
+    s3r.seed_module(hip, 2)
+    hip.to(DEV)
+    left, right = s3r.synthetic_pairs(4, seed=5)
+    left, right = left.to(DEV), right.to(DEV)
+    before = hip(left, right).clone()
+    chosen = hip.autotune(left, right, rounds=1)
+    assert set(chosen) >= {"e2", "v1", "d3"} and all(v["ms"] > 0 for v in chosen.values())
+    after = hip(left, right)
+    assert rel_l2(after.cpu(), before.cpu()) < 5e-3
+    assert torch.equal(hip(left, right), after)
+
+
 def test_bf16_and_fp32_modules_share_a_state_dict(s3r):
     a, b = s3r.Stereo2Voxel(), s3r.Stereo2Voxel(precision="bf16")
     assert a.state_dict().keys() == b.state_dict().keys()

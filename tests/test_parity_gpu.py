@@ -319,6 +319,11 @@ def test_stereo2point_vs_oracle(s3r, oracle):
     got = hip(left.to(DEV), right.to(DEV)).cpu()
     assert got.shape == (2, 2048, 3)
     assert rel_l2(got, want) < 1e-5
+    # ragged sizes: an empty batch, and a sample of an odd batch equals the sample alone (bitwise)
+    assert hip(left[:0].to(DEV), right[:0].to(DEV)).shape == (0, 2048, 3)
+    l3, r3 = s3r.synthetic_pairs(3, seed=6)
+    got3 = hip(l3.to(DEV), r3.to(DEV))
+    assert torch.equal(hip(l3[2:3].to(DEV), r3[2:3].to(DEV))[0], got3[2])
 
 
 @pytest.mark.parametrize("shape", [(32, 32768, 1024), (5, 1024, 6144), (33, 96, 40), (3, 50, 7), (70, 4096, 100)])
