@@ -177,6 +177,20 @@ def test_bf16_odd_empty_and_chunked_batches(s3r):
     assert float(dl.min()) >= 0 and float(dl.max()) <= 8 * 27 and bool((dl % 8 == 0).all())
 
 
+def test_bf16_batch_above_the_chunk_limit(s3r):
+    """258 pairs run as chunks of 256 + 2 (32-bit buffer offsets bound one launch): every sample still equals the
+    sample run alone."""
+    hip = s3r.Stereo2Voxel(precision="bf16")
+    s3r.seed_module(hip, 1)
+    hip.to(DEV)
+    n = s3r.modules.MAX_CHUNK + 2
+    left, right = s3r.synthetic_pairs(n, seed=13)
+    got = hip(left.to(DEV), right.to(DEV))
+    assert got.shape == (n, 32, 32, 32)
+    for i in (0, 255, 256, n - 1):
+        assert torch.equal(hip(left[i:i + 1].to(DEV), right[i:i + 1].to(DEV))[0], got[i])
+
+
 def test_bf16_hip_graph_replay_matches_eager(s3r):
     hip = s3r.Stereo2Voxel(precision="bf16")
     s3r.seed_module(hip, 0)

@@ -457,6 +457,21 @@ def test_errors(s3r, models):
         hip.train()
     with pytest.raises(RuntimeError):
         s3r.chamfer_distance(torch.zeros(1, 0, 3, device=DEV), torch.zeros(1, 4, 3, device=DEV))
+    # disparity read-out / end-point error: shape, device and size contracts
+    f = torch.zeros(1, 8, 4, 6, device=DEV)
+    with pytest.raises(RuntimeError):
+        s3r.disparity_wta(f, torch.zeros(1, 8, 4, 7, device=DEV))                     # shapes differ
+    with pytest.raises(RuntimeError):
+        s3r.disparity_wta(f.cpu(), f.cpu())                                           # no CPU fallback
+    with pytest.raises(s3r.S3RError):
+        s3r.disparity_wta(f, f, max_disp=0)
+    with pytest.raises(s3r.S3RError):                                                 # a row pair must fit 64 KiB of LDS
+        s3r.disparity_wta(torch.zeros(1, 64, 2, 200, device=DEV), torch.zeros(1, 64, 2, 200, device=DEV))
+    with pytest.raises(RuntimeError):
+        s3r.disparity_epe(torch.zeros(2, 4, 4, device=DEV), torch.zeros(2, 4, 5, device=DEV))
+    assert s3r.disparity_epe(torch.zeros(0, 4, 4, device=DEV), torch.zeros(0, 4, 4, device=DEV))[0].shape == (0,)
+    dl0, dr0 = s3r.disparity_wta(f[:0], f[:0])
+    assert dl0.shape == (0, 4, 6) and dr0.shape == (0, 4, 6)
 
 
 def test_non_default_stream(s3r, models):
