@@ -134,6 +134,13 @@ def test_invalid_arguments_are_reported_not_crashed(s3r, lib):
     assert lib.s3r_cost_volume_forward(None, None, None, 1, 1, 1, 1, 1, 0, None) == -1
     assert lib.s3r_chamfer_forward(None, None, None, None, None, None, 1, 1, 1, None) == -1
     assert lib.s3r_chain_forward(None, 0, None, None, None, 0, 0, None) == -1
+    assert lib.s3r_disparity_wta(None, None, None, None, 1, 1, 1, 1, 1, None) == -1
+    one = C.c_void_p(16)                                       # non-null dummies: validation fails first
+    assert lib.s3r_disparity_wta(one, one, one, one, 1, 64, 2, 200, 4, None) == -1
+    assert b"64 KiB" in lib.s3r_last_error()
+    assert lib.s3r_disparity_wta(one, one, one, one, 1, 8, 2, 8, 0, None) == -1
+    assert lib.s3r_disparity_epe(None, None, None, None, 1, 1, None) == -1
+    assert lib.s3r_disparity_epe(one, one, one, one, 0, 16, None) == -1
 
 
 def test_missing_library_fails_loudly(s3r, monkeypatch, tmp_path):
