@@ -177,6 +177,20 @@ def test_bf16_odd_empty_and_chunked_batches(s3r):
     assert float(dl.min()) >= 0 and float(dl.max()) <= 8 * 27 and bool((dl % 8 == 0).all())
 
 
+@pytest.mark.parametrize("n", [2, 7, 16, 33, 64, 100])
+def test_bf16_results_do_not_depend_on_the_batch_size(s3r, n):
+    """The library switches tiles with the batch (plane-reuse <-> row-reuse / per-tap, 128 x 128 <-> 128 x 64) but never
+    the K summation order of a layer: sample 0 is bitwise the same alone and inside any batch."""
+    hip = s3r.Stereo2Voxel(precision="bf16")
+    s3r.seed_module(hip, 6)
+    hip.to(DEV)
+    left, right = s3r.synthetic_pairs(n, seed=17)
+    alone = hip(left[:1].to(DEV), right[:1].to(DEV))[0].clone()
+    got = hip(left.to(DEV), right.to(DEV))
+    assert torch.equal(got[0], alone)
+    assert torch.equal(hip(left[n - 1:].to(DEV), right[n - 1:].to(DEV))[0], got[n - 1])
+
+
 def test_bf16_batch_above_the_chunk_limit(s3r):
     """258 pairs run as chunks of 256 + 2 (32-bit buffer offsets bound one launch): every sample still equals the
     sample run alone."""
