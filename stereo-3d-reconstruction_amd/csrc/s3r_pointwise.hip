@@ -33,9 +33,12 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     const int ih0 = oh * 2 - 1, iw0 = ow * 2 - 1;
     const float* __restrict__ xn = x + (size_t)n * 3 * Hi * Wi;
 
-    float acc[32];
+    // accumulators in pairs: the channel loop compiles to v_pk_fma_f32 (two exact fp32 FMAs per lane per instruction,
+    // the weight pair straight from SGPRs) — half the VALU instructions of the scalar form, same bits
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[16];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+    for (int c = 0; c < 16; ++c) acc2[c] = (f32x2){0.f, 0.f};
     // The (channel, row) loops stay ROLLED: fully unrolled, all 864 weights become live scalar loads at once, do not
     // fit the SGPR file, and were spilled through v_writelane / v_readlane (1536 extra instructions per thread).
     // Rolled, one iteration holds the 96 weights of its three taps.
@@ -52,11 +55,16 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
                 const int iw = iw0 + kw;
                 const bool v = vh && ((unsigned)iw < (unsigned)Wi);
                 const float xv = v ? xrow[iw] : 0.f;
+                const f32x2 xv2 = {xv, xv};
 #pragma unroll
-                for (int c = 0; c < 32; ++c) acc[c] = fmaf(xv, wrow[kw * 32 + c], acc[c]);
+                for (int c = 0; c < 16; ++c)
+                    acc2[c] = __builtin_elementwise_fma(xv2, *reinterpret_cast<const f32x2*>(wrow + kw * 32 + 2 * c), acc2[c]);
             }
         }
     }
+    float acc[32];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { acc[2 * c] = acc2[c].x; acc[2 * c + 1] = acc2[c].y; }
     float* __restrict__ yn = y + (size_t)n * 32 * y_cs + y_org + oh * y_hs + ow;   // (halo-padded) NCHW
 #pragma unroll
     for (int c = 0; c < 32; ++c) yn[(size_t)c * y_cs] = fmaxf(fmaf(acc[c], scale[c], shift[c]), 0.f);
