@@ -299,10 +299,11 @@ class Encoder(_HipChain):
     def __init__(self, precision: str = "fp32"):
         super().__init__(spec.ENCODER, spec.IMG_HW, tag_base=100, precision=precision)
 
-    def forward(self, images: torch.Tensor) -> torch.Tensor:
-        """fp32: (N,32,28,28) contiguous.  bf16: (N,32,28,28) bfloat16 in channels_last memory format."""
+    def forward(self, images: torch.Tensor, upto: Optional[str] = None) -> torch.Tensor:
+        """fp32: (N,32,28,28) contiguous.  bf16: (N,32,28,28) bfloat16 in channels_last memory format.
+        `upto`: stop after the named layer (stage-by-stage checks), as on Decoder.forward."""
         x = _check_input(images, "images", (3, spec.IMG_HW, spec.IMG_HW))
-        return self._run(x)
+        return self._run(x, upto)
 
 
 class CostVolume(nn.Module):
