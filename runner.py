@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--data", default=None, help=".npz with left, right, volume [, disp_left, disp_right]; default: synthetic")
     ap.add_argument("--dataset-root", default=None,
                     help="StereoShapeNet root (ShapeNetStereoRendering/ + ShapeNetVox32/, README.md:73-77)")
+    ap.add_argument("--disparity", action="store_true",
+                    help="with --dataset-root: also read disp_%%02d_{l,r}.exr and report the disparity end-point error")
     ap.add_argument("--samples", type=int, default=64, help="synthetic eval list length")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--seed", type=int, default=0)
@@ -60,16 +62,18 @@ def main():
         s3r.seed_module(model, args.seed)
     model.to(dev)
 
+    disp = None
     if args.dataset_root:
-        ds = s3r.data.StereoShapeNet(args.dataset_root)
+        ds = s3r.data.StereoShapeNet(args.dataset_root, with_disparity=args.disparity)
         res = s3r.evaluate.test_dataset(model, ds, batch=args.batch, device=dev)
         left = None
+        if args.disparity:
+            disp = {"epe_left": res["epe_left"], "epe_right": res["epe_right"]}
     elif args.data:
         z = np.load(args.data)
         left, right, gt = (torch.from_numpy(z[k]).float() for k in ("left", "right", "volume"))
     else:
         left, right, gt = s3r.evaluate.synthetic_eval_set(args.samples, args.seed)
-    disp = None
     if left is not None:
         res = s3r.evaluate.test_net(model, left, right, gt, batch=args.batch, device=dev)
         if args.data and "disp_left" in z.files and "disp_right" in z.files:

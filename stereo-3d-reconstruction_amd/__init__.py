@@ -8,7 +8,7 @@ reference's model code is not in the mount (/root/reference/README.md:5).
 Importing this package never touches the GPU and never loads the oracle; the HIP library
 (csrc/libs3r_hip.so) is loaded on first use and its absence is a hard error.
 """
-from . import arch_spec, checkpoint, collate, data, evaluate
+from . import arch_spec, checkpoint, collate, data, evaluate, exr
 from .graph import GraphedForward, PrefetchingLoader
 from ._lib import S3RError, LIB_PATH, load as load_library, profile_enable, profile_read, profile_reset
 from .init import seed_module, seeded_state_dict, synthetic_pairs

@@ -3,9 +3,9 @@
 File layout as the reference's config documents it (/root/reference/README.md:73-77):
     LEFT_RENDERING_PATH   <root>/ShapeNetStereoRendering/<taxonomy>/<model>/render_%02d_l.png
     RIGHT_RENDERING_PATH  <root>/ShapeNetStereoRendering/<taxonomy>/<model>/render_%02d_r.png
-    LEFT/RIGHT_DISP_PATH  .../disp_%02d_{l,r}.exr          (ground-truth disparity: NOT read here — EXR needs
-                                                            pyexr/OpenEXR, absent from this image, and the
-                                                            forward path does not consume it)
+    LEFT/RIGHT_DISP_PATH  .../disp_%02d_{l,r}.exr          (ground-truth disparity: read with this package's own
+                                                            minimal OpenEXR decoder, exr.py — pyexr/OpenEXR are
+                                                            absent from this image — when with_disparity=True)
     VOLUME_PATH           <root>/ShapeNetVox32/<taxonomy>/<model>.mat
 
 The reference's own transforms (crop / background / normalisation constants) are on unmounted branches
@@ -52,10 +52,36 @@ def _load_volume(path: str) -> np.ndarray:
     raise RuntimeError(f"{path}: no 3D array found")
 
 
-class StereoShapeNet(torch.utils.data.Dataset):
-    """One item per (taxonomy, model, view): left, right (3,224,224) float32 in [0,1], volume (32,32,32) {0,1}."""
+def _load_disparity(path: str) -> np.ndarray:
+    from . import exr
+    d = exr.disparity_channel(exr.read_exr(path))
+    if d.shape != (IMG, IMG):
+        raise RuntimeError(f"{path}: disparity map is {d.shape}, expected {(IMG, IMG)} (the renders' resolution)")
+    return np.ascontiguousarray(d, dtype=np.float32)
 
-    def __init__(self, root: str, taxonomies: Optional[Sequence[str]] = None, views: Optional[Sequence[int]] = None):
+
+def downsample_disparity(d: torch.Tensor, size: int = 28) -> torch.Tensor:
+    """(N,H,W) ground-truth disparity in render pixels -> (N,size,size): the mean over the VALID pixels (finite, >= 0)
+    of each H/size x W/size block, inf where a block has none — the resolution `Stereo2Voxel.disparity` predicts at
+    (values stay in render pixels)."""
+    n, h, w = d.shape
+    if h % size or w % size:
+        raise ValueError(f"{h}x{w} maps do not tile into {size}x{size} blocks")
+    blocks = d.reshape(n, size, h // size, size, w // size).permute(0, 1, 3, 2, 4).reshape(n, size, size, -1)
+    valid = torch.isfinite(blocks) & (blocks >= 0)
+    cnt = valid.sum(-1)
+    mean = torch.where(valid, blocks, torch.zeros_like(blocks)).sum(-1) / cnt.clamp(min=1)
+    return torch.where(cnt > 0, mean, torch.full_like(mean, float("inf")))
+
+
+class StereoShapeNet(torch.utils.data.Dataset):
+    """One item per (taxonomy, model, view): left, right (3,224,224) float32 in [0,1], volume (32,32,32) {0,1};
+    with_disparity=True appends the left / right ground-truth disparity maps (224,224) float32 (render pixels; the
+    files' own invalid markers — inf / negative — are kept) and lists only the views that have both EXR files."""
+
+    def __init__(self, root: str, taxonomies: Optional[Sequence[str]] = None, views: Optional[Sequence[int]] = None,
+                 with_disparity: bool = False):
+        self.with_disparity = with_disparity
         rdir = os.path.join(root, RENDER_DIR)
         if not os.path.isdir(rdir):
             raise FileNotFoundError(f"{rdir} not found (expected the layout of README.md:73-77 under {root})")
@@ -75,7 +101,11 @@ class StereoShapeNet(torch.utils.data.Dataset):
                     m = _VIEW.match(f)
                     if m and (views is None or int(m.group(1)) in views) and \
                             os.path.exists(os.path.join(mdir, f.replace("_l.png", "_r.png"))):
-                        self.items.append((tax, model, int(m.group(1))))
+                        v = int(m.group(1))
+                        if with_disparity and not all(os.path.exists(os.path.join(mdir, "disp_%02d_%s.exr" % (v, sd)))
+                                                      for sd in "lr"):
+                            continue
+                        self.items.append((tax, model, v))
 
     def __len__(self):
         return len(self.items)
@@ -86,11 +116,16 @@ class StereoShapeNet(torch.utils.data.Dataset):
         left = _load_png(os.path.join(mdir, "render_%02d_l.png" % view))
         right = _load_png(os.path.join(mdir, "render_%02d_r.png" % view))
         vol = _load_volume(os.path.join(self.root, VOLUME_DIR, tax, model + ".mat"))
+        if self.with_disparity:
+            dl = _load_disparity(os.path.join(mdir, "disp_%02d_l.exr" % view))
+            dr = _load_disparity(os.path.join(mdir, "disp_%02d_r.exr" % view))
+            return (torch.from_numpy(left), torch.from_numpy(right), torch.from_numpy(vol), torch.from_numpy(dl),
+                    torch.from_numpy(dr))
         return torch.from_numpy(left), torch.from_numpy(right), torch.from_numpy(vol)
 
 
 def batches(ds: StereoShapeNet, batch: int, indices: Optional[Sequence[int]] = None, workers: int = 0
             ) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
-    """Sequential (left, right, volume) host batches over `indices` (default: the whole set)."""
+    """Sequential (left, right, volume[, disp_left, disp_right]) host batches over `indices` (default: the whole set)."""
     sub = ds if indices is None else torch.utils.data.Subset(ds, list(indices))
     yield from torch.utils.data.DataLoader(sub, batch_size=batch, shuffle=False, num_workers=workers, pin_memory=False)

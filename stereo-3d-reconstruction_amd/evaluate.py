@@ -36,7 +36,8 @@ def test_dataset(model, ds, batch: int = 32, thresholds: Sequence[float] = THRES
                  workers: int = 0) -> Dict[str, object]:
     """test_net over a data.StereoShapeNet: each rank decodes and evaluates only its shard_bounds slice of the item
     list, host batches cross PCIe on a copy stream while the previous batch runs (graph.PrefetchingLoader), and the
-    per-sample IoUs are all-gathered in list order."""
+    per-sample IoUs are all-gathered in list order.  A dataset built with_disparity=True also yields the end-point error
+    of the model's disparity read-out against the EXR ground truth, pooled over valid pixels (see test_disparity)."""
     import torch.distributed as dist
     from . import data as _data
     from .graph import PrefetchingLoader
@@ -46,17 +47,33 @@ def test_dataset(model, ds, batch: int = 32, thresholds: Sequence[float] = THRES
     total = len(ds)
     b0, e0 = collate.shard_bounds(total, world, rank)
     ious = torch.empty((e0 - b0, len(thresholds)), dtype=torch.float32, device=device)
+    with_disp = bool(getattr(ds, "with_disparity", False))
+    rows = torch.zeros((e0 - b0, 4), dtype=torch.float64, device=device)          # epe_l, n_l, epe_r, n_r
     host = _data.batches(ds, batch, range(b0, e0), workers)
     done = 0
-    for l, r, g in PrefetchingLoader(host, device):
+    for item in PrefetchingLoader(host, device):
+        l, r, g = item[:3]
         pred = model(l, r)
         for j, t in enumerate(thresholds):
             ious[done:done + l.shape[0], j] = voxel_iou(pred, g, t)
+        if with_disp:
+            dl, dr = model.disparity(l, r)
+            el, nl = disparity_epe(dl, _data.downsample_disparity(item[3], dl.shape[-1]))
+            er, nr = disparity_epe(dr, _data.downsample_disparity(item[4], dr.shape[-1]))
+            rows[done:done + l.shape[0]] = torch.stack([el.double(), nl.double(), er.double(), nr.double()], 1)
         done += l.shape[0]
     if dist_on:
         ious = collate.all_gather_ragged(ious, total, group)
+        if with_disp:
+            rows = collate.all_gather_ragged(rows, total, group)
     mean = ious.mean(0).cpu().tolist() if total else [float("nan")] * len(thresholds)
-    return {"samples": total, "thresholds": list(thresholds), "mean_iou": mean, "per_sample": ious.cpu()}
+    out = {"samples": total, "thresholds": list(thresholds), "mean_iou": mean, "per_sample": ious.cpu()}
+    if with_disp:
+        rows = rows.cpu()
+        nl, nr = rows[:, 1].sum().item(), rows[:, 3].sum().item()
+        out["epe_left"] = (rows[:, 0] * rows[:, 1]).sum().item() / nl if nl else float("nan")
+        out["epe_right"] = (rows[:, 2] * rows[:, 3]).sum().item() / nr if nr else float("nan")
+    return out
 
 
 @torch.no_grad()

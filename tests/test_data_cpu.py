@@ -44,6 +44,29 @@ def test_dataset_reads_the_readme_layout(s3r, tmp_path):
     assert len(only) == 3 and all(v == 1 for _, _, v in only.items)
 
 
+def test_dataset_with_exr_disparity(s3r, tmp_path):
+    """with_disparity=True: the disp_%02d_{l,r}.exr files of README.md:75-76 through exr.py; views without both files
+    are not listed."""
+    _make_tree(str(tmp_path), n_models=2, views=(0, 1))
+    rng = np.random.default_rng(5)
+    want = {}
+    for m in range(2):
+        rdir = os.path.join(str(tmp_path), "ShapeNetStereoRendering", "02691156", f"model{m:02d}")
+        for side in "lr":                                          # view 0 only
+            d = (rng.random((224, 224), dtype=np.float32) * 60)
+            d[:30] = np.inf
+            want[(m, side)] = d
+            s3r.exr.write_exr(os.path.join(rdir, "disp_00_%s.exr" % side), {"R": d, "G": d, "B": d}, "ZIP", half=False)
+    ds = s3r.data.StereoShapeNet(str(tmp_path), with_disparity=True)
+    assert len(ds) == 2 and all(v == 0 for _, _, v in ds.items)
+    left, right, vol, dl, dr = ds[1]
+    assert dl.shape == (224, 224) and dl.dtype == torch.float32
+    assert np.array_equal(dl.numpy(), want[(1, "l")]) and np.array_equal(dr.numpy(), want[(1, "r")])
+    batch = next(iter(s3r.data.batches(ds, 2)))
+    assert len(batch) == 5 and batch[3].shape == (2, 224, 224)
+    assert len(s3r.data.StereoShapeNet(str(tmp_path))) == 4       # without disparity every view is listed
+
+
 def test_dataset_errors(s3r, tmp_path):
     with pytest.raises(FileNotFoundError, match="README.md:73-77"):
         s3r.data.StereoShapeNet(str(tmp_path / "nope"))

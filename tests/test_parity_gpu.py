@@ -535,6 +535,34 @@ def test_dataset_eval_matches_tensor_eval(s3r, models, tmp_path):
     assert a["samples"] == 3 and torch.equal(a["per_sample"], b["per_sample"])
 
 
+def test_dataset_eval_with_exr_disparity(s3r, models, tmp_path):
+    """The whole next-row chain: PNG / MAT / EXR decode -> prefetch -> forward + IoU, disparity read-out + end-point error
+    against the EXR ground truth (block-averaged to the read-out's resolution) — equal to the tensor-level drivers."""
+    import os
+    import numpy as np
+    from tests.test_data_cpu import _make_tree
+    hip, _ = models
+    _make_tree(str(tmp_path), n_models=3, views=(0,), size=224)
+    rng = np.random.default_rng(3)
+    for m in range(3):
+        rdir = os.path.join(str(tmp_path), "ShapeNetStereoRendering", "02691156", f"model{m:02d}")
+        for side in "lr":
+            d = (rng.random((224, 224), dtype=np.float32) * 200)
+            d[:, :40] = np.inf
+            s3r.exr.write_exr(os.path.join(rdir, "disp_00_%s.exr" % side), {"Z": d}, "ZIP", half=(m == 1))
+    ds = s3r.data.StereoShapeNet(str(tmp_path), with_disparity=True)
+    a = s3r.evaluate.test_dataset(hip, ds, batch=2, device=DEV)
+    items = [ds[i] for i in range(len(ds))]
+    left, right, gt, dl, dr = (torch.stack([it[k] for it in items]) for k in range(5))
+    b = s3r.evaluate.test_net(hip, left, right, gt, batch=2, device=DEV)
+    c = s3r.evaluate.test_disparity(hip, left, right, s3r.data.downsample_disparity(dl), s3r.data.downsample_disparity(dr),
+                                    batch=2, device=DEV)
+    assert torch.equal(a["per_sample"], b["per_sample"])
+    # (the block means are formed on the device there and on the host here: fp32 summation order differs)
+    assert abs(a["epe_left"] - c["epe_left"]) < 1e-5 * c["epe_left"] and abs(a["epe_right"] - c["epe_right"]) < 1e-5 * c["epe_right"]
+    assert a["epe_left"] > 0
+
+
 def test_bench_two_ranks_on_one_gpu(tmp_path):
     """bench.py's N>1 path (sharded batch, all-gather collation, barrier, max-over-ranks timing, rank-0 JSON) run
     with two ranks sharing cuda:0 over gloo — the RCCL run itself needs a multi-GPU node."""

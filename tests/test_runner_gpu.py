@@ -41,6 +41,24 @@ def test_runner_test_mode_matches_in_process_eval(tmp_path):
     assert out["disparity_epe_right_px"] == round(wd["epe_right"], 4)
 
 
+@pytest.mark.gpu
+def test_runner_on_a_dataset_tree_with_disparity(tmp_path):
+    import s3r
+    from tests.test_data_cpu import _make_tree
+    _make_tree(str(tmp_path), n_models=2, views=(0,), size=224)
+    rng = np.random.default_rng(1)
+    for m in range(2):
+        rdir = os.path.join(str(tmp_path), "ShapeNetStereoRendering", "02691156", f"model{m:02d}")
+        for side in "lr":
+            s3r.exr.write_exr(os.path.join(rdir, "disp_00_%s.exr" % side),
+                              {"Z": (rng.random((224, 224), dtype=np.float32) * 100)}, "ZIP")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "runner.py"), "--test", "--dataset-root", str(tmp_path), "--disparity",
+                        "--batch", "2", "--seed", "3"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["samples"] == 2 and out["disparity_epe_left_px"] > 0 and out["disparity_epe_right_px"] > 0
+
+
 def test_runner_refuses_what_it_does_not_implement():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "runner.py")], capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert r.returncode != 0 and "only --test is implemented" in (r.stderr + r.stdout)
