@@ -85,6 +85,9 @@ def main():
                "mean_iou": [round(x, 6) for x in res["mean_iou"]],
                "weights": args.weights or f"seeded random init (seed {args.seed})",
                "data": args.dataset_root or args.data or "synthetic"}
+        if "per_taxonomy" in res:
+            out["per_taxonomy"] = {k: {"samples": v["samples"], "mean_iou": [round(x, 6) for x in v["mean_iou"]]}
+                                   for k, v in res["per_taxonomy"].items()}
         if disp is not None:
             out.update({"disparity_epe_left_px": round(disp["epe_left"], 4), "disparity_epe_right_px": round(disp["epe_right"], 4)})
         print(json.dumps(out))

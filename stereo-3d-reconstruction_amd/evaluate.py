@@ -68,6 +68,13 @@ def test_dataset(model, ds, batch: int = 32, thresholds: Sequence[float] = THRES
             rows = collate.all_gather_ragged(rows, total, group)
     mean = ious.mean(0).cpu().tolist() if total else [float("nan")] * len(thresholds)
     out = {"samples": total, "thresholds": list(thresholds), "mean_iou": mean, "per_sample": ious.cpu()}
+    # per-taxonomy breakdown (what a ShapeNet test log lists): mean IoU per threshold and sample count per category
+    per_tax: Dict[str, Dict[str, object]] = {}
+    cpu = out["per_sample"]
+    for tax in sorted({it[0] for it in getattr(ds, "items", [])}):
+        idx = [i for i, it in enumerate(ds.items) if it[0] == tax]
+        per_tax[tax] = {"samples": len(idx), "mean_iou": cpu[idx].mean(0).tolist()}
+    out["per_taxonomy"] = per_tax
     if with_disp:
         rows = rows.cpu()
         nl, nr = rows[:, 1].sum().item(), rows[:, 3].sum().item()

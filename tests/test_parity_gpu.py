@@ -533,6 +533,8 @@ def test_dataset_eval_matches_tensor_eval(s3r, models, tmp_path):
     left, right, gt = (torch.stack([it[k] for it in items]) for k in range(3))
     b = s3r.evaluate.test_net(hip, left, right, gt, batch=2, device=DEV)
     assert a["samples"] == 3 and torch.equal(a["per_sample"], b["per_sample"])
+    assert list(a["per_taxonomy"]) == ["02691156"] and a["per_taxonomy"]["02691156"]["samples"] == 3
+    assert a["per_taxonomy"]["02691156"]["mean_iou"] == pytest.approx(a["mean_iou"])
 
 
 def test_dataset_eval_with_exr_disparity(s3r, models, tmp_path):
