@@ -118,9 +118,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     B = args.batch
-    if args.dtype == "bf16" and args.variant != "voxel":
-        sys.exit("the bf16 path exists for Stereo2Voxel only")
-    model = s3r.Stereo2Voxel("bf16" if args.dtype == "bf16" else "fp32") if args.variant == "voxel" else s3r.Stereo2Point()
+    prec = "bf16" if args.dtype == "bf16" else "fp32"
+    model = s3r.Stereo2Voxel(prec) if args.variant == "voxel" else s3r.Stereo2Point(prec)
     s3r.seed_module(model, 0)
     model.to(dev)
     left, right = s3r.synthetic_pairs(B, seed=1000 + rank)      # random data (never zeros: DVFS, rule 25)

@@ -408,16 +408,21 @@ class VolumeEncoder(_HipChain):
     """The down half of the hourglass alone (Stereo2Point): cost volume -> (B,512,4,4,4) latent."""
     _entry = "s3r_decoder_forward"
 
-    def __init__(self):
-        super().__init__(spec.DECODER_DOWN, spec.MAX_DISP, tag_base=200)
+    def __init__(self, precision: str = "fp32"):
+        super().__init__(spec.DECODER_DOWN, spec.MAX_DISP, tag_base=200, precision=precision)
 
     def forward(self, volume: torch.Tensor) -> torch.Tensor:
-        x = _check_input(volume, "volume", (2 * spec.FEAT_C, spec.MAX_DISP, spec.FEAT_HW, spec.FEAT_HW))
-        return self._run(x)
+        tail = (2 * spec.FEAT_C, spec.MAX_DISP, spec.FEAT_HW, spec.FEAT_HW)
+        if self.precision == "bf16":
+            return self._run(_to_channels_last_physical(_check_input(volume, "volume", tail, torch.bfloat16)))
+        return self._run(_check_input(volume, "volume", tail))
 
     def forward_padded(self, volume_padded: torch.Tensor, halo: int = 1) -> torch.Tensor:
-        x = _check_input(volume_padded, "volume_padded", (2 * spec.FEAT_C, spec.MAX_DISP + 2 * halo,
-                                                           spec.FEAT_HW + 2 * halo, spec.FEAT_HW + 2 * halo))
+        n = (spec.MAX_DISP + 2 * halo, spec.FEAT_HW + 2 * halo, spec.FEAT_HW + 2 * halo)
+        if self.precision == "bf16":            # physical (B,D+2h,H+2h,W+2h,2C) bf16 -> logical (B,512,4,4,4) bf16
+            x = _check_input(volume_padded, "volume_padded", n + (2 * spec.FEAT_C,), torch.bfloat16)
+        else:
+            x = _check_input(volume_padded, "volume_padded", (2 * spec.FEAT_C,) + n)
         return self._run(x, None, in_halo=halo)
 
 
@@ -502,13 +507,17 @@ class Stereo2Voxel(nn.Module):
 
 
 class Stereo2Point(nn.Module):
-    """left,right (B,3,224,224) -> (B,2048,3) point cloud.  Keys: encoder.*, decoder.*, point_head.*"""
+    """left,right (B,3,224,224) -> (B,2048,3) point cloud.  Keys: encoder.*, decoder.*, point_head.*
 
-    def __init__(self):
+    precision="bf16": the convolutional part (encoder, cost volume, v1-v6) on the bf16 MFMA path; the latent is handed
+    to the point head as fp32 and the three linear layers stay fp32 (they stream 168 MB of weights: HBM-bound)."""
+
+    def __init__(self, precision: str = "fp32"):
         super().__init__()
-        self.encoder = Encoder()
-        self.cost_volume = CostVolume()
-        self.decoder = VolumeEncoder()
+        self.precision = precision
+        self.encoder = Encoder(precision)
+        self.cost_volume = CostVolume(precision=precision)
+        self.decoder = VolumeEncoder(precision)
         self.point_head = PointHead()
         self.eval()
 
@@ -529,7 +538,10 @@ class Stereo2Point(nn.Module):
             b = l.shape[0]
             feats = self.encoder(torch.cat([l, r], 0))
             vol = self.cost_volume.forward_padded(feats[:b], feats[b:])
-            outs.append(self.point_head(self.decoder.forward_padded(vol)))
+            latent = self.decoder.forward_padded(vol)
+            if latent.dtype != torch.float32:                      # bf16 channels-last view -> fp32 (B,512,4,4,4)
+                latent = latent.float().contiguous()
+            outs.append(self.point_head(latent))
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
 

@@ -234,6 +234,25 @@ def test_bf16_autotune_keeps_the_result_within_bf16_tolerance(s3r):
     assert torch.equal(hip(left, right), after)
 
 
+def test_stereo2point_bf16_vs_fp32_oracle(s3r, oracle):
+    """Stereo2Point with the convolutional part on the bf16 path (the point head stays fp32): same state_dict as the
+    fp32 module, point cloud within bf16 tolerance of the fp32 oracle, batch-invariant."""
+    hip = s3r.Stereo2Point(precision="bf16")
+    s3r.seed_module(hip, 1)
+    ref = oracle.OracleStereo2Point().eval()
+    ref.load_state_dict(hip.state_dict())
+    hip.to(DEV)
+    left, right = s3r.synthetic_pairs(3, seed=2)
+    with torch.no_grad():
+        want = ref(left, right)
+    got = hip(left.to(DEV), right.to(DEV))
+    assert got.shape == (3, 2048, 3) and got.dtype == torch.float32
+    assert rel_l2(got.cpu(), want) < 2e-2
+    assert torch.equal(hip(left[1:2].to(DEV), right[1:2].to(DEV))[0], got[1])
+    assert hip(left[:0].to(DEV), right[:0].to(DEV)).shape == (0, 2048, 3)
+    assert s3r.Stereo2Point().state_dict().keys() == hip.state_dict().keys()
+
+
 def test_bf16_and_fp32_modules_share_a_state_dict(s3r):
     a, b = s3r.Stereo2Voxel(), s3r.Stereo2Voxel(precision="bf16")
     assert a.state_dict().keys() == b.state_dict().keys()
