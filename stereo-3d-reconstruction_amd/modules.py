@@ -437,7 +437,32 @@ class PointHead(_HipChain):
         return self._run(x.view(x.shape[0], spec.LATENT_C * 64)).view(x.shape[0], spec.N_POINTS, 3)   # (B may be 0)
 
 
-class Stereo2Voxel(nn.Module):
+class _DisparityMixin:
+    """`disparity()` for the networks that hold an `encoder` and a `cost_volume`."""
+
+    @torch.no_grad()
+    def disparity(self, left: torch.Tensor, right: torch.Tensor, in_pixels: bool = True):
+        """Predicted (left, right) disparity maps, (B,28,28) each: the winner-take-all read-out of the cost volume's
+        shift-and-diff costs on this model's encoder features (`disparity_wta`).  in_pixels scales feature-resolution
+        disparities to 224x224 render pixels (x8), the unit of the dataset's EXR ground truth."""
+        left = _check_input(left, "left", (3, spec.IMG_HW, spec.IMG_HW))
+        right = _check_input(right, "right", (3, spec.IMG_HW, spec.IMG_HW))
+        if left.shape[0] != right.shape[0]:
+            raise RuntimeError("left and right batch sizes differ")
+        dls, drs = [], []
+        for s in range(0, max(left.shape[0], 1), MAX_CHUNK):
+            l, r = left[s:s + MAX_CHUNK], right[s:s + MAX_CHUNK]
+            b = l.shape[0]
+            feats = self.encoder(torch.cat([l, r], 0)).float().contiguous()     # (bf16 path: back to fp32 NCHW)
+            dl, dr = disparity_wta(feats[:b], feats[b:], self.cost_volume.max_disp)
+            dls.append(dl), drs.append(dr)
+        dl = dls[0] if len(dls) == 1 else torch.cat(dls, 0)
+        dr = drs[0] if len(drs) == 1 else torch.cat(drs, 0)
+        scale = float(spec.IMG_HW // spec.FEAT_HW) if in_pixels else 1.0
+        return dl * scale, dr * scale
+
+
+class Stereo2Voxel(_DisparityMixin, nn.Module):
     """left,right (B,3,224,224) -> (B,32,32,32) occupancy.  state_dict keys: encoder.*, decoder.*
 
     precision="fp32": exact-fp32 MFMA path, NCHW (BASELINE configs[1]).  precision="bf16": bf16 MFMA path,
@@ -473,27 +498,6 @@ class Stereo2Voxel(nn.Module):
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
     @torch.no_grad()
-    def disparity(self, left: torch.Tensor, right: torch.Tensor, in_pixels: bool = True):
-        """Predicted (left, right) disparity maps, (B,28,28) each: the winner-take-all read-out of the cost volume's
-        shift-and-diff costs on this model's encoder features (`disparity_wta`).  in_pixels scales feature-resolution
-        disparities to 224x224 render pixels (x8), the unit of the dataset's EXR ground truth."""
-        left = _check_input(left, "left", (3, spec.IMG_HW, spec.IMG_HW))
-        right = _check_input(right, "right", (3, spec.IMG_HW, spec.IMG_HW))
-        if left.shape[0] != right.shape[0]:
-            raise RuntimeError("left and right batch sizes differ")
-        dls, drs = [], []
-        for s in range(0, max(left.shape[0], 1), MAX_CHUNK):
-            l, r = left[s:s + MAX_CHUNK], right[s:s + MAX_CHUNK]
-            b = l.shape[0]
-            feats = self.encoder(torch.cat([l, r], 0)).float().contiguous()     # (bf16 path: back to fp32 NCHW)
-            dl, dr = disparity_wta(feats[:b], feats[b:], self.cost_volume.max_disp)
-            dls.append(dl), drs.append(dr)
-        dl = dls[0] if len(dls) == 1 else torch.cat(dls, 0)
-        dr = drs[0] if len(drs) == 1 else torch.cat(drs, 0)
-        scale = float(spec.IMG_HW // spec.FEAT_HW) if in_pixels else 1.0
-        return dl * scale, dr * scale
-
-    @torch.no_grad()
     def autotune(self, left: torch.Tensor, right: torch.Tensor, rounds: int = 3, log=None):
         """Measure-and-pick the per-layer kernel configuration on a representative batch (see
         _HipChain.autotune).  Returns {layer: {tile, ksplit, ms}}."""
@@ -506,7 +510,7 @@ class Stereo2Voxel(nn.Module):
         return chosen
 
 
-class Stereo2Point(nn.Module):
+class Stereo2Point(_DisparityMixin, nn.Module):
     """left,right (B,3,224,224) -> (B,2048,3) point cloud.  Keys: encoder.*, decoder.*, point_head.*
 
     precision="bf16": the convolutional part (encoder, cost volume, v1-v6) on the bf16 MFMA path; the latent is handed

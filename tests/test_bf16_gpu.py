@@ -251,6 +251,8 @@ def test_stereo2point_bf16_vs_fp32_oracle(s3r, oracle):
     assert torch.equal(hip(left[1:2].to(DEV), right[1:2].to(DEV))[0], got[1])
     assert hip(left[:0].to(DEV), right[:0].to(DEV)).shape == (0, 2048, 3)
     assert s3r.Stereo2Point().state_dict().keys() == hip.state_dict().keys()
+    dl, dr = hip.disparity(left.to(DEV), right.to(DEV))                  # the read-out is shared with Stereo2Voxel
+    assert dl.shape == (3, 28, 28) and dr.shape == (3, 28, 28)
 
 
 def test_bf16_and_fp32_modules_share_a_state_dict(s3r):
