@@ -13,7 +13,7 @@ from typing import Dict, Iterable, Optional, Sequence, Tuple
 import torch
 
 from . import collate
-from .modules import disparity_epe, voxel_iou
+from .modules import chamfer_distance, disparity_epe, voxel_iou
 
 THRESHOLDS = (0.2, 0.3, 0.4, 0.5)
 
@@ -81,6 +81,30 @@ def test_dataset(model, ds, batch: int = 32, thresholds: Sequence[float] = THRES
         out["epe_left"] = (rows[:, 0] * rows[:, 1]).sum().item() / nl if nl else float("nan")
         out["epe_right"] = (rows[:, 2] * rows[:, 3]).sum().item() / nr if nr else float("nan")
     return out
+
+
+@torch.no_grad()
+def test_point_net(model, left: torch.Tensor, right: torch.Tensor, gt_clouds: torch.Tensor, batch: int = 32, device="cuda",
+                   group=None) -> Dict[str, object]:
+    """Stereo2Point's metric (the reference's one native op, extensions/chamfer_dist, README.md:59-66): per-sample
+    Chamfer distance mean_i min_j |p_i - q_j|^2 + mean_j min_i |p_i - q_j|^2 between the predicted (N,2048,3) cloud and
+    the ground-truth (N,M,3) cloud, on the device; with torch.distributed initialised the per-sample scalars of every
+    rank's shard are all-gathered in list order.  (Squared / mean is this build's stated choice — SURVEY.md §8a row 5.)"""
+    import torch.distributed as dist
+    dist_on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if dist_on else 1
+    rank = dist.get_rank(group) if dist_on else 0
+    total = left.shape[0]
+    b0, e0 = collate.shard_bounds(total, world, rank)
+    cd = torch.empty((e0 - b0,), dtype=torch.float32, device=device)
+    for s in range(b0, e0, batch):
+        e = min(e0, s + batch)
+        pred = model(left[s:e].to(device), right[s:e].to(device))
+        d1, d2, _, _ = chamfer_distance(pred, gt_clouds[s:e].to(device))
+        cd[s - b0:e - b0] = d1.mean(1) + d2.mean(1)
+    if dist_on:
+        cd = collate.all_gather_ragged(cd, total, group)
+    return {"samples": total, "mean_chamfer": cd.mean().item() if total else float("nan"), "per_sample": cd.cpu()}
 
 
 @torch.no_grad()

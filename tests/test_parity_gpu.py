@@ -427,6 +427,24 @@ def test_model_disparity_and_eval_driver(s3r, oracle, models):
     assert abs(res["epe_right"] - float((er.double() * nr).sum() / nr.sum())) < 1e-4
 
 
+def test_point_eval_driver_matches_oracle_chamfer(s3r, oracle):
+    hip = s3r.Stereo2Point()
+    s3r.seed_module(hip, 5)
+    ref = oracle.OracleStereo2Point().eval()
+    ref.load_state_dict(hip.state_dict())
+    hip.to(DEV)
+    left, right = s3r.synthetic_pairs(5, seed=8)
+    gt = torch.rand(5, 1500, 3, generator=torch.Generator().manual_seed(4)) - 0.5
+    res = s3r.evaluate.test_point_net(hip, left, right, gt, batch=2, device=DEV)
+    with torch.no_grad():
+        pred = ref(left, right)
+    d1, d2, _, _ = oracle.chamfer_distance(pred, gt)
+    want = d1.mean(1) + d2.mean(1)
+    assert res["samples"] == 5 and res["per_sample"].shape == (5,)
+    assert (res["per_sample"] - want).abs().max().item() < 1e-4 * want.abs().max().item()
+    assert abs(res["mean_chamfer"] - want.mean().item()) < 1e-4 * want.mean().item()
+
+
 def test_eval_driver_matches_oracle_iou(s3r, oracle, models):
     """evaluate.test_net (device-side IoU per threshold) against the oracle's forward + IoU."""
     hip, ref = models
