@@ -31,6 +31,10 @@ def main():
                     help="StereoShapeNet root (ShapeNetStereoRendering/ + ShapeNetVox32/, README.md:73-77)")
     ap.add_argument("--disparity", action="store_true",
                     help="with --dataset-root: also read disp_%%02d_{l,r}.exr and report the disparity end-point error")
+    ap.add_argument("--variant", default="voxel", choices=["voxel", "point"],
+                    help="voxel: Stereo2Voxel + IoU (default); point: Stereo2Point + Chamfer distance (.npz key `points`, "
+                         "(N,M,3); synthetic clouds otherwise)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="fp32 (exact-fp32 MFMA) or the bf16 MFMA path")
     ap.add_argument("--samples", type=int, default=64, help="synthetic eval list length")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--seed", type=int, default=0)
@@ -54,13 +58,32 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    model = s3r.Stereo2Voxel()
+    model = s3r.Stereo2Voxel(args.precision) if args.variant == "voxel" else s3r.Stereo2Point(args.precision)
     if args.weights:
         keymap = json.load(open(args.keymap)) if args.keymap else None
         s3r.checkpoint.load_checkpoint(model, args.weights, keymap)
     else:
         s3r.seed_module(model, args.seed)
     model.to(dev)
+
+    if args.variant == "point":
+        if args.dataset_root:
+            sys.exit("runner.py --variant point reads an .npz (left, right, points) or synthetic data, not a dataset tree")
+        if args.data:
+            z = np.load(args.data)
+            left, right, clouds = (torch.from_numpy(z[k]).float() for k in ("left", "right", "points"))
+        else:
+            left, right, _ = s3r.evaluate.synthetic_eval_set(args.samples, args.seed)
+            clouds = torch.rand(args.samples, 2048, 3, generator=torch.Generator().manual_seed(args.seed)) - 0.5
+        res = s3r.evaluate.test_point_net(model, left, right, clouds, batch=args.batch, device=dev)
+        if rank == 0:
+            print(json.dumps({"samples": res["samples"], "n_gpus": world, "mean_chamfer": round(res["mean_chamfer"], 8),
+                              "precision": args.precision,
+                              "weights": args.weights or f"seeded random init (seed {args.seed})",
+                              "data": args.data or "synthetic"}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     disp = None
     if args.dataset_root:
@@ -83,6 +106,7 @@ def main():
     if rank == 0:
         out = {"samples": res["samples"], "n_gpus": world, "thresholds": res["thresholds"],
                "mean_iou": [round(x, 6) for x in res["mean_iou"]],
+               "precision": args.precision,
                "weights": args.weights or f"seeded random init (seed {args.seed})",
                "data": args.dataset_root or args.data or "synthetic"}
         if "per_taxonomy" in res:

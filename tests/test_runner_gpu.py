@@ -59,6 +59,17 @@ def test_runner_on_a_dataset_tree_with_disparity(tmp_path):
     assert out["samples"] == 2 and out["disparity_epe_left_px"] > 0 and out["disparity_epe_right_px"] > 0
 
 
+@pytest.mark.gpu
+def test_runner_point_variant_and_bf16_precision():
+    for extra, key in ((["--variant", "point", "--samples", "3"], "mean_chamfer"),
+                       (["--precision", "bf16", "--samples", "3"], "mean_iou")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "runner.py"), "--test", "--batch", "2"] + extra,
+                           capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        assert out["samples"] == 3 and key in out and out["precision"] in ("fp32", "bf16")
+
+
 def test_runner_refuses_what_it_does_not_implement():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "runner.py")], capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert r.returncode != 0 and "only --test is implemented" in (r.stderr + r.stdout)
