@@ -81,6 +81,58 @@ def test_zip_chunk_written_by_hand(s3r, tmp_path):
     assert np.array_equal(s3r.exr.read_exr(str(p))["Z"], img)
 
 
+def test_rle_file(s3r, tmp_path):
+    """compression 1: signed run lengths (n >= 0: n + 1 copies of the next byte; n < 0: -n literal bytes) over the same
+    predicted / split byte stream as ZIP.  Encoded here with an independent greedy run-length encoder."""
+    img = np.zeros((5, 40), np.float32)
+    img[1, 3:30] = 7.5
+    img[3] = np.arange(40, dtype=np.float32) / 3
+    img[4, 20:] = np.inf
+
+    def predict_loops(raw: bytes) -> bytes:
+        t = bytes(raw[0::2]) + bytes(raw[1::2])
+        d = bytearray(t)
+        for i in range(len(t) - 1, 0, -1):
+            d[i] = (t[i] - t[i - 1] + 128) & 0xFF
+        return bytes(d)
+
+    def rle(b: bytes) -> bytes:
+        out, i = bytearray(), 0
+        while i < len(b):
+            j = i
+            while j + 1 < len(b) and b[j + 1] == b[i] and j - i < 126:
+                j += 1
+            if j - i >= 2:                                         # a run of j - i + 1 equal bytes
+                out += struct.pack("b", j - i) + b[i:i + 1]
+                i = j + 1
+            else:                                                  # literals up to the next run of >= 3
+                k = i
+                while k < len(b) and k - i < 127 and not (k + 2 < len(b) and b[k] == b[k + 1] == b[k + 2]):
+                    k += 1
+                out += struct.pack("b", -(k - i)) + b[i:k]
+                i = k
+        return bytes(out)
+
+    def attr(name, typ, val):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(val)) + val
+    head = struct.pack("<ii", 20000630, 2)
+    head += attr("channels", "chlist", b"Z\0" + struct.pack("<iB3xii", 2, 0, 1, 1) + b"\0")
+    head += attr("compression", "compression", b"\x01")
+    head += attr("dataWindow", "box2i", struct.pack("<4i", 0, 0, 39, 4)) + b"\0"
+    chunks, off = [], len(head) + 8 * 5
+    offsets = []
+    for y in range(5):
+        enc = rle(predict_loops(img[y].tobytes()))
+        data = enc if len(enc) < 160 else img[y].tobytes()        # stored raw when RLE does not pay (as OpenEXR does)
+        offsets.append(off)
+        chunks.append(struct.pack("<ii", y, len(data)) + data)
+        off += len(chunks[-1])
+    p = tmp_path / "rle.exr"
+    p.write_bytes(head + struct.pack("<5Q", *offsets) + b"".join(chunks))
+    assert np.array_equal(s3r.exr.read_exr(str(p))["Z"], img)
+    assert s3r.exr._unrle(bytes([0xFD, 1, 2, 3, 4, 9]), 8).tolist() == [1, 2, 3, 9, 9, 9, 9, 9]
+
+
 def test_exr_errors(s3r, tmp_path):
     p = tmp_path / "x.exr"
     p.write_bytes(b"not an exr file at all")
