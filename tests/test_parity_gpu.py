@@ -492,6 +492,44 @@ def test_errors(s3r, models):
     assert dl0.shape == (0, 4, 6) and dr0.shape == (0, 4, 6)
 
 
+def test_two_host_threads_two_streams(s3r):
+    """INTEGRATION.md's threading contract: the library is re-entrant — two host threads, each with its own module and
+    HIP stream, run forwards concurrently and get the bits a serial run gets; error strings are per thread."""
+    import threading
+    mods, wants, ins = [], [], []
+    for k in range(2):
+        m = s3r.Stereo2Voxel("bf16" if k else "fp32")
+        s3r.seed_module(m, 10 + k)
+        m.to(DEV)
+        l, r = s3r.synthetic_pairs(3, seed=40 + k)
+        l, r = l.to(DEV), r.to(DEV)
+        mods.append(m), ins.append((l, r)), wants.append(m(l, r).clone())
+    torch.cuda.synchronize()
+    got, errs = [None, None], [None, None]
+
+    def work(k):
+        try:
+            st = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(st):
+                for _ in range(5):
+                    y = mods[k](*ins[k])
+                if k == 0:                                      # a deliberate error on this thread only
+                    try:
+                        s3r.disparity_wta(torch.zeros(1, 64, 2, 200, device=DEV), torch.zeros(1, 64, 2, 200, device=DEV))
+                    except s3r.S3RError as e:
+                        errs[k] = str(e)
+            st.synchronize()
+            got[k] = y.clone()
+        except Exception as e:                                  # pragma: no cover
+            errs[k] = f"unexpected {type(e).__name__}: {e}"
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert errs[1] is None and errs[0] is not None and "64 KiB" in errs[0]
+    assert torch.equal(got[0], wants[0]) and torch.equal(got[1], wants[1])
+
+
 def test_non_default_stream(s3r, models):
     hip, _ = models
     left, right = s3r.synthetic_pairs(1, seed=0)
