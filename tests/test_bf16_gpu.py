@@ -73,7 +73,7 @@ def test_each_layer_bf16_vs_oracle(s3r, oracle, idx):
 @pytest.mark.parametrize("tm", [1, 2, 3, 4, 5, 6, 9, 10, 17, 18, 19, 21, 22, 23])
 @pytest.mark.parametrize("kind", ["conv3d_s1", "conv3d_s2", "deconv", "conv2d_s2", "conv3d_k4_valid_ks2", "cout32",
                                   "conv2d_s1_w28", "conv3d_s1_w14", "conv3d_s1_c64", "deconv_c64", "deconv_c128_w8",
-                                  "conv3d_k4_valid_c128_ks2", "conv2d_s1_c128_w9", "cout36_narrow_stores", "cout100_s2"])
+                                  "conv3d_k4_valid_c128_ks2", "conv2d_s1_c128_w9", "cout36_narrow_stores", "cout100_s2", "c128_cout128_ks2"])
 def test_bf16_tiles_and_split_k(s3r, oracle, tm, kind):
     Layer = s3r.arch_spec.Layer
     layer, n_in, B, ks = {
@@ -92,6 +92,7 @@ def test_bf16_tiles_and_split_k(s3r, oracle, tm, kind):
         "conv2d_s1_c128_w9": (Layer("t", "conv2d", 128, 64, 3, 1, 1), 9, 21, 0),
         "cout36_narrow_stores": (Layer("t", "conv2d", 64, 36, 3, 1, 1), 9, 3, 0),    # Cout % 8 != 0: 2-byte stores
         "cout100_s2": (Layer("t", "conv3d", 32, 100, 3, 2, 1), 9, 2, 0),             # Cout % 8 != 0, two cout tiles
+        "c128_cout128_ks2": (Layer("t", "conv3d", 128, 128, 3, 1, 1), 6, 2, 2),       # split-K under the 128-cout tiles
     }[kind]
     ch = s3r.modules._HipChain([layer], n_in, precision="bf16")
     s3r.seed_module(ch, 7)
@@ -111,6 +112,8 @@ def test_bf16_tiles_and_split_k(s3r, oracle, tm, kind):
     plane_ok = (layer.s == 1 or layer.op == "deconv3d") and layer.cin % kc == 0 and (ks == 0 or (layer.cin // kc) % ks == 0)
     if tm in (6, 22, 23) and kind in ("conv3d_k4_valid_c128_ks2", "conv3d_k4_valid_ks2"):
         plane_ok = False                       # 16-position planes: a 256-position tile spans 17 of them (+ halos)
+    if tm == 6 and kind == "c128_cout128_ks2":
+        plane_ok = False                       # 36-position planes: 506 image rows of 128 B, above the 480-row cap
     wide_ok = (-(-layer.cout // 64)) % 2 == 0          # 128-cout workgroup tiles need an even number of 64-cout tiles
     if (tm == 10 and kind in ("conv3d_s2", "cout100_s2")) or (tm in (5, 6, 21, 22, 23) and not plane_ok) or \
             (tm in (3, 19, 23) and not wide_ok):
