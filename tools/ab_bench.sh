@@ -2,6 +2,10 @@
 # A/B two builds of libs3r_hip.so on ONE device (device clocks differ by up to 12 % across the pool, so
 # numbers from different gpurun calls do not compare): tools/alt/base.so vs the in-tree build, alternating.
 #   bash tools/ab_bench.sh <outdir> [layer_bench args...]
+# tools/alt/base.so is the baseline build (git-ignored): e.g.
+#   git archive HEAD stereo-3d-reconstruction_amd/csrc include | tar x -C /tmp/base && make -C /tmp/base/stereo-3d-reconstruction_amd/csrc
+#   mkdir -p tools/alt && cp /tmp/base/stereo-3d-reconstruction_amd/csrc/libs3r_hip.so tools/alt/base.so
+# (two builds of IDENTICAL source differ by up to 4 % per layer with this method: treat < 5 % as noise)
 OUT=$1; shift
 mkdir -p $OUT
 for i in 1 2 3; do
