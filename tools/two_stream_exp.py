@@ -13,11 +13,12 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--streams", type=int, default=2)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--half", action="store_true")
+ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 B, S = a.batch, a.streams
 per = B // S if a.half else B
-models = [s3r.Stereo2Voxel() for _ in range(S)]
+models = [s3r.Stereo2Voxel(a.precision) for _ in range(S)]
 s3r.seed_module(models[0], 0)
 for m in models[1:]:
     m.load_state_dict(models[0].state_dict())
