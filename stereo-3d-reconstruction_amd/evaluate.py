@@ -18,6 +18,30 @@ from .modules import chamfer_distance, disparity_epe, voxel_iou
 THRESHOLDS = (0.2, 0.3, 0.4, 0.5)
 
 
+def _device_batches(tensors: Sequence[torch.Tensor], b0: int, e0: int, batch: int, device):
+    """[b0, e0) of a host-resident eval list as device batches.  The list is page-locked IN PLACE for the duration
+    (hipHostRegister: 3 ms for 150 MB, no copy), so every slice is DMA-able at PCIe rate (~50 GB/s here against 4.6 GB/s
+    from pageable memory) and the next batch crosses on a side stream while the current one runs
+    (graph.PrefetchingLoader).  A plain `.to(device)` per batch made this loop 10x slower than the forward."""
+    from .graph import PrefetchingLoader
+    if torch.device(device).type != "cuda" or any(t.is_cuda for t in tensors):
+        for s in range(b0, e0, batch):
+            yield tuple(t[s:min(e0, s + batch)].to(device) for t in tensors)
+        return
+    rt, registered = torch.cuda.cudart(), []
+    try:
+        for t in tensors:
+            if t.numel() and t.is_contiguous() and not t.is_pinned():
+                if int(rt.cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)) == 0:
+                    registered.append(t)
+        host = (tuple(t[s:min(e0, s + batch)] for t in tensors) for s in range(b0, e0, batch))
+        yield from PrefetchingLoader(host, device)
+    finally:
+        torch.cuda.synchronize(device)
+        for t in registered:
+            rt.cudaHostUnregister(t.data_ptr())
+
+
 def synthetic_eval_set(n: int, seed: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """n synthetic (left, right, ground-truth 32^3 occupancy) triples: there is no dataset in this
     container (README.md:29 is a download link).  GT is a random axis-aligned box per sample."""
@@ -97,11 +121,11 @@ def test_point_net(model, left: torch.Tensor, right: torch.Tensor, gt_clouds: to
     total = left.shape[0]
     b0, e0 = collate.shard_bounds(total, world, rank)
     cd = torch.empty((e0 - b0,), dtype=torch.float32, device=device)
-    for s in range(b0, e0, batch):
-        e = min(e0, s + batch)
-        pred = model(left[s:e].to(device), right[s:e].to(device))
-        d1, d2, _, _ = chamfer_distance(pred, gt_clouds[s:e].to(device))
-        cd[s - b0:e - b0] = d1.mean(1) + d2.mean(1)
+    done = 0
+    for l, r, g in _device_batches((left, right, gt_clouds), b0, e0, batch, device):
+        d1, d2, _, _ = chamfer_distance(model(l, r), g)
+        cd[done:done + l.shape[0]] = d1.mean(1) + d2.mean(1)
+        done += l.shape[0]
     if dist_on:
         cd = collate.all_gather_ragged(cd, total, group)
     return {"samples": total, "mean_chamfer": cd.mean().item() if total else float("nan"), "per_sample": cd.cpu()}
@@ -122,12 +146,13 @@ def test_disparity(model, left: torch.Tensor, right: torch.Tensor, disp_l_gt: to
     total = left.shape[0]
     b0, e0 = collate.shard_bounds(total, world, rank)
     rows = torch.zeros((e0 - b0, 4), dtype=torch.float64, device=device)        # epe_l, n_l, epe_r, n_r
-    for s in range(b0, e0, batch):
-        e = min(e0, s + batch)
-        dl, dr = model.disparity(left[s:e].to(device), right[s:e].to(device))
-        el, nl = disparity_epe(dl, disp_l_gt[s:e].to(device))
-        er, nr = disparity_epe(dr, disp_r_gt[s:e].to(device))
-        rows[s - b0:e - b0] = torch.stack([el.double(), nl.double(), er.double(), nr.double()], 1)
+    done = 0
+    for l, r, gl, gr in _device_batches((left, right, disp_l_gt, disp_r_gt), b0, e0, batch, device):
+        dl, dr = model.disparity(l, r)
+        el, nl = disparity_epe(dl, gl)
+        er, nr = disparity_epe(dr, gr)
+        rows[done:done + l.shape[0]] = torch.stack([el.double(), nl.double(), er.double(), nr.double()], 1)
+        done += l.shape[0]
     if dist_on:
         rows = collate.all_gather_ragged(rows, total, group)
     rows = rows.cpu()
@@ -150,13 +175,13 @@ def test_net(model, left: torch.Tensor, right: torch.Tensor, gt: torch.Tensor, b
     total = left.shape[0]
     b0, e0 = collate.shard_bounds(total, world, rank)
     ious = torch.empty((e0 - b0, len(thresholds)), dtype=torch.float32, device=device)
-    for s in range(b0, e0, batch):
-        e = min(e0, s + batch)
-        l, r, g = left[s:e].to(device), right[s:e].to(device), gt[s:e].to(device)
+    done = 0
+    for l, r, g in _device_batches((left, right, gt), b0, e0, batch, device):
         pred = model(l, r)
         for j, t in enumerate(thresholds):
             # the device kernel thresholds both operands at t; GT is binary {0,1}, so gt > t == (gt == 1)
-            ious[s - b0:e - b0, j] = voxel_iou(pred, g, t)
+            ious[done:done + l.shape[0], j] = voxel_iou(pred, g, t)
+        done += l.shape[0]
     if dist_on:
         ious = collate.all_gather_ragged(ious, total, group)
     mean = ious.mean(0).cpu().tolist() if total else [float("nan")] * len(thresholds)
