@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="fp32 (exact-fp32 MFMA) or the bf16 MFMA path")
     ap.add_argument("--samples", type=int, default=64, help="synthetic eval list length")
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--workers", type=int, default=0, help="with --dataset-root: DataLoader decode workers (PNG / MAT / EXR "
+                                                           "decoding is host work: ~300 pairs/s per worker)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     if not args.test:
@@ -106,7 +108,7 @@ def main():
     disp = None
     if args.dataset_root:
         ds = s3r.data.StereoShapeNet(args.dataset_root, with_disparity=args.disparity)
-        res = timed(s3r.evaluate.test_dataset, model, ds, batch=args.batch, device=dev)
+        res = timed(s3r.evaluate.test_dataset, model, ds, batch=args.batch, device=dev, workers=args.workers)
         left = None
         if args.disparity:
             disp = {"epe_left": res["epe_left"], "epe_right": res["epe_right"]}
