@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--test", action="store_true", help="evaluate (the only mode this build implements)")
     ap.add_argument("--weights", default=None, help="checkpoint (.pth) to load")
     ap.add_argument("--keymap", default=None, help="JSON: reference state_dict key -> this build's key")
+    ap.add_argument("--suggest-keymap", action="store_true",
+                    help="print the key map derived from --weights by tensor order and shape (JSON) and exit; needs no GPU")
     ap.add_argument("--data", default=None, help=".npz with left, right, volume [, disp_left, disp_right]; default: synthetic")
     ap.add_argument("--dataset-root", default=None,
                     help="StereoShapeNet root (ShapeNetStereoRendering/ + ShapeNetVox32/, README.md:73-77)")
@@ -41,6 +43,15 @@ def main():
                                                            "decoding is host work: ~300 pairs/s per worker)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
+    if args.suggest_keymap:
+        import torch
+        import s3r
+        if not args.weights:
+            sys.exit("--suggest-keymap needs --weights")
+        m = s3r.Stereo2Voxel(args.precision) if args.variant == "voxel" else s3r.Stereo2Point(args.precision)
+        print(json.dumps(s3r.checkpoint.suggest_keymap(torch.load(args.weights, map_location="cpu", weights_only=True), m),
+                         indent=1))
+        return
     if not args.test:
         sys.exit("runner.py: only --test is implemented (forward/inference path; training is out of scope)")
 

@@ -10,7 +10,9 @@ is the mechanism a maintainer needs once the keys are known:
   * a key map (JSON, reference key -> build key; `keymap.json` beside this file, shipped EMPTY) applied
     before load_state_dict — filling that file in is the only step needed to adopt reference weights
     whose tensors have this build's shapes;
-  * strict shape checking with a readable report of what did not match.
+  * strict shape checking with a readable report of what did not match;
+  * `suggest_keymap`: when a checkpoint's tensors have this build's shapes in this build's order under other names
+    (the usual situation after a refactor), the key map is derived by walking both state_dicts in order.
 """
 from __future__ import annotations
 
@@ -69,6 +71,25 @@ def remap(sd: Dict[str, torch.Tensor], keymap: Dict[str, str]) -> Dict[str, torc
         if nk in out:
             raise KeyError(f"key map sends two checkpoint keys to {nk!r}")
         out[nk] = v
+    return out
+
+
+def suggest_keymap(sd: Dict[str, torch.Tensor], model: torch.nn.Module) -> Dict[str, str]:
+    """Checkpoint key -> model key by ORDER and SHAPE: both state_dicts are walked in their own order (BatchNorm's
+    `num_batches_tracked` counters are skipped on both sides) and paired while every pair has equal shapes.  Raises with
+    the first mismatch otherwise — a map is only ever suggested when it is unambiguous in this sense.  Keys that already
+    agree are left out of the result, so an identical naming yields {}."""
+    def items(d):
+        return [(k, tuple(v.shape)) for k, v in d.items() if not k.endswith("num_batches_tracked")]
+    a, b = items(unwrap(sd)), items(model.state_dict())
+    if len(a) != len(b):
+        raise ValueError(f"checkpoint has {len(a)} tensors, the model {len(b)}: no order-based map exists")
+    out = {}
+    for (ka, sa), (kb, sb) in zip(a, b):
+        if sa != sb:
+            raise ValueError(f"order-based pairing breaks at {ka!r} {sa} vs {kb!r} {sb}")
+        if ka != kb:
+            out[ka] = kb
     return out
 
 

@@ -55,3 +55,38 @@ def test_synthetic_eval_set_is_seeded(s3r):
     b = s3r.evaluate.synthetic_eval_set(3, 5)
     assert all(torch.equal(x, y) for x, y in zip(a, b))
     assert a[2].shape == (3, 32, 32, 32) and set(a[2].unique().tolist()) <= {0.0, 1.0} and a[2].sum() > 0
+
+
+def test_suggest_keymap_from_order_and_shape(s3r, tmp_path):
+    """A checkpoint with this build's tensors under other names: the map is derived, saved as JSON, and loads."""
+    import json
+    import torch
+    model = s3r.Stereo2Voxel()
+    s3r.seed_module(model, 3)
+    renamed = {}
+    for k, v in model.state_dict().items():
+        nk = k.replace("encoder.", "feat_net.").replace("decoder.", "vol_net.").replace(".conv.", ".c.").replace(".bn.", ".norm.")
+        renamed["module." + nk] = v.clone()
+    km = s3r.checkpoint.suggest_keymap({"state_dict": renamed}, model)
+    assert km["feat_net.e1.c.weight"] == "encoder.e1.conv.weight" and all(not k.endswith("num_batches_tracked") for k in km)
+    assert s3r.checkpoint.suggest_keymap(model.state_dict(), model) == {}
+    ck, kmf = tmp_path / "c.pth", tmp_path / "km.json"
+    torch.save({"state_dict": renamed}, ck)
+    # counters ride along under the same renaming rule: extend the suggested map with prefix entries
+    km.update({"feat_net.": "encoder.", "vol_net.": "decoder."})
+    full = {}
+    for k in s3r.checkpoint.unwrap({"state_dict": renamed}):
+        if k.endswith("num_batches_tracked"):
+            full[k] = k.replace("feat_net.", "encoder.").replace("vol_net.", "decoder.").replace(".norm.", ".bn.")
+    km.update(full)
+    kmf.write_text(json.dumps(km))
+    fresh = s3r.Stereo2Voxel()
+    missing, unexpected = s3r.checkpoint.load_checkpoint(fresh, str(ck), json.loads(kmf.read_text()))
+    assert not missing and not unexpected
+    assert all(torch.equal(a, b) for a, b in zip(fresh.state_dict().values(), model.state_dict().values()))
+    other = dict(renamed)
+    first = next(iter(other))
+    other[first] = torch.zeros(5)
+    import pytest
+    with pytest.raises(ValueError, match="pairing breaks"):
+        s3r.checkpoint.suggest_keymap(other, model)
