@@ -16,6 +16,10 @@ import json
 import os
 import sys
 
+# the host driver of this pool only supports dmabuf IPC: without this RCCL's buffer exchange between the per-GPU
+# processes fails with `hipIpcGetMemHandle: invalid argument` (must be set before the HIP runtime starts)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
