@@ -621,6 +621,7 @@ def test_dataset_eval_with_exr_disparity(s3r, models, tmp_path):
     assert a["epe_left"] > 0
 
 
+@pytest.mark.timeout(300)
 def test_bench_two_ranks_on_one_gpu(tmp_path):
     """bench.py's N>1 path (sharded batch, all-gather collation, barrier, max-over-ranks timing, rank-0 JSON) run
     with two ranks sharing cuda:0 over gloo — the RCCL run itself needs a multi-GPU node."""
@@ -632,7 +633,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
            "--warmup", "1", "--batch", "4", "--backend", "gloo", "--same-device", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # exactly one JSON line, from rank 0

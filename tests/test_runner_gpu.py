@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(300)
 def test_runner_test_mode_matches_in_process_eval(tmp_path):
     import s3r
     left, right, gt = s3r.evaluate.synthetic_eval_set(3, 5)
@@ -28,7 +29,7 @@ def test_runner_test_mode_matches_in_process_eval(tmp_path):
     torch.save({"epoch": 7, "state_dict": {"module." + k: v for k, v in model.state_dict().items()}}, ckpt)
 
     r = subprocess.run([sys.executable, os.path.join(ROOT, "runner.py"), "--test", "--weights", str(ckpt), "--data", str(data),
-                        "--batch", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--batch", "2"], capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["samples"] == 3 and out["n_gpus"] == 1 and len(out["mean_iou"]) == len(out["thresholds"])
@@ -42,6 +43,7 @@ def test_runner_test_mode_matches_in_process_eval(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(300)
 def test_runner_on_a_dataset_tree_with_disparity(tmp_path):
     import s3r
     from tests.test_data_cpu import _make_tree
@@ -53,18 +55,19 @@ def test_runner_on_a_dataset_tree_with_disparity(tmp_path):
             s3r.exr.write_exr(os.path.join(rdir, "disp_00_%s.exr" % side),
                               {"Z": (rng.random((224, 224), dtype=np.float32) * 100)}, "ZIP")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "runner.py"), "--test", "--dataset-root", str(tmp_path), "--disparity",
-                        "--batch", "2", "--seed", "3"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--batch", "2", "--seed", "3"], capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["samples"] == 2 and out["disparity_epe_left_px"] > 0 and out["disparity_epe_right_px"] > 0
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(300)
 def test_runner_point_variant_and_bf16_precision():
     for extra, key in ((["--variant", "point", "--samples", "3"], "mean_chamfer"),
                        (["--precision", "bf16", "--samples", "3"], "mean_iou")):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "runner.py"), "--test", "--batch", "2"] + extra,
-                           capture_output=True, text=True, timeout=600, cwd=ROOT)
+                           capture_output=True, text=True, timeout=240, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-2000:]
         out = json.loads(r.stdout.strip().splitlines()[-1])
         assert out["samples"] == 3 and key in out and out["precision"] in ("fp32", "bf16")
