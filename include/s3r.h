@@ -78,7 +78,10 @@ typedef struct s3r_conv_desc {
     int32_t k, stride, pad;
     int32_t act;       /* s3r_act */
     int32_t tag;       /* caller's label, echoed by the profiler */
-    int32_t tile;      /* -1: library picks; >=0: force MFMA tile cfg + 16*gather_width (tuning) */
+    int32_t tile;      /* -1: library picks; >=0 (tuning): S3R_F32: MFMA tile cfg 0..7 + 16*gather_width;
+                          S3R_BF16: 1,2,4 per-tap gather x128 positions (3: 128x128 couts; +16: 32-channel K tiles),
+                          9,10 row-reuse gather, 5,6 / 21,22 plane-reuse gather (64- / 32-channel K tiles),
+                          23 plane-reuse 256x128 couts */
     int32_t in_halo;   /* zero halo of the input buffer  (elements per spatial axis side) */
     int32_t out_halo;  /* zero halo of the output buffer */
     int32_t ksplit;    /* 0: library picks; >=1: force the split-K factor (must divide cin/16; bf16: cin/32) */
