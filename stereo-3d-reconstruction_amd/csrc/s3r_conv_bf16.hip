@@ -880,8 +880,8 @@ static int rowreuse_rows(const ConvParamsH& p, int bm);
 static int plane_rows(const ConvParamsH& p, int bm, int kc);
 
 // Tile / gather choice (tools/layer_bench.py --dtype bf16, B = 256, MI355X):
-//   * stride-1 layers from K = 512 up whose 256-position plane image leaves room for THREE workgroups per CU
-//     (e4, e6, e7, v1, v3, v5, d1, d2, d3) run the plane-reuse gather with 32-channel K tiles (code 22): 5-25 %
+//   * stride-1 layers with 4+ taps per plane and K >= 256 whose 256-position plane image leaves room for THREE
+//     workgroups per CU (e2, e4, e6, e7, v1, v3, v5, d1, d2, d3) run the plane-reuse gather with 32-channel K tiles (code 22): 5-25 %
 //     faster than the per-tap / row-reuse kernels, and 2-7 % faster than its own 64-channel form (code 6, two
 //     workgroups per CU): overlapping one workgroup's image reload and stores with the others' MFMAs is worth
 //     more than whole-line gathers once the image is fetched only once per kh*kw taps;
@@ -897,7 +897,8 @@ int conv_bf16_pick_tm(const ConvParamsH& p) {
     // plane / row-reuse kernels and the 32-channel per-tap kernel accumulate chunk32-major, the 64-channel per-tap
     // kernel chunk64-major.  So the FAMILY is chosen from per-sample geometry, only the tile from the batch.
     const int pr = plane_rows(p, 256, 32);
-    const bool plane_family = pr > 0 && pr <= 576 && (p.Cin / 32) % p.ksplit == 0 && (long)p.Cin * p.T >= 512;
+    const bool plane_family = pr > 0 && pr <= 576 && (p.Cin / 32) % p.ksplit == 0 && p.kh * p.kw >= 4 &&
+                              (long)p.Cin * p.T >= 256;      // (e2, K = 288: -12 % once its planes tile exactly)
     // (transposed classes have only 4 taps per image: its 256 x 128-cout form, code 23, amortises the image over twice
     //  the couts — d1 -10 %, d2 -6 %; the 9-tap layers are level or slower with it)
     if (plane_family && wgs(2) >= 512) return (p.transposed && n_tiles % 2 == 0 && wgs(2) / 2 >= 512) ? 23 : 22;
@@ -969,8 +970,10 @@ static int plane_rows(const ConvParamsH& p, int bm, int kc) {
     if (p.stride != 1 || p.Cin % kc != 0 || p.x_hs % p.x_ws != 0) return 0;
     const int in_p = p.x_hs / p.x_ws, P = p.Nh * p.Nw;
     const int halo = (p.kh - 1) * in_p + p.kw - 1;
-    const int rows_touched = (bm + p.Nw - 2) / p.Nw + 1;
-    const int nseg = (bm + P - 2) / P + 1;
+    // tiles start at multiples of bm: when rows / planes divide bm (or bm divides the plane) they are never straddled
+    // (e2: 112^2 = 49 x 256; d3: 16^2 = 256; d2: 4 planes of 64, d1: 16 planes of 16 per tile)
+    const int rows_touched = (bm % p.Nw == 0) ? bm / p.Nw : (bm + p.Nw - 2) / p.Nw + 1;
+    const int nseg = (P % bm == 0) ? 1 : (bm % P == 0) ? bm / P : (bm + P - 2) / P + 1;
     const int r = bm + (in_p - p.Nw) * rows_touched + nseg * halo;
     const int unit = kc == 64 ? 32 : 64;           // rows per (piece x 4 waves)
     return (r + unit - 1) / unit * unit;
