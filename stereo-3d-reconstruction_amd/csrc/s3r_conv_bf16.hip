@@ -725,12 +725,12 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
     __syncthreads();
 
     // ---- loop-invariant DMA source offsets
-    const int npa = r_max / (4 * RPP);                        // A pieces per wave (r_max % (4*RPP) == 0)
+    // A pieces (RPP rows each) are dealt round-robin to the four waves; r_max is a whole number of pieces
     int avoff[NPA_CAP];
 #pragma unroll
     for (int q = 0; q < NPA_CAP; ++q) {
         const int j = (wave + 4 * q) * RPP + lane / LPR;
-        avoff[q] = (q < npa ? asrc[j] : 0) + (((lane % LPR) ^ swz<KC>(j)) << 4);
+        avoff[q] = (j < r_max ? asrc[j] : 0) + (((lane % LPR) ^ swz<KC>(j)) << 4);
     }
     int lr[TM];
 #pragma unroll
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
         const int a_base = (a_cc * KC + a_td * p.x_ds) * 2;
 #pragma unroll
         for (int q = 0; q < NPA_CAP; ++q)
-            if (q < npa) dma16(xrsrc, smem + ((wave + 4 * q) << 10), avoff[q], a_base);
+            if ((wave + 4 * q) * RPP < r_max) dma16(xrsrc, smem + ((wave + 4 * q) << 10), avoff[q], a_base);
         if (++a_td == p.kd) { a_td = 0; ++a_cc; }
     };
     f32x16 acc[NH][TM][2];
@@ -965,7 +965,7 @@ static hipError_t launch_tm_rowreuse(ConvParamsH p, hipStream_t stream) {
 }
 
 // LDS rows (128 B each) of the plane-reuse kernel's A image for a BM-position tile: an upper bound over all
-// tiles (see conv_bf16p_kernel), in whole 32-row units (8-row pieces x 4 waves); 0 = layer not eligible
+// tiles (see conv_bf16p_kernel), in whole 1 KiB LDS-DMA pieces (8 / 16 rows); 0 = layer not eligible
 static int plane_rows(const ConvParamsH& p, int bm, int kc) {
     if (p.stride != 1 || p.Cin % kc != 0 || p.x_hs % p.x_ws != 0) return 0;
     const int in_p = p.x_hs / p.x_ws, P = p.Nh * p.Nw;
@@ -975,7 +975,7 @@ static int plane_rows(const ConvParamsH& p, int bm, int kc) {
     const int rows_touched = (bm % p.Nw == 0) ? bm / p.Nw : (bm + p.Nw - 2) / p.Nw + 1;
     const int nseg = (P % bm == 0) ? 1 : (bm % P == 0) ? bm / P : (bm + P - 2) / P + 1;
     const int r = bm + (in_p - p.Nw) * rows_touched + nseg * halo;
-    const int unit = kc == 64 ? 32 : 64;           // rows per (piece x 4 waves)
+    const int unit = kc == 64 ? 8 : 16;            // rows per 1 KiB LDS-DMA piece
     return (r + unit - 1) / unit * unit;
 }
 
