@@ -3,17 +3,26 @@
 224x224 stereo pair -> 32^3 voxels, fp32, synthetic inputs, random-init weights (BUILD-SPECIFIED
 architecture, arch_spec.py — the reference's model code is not in the mount).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--variant voxel|point]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--variant voxel|point] [--dtype f32|bf16]
 
 A "step" is one forward of the hot path over one resident batch of B pairs per GPU (inputs already in
 HBM).  N>1: one process per GPU, the batch is sharded (weak scaling: B pairs per rank), and each step
 ends with the one exchange the path has — an RCCL all-gather of the (B,32,32,32) predictions for eval
-collation.  Rank 0 prints ONE JSON line.
+collation.  `python bench.py --gpus N` launches its own N ranks (child `torch.distributed.run`, started
+before anything touches the GPU); under an external launcher (WORLD_SIZE set) it is one of the ranks.
+Rank 0 prints ONE JSON line.
+
+Besides the headline (BASELINE configs[1]) the same process measures, untimed for `value`, the two other
+single-GPU configurations BASELINE.json names — configs[2] (bf16 MFMA path, batch 256) and configs[3]
+(Stereo2Point + Chamfer, batch 32) — and reports them under `secondary` (N=1 only; --no-secondary skips).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -46,31 +55,207 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(budget_s=12.0):
-    """The oracle (this build's PyTorch-CPU restatement, NOT the reference) timed on the host cores."""
+def csrc_sha256():
+    """Hash of the kernel sources the loaded library was built from (csrc/*.hip, *.h, include/s3r.h): the key that
+    ties a committed rocprofv3 counter summary (profiles/traffic_*.json) to the code it was measured on."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "stereo-3d-reconstruction_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "stereo-3d-reconstruction_amd", "csrc", "*.h")) +
+                   [os.path.join(ROOT, "include", "s3r.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def _time_oracle(O, s3r, torch, B, budget_s):
+    m = O.OracleStereo2Voxel().eval()
+    s3r.seed_module(m, 0)
+    left, right = s3r.synthetic_pairs(B, seed=0)
+    with torch.no_grad():
+        m(left, right)                              # warm-up (allocations, MKL-DNN primitive cache)
+        times = []
+        t_end = time.perf_counter() + budget_s
+        while (time.perf_counter() < t_end or len(times) < 3) and len(times) < 1000:
+            t0 = time.perf_counter()
+            m(left, right)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    return B / times[len(times) // 2], len(times), sum(times)
+
+
+def cpu_baseline(batch=32, budget_s=12.0):
+    """The oracle (this build's PyTorch-CPU restatement, NOT the reference) timed on the host cores: the headline's
+    own workload (batch 32) and BASELINE.json configs[0] (batch 2)."""
     import torch
     import s3r
     from oracle import s2v_oracle as O
     ncpu = usable_cpus()
     log(f"cpu_baseline: os.cpu_count()={os.cpu_count()} usable={ncpu}")
     torch.set_num_threads(ncpu)
-    m = O.OracleStereo2Voxel().eval()
-    s3r.seed_module(m, 0)
-    B = 2                                           # BASELINE.json configs[0]
-    left, right = s3r.synthetic_pairs(B, seed=0)
-    with torch.no_grad():
-        m(left, right)                              # warm-up (allocations, MKL-DNN primitive cache)
-        times = []
-        t_end = time.perf_counter() + budget_s
-        while time.perf_counter() < t_end and len(times) < 1000:
-            t0 = time.perf_counter()
-            m(left, right)
-            times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": round(B / med, 3), "unit": "stereo pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (torch CPU fp32, eval, no_grad) Stereo2Voxel forward, batch {B}, median of "
-                      f"{len(times)} iterations (~{sum(times):.1f} s of CPU work)"}
+    v, n, s = _time_oracle(O, s3r, torch, batch, budget_s)
+    v2, n2, s2 = _time_oracle(O, s3r, torch, 2, budget_s / 2)
+    return {"value": round(v, 3), "unit": "stereo pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (torch CPU fp32, eval, no_grad) Stereo2Voxel forward, batch {batch}, median of "
+                      f"{n} iterations (~{s:.1f} s of CPU work)",
+            "batch2": {"value": round(v2, 3), "sample": f"same oracle at batch 2 (BASELINE.json configs[0]), median of "
+                                                        f"{n2} iterations (~{s2:.1f} s)"}}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as a CHILD process (never exec:
+    this process stays the parent and has not touched the GPU), relay rank 0's JSON line (the child shares our
+    stdout) and return the child's exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: launching " + " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def family_table(records, steps):
+    fam = {}
+    for r in records:
+        f = fam.setdefault(r["family"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0, "launches": 0})
+        f["ms"] += r["ms"]; f["flops"] += r["flops"]; f["bytes"] += r["bytes"]; f["n"] += 1
+        f["launches"] += r["launches"]
+    return fam
+
+
+def pmc_summary(variant, dtype, B, plain_run):
+    """Counters from the committed rocprofv3 passes of THIS configuration (tools/profile.sh ->
+    tools/summarize_profile.py -> profiles/traffic_<tag>.json).  They are emitted only when that file records the
+    hash of the kernel sources this run was built from and the run is the profiled configuration (no autotune, no
+    tile overrides): otherwise traffic is null — a stale constant is not a measurement."""
+    if not plain_run or variant != "voxel":
+        return None
+    want = csrc_sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
+        try:
+            tj = json.load(open(path))
+        except Exception:
+            continue
+        if tj.get("csrc_sha256") == want and tj.get("dtype") == dtype and tj.get("batch") == B:
+            return {"file": os.path.relpath(path, ROOT), "csrc_sha256": want,
+                    "hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch"),
+                    "mfma_utilisation_pmc": tj.get("mfma_utilisation_pmc"),
+                    "shader_clock_ghz_pmc": tj.get("shader_clock_ghz_pmc")}
+    return None
+
+
+def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False):
+    """Roofline of the dominant kernel family (the MFMA implicit-GEMM convolution): algorithmic FLOPs of its launches
+    / their HIP-event durations (events recorded by the library on the stream it launches on)."""
+    if not records:
+        return None, {}
+    fam = family_table(records, steps)
+    per_layer = {}
+    for r in records:
+        if r["family"] == "conv_mfma":
+            e = per_layer.setdefault(r["tag"], {"ms": 0.0, "flops": 0.0, "n": 0})
+            e["ms"] += r["ms"]; e["flops"] += r["flops"]; e["n"] += 1
+    names = {100 + i: l.name for i, l in enumerate(spec.ENCODER)}
+    names.update({200 + i: l.name for i, l in enumerate(spec.DECODER)})
+    bf = dtype == "bf16"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_FP32_MFMA_TFLOPS
+    if not quiet:
+        log(f"[{variant} {dtype} B={B}] kernel family  launches   ms/step   TFLOP/s    GB/s(algorithmic)")
+        for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+            log(f"  {k:20s} {f['n']:8d} {f['ms'] / steps:9.3f} {f['flops'] / f['ms'] / 1e9 if f['ms'] else 0:9.2f} "
+                f"{f['bytes'] / f['ms'] / 1e6 if f['ms'] else 0:9.1f}")
+        log(f"conv_mfma per layer:   ms/launch   TFLOP/s   frac of {'bf16' if bf else 'fp32'} MFMA peak")
+        for tag, e in sorted(per_layer.items()):
+            tf = e["flops"] / e["ms"] / 1e9
+            log(f"  {names.get(tag, tag)!s:6s} {e['ms'] / e['n']:12.4f} {tf:9.2f} {tf / peak:8.3f}")
+    kernels = {k: {"ms_per_step": round(f["ms"] / steps, 4),
+                   "tflops": round(f["flops"] / f["ms"] / 1e9, 2) if f["ms"] else None,
+                   "algorithmic_gbs": round(f["bytes"] / f["ms"] / 1e6, 1) if f["ms"] else None,
+                   "launches_per_step": f["launches"] // steps} for k, f in fam.items()}
+    c = fam.get("conv_mfma")
+    if not c or c["ms"] <= 0:
+        return None, kernels
+    achieved = c["flops"] / c["ms"] / 1e9            # TFLOP/s
+    # §8d's formulas count the taps that multiply padding zeros; without them (arch_spec.layer_macs_interior)
+    ratio = spec.mfma_flops_per_pair(variant, interior=True) / spec.mfma_flops_per_pair(variant)
+    pmc = pmc_summary(variant, dtype, B, plain_run)
+    roof = {"bound": "mfma",
+            "kernel": "conv_bf16{,r,p}_kernel (bf16 MFMA implicit-GEMM conv, channels-last, LDS-DMA; "
+                      "per-tap / row-reuse / plane-reuse gathers)" if bf
+            else "conv_glds_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv, LDS-DMA operand staging)",
+            "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4),
+            "frac_border_excluded": round(achieved / peak * ratio, 4),
+            "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
+            "pmc_source": pmc,
+            "layers_per_step": c["n"] // steps,
+            "launches_per_step": c["launches"] // steps,
+            "algorithmic_gflop_per_launch": round(c["flops"] / c["launches"] / 1e9, 3),
+            "avg_launch_ms": round(c["ms"] / c["launches"], 5),
+            "algorithmic_gflop_per_step": round(c["flops"] / steps / 1e9, 3),
+            "kernel_ms_per_step": round(c["ms"] / steps, 4)}
+    return roof, kernels
+
+
+def eager_records(s3r, torch, model, left, right, gt_cloud, steps):
+    """Per-kernel HIP events cannot bracket kernels inside a graph replay: run the same K steps eagerly (untimed)."""
+    s3r.profile_enable(64 * steps + 64)
+    for _ in range(steps):
+        yy = model(left, right)
+        if gt_cloud is not None:
+            s3r.chamfer_distance(yy, gt_cloud)
+    torch.cuda.synchronize()
+    records = s3r.profile_read(64 * steps + 64)
+    s3r.profile_enable(0)
+    return records
+
+
+def secondary_config(s3r, torch, dev, variant, dtype, B, steps, warmup):
+    """One more single-GPU configuration of BASELINE.json, measured the way the headline is (graph replay of K
+    steps over one resident batch between synchronisations), in this process, after the headline's timed region."""
+    spec = s3r.arch_spec
+    prec = "bf16" if dtype == "bf16" else "fp32"
+    model = s3r.Stereo2Voxel(prec) if variant == "voxel" else s3r.Stereo2Point(prec)
+    s3r.seed_module(model, 0)
+    model.to(dev)
+    left, right = s3r.synthetic_pairs(B, seed=2000)
+    left, right = left.to(dev), right.to(dev)
+    gt_cloud = None
+    if variant == "point":
+        gt_cloud = torch.rand(B, spec.N_POINTS, 3, generator=torch.Generator().manual_seed(78)).to(dev)
+    graphed = s3r.GraphedForward(model, B, dev)
+    graphed.left.copy_(left)
+    graphed.right.copy_(right)
+
+    def step():
+        y = graphed()
+        if gt_cloud is not None:
+            s3r.chamfer_distance(y, gt_cloud)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    records = eager_records(s3r, torch, model, left, right, gt_cloud, steps)
+    roof, kernels = roofline_of(records, steps, dtype, variant, B, spec, plain_run=True)
+    fl = spec.flops_per_pair(variant)
+    out = {"workload": f"Stereo2{'Voxel' if variant == 'voxel' else 'Point'} forward"
+                       f"{' + Chamfer distance vs a (B,2048,3) cloud' if variant == 'point' else ''}, batch={B}, "
+                       f"{'bf16 MFMA path' if dtype == 'bf16' else 'fp32'}, 1 GPU",
+           "value": round(B * steps / elapsed, 2), "unit": "stereo pairs/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(1e3 * elapsed / steps, 4), "dtype": dtype,
+           "end_to_end_tflops": round(B * steps / elapsed * fl["total"] / 1e12, 3),
+           "roofline": roof, "kernels": kernels}
+    del graphed, model
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -78,12 +263,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="stereo pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="stereo pairs per GPU per step (--batch 256 --gpus 8 is "
+                                                          "BASELINE configs[4]'s 8 x 256)")
     ap.add_argument("--variant", default="voxel", choices=["voxel", "point"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32: exact-fp32 MFMA path (the headline, BASELINE configs[1]); bf16: bf16 MFMA path, "
                          "channels-last bf16 activations (configs[2], quoted at --batch 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the configs[2] / configs[3] measurements that follow the headline at N=1")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the ~20 kernels of a step eagerly instead of replaying the captured HIP graph")
@@ -97,6 +285,9 @@ def main():
                     help="time tile / split-K candidates per layer in warm-up instead of using the library's table")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))              # nothing has touched the GPU in this process
+
     import torch
     import s3r
     spec = s3r.arch_spec
@@ -105,8 +296,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        log(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}` "
-            f"(WORLD_SIZE={world})")
+        log(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
         sys.exit(2)
     dist = None
     if args.same_device:
@@ -130,6 +320,7 @@ def main():
     left, right = left.to(dev), right.to(dev)
     gathered = None
     out_shape = (B, 32, 32, 32) if args.variant == "voxel" else (B, spec.N_POINTS, 3)
+    n_ranks_seen = 1
     if world > 1:
         # eval collation is double-buffered: step k's all-gather (RCCL, its own stream) runs under step k+1's forward
         gathered = [torch.empty((world * B,) + out_shape[1:], dtype=torch.float32, device=dev) for _ in range(2)]
@@ -190,6 +381,9 @@ def main():
 
     if world > 1:          # build the RCCL communicator outside the timed region even when --warmup 0
         dist.all_gather_into_tensor(gathered[0], torch.zeros(out_shape, dtype=torch.float32, device=dev))
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one)                              # every rank the launcher started is really in the job
+        n_ranks_seen = int(one.item())
     for _ in range(args.warmup):
         step()
     drain()
@@ -217,78 +411,25 @@ def main():
     records = []
     if profiling:
         if graphed is not None:      # per-kernel HIP events: the same K steps again, launched eagerly (untimed)
-            s3r.profile_enable(64 * args.steps + 64)
-            for _ in range(args.steps):
-                yy = model(left, right)
-                if gt_cloud is not None:
-                    s3r.chamfer_distance(yy, gt_cloud)
-            torch.cuda.synchronize()
-        records = s3r.profile_read(64 * args.steps + 64)
-        s3r.profile_enable(0)
+            records = eager_records(s3r, torch, model, left, right, gt_cloud, args.steps)
+        else:
+            records = s3r.profile_read(64 * args.steps + 64)
+            s3r.profile_enable(0)
 
     if rank == 0:
         pairs = world * B * args.steps
         value = pairs / elapsed
         ms_per_step = 1e3 * elapsed / args.steps
         fl = spec.flops_per_pair(args.variant)
-        # ---- roofline of the dominant kernel family: the fp32-MFMA implicit-GEMM convolution
-        roof = None
-        if records:
-            fam = {}
-            for r in records:
-                f = fam.setdefault(r["family"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0, "launches": 0})
-                f["ms"] += r["ms"]; f["flops"] += r["flops"]; f["bytes"] += r["bytes"]; f["n"] += 1
-                f["launches"] += r["launches"]
-            per_layer = {}
-            for r in records:
-                if r["family"] == "conv_mfma":
-                    e = per_layer.setdefault(r["tag"], {"ms": 0.0, "flops": 0.0, "n": 0})
-                    e["ms"] += r["ms"]; e["flops"] += r["flops"]; e["n"] += 1
-            names = {100 + i: l.name for i, l in enumerate(spec.ENCODER)}
-            names.update({200 + i: l.name for i, l in enumerate(spec.DECODER)})
-            log("kernel family          launches   ms/step   TFLOP/s    GB/s(algorithmic)")
-            for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
-                log(f"  {k:20s} {f['n']:8d} {f['ms'] / args.steps:9.3f} {f['flops'] / f['ms'] / 1e9 if f['ms'] else 0:9.2f} "
-                    f"{f['bytes'] / f['ms'] / 1e6 if f['ms'] else 0:9.1f}")
-            log("conv_mfma per layer:   ms/launch   TFLOP/s   frac of fp32 MFMA peak")
-            for tag, e in sorted(per_layer.items()):
-                tf = e["flops"] / e["ms"] / 1e9
-                pk = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
-                log(f"  {names.get(tag, tag)!s:6s} {e['ms'] / e['n']:12.4f} {tf:9.2f} {tf / pk:8.3f}")
-            c = fam.get("conv_mfma")
-            if c and c["ms"] > 0:
-                # dominant kernel = conv_glds_kernel (one template, 16 launches per step): algorithmic FLOPs
-                # per launch / average launch duration, both over the timed region's launches (HIP events
-                # recorded by the library on the stream it launches on)
-                achieved = c["flops"] / c["ms"] / 1e9            # TFLOP/s
-                traffic = pmc_util = pmc_clock = None
-                bf = args.dtype == "bf16"
-                tpath = os.path.join(ROOT, "profiles", "traffic_r01_bf16.json" if bf else "traffic_r01.json")
-                # the committed counters are those of the default fp32 run (B=32) / the bf16 run at B=256 only
-                if os.path.exists(tpath) and args.variant == "voxel" and B == (256 if bf else 32):
-                    try:
-                        tj = json.load(open(tpath))
-                        traffic = tj.get("hbm_bytes_per_launch")                         # rocprofv3 PMC, per launch
-                        pmc_util, pmc_clock = tj.get("mfma_utilisation_pmc"), tj.get("shader_clock_ghz_pmc")
-                    except Exception:
-                        traffic = None
-                peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_FP32_MFMA_TFLOPS
-                roof = {"bound": "mfma",
-                        "kernel": "conv_bf16{,r,p}_kernel (v_mfma_f32_32x32x16_bf16 implicit-GEMM conv, channels-last, LDS-DMA; "
-                                  "per-tap / row-reuse / plane-reuse gathers)" if bf
-                        else "conv_glds_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv, LDS-DMA operand staging)",
-                        "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(achieved / peak, 4), "traffic": traffic,
-                        # from the committed rocprofv3 SQ pass of this command (profiles/traffic_*.json): MFMA pipe
-                        # cycles / (1024 SIMDs x elapsed shader cycles), and the shader clock the chip held
-                        "mfma_utilisation_pmc": round(pmc_util, 4) if pmc_util else None,
-                        "shader_clock_ghz_pmc": round(pmc_clock, 3) if pmc_clock else None,
-                        "layers_per_step": c["n"] // args.steps,
-                        "launches_per_step": c["launches"] // args.steps,
-                        "algorithmic_gflop_per_launch": round(c["flops"] / c["launches"] / 1e9, 3),
-                        "avg_launch_ms": round(c["ms"] / c["launches"], 5),
-                        "algorithmic_gflop_per_step": round(c["flops"] / args.steps / 1e9, 3),
-                        "kernel_ms_per_step": round(c["ms"] / args.steps, 4)}
+        overrides = any(k.startswith(("S3R_TILE_", "S3R_KSPLIT_")) for k in os.environ)
+        plain_run = not args.autotune and not args.no_graph and not overrides and not args.include_h2d
+        roof, kernels = roofline_of(records, args.steps, args.dtype, args.variant, B, spec, plain_run)
+        rccl = None
+        if world > 1 and args.backend == "nccl":
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rccl = None
         out = {
             "metric": f"stereo pairs/s forward (batch {B}, 224x224 -> 32^3 voxel)" if args.variant == "voxel"
                       else f"stereo pairs/s forward (batch {B}, 224x224 -> 2048-pt cloud)",
@@ -303,14 +444,28 @@ def main():
                        "per_gpu_batch": B, "global_batch": world * B,
                        "parallelism": f"batch-sharded x{world}, RCCL all-gather of predictions every step (overlapped "
                                       f"with the next step's forward)" if world > 1 else "single GPU"},
+            "n_ranks_seen": n_ranks_seen, "collective_backend": (args.backend if world > 1 else None),
+            "rccl_version": rccl,
             "end_to_end_tflops": round(value * fl["total"] / 1e12, 3),
             "launch": "eager" if graphed is None else "hipGraph replay (1 launch per step); per-kernel HIP-event timing "
                       "for `roofline` taken on an eager re-run of the same K steps right after the timed region",
             "autotuned": {k: [v["tile"], v["ksplit"]] for k, v in tuned.items()} if tuned else None,
-            "roofline": roof,
+            "roofline": roof, "kernels": kernels,
         }
+        if world == 1 and not args.no_secondary and args.variant == "voxel" and args.dtype == "f32" and not args.include_h2d:
+            # BASELINE.json configs[2] and configs[3], measured in the same process (never part of `value`)
+            graphed = None                           # (its buffers stay with the model; the secondaries build their own)
+            sec = {}
+            k2 = max(5, min(args.steps, 10))
+            for name, (v, d, b) in {"bf16_b256": ("voxel", "bf16", 256), "point_b32": ("point", "f32", 32)}.items():
+                try:
+                    sec[name] = secondary_config(s3r, torch, dev, v, d, b, k2, max(2, min(args.warmup, 3)))
+                except Exception as e:
+                    log(f"secondary {name} failed: {type(e).__name__}: {e}")
+                    sec[name] = {"error": f"{type(e).__name__}: {e}"}
+            out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(32)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

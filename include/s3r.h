@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define S3R_ABI_VERSION 2
+#define S3R_ABI_VERSION 3
 
 typedef enum s3r_status {
     S3R_OK = 0,
@@ -125,10 +125,14 @@ int s3r_chain_forward(const s3r_layer* layers, int n_layers, const void* x, void
                       int ws_fresh, void* stream);
 
 /* Stage entry points (thin, shape-checked views of s3r_chain_forward):
- *   encoder: images (N,3,224,224) -> features (N,C,28,28); N = 2B (left batch then right batch)
+ *   encoder: renders -> features (N,C,28,28), N = layers[0].desc.batch = 2B images: the B left renders
+ *            (B,3,224,224) at `images_left`, the B right renders at `images_right` — two tensors, as the
+ *            reference's forward receives them (README.md:73-74); the shared-weight tower runs once over all 2B
+ *            images and the first kernel picks its source by image index, so nothing is concatenated.
+ *            images_right = NULL: `images_left` holds all N images (any N).
  *   decoder: cost volume (B,2C,D,H,W) -> occupancy (B,32,32,32)  */
-int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* images, void* features, float* ws,
-                        int64_t ws_elems, int ws_fresh, void* stream);
+int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* images_left, const float* images_right,
+                        void* features, float* ws, int64_t ws_elems, int ws_fresh, void* stream);
 int s3r_decoder_forward(const s3r_layer* layers, int n_layers, const void* volume, float* occupancy, float* ws,
                         int64_t ws_elems, int ws_fresh, void* stream);
 

@@ -2,7 +2,8 @@
 """runner.py — the reference's entry point for this path, on the MI355X-native modules.
 
     python3 runner.py --test --weights=/path/to/Stereo2Voxel.pth          (/root/reference/README.md:91)
-    python -m torch.distributed.run --nproc-per-node 8 runner.py --test ...   (one process per GPU)
+    python3 runner.py --test --gpus 8 ...             (starts its own 8 ranks, one process per GPU, as a child)
+    python -m torch.distributed.run --nproc-per-node 8 runner.py --test ...   (or under an external launcher)
 
 Only `--test` exists here: the forward/inference path is what this build implements (training is out of
 scope) and `python3 runner.py` without --test says so.  Without --weights the model
@@ -14,6 +15,8 @@ environment (README.md:29 is a download link), so the eval list is synthetic unl
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 
 # the host driver of this pool only supports dmabuf IPC: without this RCCL's buffer exchange between the per-GPU
@@ -46,7 +49,19 @@ def main():
     ap.add_argument("--workers", type=int, default=0, help="with --dataset-root: DataLoader decode workers (PNG / MAT / EXR "
                                                            "decoding is host work: ~300 pairs/s per worker)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="evaluate on N GPUs of this node: the eval list is sharded over one process per GPU (RCCL "
+                         "all-gather of the per-sample metrics); runner.py starts the ranks itself")
     args = ap.parse_args()
+    if args.test and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # single-process entry point (README.md:85,91) kept: the ranks are a CHILD process started before anything
+        # here touches the GPU (never exec from a process that has); rank 0's JSON line reaches our stdout
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")).returncode)
     if args.suggest_keymap:
         import torch
         import s3r

@@ -18,7 +18,7 @@ DTYPE = {"fp32": 0, "bf16": 1}
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}
 FAMILY = {0: "conv_mfma", 1: "stem", 2: "head", 3: "cost_volume", 4: "linear", 5: "chamfer", 6: "iou", 7: "pack",
           8: "pad_copy", 9: "disparity"}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ConvDesc(C.Structure):
@@ -56,8 +56,8 @@ SIGNATURES = {
     "s3r_chain_workspace_elems": (C.c_int64, [C.POINTER(Layer), C.c_int]),
     "s3r_chain_forward": (C.c_int, [C.POINTER(Layer), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                     C.c_int, C.c_void_p]),
-    "s3r_encoder_forward": (C.c_int, [C.POINTER(Layer), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
-                                      C.c_int, C.c_void_p]),
+    "s3r_encoder_forward": (C.c_int, [C.POINTER(Layer), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int64, C.c_int, C.c_void_p]),
     "s3r_decoder_forward": (C.c_int, [C.POINTER(Layer), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_int, C.c_void_p]),
     "s3r_cost_volume_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

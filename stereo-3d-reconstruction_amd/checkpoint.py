@@ -79,9 +79,10 @@ def suggest_keymap(sd: Dict[str, torch.Tensor], model: torch.nn.Module) -> Dict[
     `num_batches_tracked` counters are skipped on both sides) and paired while every pair has equal shapes.  Raises with
     the first mismatch otherwise — a map is only ever suggested when it is unambiguous in this sense.  Keys that already
     agree are left out of the result, so an identical naming yields {}."""
-    def items(d):
-        return [(k, tuple(v.shape)) for k, v in d.items() if not k.endswith("num_batches_tracked")]
-    a, b = items(unwrap(sd)), items(model.state_dict())
+    def items(d, counters):
+        return [(k, tuple(v.shape)) for k, v in d.items() if k.endswith("num_batches_tracked") == counters]
+    src, own = unwrap(sd), model.state_dict()
+    a, b = items(src, False), items(own, False)
     if len(a) != len(b):
         raise ValueError(f"checkpoint has {len(a)} tensors, the model {len(b)}: no order-based map exists")
     out = {}
@@ -90,6 +91,11 @@ def suggest_keymap(sd: Dict[str, torch.Tensor], model: torch.nn.Module) -> Dict[
             raise ValueError(f"order-based pairing breaks at {ka!r} {sa} vs {kb!r} {sb}")
         if ka != kb:
             out[ka] = kb
+    # the BatchNorm step counters ride along when both sides carry one per BatchNorm (a checkpoint written by an old
+    # torch has none: load_checkpoint does not miss them)
+    ca, cb = items(src, True), items(own, True)
+    if len(ca) == len(cb):
+        out.update({ka: kb for (ka, _), (kb, _) in zip(ca, cb) if ka != kb})
     return out
 
 
@@ -104,8 +110,11 @@ def load_checkpoint(model: torch.nn.Module, path: str, keymap: Optional[Dict[str
         raise RuntimeError("checkpoint tensors do not have this build's shapes (arch_spec is build-specified, "
                            "SURVEY.md §0):\n  " + "\n  ".join(bad[:12]))
     res = model.load_state_dict(sd, strict=False)
+    # BatchNorm's num_batches_tracked counters play no part in an eval-mode forward: neither a checkpoint without
+    # them nor one whose counters kept their foreign names is a mismatch
     missing = [k for k in res.missing_keys if not k.endswith("num_batches_tracked")]
-    if strict and (missing or res.unexpected_keys):
+    unexpected = [k for k in res.unexpected_keys if not k.endswith("num_batches_tracked")]
+    if strict and (missing or unexpected):
         raise RuntimeError(f"state_dict mismatch: missing {missing[:8]}{'...' if len(missing) > 8 else ''}, "
-                           f"unexpected {list(res.unexpected_keys)[:8]}; extend {KEYMAP_PATH}")
-    return missing, list(res.unexpected_keys)
+                           f"unexpected {unexpected[:8]}; extend {KEYMAP_PATH}")
+    return missing, unexpected

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -40,32 +41,46 @@ enum Family { F_MFMA = 0, F_STEM = 1, F_HEAD = 2, F_COSTVOL = 3, F_LINEAR = 4, F
 
 struct Prof {
     std::mutex mu;
-    bool on = false;
+    std::atomic<bool> on{false};
     int cap = 0;
+    unsigned gen = 0;             // bumped by every enable / disable: a scope opened under an older pool skips its stop
+    int device = -1;              // the device the event pool was created on
     std::vector<hipEvent_t> ev;   // 2 per record
     std::vector<s3r_prof_record> rec;
 } g_prof;
 
+// A scope takes COPIES of its two event handles under the lock, so nothing of the pool is touched outside it; its
+// stop record happens under the lock as well and is skipped when the pool was rebuilt meanwhile (s3r_profile_enable
+// from another thread: the handles would be destroyed events).  Events live on the device that was current at
+// s3r_profile_enable: launches on another device are not profiled (a record there would fail).
 struct ProfScope {
     bool active = false;
     int slot = -1;
+    unsigned gen = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     int launches = 1;     // kernel launches inside the scope (a conv may be cut into bulk + remainder, + split-K finish)
     hipStream_t stream;
     ProfScope(hipStream_t s, int family, int tag, double flops, double bytes) : stream(s) {
-        if (!g_prof.on) return;
+        if (!g_prof.on.load(std::memory_order_relaxed)) return;
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return;
         std::lock_guard<std::mutex> lk(g_prof.mu);
-        if (!g_prof.on || (int)g_prof.rec.size() >= g_prof.cap) return;
+        if (!g_prof.on.load(std::memory_order_relaxed) || dev != g_prof.device || (int)g_prof.rec.size() >= g_prof.cap) return;
         slot = (int)g_prof.rec.size();
         s3r_prof_record r;
         r.family = family; r.tag = tag; r.ms = 0.f; r.flops = flops; r.bytes = bytes; r.launches = 1;
         g_prof.rec.push_back(r);
-        active = true;
-        (void)hipEventRecord(g_prof.ev[2 * slot], stream);
+        gen = g_prof.gen;
+        e0 = g_prof.ev[2 * slot];
+        e1 = g_prof.ev[2 * slot + 1];
+        active = hipEventRecord(e0, stream) == hipSuccess;
+        if (!active) g_prof.rec.pop_back();
     }
     ~ProfScope() {
         if (!active) return;
-        (void)hipEventRecord(g_prof.ev[2 * slot + 1], stream);
         std::lock_guard<std::mutex> lk(g_prof.mu);
+        if (gen != g_prof.gen) return;                       // the pool this scope belongs to is gone
+        (void)hipEventRecord(e1, stream);
         if (slot < (int)g_prof.rec.size()) g_prof.rec[slot].launches = launches;
     }
 };
@@ -419,7 +434,16 @@ int s3r_abi_version(void) { return S3R_ABI_VERSION; }
 
 const char* s3r_last_error(void) { return g_err; }
 
-int s3r_conv_out_size(const s3r_conv_desc* d) { return d ? out_size(d) : S3R_ERR_INVALID; }
+int s3r_conv_out_size(const s3r_conv_desc* d) {
+    if (!d) return fail(S3R_ERR_INVALID, "null descriptor");
+    if (d->op == S3R_OP_LINEAR) return 1;
+    if (d->op != S3R_OP_CONV && d->op != S3R_OP_DECONV) return fail(S3R_ERR_INVALID, "unknown op %d", d->op);
+    if (d->in_size <= 0 || d->k <= 0 || d->stride <= 0 || d->pad < 0)
+        return fail(S3R_ERR_INVALID, "bad size/k/stride/pad (in_size=%d k=%d stride=%d pad=%d)", d->in_size, d->k, d->stride, d->pad);
+    const int n = out_size(d);
+    if (n <= 0) return fail(S3R_ERR_INVALID, "empty output");
+    return n;
+}
 
 int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems) {
     Geo g; Route r;
@@ -487,9 +511,30 @@ int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d) {
     return s3r::conv_scratch_elems(p, L.cfg);
 }
 
+}  // extern "C"
+
+namespace {
+// s3r_conv_forward with an optional SECOND input tensor for the stem: images [0, nsplit) are read from xv, images
+// [nsplit, batch) from x2v (left / right renders of a stereo batch: no concatenation copy)
+int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, int nsplit, const void* packed_wv,
+                      const float* scale, const float* shift, void* yv, float* scratch, int64_t scratch_elems, void* stream);
+}
+
+extern "C" {
+
 int s3r_conv_forward(const s3r_conv_desc* d, const void* xv, const void* packed_wv, const float* scale,
                      const float* shift, void* yv, float* scratch, int64_t scratch_elems, void* stream) {
+    return conv_forward_impl(d, xv, nullptr, 0, packed_wv, scale, shift, yv, scratch, scratch_elems, stream);
+}
+
+}  // extern "C"
+
+namespace {
+
+int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, int nsplit, const void* packed_wv,
+                      const float* scale, const float* shift, void* yv, float* scratch, int64_t scratch_elems, void* stream) {
     const float* x = static_cast<const float*>(xv);
+    const float* x2 = static_cast<const float*>(x2v);
     const float* packed_w = static_cast<const float*>(packed_wv);
     float* y = static_cast<float*>(yv);
     Geo g; Route r;
@@ -498,6 +543,8 @@ int s3r_conv_forward(const s3r_conv_desc* d, const void* xv, const void* packed_
     if ((rc = route(d, &r))) return rc;
     if ((rc = check_halos(d, r))) return rc;
     if (!x || !packed_w || !y) return fail(S3R_ERR_INVALID, "null tensor pointer");
+    if (x2 && r != R_STEM) return fail(S3R_ERR_INVALID, "only the stem convolution takes a second input tensor");
+    if (x2 && (nsplit <= 0 || nsplit >= d->batch)) return fail(S3R_ERR_INVALID, "split %d outside (0, batch=%d)", nsplit, d->batch);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipSuccess;
     if (d->dtype == S3R_BF16) {
@@ -507,7 +554,7 @@ int s3r_conv_forward(const s3r_conv_desc* d, const void* xv, const void* packed_
             case R_STEM: {
                 if (!scale || !shift) return fail(S3R_ERR_INVALID, "stem needs scale and shift");
                 ProfScope ps(s, F_STEM, d->tag, g.flops, g.bytes);
-                e = s3r::launch_stem_bf16(x, packed_w, scale, shift, yv, d->batch, g.in, g.in, g.out, g.out,
+                e = s3r::launch_stem_bf16(x, x2, nsplit, packed_w, scale, shift, yv, d->batch, g.in, g.in, g.out, g.out,
                                           g.out_p * g.out_p * 32, g.out_p * 32, d->out_halo * (g.out_p + 1) * 32, s);
                 break;
             }
@@ -543,7 +590,7 @@ int s3r_conv_forward(const s3r_conv_desc* d, const void* xv, const void* packed_
         case R_STEM: {
             if (!scale || !shift) return fail(S3R_ERR_INVALID, "stem needs scale and shift");
             ProfScope ps(s, F_STEM, d->tag, g.flops, g.bytes);
-            e = s3r::launch_stem(x, packed_w, scale, shift, y, d->batch, g.in, g.in, g.out, g.out, g.out_p * g.out_p,
+            e = s3r::launch_stem(x, x2, nsplit, packed_w, scale, shift, y, d->batch, g.in, g.in, g.out, g.out, g.out_p * g.out_p,
                                  g.out_p, d->out_halo * (g.out_p + 1), s);
             break;
         }
@@ -584,6 +631,13 @@ int s3r_conv_forward(const s3r_conv_desc* d, const void* xv, const void* packed_
     return S3R_OK;
 }
 
+int chain_forward_impl(const s3r_layer* layers, int n_layers, const void* x, const void* x2, int nsplit, void* y, float* ws,
+                       int64_t ws_elems, int ws_fresh, void* stream);
+
+}  // namespace
+
+extern "C" {
+
 int64_t s3r_chain_workspace_elems(const s3r_layer* layers, int n_layers) {
     Plan pl;
     int rc = plan_chain(layers, n_layers, &pl);
@@ -593,6 +647,15 @@ int64_t s3r_chain_workspace_elems(const s3r_layer* layers, int n_layers) {
 
 int s3r_chain_forward(const s3r_layer* layers, int n_layers, const void* x, void* y, float* ws, int64_t ws_elems,
                       int ws_fresh, void* stream) {
+    return chain_forward_impl(layers, n_layers, x, nullptr, 0, y, ws, ws_elems, ws_fresh, stream);
+}
+
+}  // extern "C"
+
+namespace {
+
+int chain_forward_impl(const s3r_layer* layers, int n_layers, const void* x, const void* x2, int nsplit, void* y, float* ws,
+                       int64_t ws_elems, int ws_fresh, void* stream) {
     Plan pl;
     int rc = plan_chain(layers, n_layers, &pl);
     if (rc) return rc;
@@ -606,6 +669,8 @@ int s3r_chain_forward(const s3r_layer* layers, int n_layers, const void* x, void
         if (e != hipSuccess) return hip_fail(e, "workspace memset");
     }
     const void* cur = x;
+    if (x2 && (pl.pad_input || pl.r[0] != R_STEM))
+        return fail(S3R_ERR_INVALID, "a second input tensor needs a chain that starts with the stem convolution");
     if (pl.pad_input) {
         const s3r_conv_desc& d0 = pl.d[0];
         const int hl = d0.in_halo, is3 = d0.ndim == 3;
@@ -639,16 +704,20 @@ int s3r_chain_forward(const s3r_layer* layers, int n_layers, const void* x, void
             continue;
         }
         void* out = (i == n_layers - 1) ? y : static_cast<void*>(ws + pl.off[i]);
-        rc = s3r_conv_forward(&pl.d[i], cur, L.packed_w, L.scale, L.shift, out,
-                              pl.scratch_elems ? ws + pl.scratch_off : nullptr, pl.scratch_elems, stream);
+        rc = conv_forward_impl(&pl.d[i], cur, i == 0 ? x2 : nullptr, nsplit, L.packed_w, L.scale, L.shift, out,
+                               pl.scratch_elems ? ws + pl.scratch_off : nullptr, pl.scratch_elems, stream);
         if (rc) return rc;
         cur = out;
     }
     return S3R_OK;
 }
 
-int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* images, void* features, float* ws,
-                        int64_t ws_elems, int ws_fresh, void* stream) {
+}  // namespace
+
+extern "C" {
+
+int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* images_left, const float* images_right,
+                        void* features, float* ws, int64_t ws_elems, int ws_fresh, void* stream) {
     if (!layers || n_layers <= 0) return fail(S3R_ERR_INVALID, "empty encoder");
     const s3r_conv_desc& f = layers[0].desc;
     if (f.op != S3R_OP_CONV || f.ndim != 2 || f.cin != 3)
@@ -656,7 +725,9 @@ int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* imag
     for (int i = 0; i < n_layers; ++i)
         if (layers[i].desc.op != S3R_OP_CONV || layers[i].desc.ndim != 2)
             return fail(S3R_ERR_INVALID, "encoder layer %d is not a 2D convolution", i);
-    return s3r_chain_forward(layers, n_layers, images, features, ws, ws_elems, ws_fresh, stream);
+    if (images_right && (f.batch < 2 || (f.batch & 1)))
+        return fail(S3R_ERR_INVALID, "a (left, right) pair of tensors needs an even image count N = 2B (got %d)", f.batch);
+    return chain_forward_impl(layers, n_layers, images_left, images_right, f.batch / 2, features, ws, ws_elems, ws_fresh, stream);
 }
 
 int s3r_decoder_forward(const s3r_layer* layers, int n_layers, const void* volume, float* occupancy, float* ws,
@@ -777,16 +848,23 @@ int s3r_disparity_epe(const float* pred, const float* gt, float* epe, int32_t* c
 
 int s3r_profile_enable(int max_records) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.on = false;
+    ++g_prof.gen;                                            // live scopes of the old pool skip their stop record
     for (hipEvent_t ev : g_prof.ev) (void)hipEventDestroy(ev);
     g_prof.ev.clear();
     g_prof.rec.clear();
-    g_prof.on = false;
     g_prof.cap = 0;
+    g_prof.device = -1;
     if (max_records <= 0) return S3R_OK;
-    g_prof.ev.resize((size_t)2 * max_records);
+    if (hipGetDevice(&g_prof.device) != hipSuccess) g_prof.device = -1;
+    g_prof.ev.assign((size_t)2 * max_records, nullptr);
     for (auto& ev : g_prof.ev) {
         hipError_t e = hipEventCreate(&ev);
-        if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
+        if (e != hipSuccess) {
+            for (hipEvent_t x : g_prof.ev) if (x) (void)hipEventDestroy(x);
+            g_prof.ev.clear();
+            return hip_fail(e, "hipEventCreate");
+        }
     }
     g_prof.rec.reserve(max_records);
     g_prof.cap = max_records;

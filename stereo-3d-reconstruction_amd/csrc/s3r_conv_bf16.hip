@@ -1,5 +1,5 @@
 // bf16 MFMA path (BASELINE.json configs[2]): 2D/3D convolution and transposed convolution as an implicit
-// GEMM on v_mfma_f32_32x32x16_bf16, bf16 activations in CHANNELS-LAST layout with a zero halo, fp32
+// GEMM on the bf16 matrix cores, bf16 activations in CHANNELS-LAST layout with a zero halo, fp32
 // accumulation, folded-BN affine + activation + bf16 rounding fused into the epilogue.
 //
 //   D[pos][cout] = sum_{chunk, tap, c} X[b(pos)][in(pos) + tap][chunk*32 + c] * Wp[(chunk*T + tap)][cout][c]
@@ -7,25 +7,31 @@
 //   GEMM M = B*Nd*Nh*Nw positions (A operand: gathered activations), N = Cout (B operand: weights),
 //   K = Cin*T in K tiles of ONE tap x 32 channels = 64 contiguous bytes per position.
 //
-// Why channels-last here when the fp32 path is NCHW: the bf16 MFMA takes 8 consecutive k per lane
-// (A: lane (r,h) holds A[row r][k = 8h..8h+7]), i.e. 16 contiguous BYTES of one position's channel
-// vector — one ds_read_b128 — whereas the fp32 MFMA takes one k per lane and wants position-contiguous
-// rows.  The output falls out channels-last as well: D has the cout on the LANE and the position in the
-// registers, so a register row is 32 lanes x consecutive couts = one contiguous run per position.
+// Why channels-last here when the fp32 path is NCHW: the bf16 MFMA takes 8 consecutive k per lane, i.e. 16
+// contiguous BYTES of one position's channel vector — one ds_read_b128 — whereas the fp32 MFMA takes one k
+// per lane and wants position-contiguous rows.  The output falls out channels-last as well.
 //
-// LDS images (per K tile): As[pos][4 slots x 16 B], Bs[cout row][4 slots x 16 B], slot = kgroup ^
-// ((row >> 2) & 3).  With 64-byte rows a plain image makes every ds_read_b128 lane group hit the same
-// 16-byte column of four rows; the XOR spreads the four rows of each bank-row residue over the four
-// slots (conflict-free for the b128 lane groups {0-3,12-15,20-27}, ...).  Both operands arrive by
+// Two matrix instructions, one code path (template parameter SH; MI355X_MICROARCH.md "DVFS give-back" item 7 and
+// cdna_hip_programming.md rule 28: the chip can hold a higher clock on one shape than on the other, so both are
+// built at the same per-wave output tile and the faster BY WALL ON RANDOM DATA is kept):
+//   SH = 32: v_mfma_f32_32x32x16_bf16  lane = (row li = lane & 31, k group lk = lane >> 5), 16 acc registers
+//   SH = 16: v_mfma_f32_16x16x32_bf16  lane = (row li = lane & 15, k group lk = lane >> 4),  4 acc registers
+// A wave owns 32*TM positions x 64*NH couts as MFMA tiles of MT x MT (MT = SH).  The MFMA is issued with the
+// WEIGHTS as its A operand, so D = [cout][position]: a lane owns ONE position per position tile, and the pack
+// kernel permutes the weight rows so that the couts a lane holds are CONSECUTIVE (16 per 32 couts for SH = 32, 16 per
+// 64 couts for SH = 16): 32 contiguous bytes of the channels-last output per group, one output offset per position,
+// and the fused head's reduction over the couts stays inside the lane (+ one or two cross-lane exchanges).
+//
+// LDS images (per K tile): As[pos][slots x 16 B], Bs[cout row][slots x 16 B], slot = kgroup ^ swz(row).  A plain
+// image makes every ds_read_b128 lane group hit the same 16-byte column of several rows; the XOR spreads them
+// (swz below: conflict-free for BOTH instruction shapes' lane -> (row, k group) maps).  Both operands arrive by
 // LDS-DMA (16 B per lane, lane-linear destination), so the swizzle is applied on the SOURCE side: a lane
-// fetches channel group slot ^ f(row) of its position; weights are stored pre-swizzled by the pack kernel.
+// fetches channel group slot ^ swz(row) of its position; weights are stored pre-swizzled by the pack kernel.
 //
-// Workgroup: 4 waves along M, each 32*TM positions x 64 couts (TN = 2 MFMA tiles).  The MFMA is issued
-// with the weights as its A operand, so D = [cout][position]: a lane owns ONE position and 16 consecutive
-// couts per MFMA tile (32 contiguous bytes of the channels-last output: two 16-byte stores).
-// Per-position input / output offsets are decoded once per workgroup into LDS.
+// Workgroup: 4 waves along M.  Per-position input / output offsets are decoded once per workgroup into LDS.
 #include "s3r_kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace s3r {
 
@@ -52,14 +58,54 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, S3R_LDS_PTR(lds_dst), 16, voffset, soffset, 0, 0);
 }
 
+// ---- the two matrix instructions behind one interface
+template <int SH> struct Mf;
+template <> struct Mf<32> {
+    static constexpr int MT = 32;      // rows / columns of one MFMA tile
+    static constexpr int KS = 16;      // k per instruction
+    static constexpr int NK = 2;       // k groups of 8 per instruction = lane groups
+    typedef f32x16 acc_t;
+    static constexpr int NACC = 16;
+};
+template <> struct Mf<16> {
+    static constexpr int MT = 16;
+    static constexpr int KS = 32;
+    static constexpr int NK = 4;
+    typedef f32x4 acc_t;
+    static constexpr int NACC = 4;
+};
+template <int SH>
+__device__ __forceinline__ typename Mf<SH>::acc_t mma(const bf16x8& w, const bf16x8& a, const typename Mf<SH>::acc_t& c) {
+    if constexpr (SH == 32) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, c, 0, 0, 0);
+}
+// The 16 CONSECUTIVE couts a lane holds in one group: element r (0..15) of group gi of position tile `acc[..]`.
+//   SH = 32: acc[gi = 32-cout tile][r]                 couts  gi*32 + 16*lk + r      (2 groups per 64 couts)
+//   SH = 16: acc[r >> 2 = 16-cout tile][r & 3]         couts          16*lk + r      (1 group  per 64 couts)
+template <int SH> constexpr int groups_per_64() { return SH == 32 ? 2 : 1; }
+template <int SH> __device__ __forceinline__ int group_cout(int gi, int lk) { return SH == 32 ? gi * 32 + 16 * lk : 16 * lk; }
+template <int SH>
+__device__ __forceinline__ float acc_at(const typename Mf<SH>::acc_t (&t)[64 / Mf<SH>::MT], int gi, int r) {
+    if constexpr (SH == 32) return t[gi][r]; else return t[r >> 2][r & 3];
+}
+
+// which instruction the library uses: S3R_BF16_MFMA = 16 | 32 (read per call: the A/B tools flip it in-process;
+// the weights must be packed under the same value — the Python module keys its pack cache on it)
+int conv_bf16_shape() {
+    const char* e = getenv("S3R_BF16_MFMA");
+    if (e && atoi(e) == 16) return 16;
+    if (e && atoi(e) == 32) return 32;
+    return S3R_BF16_MFMA_DEFAULT;
+}
+
 constexpr int HKC = 32;    // channels per K tile
 constexpr int HBN = 64;    // couts per workgroup
 
-// Epilogue shared by both bf16 kernels.  The MFMA runs with the WEIGHTS as its A operand, so D is [cout][position]:
-// lane c owns position row wave*32*TM + tm*32 + c of the tile, and its 16 registers of MFMA tile tn are the 16
-// CONSECUTIVE couts n0 + tn*32 + 16h + r (the pack kernel permutes the weight rows to make them consecutive).
-// A lane therefore stores 32 contiguous bytes per MFMA tile (two 16-byte stores), needs one output offset per
-// position, and the fused head's reduction over the couts stays inside the lane (one cross-half exchange).
+// Epilogue shared by the bf16 kernels.  D is [cout][position]: lane (li, lk) owns position row
+// wave*32*TM + pt*MT + li of the tile for each position tile pt, and per 64-cout block the 16-cout groups of
+// group_cout() (the pack kernel permutes the weight rows to make them consecutive).  A lane therefore stores 32
+// contiguous bytes per group, needs one output offset per position, and the fused head's reduction over the couts
+// stays inside the lane (then one exchange per lane-group bit).
 // ep = LDS [3][64]: folded-BN scale, shift and head weight of the workgroup's 64 couts; yoff[row] = the
 // position's output element offset (-1: past the end).
 constexpr int EP_BYTES = 3 * 64 * 4;
@@ -91,35 +137,52 @@ __device__ __forceinline__ void store_ep(const EpRegs& e, float* ep, int tid, in
     __syncthreads();
 }
 
-template <int TM, bool HEAD>
-__device__ __forceinline__ void epilogue_h(const ConvParamsH& p, f32x16 (&acc)[TM][2], const int* yoff, const float* ep,
-                                           char* stage, int wave, int c, int h, int m0, int n0, int cls, int kz, int bm) {
+// acc: the wave's accumulators of ONE 64-cout block: [position tile][cout tile of MT].
+template <int SH, int TM, bool HEAD>
+__device__ __forceinline__ void epilogue_h(const ConvParamsH& p, typename Mf<SH>::acc_t (&acc)[32 * TM / Mf<SH>::MT][64 / Mf<SH>::MT],
+                                           const int* yoff, const float* ep, char* stage, int wave, int li, int lk, int m0,
+                                           int n0, int cls, int kz, int bm) {
+    constexpr int MT = Mf<SH>::MT;
+    constexpr int NPT = 32 * TM / MT;             // position tiles per wave
+    constexpr int PPU = 32 / MT;                  // position tiles per 32-row staging unit (1 or 2)
+    constexpr int GL = groups_per_64<SH>();       // 16-cout groups a lane holds per 64 couts
     // `stage`: this wave's 32 x ST_ROW bytes of the (now idle) operand buffers.  A lane holds 32 B (bf16) /
-    // 64 B (fp32 slab) of ONE position; stored as they stand, a wave instruction would touch 32 rows with
+    // 64 B (fp32 slab) pieces of ONE position; stored as they stand, a wave instruction would touch 16-32 rows with
     // 16-byte pieces.  Staged through LDS, lanes 8r..8r+7 write the 128 contiguous bytes of row r: every store
     // instruction covers eight whole 128-byte lines.
-    const int lane = c + 32 * h;
+    const int lane = threadIdx.x & 63;
     const int srow = lane >> 3, spiece = lane & 7;
     if (p.ksplit > 1) {
-        // split-K: fp32 partial sums [cls][kz][position][CoutPad]; conv_finish_bf16 reduces in kz order
+        // split-K: fp32 partial sums [cls][kz][position][CoutPad]; conv_finish_bf16 reduces in kz order.
+        // One staging unit = 32 positions x 32 couts fp32 (128-byte rows).
         const int mpad = p.m_tiles * bm;
         float* __restrict__ slab = p.part + ((size_t)(cls * p.ksplit + kz) * mpad + m0) * p.CoutPad + n0 + 4 * spiece;
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int u = 0; u < TM; ++u)
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {       // one MFMA tile = 32 positions x 32 couts fp32 = 128-byte rows
+            for (int ch = 0; ch < 2; ++ch) {       // 32-cout half of the 64-cout block
+                if constexpr (SH == 32) {          // cout tile ch: lane (li, lk) holds couts ch*32 + 16 lk + r
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 t = {acc[tm][tn][4 * j], acc[tm][tn][4 * j + 1], acc[tm][tn][4 * j + 2],
-                                     acc[tm][tn][4 * j + 3]};
-                    *reinterpret_cast<f32x4*>(stage + c * ST_ROW + h * 64 + j * 16) = t;
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 t = {acc[u][ch][4 * j], acc[u][ch][4 * j + 1], acc[u][ch][4 * j + 2], acc[u][ch][4 * j + 3]};
+                        *reinterpret_cast<f32x4*>(stage + li * ST_ROW + lk * 64 + j * 16) = t;
+                    }
+                } else {                           // lanes with lk >> 1 == ch hold this half: couts 16 lk + r
+                    if ((lk >> 1) == ch) {
+#pragma unroll
+                        for (int q = 0; q < PPU; ++q)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                *reinterpret_cast<f32x4*>(stage + (q * MT + li) * ST_ROW + (lk & 1) * 64 + j * 16) =
+                                    acc[u * PPU + q][j];
+                    }
                 }
                 if (S3R_ABLH(p, 1)) continue;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = i * 8 + srow;
                     const f32x4 t = *reinterpret_cast<const f32x4*>(stage + r * ST_ROW + spiece * 16);
-                    *reinterpret_cast<f32x4*>(slab + (size_t)(wave * 32 * TM + tm * 32 + r) * p.CoutPad + tn * 32) = t;
+                    *reinterpret_cast<f32x4*>(slab + (size_t)(wave * 32 * TM + u * 32 + r) * p.CoutPad + ch * 32) = t;
                 }
             }
         return;
@@ -128,42 +191,43 @@ __device__ __forceinline__ void epilogue_h(const ConvParamsH& p, f32x16 (&acc)[T
     const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
     const bool sig = p.act == ACT_SIGMOID;
     if constexpr (HEAD) {
-        int ye[TM];
+        int ye[NPT];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) ye[tm] = yoff[wave * 32 * TM + tm * 32 + c];
+        for (int pt = 0; pt < NPT; ++pt) ye[pt] = yoff[wave * 32 * TM + pt * MT + li];
         // fused pointwise head (conv -> 1x1x1 conv to ONE channel + activation; the workgroup's 64-cout tile
-        // is the whole channel axis): 32 FMAs in the lane, one exchange with the other half, one fp32 store per
+        // is the whole channel axis): 16 * GL FMAs in the lane, an exchange per lane-group bit, one fp32 store per
         // position.  The conv's own bf16 output — the largest activation of the network — is never written.
-        float t[TM];
+        float t[NPT];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) t[tm] = 0.f;
+        for (int pt = 0; pt < NPT; ++pt) t[pt] = 0.f;
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const float* e = ep + tn * 32 + 16 * h;
+        for (int gi = 0; gi < GL; ++gi) {
+            const float* e = ep + group_cout<SH>(gi, lk);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(e + 4 * q);
                 const f32x4 sf = *reinterpret_cast<const f32x4*>(e + 64 + 4 * q);
                 const f32x4 hw = *reinterpret_cast<const f32x4*>(e + 128 + 4 * q);
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) {
-                    t[tm] = fmaf(fmaxf(fmaf(acc[tm][tn][4 * q + 0], sc.x, sf.x), lo), hw.x, t[tm]);
-                    t[tm] = fmaf(fmaxf(fmaf(acc[tm][tn][4 * q + 1], sc.y, sf.y), lo), hw.y, t[tm]);
-                    t[tm] = fmaf(fmaxf(fmaf(acc[tm][tn][4 * q + 2], sc.z, sf.z), lo), hw.z, t[tm]);
-                    t[tm] = fmaf(fmaxf(fmaf(acc[tm][tn][4 * q + 3], sc.w, sf.w), lo), hw.w, t[tm]);
+                for (int pt = 0; pt < NPT; ++pt) {
+                    t[pt] = fmaf(fmaxf(fmaf(acc_at<SH>(acc[pt], gi, 4 * q + 0), sc.x, sf.x), lo), hw.x, t[pt]);
+                    t[pt] = fmaf(fmaxf(fmaf(acc_at<SH>(acc[pt], gi, 4 * q + 1), sc.y, sf.y), lo), hw.y, t[pt]);
+                    t[pt] = fmaf(fmaxf(fmaf(acc_at<SH>(acc[pt], gi, 4 * q + 2), sc.z, sf.z), lo), hw.z, t[pt]);
+                    t[pt] = fmaf(fmaxf(fmaf(acc_at<SH>(acc[pt], gi, 4 * q + 3), sc.w, sf.w), lo), hw.w, t[pt]);
                 }
             }
         }
         const float hsc = p.head_scale ? p.head_scale[0] : 1.f, hsf = p.head_shift ? p.head_shift[0] : 0.f;
         float* __restrict__ y = reinterpret_cast<float*>(p.y);
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            float v = t[tm] + __shfl_xor(t[tm], 32, 64);
-            if (h == 0 && ye[tm] >= 0) {
+        for (int pt = 0; pt < NPT; ++pt) {
+            float v = t[pt] + __shfl_xor(t[pt], 32, 64);          // fixed order: (lk) + (lk ^ 2 | lk ^ 1 for SH = 32) ...
+            if constexpr (SH == 16) v += __shfl_xor(v, 16, 64);
+            if (lk == 0 && ye[pt] >= 0) {
                 v = fmaf(v, hsc, hsf);
                 if (p.head_act == ACT_RELU) v = fmaxf(v, 0.f);
                 else if (p.head_act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-                y[ye[tm]] = v;
+                y[ye[pt]] = v;
             }
         }
         return;
@@ -171,33 +235,35 @@ __device__ __forceinline__ void epilogue_h(const ConvParamsH& p, f32x16 (&acc)[T
     unsigned short* __restrict__ y = reinterpret_cast<unsigned short*>(p.y);
     const bool wide = (p.Cout & 7) == 0;          // 16-byte stores need the channel axis in whole groups of 8
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
+    for (int u = 0; u < TM; ++u) {                // one staging unit = 32 positions x 64 couts bf16 (128-byte rows)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
+        for (int q = 0; q < PPU; ++q)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int cl = tn * 32 + 16 * h + 8 * g;          // (tile-local) cout of register 8g
-                const f32x4 sc0 = *reinterpret_cast<const f32x4*>(ep + cl);
-                const f32x4 sc1 = *reinterpret_cast<const f32x4*>(ep + cl + 4);
-                const f32x4 sf0 = *reinterpret_cast<const f32x4*>(ep + 64 + cl);
-                const f32x4 sf1 = *reinterpret_cast<const f32x4*>(ep + 64 + cl + 4);
-                const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
-                const float sf[8] = {sf0.x, sf0.y, sf0.z, sf0.w, sf1.x, sf1.y, sf1.z, sf1.w};
-                float v[8];
+            for (int gi = 0; gi < GL; ++gi)
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    v[r] = fmaf(acc[tm][tn][8 * g + r], sc[r], sf[r]);
-                    v[r] = sig ? __builtin_amdgcn_rcpf(1.f + __expf(-v[r])) : fmaxf(v[r], lo);
+                for (int g = 0; g < 2; ++g) {
+                    const int cl = group_cout<SH>(gi, lk) + 8 * g;      // (tile-local) cout of element 8g of the group
+                    const f32x4 sc0 = *reinterpret_cast<const f32x4*>(ep + cl);
+                    const f32x4 sc1 = *reinterpret_cast<const f32x4*>(ep + cl + 4);
+                    const f32x4 sf0 = *reinterpret_cast<const f32x4*>(ep + 64 + cl);
+                    const f32x4 sf1 = *reinterpret_cast<const f32x4*>(ep + 64 + cl + 4);
+                    const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+                    const float sf[8] = {sf0.x, sf0.y, sf0.z, sf0.w, sf1.x, sf1.y, sf1.z, sf1.w};
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        v[r] = fmaf(acc_at<SH>(acc[u * PPU + q], gi, 8 * g + r), sc[r], sf[r]);
+                        v[r] = sig ? __builtin_amdgcn_rcpf(1.f + __expf(-v[r])) : fmaxf(v[r], lo);
+                    }
+                    const uint4 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]),
+                                      pack_bf16(v[6], v[7])};
+                    *reinterpret_cast<uint4*>(stage + (q * MT + li) * ST_ROW + cl * 2) = pk;
                 }
-                const uint4 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]),
-                                  pack_bf16(v[6], v[7])};
-                *reinterpret_cast<uint4*>(stage + c * ST_ROW + cl * 2) = pk;
-            }
         if (S3R_ABLH(p, 1)) continue;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = i * 8 + srow;
-            const int ye = yoff[wave * 32 * TM + tm * 32 + r];
+            const int ye = yoff[wave * 32 * TM + u * 32 + r];
             const int co = n0 + 8 * spiece;
             const uint4 pk = *reinterpret_cast<const uint4*>(stage + r * ST_ROW + spiece * 16);
             if (ye < 0 || co >= p.Cout) continue;
@@ -221,10 +287,15 @@ constexpr int min_waves_h(int tm, int kc, bool head) {
 }
 
 // LDS rows are KC channels = KC*2 bytes = KC/8 sixteen-byte slots; slot = kgroup ^ swz(row) keeps every
-// ds_read_b128 lane group on 16 distinct (bank half, slot) pairs:  64-byte rows: (row >> 2) & 3,
-// 128-byte rows: (row >> 1) & 7  (the b128 lane groups are {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...).
+// ds_read_b128 lane group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... of each 32) on 16 distinct 16-byte slots of
+// the 256-byte bank row, for BOTH lane maps (SH = 32: 32 consecutive rows, one k group per lane half; SH = 16: 16
+// consecutive rows x 4 k groups):
+//   128-byte rows (2 rows per bank row): (row >> 1) & 7;
+//   64-byte rows (4 rows per bank row): (-(row >> 2)) & 3 — for SH = 16 a lane group mixes k groups g and g + 1 on rows
+//   {0-3, 12-15} and {4-11}: with t = (row >> 2) & 3 the four slots (g ^ f(0), g ^ f(3), (g+1) ^ f(1), (g+1) ^ f(2)) are
+//   distinct for f = (0, 3, 2, 1) (the plain f(t) = t collides); any bijection serves SH = 32.
 template <int KC>
-__device__ __forceinline__ int swz(int row) { return KC == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
+__device__ __host__ __forceinline__ int swz(int row) { return KC == 64 ? (row >> 1) & 7 : (0 - (row >> 2)) & 3; }
 
 // Per-tap kernel.  K tile = ONE tap x KC channels.  KC = 64 (Cin % 64 == 0) makes every gathered piece a WHOLE
 // 128-byte line of the channels-last input (KC = 32 fetches half of each line, and the other half again one
@@ -234,9 +305,14 @@ __device__ __forceinline__ int swz(int row) { return KC == 64 ? (row >> 1) & 7 :
 // NH = 64-cout halves per workgroup: 2 (a 128 x 128 tile; Cout % 128 == 0) gathers the activations once for twice
 // the couts — 1.5x the FLOPs per byte brought into LDS, for the layers this kernel keeps (stride 2), which are
 // bound by exactly that.
-template <int TM, int KC, bool HEAD, int NH>
+template <int SH, int TM, int KC, bool HEAD, int NH>
 __global__ __launch_bounds__(256, NH == 2 ? (KC == 64 ? 2 : 3) : min_waves_h(TM, KC, HEAD)) void conv_bf16_kernel(const ConvParamsH p) {
     static_assert(NH == 1 || !HEAD, "the fused head needs the whole channel axis in one 64-cout tile");
+    typedef Mf<SH> M;
+    constexpr int MT = M::MT;
+    constexpr int NPT = 32 * TM / MT;              // position tiles per wave
+    constexpr int NCT = 64 / MT;                   // cout tiles per 64-cout block
+    constexpr int NKS = KC / M::KS;                // MFMA k steps per K tile
     constexpr int BM = 128 * TM;
     constexpr int BNW = HBN * NH;                  // couts per workgroup
     constexpr int ROWB = KC * 2;                   // bytes per LDS row
@@ -255,7 +331,7 @@ __global__ __launch_bounds__(256, NH == 2 ? (KC == 64 ? 2 : 3) : min_waves_h(TM,
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, h = lane >> 5;
+    const int li = lane % MT, lk = lane / MT;
 
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
@@ -343,31 +419,31 @@ __global__ __launch_bounds__(256, NH == 2 ? (KC == 64 ? 2 : 3) : min_waves_h(TM,
         if (++c_tap == T) { c_tap = 0; c_td = 0; c_th = 0; c_tw = 0; ++c_cc; }
     };
 
-    f32x16 acc[NH][TM][2];
+    typename M::acc_t acc[NH][NPT][NCT];
 #pragma unroll
     for (int nh = 0; nh < NH; ++nh)
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < NPT; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < NCT; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nh][a][b][r] = 0.f;
+                for (int r = 0; r < M::NACC; ++r) acc[nh][a][b][r] = 0.f;
 
     issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // fragment byte offsets inside a K tile image: row*ROWB + ((2q + h) ^ swz(row))*16; q toggles bits 5..
-    int a_off[TM], b_off[2 * NH];
+    // fragment byte offsets inside a K tile image: row*ROWB + ((NK*q + lk) ^ swz(row))*16; q toggles the bits above lk's
+    int a_off[NPT], b_off[NCT * NH];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        const int row = wave * 32 * TM + tm * 32 + c;
-        a_off[tm] = row * ROWB + ((h ^ swz<KC>(row)) << 4);
+    for (int pt = 0; pt < NPT; ++pt) {
+        const int row = wave * 32 * TM + pt * MT + li;
+        a_off[pt] = row * ROWB + ((lk ^ swz<KC>(row)) << 4);
     }
 #pragma unroll
-    for (int tn = 0; tn < 2 * NH; ++tn) {
-        const int row = tn * 32 + c;
-        b_off[tn] = row * ROWB + ((h ^ swz<KC>(row)) << 4);
+    for (int ct = 0; ct < NCT * NH; ++ct) {
+        const int row = ct * MT + li;
+        b_off[ct] = row * ROWB + ((lk ^ swz<KC>(row)) << 4);
     }
 
     for (int kt = 0; kt < nkt; ++kt) {
@@ -376,18 +452,17 @@ __global__ __launch_bounds__(256, NH == 2 ? (KC == 64 ? 2 : 3) : min_waves_h(TM,
         const char* a = As + cur * A_BYTES;
         const char* b = Bs + cur * B_BYTES;
 #pragma unroll
-        for (int q = 0; q < KC / 16; ++q) {
-            bf16x8 av[TM], bv[2 * NH];
+        for (int q = 0; q < NKS; ++q) {
+            bf16x8 av[NPT], bv[NCT * NH];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) av[tm] = *reinterpret_cast<const bf16x8*>(a + (a_off[tm] ^ (q << 5)));
+            for (int pt = 0; pt < NPT; ++pt) av[pt] = *reinterpret_cast<const bf16x8*>(a + (a_off[pt] ^ (q * M::NK * 16)));
 #pragma unroll
-            for (int tn = 0; tn < 2 * NH; ++tn) bv[tn] = *reinterpret_cast<const bf16x8*>(b + (b_off[tn] ^ (q << 5)));
+            for (int ct = 0; ct < NCT * NH; ++ct) bv[ct] = *reinterpret_cast<const bf16x8*>(b + (b_off[ct] ^ (q * M::NK * 16)));
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+            for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
-                for (int tn = 0; tn < 2 * NH; ++tn)
-                    acc[tn >> 1][tm][tn & 1] =
-                        __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[tn], av[tm], acc[tn >> 1][tm][tn & 1], 0, 0, 0);
+                for (int ct = 0; ct < NCT * NH; ++ct)
+                    acc[ct / NCT][pt][ct % NCT] = mma<SH>(bv[ct], av[pt], acc[ct / NCT][pt][ct % NCT]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -396,12 +471,12 @@ __global__ __launch_bounds__(256, NH == 2 ? (KC == 64 ? 2 : 3) : min_waves_h(TM,
     store_ep(epr, ep, tid, BNW);
 #pragma unroll
     for (int nh = 0; nh < NH; ++nh)
-        epilogue_h<TM, HEAD>(p, acc[nh], yoff, ep + nh * 192, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0 + nh * HBN, cls,
-                             kz, BM);
+        epilogue_h<SH, TM, HEAD>(p, acc[nh], yoff, ep + nh * 192, smem + wave * (32 * ST_ROW), wave, li, lk, m0, n0 + nh * HBN,
+                                 cls, kz, BM);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Row-reuse variant (the default): the kw taps of one (chunk, td, th) group read the SAME gathered input
+// Row-reuse variant: the kw taps of one (chunk, td, th) group read the SAME gathered input
 // rows shifted by one position, so the A operand is fetched ONCE per group instead of once per tap.
 //
 // LDS A image = the input positions the tile needs for a fixed (td, th), in input order: for every run of
@@ -410,11 +485,14 @@ __global__ __launch_bounds__(256, NH == 2 ? (KC == 64 ? 2 : 3) : min_waves_h(TM,
 // is not stored (the halo columns sit in LDS but no MFMA row maps to them), the gather is kw (x stride)
 // times smaller, and it is CONTIGUOUS in HBM (whole runs of positions) instead of 64-byte pieces.
 // The weights of the group's kw taps (kw x 4 KiB, consecutive in the packed image) ride along, so there
-// is one barrier per GROUP: kw*2*TM*2 MFMAs per wave between barriers.
+// is one barrier per GROUP.
 constexpr int NPA_MAX = 10;    // 16-position A pieces per wave per group, upper bound (registers)
 
-template <int TM>
+template <int SH, int TM>
 __global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p, int r_max) {
+    typedef Mf<SH> M;
+    constexpr int MT = M::MT;
+    constexpr int NPT = 32 * TM / MT, NCT = 64 / MT, NKS = HKC / M::KS;
     constexpr int BM = 128 * TM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int kw = p.kw;
@@ -426,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p,
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, h = lane >> 5;
+    const int li = lane % MT, lk = lane / MT;
 
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
@@ -497,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p,
         const int pd = p.dH.div(rem);
         const int ph = rem - pd * p.Nh;
         const int e = b * p.x_bs + p.x_org + (pd * p.x_ds + ph * p.x_hs) * p.stride + off * p.x_ws + cls_x;
-        const int kg = (lane & 3) ^ ((lr >> 2) & 3);          // swizzle on the source side
+        const int kg = (lane & 3) ^ swz<32>(lr);              // swizzle on the source side
         avoff[q] = e * 2 + kg * 16;
     }
     const int bvoff = lane * 16;
@@ -524,26 +602,26 @@ __global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p,
         if (++c_th == p.kh) { c_th = 0; if (++c_td == p.kd) { c_td = 0; ++c_cc; } }
     };
 
-    f32x16 acc[TM][2];
+    typename M::acc_t acc[NPT][NCT];
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+    for (int a = 0; a < NPT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NCT; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int r = 0; r < M::NACC; ++r) acc[a][b][r] = 0.f;
 
     issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                          // also publishes yoff / lrow
 
-    int lr[TM];
+    int lr[NPT];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) lr[tm] = lrow[wave * 32 * TM + tm * 32 + c];
-    int b_off[2];
+    for (int pt = 0; pt < NPT; ++pt) lr[pt] = lrow[wave * 32 * TM + pt * MT + li];
+    int b_off[NCT];
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const int row = tn * 32 + c;
-        b_off[tn] = row * 64 + ((h ^ ((row >> 2) & 3)) << 4);
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int row = ct * MT + li;
+        b_off[ct] = row * 64 + ((lk ^ swz<32>(row)) << 4);
     }
 
     for (int g = 0; g < ngroups; ++g) {
@@ -552,25 +630,25 @@ __global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p,
         const char* a = smem + cur * stage_bytes;
         const char* b = a + a_bytes;
         for (int tw = 0; tw < kw; ++tw) {
-            int a_off[TM];
+            int a_off[NPT];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int row = lr[tm] + tw;
-                a_off[tm] = (row << 6) + (((h ^ (row >> 2)) & 3) << 4);
+            for (int pt = 0; pt < NPT; ++pt) {
+                const int row = lr[pt] + tw;
+                a_off[pt] = (row << 6) + ((lk ^ swz<32>(row)) << 4);
             }
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                bf16x8 av[TM], bv[2];
+            for (int q = 0; q < NKS; ++q) {
+                bf16x8 av[NPT], bv[NCT];
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) av[tm] = *reinterpret_cast<const bf16x8*>(a + (a_off[tm] ^ (q << 5)));
+                for (int pt = 0; pt < NPT; ++pt) av[pt] = *reinterpret_cast<const bf16x8*>(a + (a_off[pt] ^ (q * M::NK * 16)));
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
-                    bv[tn] = *reinterpret_cast<const bf16x8*>(b + tw * 4096 + (b_off[tn] ^ (q << 5)));
+                for (int ct = 0; ct < NCT; ++ct)
+                    bv[ct] = *reinterpret_cast<const bf16x8*>(b + tw * 4096 + (b_off[ct] ^ (q * M::NK * 16)));
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
+                for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[tn], av[tm], acc[tm][tn], 0, 0, 0);
+                    for (int ct = 0; ct < NCT; ++ct)
+                        acc[pt][ct] = mma<SH>(bv[ct], av[pt], acc[pt][ct]);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -578,20 +656,20 @@ __global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p,
     }
 
     store_ep(epr, ep, tid);
-    if (p.head_w) epilogue_h<TM, true>(p, acc, yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
-    else epilogue_h<TM, false>(p, acc, yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
+    if (p.head_w) epilogue_h<SH, TM, true>(p, acc, yoff, ep, smem + wave * (32 * ST_ROW), wave, li, lk, m0, n0, cls, kz, BM);
+    else epilogue_h<SH, TM, false>(p, acc, yoff, ep, smem + wave * (32 * ST_ROW), wave, li, lk, m0, n0, cls, kz, BM);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Plane-reuse variant (stride-1 layers with Cin % 64 == 0): ALL kh*kw taps of one (64-channel chunk, td) group
+// Plane-reuse variant (stride-1 layers): ALL kh*kw taps of one (KC-channel chunk, td) group
 // read the same gathered input PLANE, shifted by th*in_p + tw positions, so the A operand is fetched once per
 // kh*kw taps (9 for a 3x3[x3] conv, 4 for a transposed-conv class) instead of once per tap / per kw taps.
 //
 // LDS A image = for every (batch, depth) plane the tile touches, the contiguous run of padded-input positions
-// u = ph*in_p + pw .. that its output positions need (128 B = 64 channels each, whole 128-byte lines), plus
+// u = ph*in_p + pw .. that its output positions need, plus
 // HALO = (kh-1)*in_p + kw-1 trailing positions; MFMA row r reads LDS row lrow[r] + th*in_p + tw.  The image is
-// SINGLE-buffered (two workgroups per CU overlap one's reload with the other's MFMAs); the weights (8 KiB per
-// tap) stream through a 3-slot ring with one barrier per tap: 4*TM*2 MFMAs per wave between barriers.
+// SINGLE-buffered (two or three workgroups per CU overlap one's reload with the others' MFMAs); the weights
+// stream through a 3-slot ring with one barrier per tap.
 constexpr int NPA_PL = 15;     // 8-row A pieces per wave, upper bound (registers), 128-byte rows
 constexpr int NPA_PL32 = 12;   // 16-row pieces, 64-byte rows
 constexpr int PL_NB = 3;       // weight ring slots
@@ -599,8 +677,11 @@ constexpr int PL_NB = 3;       // weight ring slots
 // KC = 64: 128-byte image rows (whole lines), two workgroups per CU; KC = 32: 64-byte rows, half the LDS, three
 // workgroups per CU (and the only form for Cin = 32).
 // NH = 64-cout halves per workgroup (2: a 256 x 128 tile, the image serves twice the couts; two workgroups per CU).
-template <int TM, int KC, int NH>
+template <int SH, int TM, int KC, int NH>
 __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p_kernel(const ConvParamsH p, int r_max) {
+    typedef Mf<SH> M;
+    constexpr int MT = M::MT;
+    constexpr int NPT = 32 * TM / MT, NCT = 64 / MT, NKS = KC / M::KS;
     constexpr int BM = 128 * TM;
     constexpr int BNW = HBN * NH;                  // couts per workgroup
     constexpr int ROWB = KC * 2;                   // bytes per LDS row
@@ -620,7 +701,7 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, h = lane >> 5;
+    const int li = lane % MT, lk = lane / MT;
 
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
@@ -732,14 +813,14 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
         const int j = (wave + 4 * q) * RPP + lane / LPR;
         avoff[q] = (j < r_max ? asrc[j] : 0) + (((lane % LPR) ^ swz<KC>(j)) << 4);
     }
-    int lr[TM];
+    int lr[NPT];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) lr[tm] = lrow[wave * 32 * TM + tm * 32 + c];
-    int b_off[2 * NH];
+    for (int pt = 0; pt < NPT; ++pt) lr[pt] = lrow[wave * 32 * TM + pt * MT + li];
+    int b_off[NCT * NH];
 #pragma unroll
-    for (int tn = 0; tn < 2 * NH; ++tn) {
-        const int row = tn * 32 + c;
-        b_off[tn] = row * ROWB + ((h ^ swz<KC>(row)) << 4);
+    for (int ct = 0; ct < NCT * NH; ++ct) {
+        const int row = ct * MT + li;
+        b_off[ct] = row * ROWB + ((lk ^ swz<KC>(row)) << 4);
     }
 
     const __amdgpu_buffer_rsrc_t xrsrc =
@@ -752,15 +833,15 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
             if ((wave + 4 * q) * RPP < r_max) dma16(xrsrc, smem + ((wave + 4 * q) << 10), avoff[q], a_base);
         if (++a_td == p.kd) { a_td = 0; ++a_cc; }
     };
-    f32x16 acc[NH][TM][2];
+    typename M::acc_t acc[NH][NPT][NCT];
 #pragma unroll
     for (int nh = 0; nh < NH; ++nh)
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < NPT; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < NCT; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nh][a][b][r] = 0.f;
+                for (int r = 0; r < M::NACC; ++r) acc[nh][a][b][r] = 0.f;
 
     issue_a();                                                // (asrc aliases the LAST ring slot, first filled
                                                               //  behind the loop's first barrier)
@@ -778,46 +859,47 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
             asm volatile("s_barrier" ::: "memory");           // ... for every wave; ring slot (tt+2)%3 is free
             if (tt + 2 < total && !S3R_ABLH(p, 3)) issue_b();
             const char* b = Bs + c_slot * B_BYTES;
-            int a_off[TM];
+            int a_off[NPT];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int row = lr[tm] + tapoff;
-                a_off[tm] = row * ROWB + ((h ^ swz<KC>(row)) << 4);
+            for (int pt = 0; pt < NPT; ++pt) {
+                const int row = lr[pt] + tapoff;
+                a_off[pt] = row * ROWB + ((lk ^ swz<KC>(row)) << 4);
             }
             // fragments of k-step q+1 are requested before the MFMAs of k-step q
-            bf16x8 av[2][TM], bv[2][2 * NH];
+            bf16x8 av[2][NPT], bv[2][NCT * NH];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) av[0][tm] = *reinterpret_cast<const bf16x8*>(smem + a_off[tm]);
+            for (int pt = 0; pt < NPT; ++pt) av[0][pt] = *reinterpret_cast<const bf16x8*>(smem + a_off[pt]);
 #pragma unroll
-            for (int tn = 0; tn < 2 * NH; ++tn) bv[0][tn] = *reinterpret_cast<const bf16x8*>(b + b_off[tn]);
+            for (int ct = 0; ct < NCT * NH; ++ct) bv[0][ct] = *reinterpret_cast<const bf16x8*>(b + b_off[ct]);
 #pragma unroll
-            for (int q = 0; q < KC / 16; ++q) {
-                if (q < KC / 16 - 1) {
+            for (int q = 0; q < NKS; ++q) {
+                if (q < NKS - 1) {
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-                        av[(q + 1) & 1][tm] = *reinterpret_cast<const bf16x8*>(smem + (a_off[tm] ^ ((q + 1) << 5)));
+                    for (int pt = 0; pt < NPT; ++pt)
+                        av[(q + 1) & 1][pt] = *reinterpret_cast<const bf16x8*>(smem + (a_off[pt] ^ ((q + 1) * M::NK * 16)));
 #pragma unroll
-                    for (int tn = 0; tn < 2 * NH; ++tn)
-                        bv[(q + 1) & 1][tn] = *reinterpret_cast<const bf16x8*>(b + (b_off[tn] ^ ((q + 1) << 5)));
+                    for (int ct = 0; ct < NCT * NH; ++ct)
+                        bv[(q + 1) & 1][ct] = *reinterpret_cast<const bf16x8*>(b + (b_off[ct] ^ ((q + 1) * M::NK * 16)));
                 }
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
+                for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
-                    for (int tn = 0; tn < 2 * NH; ++tn)
-                        acc[tn >> 1][tm][tn & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            bv[q & 1][tn], av[q & 1][tm], acc[tn >> 1][tm][tn & 1], 0, 0, 0);
+                    for (int ct = 0; ct < NCT * NH; ++ct)
+                        acc[ct / NCT][pt][ct % NCT] = mma<SH>(bv[q & 1][ct], av[q & 1][pt], acc[ct / NCT][pt][ct % NCT]);
             }
             // pin the issue order (the scheduler otherwise reuses the fragment registers and serialises
             // read -> wait -> MFMA): k-step 0's reads, then per k-step one read of the NEXT step behind each MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, TM + 2 * NH, 0);
+            if constexpr (NKS > 1) {
+                __builtin_amdgcn_sched_group_barrier(0x100, NPT + NCT * NH, 0);
 #pragma unroll
-            for (int q = 0; q < KC / 16 - 1; ++q)
+                for (int q = 0; q < NKS - 1; ++q)
 #pragma unroll
-                for (int i = 0; i < 2 * NH * TM; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (i < TM + 2 * NH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NH * TM, 0);
+                    for (int i = 0; i < NCT * NH * NPT; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (i < NPT + NCT * NH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                __builtin_amdgcn_sched_group_barrier(0x008, NCT * NH * NPT, 0);
+            }
             if (++c_slot == PL_NB) c_slot = 0;
             ++tapoff;
             if (++c_tw == kw) { c_tw = 0; tapoff += in_p - kw; }
@@ -828,13 +910,13 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
 
     store_ep(epr, ep, tid, BNW);
     if constexpr (NH == 1) {
-        if (p.head_w) epilogue_h<TM, true>(p, acc[0], yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
-        else epilogue_h<TM, false>(p, acc[0], yoff, ep, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0, cls, kz, BM);
+        if (p.head_w) epilogue_h<SH, TM, true>(p, acc[0], yoff, ep, smem + wave * (32 * ST_ROW), wave, li, lk, m0, n0, cls, kz, BM);
+        else epilogue_h<SH, TM, false>(p, acc[0], yoff, ep, smem + wave * (32 * ST_ROW), wave, li, lk, m0, n0, cls, kz, BM);
     } else {
 #pragma unroll
         for (int nh = 0; nh < NH; ++nh)
-            epilogue_h<TM, false>(p, acc[nh], yoff, ep + nh * 192, smem + wave * (32 * ST_ROW), wave, c, h, m0, n0 + nh * HBN,
-                                  cls, kz, BM);
+            epilogue_h<SH, TM, false>(p, acc[nh], yoff, ep + nh * 192, smem + wave * (32 * ST_ROW), wave, li, lk, m0, n0 + nh * HBN,
+                                      cls, kz, BM);
     }
 }
 
@@ -947,8 +1029,8 @@ static hipError_t launch_tm_rowreuse(ConvParamsH p, hipStream_t stream) {
     const int r_max = rowreuse_rows(p, BM);
     if (r_max > 64 * NPA_MAX) return hipErrorInvalidValue;
     const size_t lds = (size_t)2 * (r_max * 64 + p.kw * 4096) + 2 * BM * sizeof(int) + EP_BYTES;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16r_kernel<TM>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static LdsAttr lds_attr;                       // (per device: see LdsAttr)
+    const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_bf16r_kernel<TM>), 160 * 1024);
     if (attr != hipSuccess) return attr;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(p.m_tiles * p.n_tiles, p.transposed ? 8 : 1, p.ksplit);
@@ -990,8 +1072,8 @@ static hipError_t launch_tm_plane(ConvParamsH p, hipStream_t stream) {
     if (NH == 2 && (p.n_tiles % 2 != 0 || p.head_w)) return hipErrorInvalidValue;
     const size_t lds = (size_t)r_max * KC * 2 + PL_NB * HBN * NH * KC * 2 + 2 * BM * sizeof(int) + EP_BYTES * NH;
     if (lds > 160 * 1024 || r_max * 4 > HBN * NH * KC * 2) return hipErrorInvalidValue;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16p_kernel<TM, KC, NH>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static LdsAttr lds_attr;
+    const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_bf16p_kernel<TM, KC, NH>), 160 * 1024);
     if (attr != hipSuccess) return attr;
     dim3 grid(p.m_tiles * (p.n_tiles / NH), p.transposed ? 8 : 1, p.ksplit);
     hipLaunchKernelGGL((conv_bf16p_kernel<TM, KC, NH>), grid, dim3(256), lds, stream, p, r_max);
@@ -1012,8 +1094,8 @@ static hipError_t launch_tm_k(const ConvParamsH& p, hipStream_t stream) {
     constexpr size_t lds = (size_t)2 * BM * KC * 2 + 2 * HBN * NH * KC * 2 + 2 * BM * sizeof(int) + EP_BYTES * NH;
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
     if (lds > 48 * 1024) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<TM, KC, HEAD, NH>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static LdsAttr lds_attr;
+        const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_bf16_kernel<TM, KC, HEAD, NH>), (int)lds);
         if (attr != hipSuccess) return attr;
     }
     dim3 grid(p.m_tiles * (p.n_tiles / NH), p.transposed ? 8 : 1, p.ksplit);

@@ -508,7 +508,7 @@ int conv_num_tiles() { return kNumTiles; }
 
 // ---- measured configurations -------------------------------------------------------------------
 // (tile, split-K) per layer shape, picked by Stereo2Voxel.autotune() on MI355X at the BASELINE batch
-// (32 pairs; profiles/r01_autotune.txt).  Keyed by PER-SAMPLE geometry only, so the split-K factor —
+// (32 pairs; the per-layer tables it printed are in profiles/r01_bench_stderr.txt).  Keyed by PER-SAMPLE geometry only, so the split-K factor —
 // which changes a sample's summation order — never depends on the batch a sample is computed in.
 // Shapes not listed fall back to the rules below.
 struct Tuned { int cin, cout, T, stride, S, transposed, tile, ksplit; };
@@ -588,10 +588,10 @@ static hipError_t launch_cfg(ConvParams p, hipStream_t stream) {
         p.m_tiles = (p.Cout + BM - 1) / BM;
         p.n_tiles = (p.n_end - p.n_begin + BN - 1) / BN;
         const size_t lds = (size_t)2 * GBK * (BM + BN) * sizeof(float);
-        if (lds > 48 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation
-            static const hipError_t attr = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(&conv_glds_kernel<WM, WN, TM, TN, VEC, HEAD>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 48 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation and device
+            static LdsAttr lds_attr;
+            const hipError_t attr = lds_attr.ensure(
+                reinterpret_cast<const void*>(&conv_glds_kernel<WM, WN, TM, TN, VEC, HEAD>), (int)lds);
             if (attr != hipSuccess) return attr;
         }
         dim3 grid(p.m_tiles * p.n_tiles, p.transposed ? 8 : 1, p.ksplit);

@@ -3,8 +3,25 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace s3r {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: remember per (kernel
+// instantiation, device), so a process that drives several devices raises the limit on each of them (a process-wide
+// "done once" flag left every device but the first at the 48 KiB default: a silent launch failure there).
+struct LdsAttr {
+    std::atomic<unsigned long long> done{0};          // bit d: raised on device d (devices >= 64: set every time)
+    hipError_t ensure(const void* fn, int bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64 && ((done.load(std::memory_order_relaxed) >> dev) & 1ull)) return hipSuccess;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess && dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_relaxed);
+        return e;
+    }
+};
 
 // Division of a non-negative int (< 2^31) by a launch-invariant divisor, as mulhi + add + shift (Granlund &
 // Montgomery): the position decodes of the conv kernels did ~10 integer divisions per thread, ~40 instructions each.
@@ -101,9 +118,11 @@ int conv_last_launch_count();     // kernel launches the calling thread's last l
 void conv_tile_dims(int tile_cfg, int* bm, int* bn);
 hipError_t launch_pack_conv(const float* w, float* wp, int Cin, int Cout, int CoutPad, int T, int transposed,
                             hipStream_t s);
-// y (N,32,Ho+2h,Wo+2h) <- stem conv of x (N,3,Hi,Wi); y_hs / y_cs / y_org describe the padded output
-hipError_t launch_stem(const float* x, const float* w, const float* scale, const float* shift, float* y,
-                       int N, int Hi, int Wi, int Ho, int Wo, int y_cs, int y_hs, int y_org, hipStream_t s);
+// y (N,32,Ho+2h,Wo+2h) <- stem conv of x (N,3,Hi,Wi); y_hs / y_cs / y_org describe the padded output.
+// Images [0, nsplit) are read from x, images [nsplit, N) from x2 (the left / right renders of a stereo batch live in
+// two tensors: no concatenation copy); nsplit = N, x2 = null: one tensor.
+hipError_t launch_stem(const float* x, const float* x2, int nsplit, const float* w, const float* scale, const float* shift,
+                       float* y, int N, int Hi, int Wi, int Ho, int Wo, int y_cs, int y_hs, int y_org, hipStream_t s);
 hipError_t launch_cost_volume(const float* fl, const float* fr, float* vol, int B, int C, int D, int H, int W,
                               int halo, hipStream_t s);
 hipError_t launch_pad_copy(const float* x, float* y, int64_t planes, int D, int H, int W, int hd, int hh, int hw,
@@ -123,8 +142,9 @@ int conv_bf16_pick_tm(const ConvParamsH& p);
 int conv_bf16_pick_ksplit(const ConvParamsH& p);
 int64_t conv_bf16_scratch_elems(const ConvParamsH& p, int tm);
 hipError_t launch_pack_bf16(const float* w, void* wp, int Cin, int Cout, int CoutPad, int T, int transposed, hipStream_t s);
-hipError_t launch_stem_bf16(const float* x, const float* wt, const float* scale, const float* shift, void* y, int N,
-                            int Hi, int Wi, int Ho, int Wo, int y_bs, int y_hs, int y_org, hipStream_t s);
+hipError_t launch_stem_bf16(const float* x, const float* x2, int nsplit, const float* wt, const float* scale,
+                            const float* shift, void* y, int N, int Hi, int Wi, int Ho, int Wo, int y_bs, int y_hs, int y_org,
+                            hipStream_t s);
 hipError_t launch_cost_volume_bf16(const void* fl, const void* fr, void* vol, int B, int C, int D, int H, int W, int halo,
                                    hipStream_t s);
 hipError_t launch_head_bf16(const void* x, const float* w, const float* scale, const float* shift, float* y, int C,

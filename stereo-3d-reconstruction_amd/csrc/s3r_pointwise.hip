@@ -19,7 +19,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // pixel, all 32 couts in registers, weights read through the scalar cache (wave-uniform), every
 // store a 256-byte coalesced row segment.
 //   wt: packed [27][32] (k-major, cout fastest)
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+//   images [0, nsplit) come from x, images [nsplit, N) from x2 (left / right renders: no concatenation copy)
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ x2, int nsplit,
+                                                   const float* __restrict__ wt,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    float* __restrict__ y, int N, int Hi, int Wi, int Ho, int Wo,
                                                    int y_cs, int y_hs, int y_org) {
@@ -31,7 +33,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     const int sp = (int)(gid - (long long)n * HWo);
     const int oh = sp / Wo, ow = sp - oh * Wo;
     const int ih0 = oh * 2 - 1, iw0 = ow * 2 - 1;
-    const float* __restrict__ xn = x + (size_t)n * 3 * Hi * Wi;
+    const float* __restrict__ xn = n < nsplit ? x + (size_t)n * 3 * Hi * Wi : x2 + (size_t)(n - nsplit) * 3 * Hi * Wi;
 
     // accumulators in pairs: the channel loop compiles to v_pk_fma_f32 (two exact fp32 FMAs per lane per instruction,
     // the weight pair straight from SGPRs) — half the VALU instructions of the scalar form, same bits
@@ -78,11 +80,12 @@ __global__ void pack_stem_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-hipError_t launch_stem(const float* x, const float* wt, const float* scale, const float* shift, float* y, int N,
-                       int Hi, int Wi, int Ho, int Wo, int y_cs, int y_hs, int y_org, hipStream_t s) {
+hipError_t launch_stem(const float* x, const float* x2, int nsplit, const float* wt, const float* scale, const float* shift,
+                       float* y, int N, int Hi, int Wi, int Ho, int Wo, int y_cs, int y_hs, int y_org, hipStream_t s) {
     const long long total = (long long)N * Ho * Wo;
-    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, wt, scale, shift, y,
-                       N, Hi, Wi, Ho, Wo, y_cs, y_hs, y_org);
+    if (!x2) { x2 = x; nsplit = N; }
+    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x2, nsplit, wt, scale, shift,
+                       y, N, Hi, Wi, Ho, Wo, y_cs, y_hs, y_org);
     return hipGetLastError();
 }
 
@@ -94,16 +97,19 @@ hipError_t launch_pack_stem(const float* w, float* wt, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // Cost volume: vol[b, c,   d, h, w] = L[b,c,h,w] - R[b,c,h,w-d]   (0 where w-d < 0)
 //              vol[b, C+c, d, h, w] = R[b,c,h,w] - L[b,c,h,w+d]   (0 where w+d >= W)
-// One workgroup per (b, c): both HxW planes are read from HBM exactly once into LDS, then the two
-// D*H*W output slabs are streamed out with 16-byte stores (4 consecutive w of one row), rows walked in
-// (d,h) order so consecutive lanes write consecutive HBM lines.  The volume may carry a zero halo
-// (`halo` elements on the d, h and w axes) for the 3D conv that consumes it; only the interior is
-// written.  Algorithmic bytes = 4*(2*H*W + 2*D*H*W) per (b,c); the kernel moves exactly that.
+// One workgroup per (b, c): both HxW planes are read from HBM exactly once into LDS, then the two output slabs
+// are streamed out with 16-byte stores.  The volume may carry a zero halo (`halo` elements on the d, h and w
+// axes) for the 3D conv that consumes it.  With a halo the interior rows are W-float segments inside (W+2h)-float
+// rows: written alone they leave a partial 128-byte line at almost every row end (2.7 TB/s, r01).  So the kernel
+// writes WHOLE padded planes d = halo .. halo+D-1 — halo rows and columns included, as the zeros they are — which
+// makes each slab ONE contiguous run of D*Hp*Wp floats: every store instruction covers whole lines.  (The halo
+// PLANES d < halo, d >= halo+D are never written: they keep the zeros of the buffer's one-time memset.)
+// Algorithmic bytes = 4*(2*H*W + 2*D*H*W) per (b,c); the kernel moves 4*(2*H*W + 2*D*Hp*Wp).
 typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte access
 
 __global__ __launch_bounds__(256) void cost_volume_kernel(const float* __restrict__ fl, const float* __restrict__ fr,
                                                           float* __restrict__ vol, int C, int D, int H, int W,
-                                                          int halo) {
+                                                          int halo, FastDiv dPlane, FastDiv dRow) {
     extern __shared__ __attribute__((aligned(16))) float cv_smem[];
     const int HW = H * W;
     float* sl = cv_smem;
@@ -117,49 +123,50 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(const float* __restric
         sr[i] = pr[i];
     }
     __syncthreads();
-    const int DHW = D * HW;
     const int Wp = W + 2 * halo, Hp = H + 2 * halo, Dp = D + 2 * halo;
-    const int hs = Wp, ds = Hp * Wp;
+    const int ds = Hp * Wp;
     const size_t cs = (size_t)Dp * ds;
-    const int org = halo * (ds + hs + 1);
-    float* __restrict__ ol = vol + ((size_t)b * 2 * C + c) * cs + org;
-    float* __restrict__ orr = vol + ((size_t)b * 2 * C + C + c) * cs + org;
-    if ((W & 3) == 0) {
-        const int nq = DHW >> 2;
-        for (int q = threadIdx.x; q < nq; q += 256) {
-            const int e = q << 2;
-            const int d = e / HW;
-            const int hw = e - d * HW;
-            const int hh = hw / W;
-            const int w0 = hw - hh * W;
-            v4f a, r;
+    const int run = D * ds;                              // floats of one slab's contiguous run (planes halo .. halo+D-1)
+    float* __restrict__ ol = vol + ((size_t)b * 2 * C + c) * cs + (size_t)halo * ds;
+    float* __restrict__ orr = vol + ((size_t)b * 2 * C + C + c) * cs + (size_t)halo * ds;
+    const int nq = run >> 2;
+    for (int q = threadIdx.x; q < nq; q += 256) {
+        const int e = q << 2;
+        int d = dPlane.div(e);                           // e / (Hp*Wp)
+        const int r = e - d * ds;
+        int hp = dRow.div(r);                            // r / Wp
+        int wp = r - hp * Wp;
+        v4f a, rr;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int w = w0 + k;
-                a[k] = (w >= d) ? sl[hw + k] - sr[hw + k - d] : 0.f;
-                r[k] = (w + d < W) ? sr[hw + k] - sl[hw + k + d] : 0.f;
-            }
-            const int o = d * ds + hh * hs + w0;
-            *reinterpret_cast<v4f_u*>(ol + o) = a;
-            *reinterpret_cast<v4f_u*>(orr + o) = r;
+        for (int k = 0; k < 4; ++k) {
+            const int h = hp - halo, w = wp - halo;
+            const bool in = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+            const int hw = h * W + w;
+            a[k] = (in && w >= d) ? sl[hw] - sr[hw - d] : 0.f;
+            rr[k] = (in && w + d < W) ? sr[hw] - sl[hw + d] : 0.f;
+            if (++wp == Wp) { wp = 0; if (++hp == Hp) { hp = 0; ++d; } }
         }
-    } else {
-        for (int e = threadIdx.x; e < DHW; e += 256) {
-            const int d = e / HW;
-            const int hw = e - d * HW;
-            const int hh = hw / W;
-            const int w = hw - hh * W;
-            const int o = d * ds + hh * hs + w;
-            ol[o] = (w >= d) ? sl[hw] - sr[hw - d] : 0.f;
-            orr[o] = (w + d < W) ? sr[hw] - sl[hw + d] : 0.f;
-        }
+        *reinterpret_cast<v4f_u*>(ol + e) = a;
+        *reinterpret_cast<v4f_u*>(orr + e) = rr;
+    }
+    for (int e = (nq << 2) + threadIdx.x; e < run; e += 256) {      // run % 4 != 0 (never at the network's shapes)
+        const int d = dPlane.div(e);
+        const int r = e - d * ds;
+        const int hp = dRow.div(r);
+        const int h = hp - halo, w = r - hp * Wp - halo;
+        const bool in = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+        const int hw = h * W + w;
+        ol[e] = (in && w >= d) ? sl[hw] - sr[hw - d] : 0.f;
+        orr[e] = (in && w + d < W) ? sr[hw] - sl[hw + d] : 0.f;
     }
 }
 
 hipError_t launch_cost_volume(const float* fl, const float* fr, float* vol, int B, int C, int D, int H, int W,
                               int halo, hipStream_t s) {
     const size_t lds = (size_t)2 * H * W * sizeof(float);
-    hipLaunchKernelGGL(cost_volume_kernel, dim3(B * C), dim3(256), lds, s, fl, fr, vol, C, D, H, W, halo);
+    const int Wp = W + 2 * halo, Hp = H + 2 * halo;
+    hipLaunchKernelGGL(cost_volume_kernel, dim3(B * C), dim3(256), lds, s, fl, fr, vol, C, D, H, W, halo,
+                       FastDiv((unsigned)(Hp * Wp)), FastDiv((unsigned)Wp));
     return hipGetLastError();
 }
 

@@ -19,23 +19,30 @@ __device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(f
 
 // ------------------------------------------------------------------------------------------------
 // Stem: Conv2d(3 -> 32, k3, s2, p1) + affine + ReLU, fp32 NCHW in, bf16 NHWC (halo-padded) out.
-// One thread per output pixel, 32 couts in registers -> ONE 64-byte contiguous store per thread.
-__global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+// One thread per output pixel, 32 couts in registers = 64 bytes of the channels-last output.  Stored as they
+// stand, a wave's store instruction would put 16 bytes into each of 64 pixels (one instruction touching 32
+// lines: store-issue bound, 2.7 TB/s in r01); instead the workgroup's 256 x 64 B go through LDS and every store
+// instruction writes 16 CONSECUTIVE pixels = 1 KiB contiguous (whole 128-byte lines).
+//   images [0, nsplit) come from x, images [nsplit, N) from x2 (left / right renders: no concatenation copy)
+__global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict__ x, const float* __restrict__ x2, int nsplit,
+                                                        const float* __restrict__ wt,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         unsigned short* __restrict__ y, int N, int Hi, int Wi, int Ho, int Wo,
                                                         int y_bs, int y_hs, int y_org) {
+    __shared__ __attribute__((aligned(16))) v4u st[256 * 4];      // [pixel][4 x 16 B], part q at slot q ^ ((pixel >> 1) & 3)
+    __shared__ int yo[256];                                        // output element offset of each pixel, -1 = none
     const int HWo = Ho * Wo;
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= (long long)N * HWo) return;
-    const int n = (int)(gid / HWo);
-    const int sp = (int)(gid - (long long)n * HWo);
+    const int tid = threadIdx.x;
+    const long long gid = (long long)blockIdx.x * 256 + tid;
+    const bool live = gid < (long long)N * HWo;
+    const long long g = live ? gid : (long long)N * HWo - 1;
+    const int n = (int)(g / HWo);
+    const int sp = (int)(g - (long long)n * HWo);
     const int oh = sp / Wo, ow = sp - oh * Wo;
     const int ih0 = oh * 2 - 1, iw0 = ow * 2 - 1;
-    const float* __restrict__ xn = x + (size_t)n * 3 * Hi * Wi;
+    const float* __restrict__ xn = n < nsplit ? x + (size_t)n * 3 * Hi * Wi : x2 + (size_t)(n - nsplit) * 3 * Hi * Wi;
     // accumulators in pairs: the channel loop compiles to v_pk_fma_f32 (two exact fp32 FMAs per lane per instruction,
-    // the weight pair straight from SGPRs) — half the VALU instructions of the scalar form, same bits.  (The kernel is
-    // latency-bound on its stride-2 input gathers, not VALU-bound: 0.26 ms either way at B = 256; staging the 33 x 33
-    // input patch of a 16 x 16 output tile through LDS measured 0.28 ms.)
+    // the weight pair straight from SGPRs) — half the VALU instructions of the scalar form, same bits
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 acc2[16];
 #pragma unroll
@@ -63,7 +70,8 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
     float acc[32];
 #pragma unroll
     for (int c = 0; c < 16; ++c) { acc[2 * c] = acc2[c].x; acc[2 * c + 1] = acc2[c].y; }
-    unsigned* __restrict__ yo = reinterpret_cast<unsigned*>(y + (size_t)n * y_bs + y_org + ((size_t)oh * y_hs + (size_t)ow * 32));
+    yo[tid] = live ? (int)((size_t)n * y_bs + y_org + ((size_t)oh * y_hs + (size_t)ow * 32)) : -1;
+    const int sw = (tid >> 1) & 3;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         v4u t;
@@ -72,15 +80,27 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
             const int c = q * 8 + k * 2;
             t[k] = pack2(fmaxf(fmaf(acc[c], scale[c], shift[c]), 0.f), fmaxf(fmaf(acc[c + 1], scale[c + 1], shift[c + 1]), 0.f));
         }
-        *reinterpret_cast<v4u*>(yo + q * 4) = t;       // 64-byte rows: 16-byte aligned
+        st[tid * 4 + (q ^ sw)] = t;
+    }
+    __syncthreads();
+    // lane l of wave w stores part l & 3 of pixel 64 w + 16 j + (l >> 2): 16 consecutive pixels per instruction
+    const int lane = tid & 63, wbase = tid & ~63;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pix = wbase + 16 * j + (lane >> 2), q = lane & 3;
+        const int off = yo[pix];
+        const v4u t = st[pix * 4 + (q ^ ((pix >> 1) & 3))];
+        if (off >= 0) *reinterpret_cast<v4u*>(y + (size_t)off + q * 8) = t;       // 64-byte pixels: 16-byte aligned
     }
 }
 
-hipError_t launch_stem_bf16(const float* x, const float* wt, const float* scale, const float* shift, void* y, int N,
-                            int Hi, int Wi, int Ho, int Wo, int y_bs, int y_hs, int y_org, hipStream_t s) {
+hipError_t launch_stem_bf16(const float* x, const float* x2, int nsplit, const float* wt, const float* scale,
+                            const float* shift, void* y, int N, int Hi, int Wi, int Ho, int Wo, int y_bs, int y_hs, int y_org,
+                            hipStream_t s) {
     const long long total = (long long)N * Ho * Wo;
-    hipLaunchKernelGGL(stem_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, wt, scale, shift,
-                       reinterpret_cast<unsigned short*>(y), N, Hi, Wi, Ho, Wo, y_bs, y_hs, y_org);
+    if (!x2) { x2 = x; nsplit = N; }
+    hipLaunchKernelGGL(stem_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x2, nsplit, wt, scale,
+                       shift, reinterpret_cast<unsigned short*>(y), N, Hi, Wi, Ho, Wo, y_bs, y_hs, y_org);
     return hipGetLastError();
 }
 
@@ -88,46 +108,65 @@ hipError_t launch_stem_bf16(const float* x, const float* wt, const float* scale,
 // Cost volume on channels-last bf16: fl, fr (B,H,W,C) -> vol (B, D+2h, H+2h, W+2h, 2C), interior only:
 //   vol[b,d,h,w, c]     = L[b,h,w,c] - R[b,h,w-d,c]   (0 where w-d < 0)
 //   vol[b,d,h,w, C + c] = R[b,h,w,c] - L[b,h,w+d,c]   (0 where w+d >= W)
-// One thread per (b,d,h,w, 8-channel group of the 2C outputs): two 16-byte loads, one 16-byte store,
-// every access contiguous across the lanes of a position.  The differences are formed in fp32 and rounded
-// to bf16 once.  Re-reads of the (tiny) feature maps across d are L2 hits; HBM sees them once.
+// One workgroup per (b, h) feature-row pair: both rows (W x C bf16 each) go to LDS once; a thread owns one
+// 16-byte group (8 channels) of one output position, keeps its reference operand in registers and walks the D
+// disparities: one ds_read_b128 of the shifted operand + one 16-byte store per step, no address arithmetic but an
+// add (r01's one-thread-per-output form spent its time on five integer divisions per 16 bytes: VALU-bound at
+// 3.3 TB/s).  A wave's store covers 8 consecutive positions = 1 KiB contiguous; an interior row of W positions
+// is W whole 128-byte lines (2C = 64), so interior-only writes leave no partial line.  The differences are formed
+// in fp32 and rounded to bf16 once.
 __global__ __launch_bounds__(256) void cost_volume_bf16_kernel(const unsigned short* __restrict__ fl,
                                                                const unsigned short* __restrict__ fr,
-                                                               unsigned short* __restrict__ vol, int B, int C, int D,
+                                                               unsigned short* __restrict__ vol, int C, int D,
                                                                int H, int W, int halo) {
-    const int G = (2 * C) >> 3;                       // 16-byte groups per output position
-    const long long total = (long long)B * D * H * W * G;
+    extern __shared__ __attribute__((aligned(16))) v4u cvh[];      // [2][W][C/8]
+    const int CG = C >> 3;                            // 16-byte groups per position per view
+    const int G = 2 * CG;                             // ... per output position
+    const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
+    v4u* sl = cvh;
+    v4u* sr = cvh + W * CG;
+    const v4u* __restrict__ pl = reinterpret_cast<const v4u*>(fl + ((size_t)(b * H + hh) * W) * C);
+    const v4u* __restrict__ pr = reinterpret_cast<const v4u*>(fr + ((size_t)(b * H + hh) * W) * C);
+    for (int i = threadIdx.x; i < W * CG; i += 256) {
+        sl[i] = pl[i];
+        sr[i] = pr[i];
+    }
+    __syncthreads();
     const int Wp = W + 2 * halo, Hp = H + 2 * halo, Dp = D + 2 * halo;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int g = (int)(i % G);
-        long long r = i / G;
-        const int w = (int)(r % W); r /= W;
-        const int hh = (int)(r % H); r /= H;
-        const int d = (int)(r % D);
-        const int b = (int)(r / D);
-        const bool right_ref = g >= (G >> 1);
-        const int cg = (right_ref ? g - (G >> 1) : g) * 8;
-        const int ws = right_ref ? w + d : w - d;     // the shifted operand's column
-        v4u out = {0u, 0u, 0u, 0u};
-        if (ws >= 0 && ws < W) {
-            const unsigned short* pa = (right_ref ? fr : fl) + (((size_t)b * H + hh) * W + w) * C + cg;
-            const unsigned short* pb = (right_ref ? fl : fr) + (((size_t)b * H + hh) * W + ws) * C + cg;
-            const v4u a = *reinterpret_cast<const v4u*>(pa), s = *reinterpret_cast<const v4u*>(pb);
+    const size_t dstride = (size_t)Hp * Wp * 2 * C;
+    for (int i = threadIdx.x; i < W * G; i += 256) {              // one pass at the network's shape (28 x 8 = 224)
+        const int w = i / G, g = i - w * G;
+        const bool right_ref = g >= CG;
+        const int cg = right_ref ? g - CG : g;
+        const v4u a = (right_ref ? sr : sl)[w * CG + cg];
+        const v4u* m = (right_ref ? sl : sr) + cg;
+        const int step = right_ref ? CG : -CG;
+        unsigned short* po = vol + ((((size_t)b * Dp + halo) * Hp + hh + halo) * Wp + w + halo) * (2 * C) + g * 8;
+        int ws = w, mi = w * CG;
+        const int dws = right_ref ? 1 : -1;
+#pragma unroll 4
+        for (int d = 0; d < D; ++d) {
+            v4u out = {0u, 0u, 0u, 0u};
+            if (ws >= 0 && ws < W) {
+                const v4u sft = m[mi];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) out[k] = pack2(bf_lo(a[k]) - bf_lo(s[k]), bf_hi(a[k]) - bf_hi(s[k]));
+                for (int k = 0; k < 4; ++k) out[k] = pack2(bf_lo(a[k]) - bf_lo(sft[k]), bf_hi(a[k]) - bf_hi(sft[k]));
+            }
+            *reinterpret_cast<v4u*>(po) = out;
+            po += dstride;
+            ws += dws;
+            mi += step;
         }
-        unsigned short* po = vol + ((((size_t)b * Dp + d + halo) * Hp + hh + halo) * Wp + w + halo) * (2 * C) + g * 8;
-        *reinterpret_cast<v4u*>(po) = out;
     }
 }
 
 hipError_t launch_cost_volume_bf16(const void* fl, const void* fr, void* vol, int B, int C, int D, int H, int W, int halo,
                                    hipStream_t s) {
-    const long long total = (long long)B * D * H * W * ((2 * C) >> 3);
-    const long long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(cost_volume_bf16_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s,
+    const size_t lds = (size_t)2 * W * (C >> 3) * 16;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cost_volume_bf16_kernel, dim3((unsigned)(B * H)), dim3(256), lds, s,
                        reinterpret_cast<const unsigned short*>(fl), reinterpret_cast<const unsigned short*>(fr),
-                       reinterpret_cast<unsigned short*>(vol), B, C, D, H, W, halo);
+                       reinterpret_cast<unsigned short*>(vol), C, D, H, W, halo);
     return hipGetLastError();
 }
 

@@ -29,6 +29,23 @@ def _to_channels_last_physical(x: torch.Tensor) -> torch.Tensor:
     return x.permute(0, *range(2, nd), 1).contiguous()
 
 
+def _check_input_cl(x: torch.Tensor, name: str, shape_tail: Sequence[int], dtype=torch.bfloat16) -> torch.Tensor:
+    """bf16 hand-off: validate a LOGICAL (B,C,...) tensor and return its PHYSICAL channels-last (B,...,C) form.  A
+    tensor that already is channels-last in memory (what the bf16 modules hand each other: `_to_logical` views, also
+    sliced along the batch) passes through as a view — no kernel runs; anything else is copied once."""
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not x.is_cuda:
+        raise RuntimeError(f"{name} must live on a HIP device (got {x.device}); this path has no CPU fallback")
+    if x.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype} (got {x.dtype})")
+    if tuple(x.shape[1:]) != tuple(shape_tail):
+        raise RuntimeError(f"{name} must have shape (B, {', '.join(map(str, shape_tail))}), got {tuple(x.shape)}")
+    nd = x.dim()
+    phys = x.permute(0, *range(2, nd), 1)
+    return phys if phys.is_contiguous() else phys.contiguous()
+
+
 def _to_logical(x: torch.Tensor) -> torch.Tensor:
     """physical channels-last (B,...,C) -> logical (B,C,...) view (torch's channels_last convention)."""
     nd = x.dim()
@@ -213,11 +230,13 @@ class _HipChain(nn.Module):
         return self.precision == "bf16" and not (l.cout == 1 and l.k == 1)      # the occupancy head writes fp32
 
     @torch.no_grad()
-    def _run(self, x: torch.Tensor, upto: Optional[str] = None, in_halo: int = 0) -> torch.Tensor:
+    def _run(self, x: torch.Tensor, upto: Optional[str] = None, in_halo: int = 0,
+             x2: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x: the chain input; with in_halo > 0 it is a halo-padded buffer (B, C, n+2h, ...) whose border
-        is zero (internal hand-off from the cost-volume kernel), otherwise a plain contiguous tensor."""
+        is zero (internal hand-off from the cost-volume kernel), otherwise a plain contiguous tensor.
+        x2 (encoder only): a second tensor of as many images — the chain runs over x's images, then x2's."""
         lib = _lib.load()
-        device, batch = x.device, x.shape[0]
+        device, batch = x.device, x.shape[0] + (x2.shape[0] if x2 is not None else 0)
         if batch == 0:                 # same dtype / layout contract as a non-empty batch
             n0 = len(self._layers) if upto is None else self.names.index(upto) + 1
             shape = self._out_shape(0, n0)
@@ -231,10 +250,23 @@ class _HipChain(nn.Module):
         else:
             y = torch.empty(shape, dtype=torch.float32, device=device)
         need = _lib.check(lib.s3r_chain_workspace_elems(arr, n), "workspace query")
-        ws, fresh = self._ws.get(device, need, (batch, n, in_halo))
-        entry = getattr(lib, self._entry if upto is None else "s3r_chain_forward")
-        _lib.check(entry(arr, n, x.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), fresh, _stream_ptr(device)),
-                   type(self).__name__)
+        # the arena's layout is the library's PLAN for this chain: batch, depth, input halo and every layer's
+        # requested (tile, split-K) — those decide head fusion and where the split-K scratch starts.  Any change
+        # re-zeroes the arena (fresh), so no region is ever read with another plan's bytes in its halo.
+        cfg = tuple((arr[i].desc.tile, arr[i].desc.ksplit) for i in range(n))
+        ws, fresh = self._ws.get(device, need, (batch, n, in_halo, need, cfg))
+        if x2 is not None:
+            if upto is not None or self._entry != "s3r_encoder_forward":
+                raise RuntimeError("a (left, right) tensor pair is an input of the whole encoder only")
+            _lib.check(lib.s3r_encoder_forward(arr, n, x.data_ptr(), x2.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(),
+                                               fresh, _stream_ptr(device)), type(self).__name__)
+        elif upto is None and self._entry == "s3r_encoder_forward":
+            _lib.check(lib.s3r_encoder_forward(arr, n, x.data_ptr(), None, y.data_ptr(), ws.data_ptr(), ws.numel(), fresh,
+                                               _stream_ptr(device)), type(self).__name__)
+        else:
+            entry = getattr(lib, self._entry if upto is None else "s3r_chain_forward")
+            _lib.check(entry(arr, n, x.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), fresh, _stream_ptr(device)),
+                       type(self).__name__)
         return _to_logical(y) if self._out_is_bf16(n) else y
 
 
@@ -292,7 +324,8 @@ class _HipChain(nn.Module):
 class Encoder(_HipChain):
     """Shared-weight 2D conv tower: (N,3,224,224) renders -> (N,32,28,28) features.
 
-    Call it on `torch.cat([left, right])`; the same weights serve both views.
+    The same weights serve both views: `forward_pair(left, right)` runs the tower once over both tensors (what
+    Stereo2Voxel / Stereo2Point call); `forward(images)` takes any single batch of renders.
     """
     _entry = "s3r_encoder_forward"
 
@@ -304,6 +337,18 @@ class Encoder(_HipChain):
         `upto`: stop after the named layer (stage-by-stage checks), as on Decoder.forward."""
         x = _check_input(images, "images", (3, spec.IMG_HW, spec.IMG_HW))
         return self._run(x, upto)
+
+    def forward_pair(self, left: torch.Tensor, right: torch.Tensor) -> torch.Tensor:
+        """The tower over the B left and the B right renders in ONE pass, read from their two tensors (the first
+        kernel picks its source by image index): features (2B,32,28,28), left batch first.  Equal, bit for bit, to
+        `forward(torch.cat([left, right]))` — without the concatenation copy."""
+        left = _check_input(left, "left", (3, spec.IMG_HW, spec.IMG_HW))
+        right = _check_input(right, "right", (3, spec.IMG_HW, spec.IMG_HW))
+        if left.shape[0] != right.shape[0] or left.device != right.device:
+            raise RuntimeError("left and right must be two batches of one size on one device")
+        if left.shape[0] == 0:
+            return self._run(left)
+        return self._run(left, None, 0, right)
 
 
 class CostVolume(nn.Module):
@@ -319,8 +364,8 @@ class CostVolume(nn.Module):
         """bf16 path: logical (B,C,H,W) channels_last features -> physical (B,D+2h,H+2h,W+2h,2C) volume."""
         if feat_left.shape != feat_right.shape or feat_left.dim() != 4:
             raise RuntimeError("feature maps must both be (B,C,H,W)")
-        fl = _to_channels_last_physical(_check_input(feat_left, "feat_left", feat_left.shape[1:], torch.bfloat16))
-        fr = _to_channels_last_physical(_check_input(feat_right, "feat_right", feat_left.shape[1:], torch.bfloat16))
+        fl = _check_input_cl(feat_left, "feat_left", feat_left.shape[1:])
+        fr = _check_input_cl(feat_right, "feat_right", feat_left.shape[1:])
         B, H, W, Cc = fl.shape
         shape = (B, self.max_disp + 2 * halo, H + 2 * halo, W + 2 * halo, 2 * Cc)
         if resident:
@@ -388,7 +433,7 @@ class Decoder(_HipChain):
     def forward(self, volume: torch.Tensor, upto: Optional[str] = None) -> torch.Tensor:
         tail = (2 * spec.FEAT_C, spec.MAX_DISP, spec.FEAT_HW, spec.FEAT_HW)
         if self.precision == "bf16":
-            x = _to_channels_last_physical(_check_input(volume, "volume", tail, torch.bfloat16))
+            x = _check_input_cl(volume, "volume", tail)
         else:
             x = _check_input(volume, "volume", tail)
         y = self._run(x, upto)
@@ -414,7 +459,7 @@ class VolumeEncoder(_HipChain):
     def forward(self, volume: torch.Tensor) -> torch.Tensor:
         tail = (2 * spec.FEAT_C, spec.MAX_DISP, spec.FEAT_HW, spec.FEAT_HW)
         if self.precision == "bf16":
-            return self._run(_to_channels_last_physical(_check_input(volume, "volume", tail, torch.bfloat16)))
+            return self._run(_check_input_cl(volume, "volume", tail))
         return self._run(_check_input(volume, "volume", tail))
 
     def forward_padded(self, volume_padded: torch.Tensor, halo: int = 1) -> torch.Tensor:
@@ -453,7 +498,7 @@ class _DisparityMixin:
         for s in range(0, max(left.shape[0], 1), MAX_CHUNK):
             l, r = left[s:s + MAX_CHUNK], right[s:s + MAX_CHUNK]
             b = l.shape[0]
-            feats = self.encoder(torch.cat([l, r], 0)).float().contiguous()     # (bf16 path: back to fp32 NCHW)
+            feats = self.encoder.forward_pair(l, r).float().contiguous()        # (bf16 path: back to fp32 NCHW)
             dl, dr = disparity_wta(feats[:b], feats[b:], self.cost_volume.max_disp)
             dls.append(dl), drs.append(dr)
         dl = dls[0] if len(dls) == 1 else torch.cat(dls, 0)
@@ -492,7 +537,7 @@ class Stereo2Voxel(_DisparityMixin, nn.Module):
         for s in range(0, max(left.shape[0], 1), MAX_CHUNK):
             l, r = left[s:s + MAX_CHUNK], right[s:s + MAX_CHUNK]
             b = l.shape[0]
-            feats = self.encoder(torch.cat([l, r], 0))
+            feats = self.encoder.forward_pair(l, r)          # (2b,32,28,28): left batch, then right batch
             vol = self.cost_volume.forward_padded(feats[:b], feats[b:])
             outs.append(self.decoder.forward_padded(vol))
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
@@ -502,7 +547,7 @@ class Stereo2Voxel(_DisparityMixin, nn.Module):
         """Measure-and-pick the per-layer kernel configuration on a representative batch (see
         _HipChain.autotune).  Returns {layer: {tile, ksplit, ms}}."""
         b = left.shape[0]
-        images = torch.cat([left, right], 0)
+        images = torch.cat([left, right], 0)                 # (tuning only: one tensor for _HipChain.autotune)
         chosen = dict(self.encoder.autotune(images, rounds=rounds, log=log))
         feats = self.encoder(images)
         vol = self.cost_volume.forward_padded(feats[:b], feats[b:])
@@ -540,7 +585,7 @@ class Stereo2Point(_DisparityMixin, nn.Module):
         for s in range(0, max(left.shape[0], 1), MAX_CHUNK):
             l, r = left[s:s + MAX_CHUNK], right[s:s + MAX_CHUNK]
             b = l.shape[0]
-            feats = self.encoder(torch.cat([l, r], 0))
+            feats = self.encoder.forward_pair(l, r)
             vol = self.cost_volume.forward_padded(feats[:b], feats[b:])
             latent = self.decoder.forward_padded(vol)
             if latent.dtype != torch.float32:                      # bf16 channels-last view -> fp32 (B,512,4,4,4)

@@ -26,7 +26,7 @@ def test_header_symbols_all_exported(s3r, lib):
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.s3r_abi_version() == 2
+    assert lib.s3r_abi_version() == 3
 
 
 def test_struct_layouts_match_header(s3r):
@@ -141,6 +141,37 @@ def test_invalid_arguments_are_reported_not_crashed(s3r, lib):
     assert lib.s3r_disparity_wta(one, one, one, one, 1, 8, 2, 8, 0, None) == -1
     assert lib.s3r_disparity_epe(None, None, None, None, 1, 1, None) == -1
     assert lib.s3r_disparity_epe(one, one, one, one, 0, 16, None) == -1
+
+
+def test_out_size_validates_instead_of_dividing_by_zero(s3r, lib):
+    """s3r_conv_out_size on a descriptor with stride 0 used to die with SIGFPE: every entry point
+    returns a negative status instead."""
+    spec = s3r.arch_spec
+    d = _desc(s3r, spec.Layer("x", "conv2d", 16, 8, 3, 1, 1), 1, 8)
+    assert lib.s3r_conv_out_size(C.byref(d)) == 8
+    for field, value in (("stride", 0), ("k", 0), ("in_size", 0), ("pad", -1), ("op", 7)):
+        bad = _desc(s3r, spec.Layer("x", "conv2d", 16, 8, 3, 1, 1), 1, 8)
+        setattr(bad, field, value)
+        assert lib.s3r_conv_out_size(C.byref(bad)) == -1, field
+    assert lib.s3r_conv_out_size(None) == -1
+    tiny = _desc(s3r, spec.Layer("x", "conv2d", 16, 8, 5, 1, 0), 1, 3)        # kernel larger than the input
+    assert lib.s3r_conv_out_size(C.byref(tiny)) == -1
+
+
+def test_encoder_entry_takes_a_left_right_pair(s3r, lib):
+    """ABI v3: s3r_encoder_forward(layers, n, images_left, images_right, ...) — argument validation only (no GPU)."""
+    spec = s3r.arch_spec
+    rows = spec.stage_table("encoder")
+    arr = (s3r._lib.Layer * len(rows))()
+    for i, (l, n, m) in enumerate(rows):
+        arr[i].desc = _desc(s3r, l, 3, n)                     # odd image count with two tensors: refused
+    one = C.c_void_p(16)
+    assert lib.s3r_encoder_forward(arr, len(rows), one, one, one, one, 1 << 40, 0, None) == -1
+    assert b"even image count" in lib.s3r_last_error()
+    dec = spec.stage_table("decoder")
+    arr2 = (s3r._lib.Layer * 1)()
+    arr2[0].desc = _desc(s3r, dec[0][0], 2, dec[0][1])
+    assert lib.s3r_encoder_forward(arr2, 1, one, one, one, one, 1 << 40, 0, None) == -1     # not an encoder chain
 
 
 def test_missing_library_fails_loudly(s3r, monkeypatch, tmp_path):

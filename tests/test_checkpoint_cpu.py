@@ -68,17 +68,12 @@ def test_suggest_keymap_from_order_and_shape(s3r, tmp_path):
         nk = k.replace("encoder.", "feat_net.").replace("decoder.", "vol_net.").replace(".conv.", ".c.").replace(".bn.", ".norm.")
         renamed["module." + nk] = v.clone()
     km = s3r.checkpoint.suggest_keymap({"state_dict": renamed}, model)
-    assert km["feat_net.e1.c.weight"] == "encoder.e1.conv.weight" and all(not k.endswith("num_batches_tracked") for k in km)
+    assert km["feat_net.e1.c.weight"] == "encoder.e1.conv.weight"
+    # BatchNorm's step counters are paired in order as well (one per BatchNorm on both sides): the suggested map is complete
+    assert km["feat_net.e1.norm.num_batches_tracked"] == "encoder.e1.bn.num_batches_tracked"
     assert s3r.checkpoint.suggest_keymap(model.state_dict(), model) == {}
     ck, kmf = tmp_path / "c.pth", tmp_path / "km.json"
     torch.save({"state_dict": renamed}, ck)
-    # counters ride along under the same renaming rule: extend the suggested map with prefix entries
-    km.update({"feat_net.": "encoder.", "vol_net.": "decoder."})
-    full = {}
-    for k in s3r.checkpoint.unwrap({"state_dict": renamed}):
-        if k.endswith("num_batches_tracked"):
-            full[k] = k.replace("feat_net.", "encoder.").replace("vol_net.", "decoder.").replace(".norm.", ".bn.")
-    km.update(full)
     kmf.write_text(json.dumps(km))
     fresh = s3r.Stereo2Voxel()
     missing, unexpected = s3r.checkpoint.load_checkpoint(fresh, str(ck), json.loads(kmf.read_text()))
@@ -90,3 +85,27 @@ def test_suggest_keymap_from_order_and_shape(s3r, tmp_path):
     import pytest
     with pytest.raises(ValueError, match="pairing breaks"):
         s3r.checkpoint.suggest_keymap(other, model)
+
+
+def test_renamed_batchnorm_counters_do_not_break_the_load(s3r, tmp_path):
+    """A checkpoint whose every key is renamed — BatchNorm's num_batches_tracked included — loads through the map
+    suggest_keymap derives (found by the GPU test of the `.pth` row against the oracle, round 2); counters that keep a
+    foreign name, or are absent, are not a mismatch either (they play no part in an eval-mode forward)."""
+    m = s3r.Stereo2Voxel()
+    sd = s3r.seeded_state_dict(m, 3)
+    foreign = {"module." + k.replace("encoder.", "feat.").replace(".bn.", ".norm."): v for k, v in sd.items()}
+    assert any(k.endswith("norm.num_batches_tracked") for k in foreign)
+    path = tmp_path / "renamed.pth"
+    torch.save({"network": foreign}, path)
+    keymap = s3r.checkpoint.suggest_keymap(torch.load(path, weights_only=True), m)
+    assert keymap["feat.e1.norm.num_batches_tracked"] == "encoder.e1.bn.num_batches_tracked"
+    m2 = s3r.Stereo2Voxel()
+    assert s3r.checkpoint.load_checkpoint(m2, str(path), keymap) == ([], [])
+    assert all(torch.equal(v, sd[k]) for k, v in m2.state_dict().items())
+    weights_only = {k: v for k, v in keymap.items() if not k.endswith("num_batches_tracked")}
+    m3 = s3r.Stereo2Voxel()
+    assert s3r.checkpoint.load_checkpoint(m3, str(path), weights_only) == ([], [])      # counters left unmapped
+    no_counters = {k: v for k, v in foreign.items() if not k.endswith("num_batches_tracked")}
+    torch.save(no_counters, path)
+    m4 = s3r.Stereo2Voxel()
+    assert s3r.checkpoint.load_checkpoint(m4, str(path), weights_only) == ([], [])      # counters absent

@@ -196,6 +196,26 @@ def test_stereo2voxel_vs_golden(s3r, models, golden_dir):
     assert rel_l2(feats, torch.from_numpy(z["features"])) < 1e-5
 
 
+def test_encoder_pair_entry_equals_the_concatenated_batch(s3r, models):
+    """s3r_encoder_forward(left, right): the tower reads the two render tensors in place (no torch.cat inside the
+    forward): bit for bit the features of the concatenated batch, also when the two tensors are far apart in memory."""
+    hip, _ = models
+    left, right = s3r.synthetic_pairs(3, seed=41)
+    left, right = left.to(DEV), right.to(DEV)
+    spacer = torch.empty(1 << 20, device=DEV)                # (keeps the two allocations from being neighbours)
+    right2 = right.clone()
+    want = hip.encoder(torch.cat([left, right]))
+    assert torch.equal(hip.encoder.forward_pair(left, right2), want)
+    assert hip.encoder.forward_pair(left[:0], right[:0]).shape == (0, 32, 28, 28)
+    with pytest.raises(RuntimeError):
+        hip.encoder.forward_pair(left, right[:2])
+    bf = s3r.Stereo2Voxel(precision="bf16")
+    bf.load_state_dict(hip.state_dict())
+    bf.to(DEV)
+    assert torch.equal(bf.encoder.forward_pair(left, right2), bf.encoder(torch.cat([left, right])))
+    del spacer
+
+
 def test_stage_by_stage_vs_oracle(s3r, oracle, models):
     hip, ref = models
     left, right = s3r.synthetic_pairs(2, seed=5)
@@ -324,6 +344,50 @@ def test_stereo2point_vs_oracle(s3r, oracle):
     l3, r3 = s3r.synthetic_pairs(3, seed=6)
     got3 = hip(l3.to(DEV), r3.to(DEV))
     assert torch.equal(hip(l3[2:3].to(DEV), r3[2:3].to(DEV))[0], got3[2])
+
+
+def test_stereo2point_vs_golden_points(s3r, golden_dir):
+    """The committed Stereo2Point fixture (tests/golden/make_golden.py: oracle, seed 1, pairs seed 2) on the GPU."""
+    z = np.load(f"{golden_dir}/s2p_chamfer.npz")
+    hip = s3r.Stereo2Point()
+    s3r.seed_module(hip, 1)
+    hip.to(DEV)
+    left, right = s3r.synthetic_pairs(2, seed=2)
+    got = hip(left.to(DEV), right.to(DEV)).cpu()
+    assert rel_l2(got, torch.from_numpy(z["points"])) < 1e-5
+
+
+def test_stereo2point_and_chamfer_at_baseline_size(s3r, oracle):
+    """BASELINE.json configs[3] at its stated size: Stereo2Point forward at B = 32 + Chamfer distance between
+    (32, 2048, 3) clouds.  Two samples against the oracle; the rest through size-independent properties (a
+    sample's cloud does not depend on its batch; Chamfer is symmetric under swapping the clouds, zero against
+    itself, and its indices reproduce its distances)."""
+    hip = s3r.Stereo2Point()
+    s3r.seed_module(hip, 4)
+    ref = oracle.OracleStereo2Point().eval()
+    ref.load_state_dict(hip.state_dict())
+    hip.to(DEV)
+    B = 32
+    left, right = s3r.synthetic_pairs(B, seed=61)
+    pts = hip(left.to(DEV), right.to(DEV))
+    assert pts.shape == (B, 2048, 3)
+    with torch.no_grad():
+        want = ref(left[[0, 31]], right[[0, 31]])
+    assert rel_l2(pts[[0, 31]].cpu(), want) < 1e-5
+    assert torch.equal(hip(left[17:18].to(DEV), right[17:18].to(DEV))[0], pts[17])
+    gt = (torch.rand(B, 2048, 3, generator=torch.Generator().manual_seed(9)) - 0.5).to(DEV)
+    d1, d2, i1, i2 = s3r.chamfer_distance(pts, gt)
+    for k in (3, 30):                                         # two samples against the oracle, bit for bit
+        w1, w2, wi1, wi2 = oracle.chamfer_distance(pts[k:k + 1].cpu(), gt[k:k + 1].cpu())
+        assert torch.equal(d1[k].cpu(), w1[0]) and torch.equal(d2[k].cpu(), w2[0])
+        assert torch.equal(i1[k].cpu().long(), wi1[0].long()) and torch.equal(i2[k].cpu().long(), wi2[0].long())
+    e1, e2, j1, j2 = s3r.chamfer_distance(gt, pts)            # swapping the clouds swaps the outputs
+    assert torch.equal(e1, d2) and torch.equal(e2, d1) and torch.equal(j1, i2) and torch.equal(j2, i1)
+    z1, z2, _, _ = s3r.chamfer_distance(pts, pts)
+    assert float(z1.abs().max()) == 0.0 and float(z2.abs().max()) == 0.0
+    nn = torch.gather(gt, 1, i1.long().unsqueeze(-1).expand(-1, -1, 3))        # the indices reproduce the distances
+    assert torch.allclose(((pts - nn) ** 2).sum(-1), d1, rtol=1e-5, atol=1e-7)
+    assert torch.equal(s3r.chamfer_distance(pts, gt)[0], d1)                   # deterministic
 
 
 @pytest.mark.parametrize("shape", [(32, 32768, 1024), (5, 1024, 6144), (33, 96, 40), (3, 50, 7), (70, 4096, 100)])
@@ -621,25 +685,56 @@ def test_dataset_eval_with_exr_disparity(s3r, models, tmp_path):
     assert a["epe_left"] > 0
 
 
-@pytest.mark.timeout(300)
-def test_bench_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.timeout(420)
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_ranks_on_one_gpu(tmp_path, launcher):
     """bench.py's N>1 path (sharded batch, all-gather collation, barrier, max-over-ranks timing, rank-0 JSON) run
-    with two ranks sharing cuda:0 over gloo — the RCCL run itself needs a multi-GPU node."""
+    with two ranks sharing cuda:0 over gloo — the RCCL run itself needs a multi-GPU node.  "self": plain
+    `python bench.py --gpus 2 ...` as the driver invokes it (bench starts its own ranks as a child process);
+    "torchrun": under an external launcher, as the contract's N>1 command line does."""
     import json, os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--batch", "4", "--backend", "gloo", "--same-device", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root)
+    args = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--backend",
+            "gloo", "--same-device", "--no-cpu-baseline"]
+    if launcher == "self":
+        cmd = [sys.executable] + args
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    else:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + args
+        env = dict(os.environ)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # exactly one JSON line, from rank 0
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak"
-    assert d["value"] > 0 and "cpu_baseline" not in d
+    assert d["n_ranks_seen"] == 2 and d["collective_backend"] == "gloo"
+    assert d["value"] > 0 and "cpu_baseline" not in d and "secondary" not in d
+
+
+def test_bench_line_carries_roofline_border_excluded_and_secondaries(tmp_path):
+    """The default N=1 line: roofline with frac and frac_border_excluded, no PMC constants unless the committed
+    counter file matches the sources that ran, and the configs[2] / configs[3] measurements under `secondary`."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=500, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac_border_excluded"] < r["frac"] < 1
+    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
+    if r["traffic"] is not None:                              # only ever from a counter file hashed to THESE sources
+        import bench
+        assert r["pmc_source"]["csrc_sha256"] == bench.csrc_sha256()
+    sec = d["secondary"]
+    assert sec["bf16_b256"]["dtype"] == "bf16" and sec["bf16_b256"]["value"] > d["value"]
+    assert sec["bf16_b256"]["roofline"]["peak"] == 2500.0
+    assert sec["point_b32"]["value"] > 0 and "chamfer" in sec["point_b32"]["kernels"] and "linear" in sec["point_b32"]["kernels"]
 
 
 def test_maximum_sizes_chunking_and_limits(s3r, models):

@@ -44,6 +44,53 @@ def test_runner_test_mode_matches_in_process_eval(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
+def test_renamed_checkpoint_through_keymap_vs_oracle(tmp_path):
+    """The `.pth` row against the ORACLE, not against the HIP path itself: a container with RENAMED keys (other
+    prefixes, DataParallel's `module.`) is loaded (a) into the HIP model through `suggest_keymap` + `load_checkpoint`,
+    as `runner.py --test --weights X --keymap K` does, and (b) into the oracle by plain tensor order; the two forwards
+    must agree within the fp32 tolerance, and runner.py's IoU must be the oracle's IoU on the same data."""
+    import s3r
+    from oracle import s2v_oracle as O
+    src = O.OracleStereo2Voxel().eval()
+    s3r.seed_module(src, 21)
+    own = src.state_dict()
+    renamed = {}
+    for k, v in own.items():                                   # a "reference-style" naming this build has never seen
+        nk = k.replace("encoder.", "feature_net.").replace("decoder.", "recon3d.").replace(".conv.", ".c.").replace(".bn.", ".norm.")
+        renamed["module." + nk] = v.clone()
+    ckpt = tmp_path / "renamed.pth"
+    torch.save({"epoch_idx": 250, "best_iou": 0.7, "network": renamed}, ckpt)
+
+    hip = s3r.Stereo2Voxel()
+    s3r.seed_module(hip, 99)                                   # different weights until the checkpoint is in
+    keymap = s3r.checkpoint.suggest_keymap(torch.load(ckpt, map_location="cpu", weights_only=True), hip)
+    assert keymap and all(k not in hip.state_dict() for k in keymap)
+    km = tmp_path / "keymap.json"
+    km.write_text(json.dumps(keymap))
+    missing, unexpected = s3r.checkpoint.load_checkpoint(hip, str(ckpt), keymap)
+    assert not missing and not unexpected
+    hip.to("cuda:0")
+
+    left, right, gt = s3r.evaluate.synthetic_eval_set(3, 8)
+    with torch.no_grad():
+        want = src(left, right)
+    got = hip(left.to("cuda:0"), right.to("cuda:0")).cpu()
+    assert ((got - want).norm() / want.norm()).item() < 1e-5   # north_star: 1e-4 relative
+    assert (got - want).abs().max().item() < 1e-4
+
+    data = tmp_path / "eval.npz"
+    np.savez(data, left=left.numpy(), right=right.numpy(), volume=gt.numpy())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "runner.py"), "--test", "--weights", str(ckpt), "--keymap", str(km),
+                        "--data", str(data), "--batch", "2"], capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    for t, iou in zip(out["thresholds"], out["mean_iou"]):
+        ref_iou = O.voxel_iou(want, gt, t).mean().item()
+        assert abs(iou - ref_iou) < 1e-3, (t, iou, ref_iou)    # north_star: voxel IoU within 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
 def test_runner_on_a_dataset_tree_with_disparity(tmp_path):
     import s3r
     from tests.test_data_cpu import _make_tree

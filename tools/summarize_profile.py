@@ -91,8 +91,17 @@ def main():
     # v_mfma_f32_32x32x16_bf16: it reproduces the algorithmic MFMA count); GRBM_GUI_ACTIVE sums the 8 XCDs' active
     # cycles.  utilisation = busy / (1024 x elapsed shader cycles); the clock held = elapsed cycles / elapsed time.
     cycles = gui / 8.0
+    prof = {}
+    try:      # written on the GPU box by tools/profile.sh: hash of the kernel sources that ran + the bench arguments
+        prof = json.load(open(os.path.join(src, "profiled.json")))
+    except Exception:
+        pass
+    bargs = prof.get("args", "").split()
     info = {
         "source": src, "steps_profiled": steps, "kernel": FAMILY, "launches_profiled": launches,
+        "csrc_sha256": prof.get("csrc_sha256"), "bench_args": prof.get("args"),
+        "dtype": bargs[bargs.index("--dtype") + 1] if "--dtype" in bargs else "f32",
+        "batch": int(bargs[bargs.index("--batch") + 1]) if "--batch" in bargs else 32,
         "fetch_bytes_per_step_raw": fetch / steps,
         "fetch_bytes_per_step_x2": 2 * fetch / steps,
         "write_bytes_per_step": write / steps,
