@@ -30,8 +30,13 @@
 //
 // Workgroup: 4 waves along M.  Per-position input / output offsets are decoded once per workgroup into LDS.
 #include "s3r_kernels.h"
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+
+#ifndef S3R_BF16_MFMA_DEFAULT
+#define S3R_BF16_MFMA_DEFAULT 32      // the matrix instruction used when S3R_BF16_MFMA is not set (see conv_bf16_shape)
+#endif
 
 namespace s3r {
 
@@ -154,37 +159,47 @@ __device__ __forceinline__ void epilogue_h(const ConvParamsH& p, typename Mf<SH>
     const int srow = lane >> 3, spiece = lane & 7;
     if (p.ksplit > 1) {
         // split-K: fp32 partial sums [cls][kz][position][CoutPad]; conv_finish_bf16 reduces in kz order.
-        // One staging unit = 32 positions x 32 couts fp32 (128-byte rows).
         const int mpad = p.m_tiles * bm;
-        float* __restrict__ slab = p.part + ((size_t)(cls * p.ksplit + kz) * mpad + m0) * p.CoutPad + n0 + 4 * spiece;
+        if constexpr (SH == 32) {
+            // one staging unit = 32 positions x 32 couts fp32 (128-byte rows): lane (li, lk) holds couts ch*32 + 16 lk + r
+            float* __restrict__ slab = p.part + ((size_t)(cls * p.ksplit + kz) * mpad + m0) * p.CoutPad + n0 + 4 * spiece;
 #pragma unroll
-        for (int u = 0; u < TM; ++u)
+            for (int u = 0; u < TM; ++u)
 #pragma unroll
-            for (int ch = 0; ch < 2; ++ch) {       // 32-cout half of the 64-cout block
-                if constexpr (SH == 32) {          // cout tile ch: lane (li, lk) holds couts ch*32 + 16 lk + r
+                for (int ch = 0; ch < 2; ++ch) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const f32x4 t = {acc[u][ch][4 * j], acc[u][ch][4 * j + 1], acc[u][ch][4 * j + 2], acc[u][ch][4 * j + 3]};
                         *reinterpret_cast<f32x4*>(stage + li * ST_ROW + lk * 64 + j * 16) = t;
                     }
-                } else {                           // lanes with lk >> 1 == ch hold this half: couts 16 lk + r
-                    if ((lk >> 1) == ch) {
+                    if (S3R_ABLH(p, 1)) continue;
 #pragma unroll
-                        for (int q = 0; q < PPU; ++q)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                *reinterpret_cast<f32x4*>(stage + (q * MT + li) * ST_ROW + (lk & 1) * 64 + j * 16) =
-                                    acc[u * PPU + q][j];
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = i * 8 + srow;
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(stage + r * ST_ROW + spiece * 16);
+                        *reinterpret_cast<f32x4*>(slab + (size_t)(wave * 32 * TM + u * 32 + r) * p.CoutPad + ch * 32) = t;
                     }
                 }
+        } else {
+            // one staging unit = ONE position tile: 16 positions x 64 couts fp32 (256-byte rows + 16: 4352 B of the wave's
+            // 4608).  EVERY lane writes (its 16 couts 16 lk + 4 ct + r of position li) — a unit in which only half the
+            // lanes stage data would put the writes in a divergent branch, and nothing orders the other lanes' reads
+            // behind it.  Read back as 4 rows x 256 contiguous bytes per store instruction.
+            constexpr int SR = 272;
+            float* __restrict__ slab = p.part + ((size_t)(cls * p.ksplit + kz) * mpad + m0) * p.CoutPad + n0 + 4 * (lane & 15);
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(stage + li * SR + lk * 64 + j * 16) = acc[pt][j];
                 if (S3R_ABLH(p, 1)) continue;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int r = i * 8 + srow;
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(stage + r * ST_ROW + spiece * 16);
-                    *reinterpret_cast<f32x4*>(slab + (size_t)(wave * 32 * TM + u * 32 + r) * p.CoutPad + ch * 32) = t;
+                    const int r = i * 4 + (lane >> 4);
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(stage + r * SR + (lane & 15) * 16);
+                    *reinterpret_cast<f32x4*>(slab + (size_t)(wave * 32 * TM + pt * MT + r) * p.CoutPad) = t;
                 }
             }
+        }
         return;
     }
     // ReLU / identity as ONE v_max against a wave-uniform floor; sigmoid (rare) behind a wave-uniform flag
@@ -1021,7 +1036,7 @@ static int rowreuse_rows(const ConvParamsH& p, int bm) {
     return (r + 63) / 64 * 64;
 }
 
-template <int TM>
+template <int SH, int TM>
 static hipError_t launch_tm_rowreuse(ConvParamsH p, hipStream_t stream) {
     constexpr int BM = 128 * TM;
     p.m_tiles = (p.Ntotal + BM - 1) / BM;
@@ -1030,11 +1045,11 @@ static hipError_t launch_tm_rowreuse(ConvParamsH p, hipStream_t stream) {
     if (r_max > 64 * NPA_MAX) return hipErrorInvalidValue;
     const size_t lds = (size_t)2 * (r_max * 64 + p.kw * 4096) + 2 * BM * sizeof(int) + EP_BYTES;
     static LdsAttr lds_attr;                       // (per device: see LdsAttr)
-    const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_bf16r_kernel<TM>), 160 * 1024);
+    const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_bf16r_kernel<SH, TM>), 160 * 1024);
     if (attr != hipSuccess) return attr;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(p.m_tiles * p.n_tiles, p.transposed ? 8 : 1, p.ksplit);
-    hipLaunchKernelGGL((conv_bf16r_kernel<TM>), grid, dim3(256), lds, stream, p, r_max);
+    hipLaunchKernelGGL((conv_bf16r_kernel<SH, TM>), grid, dim3(256), lds, stream, p, r_max);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && p.ksplit > 1) {
         const long long total = (long long)p.Ntotal * (p.CoutPad >> 1);
@@ -1061,7 +1076,7 @@ static int plane_rows(const ConvParamsH& p, int bm, int kc) {
     return (r + unit - 1) / unit * unit;
 }
 
-template <int TM, int KC, int NH = 1>
+template <int SH, int TM, int KC, int NH = 1>
 static hipError_t launch_tm_plane(ConvParamsH p, hipStream_t stream) {
     constexpr int BM = 128 * TM;
     p.m_tiles = (p.Ntotal + BM - 1) / BM;
@@ -1073,10 +1088,10 @@ static hipError_t launch_tm_plane(ConvParamsH p, hipStream_t stream) {
     const size_t lds = (size_t)r_max * KC * 2 + PL_NB * HBN * NH * KC * 2 + 2 * BM * sizeof(int) + EP_BYTES * NH;
     if (lds > 160 * 1024 || r_max * 4 > HBN * NH * KC * 2) return hipErrorInvalidValue;
     static LdsAttr lds_attr;
-    const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_bf16p_kernel<TM, KC, NH>), 160 * 1024);
+    const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_bf16p_kernel<SH, TM, KC, NH>), 160 * 1024);
     if (attr != hipSuccess) return attr;
     dim3 grid(p.m_tiles * (p.n_tiles / NH), p.transposed ? 8 : 1, p.ksplit);
-    hipLaunchKernelGGL((conv_bf16p_kernel<TM, KC, NH>), grid, dim3(256), lds, stream, p, r_max);
+    hipLaunchKernelGGL((conv_bf16p_kernel<SH, TM, KC, NH>), grid, dim3(256), lds, stream, p, r_max);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && p.ksplit > 1) {
         const long long total = (long long)p.Ntotal * (p.CoutPad >> 1);
@@ -1088,24 +1103,24 @@ static hipError_t launch_tm_plane(ConvParamsH p, hipStream_t stream) {
     return e;
 }
 
-template <int TM, int KC, bool HEAD, int NH>
+template <int SH, int TM, int KC, bool HEAD, int NH>
 static hipError_t launch_tm_k(const ConvParamsH& p, hipStream_t stream) {
     constexpr int BM = 128 * TM;
     constexpr size_t lds = (size_t)2 * BM * KC * 2 + 2 * HBN * NH * KC * 2 + 2 * BM * sizeof(int) + EP_BYTES * NH;
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
     if (lds > 48 * 1024) {
         static LdsAttr lds_attr;
-        const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_bf16_kernel<TM, KC, HEAD, NH>), (int)lds);
+        const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_bf16_kernel<SH, TM, KC, HEAD, NH>), (int)lds);
         if (attr != hipSuccess) return attr;
     }
     dim3 grid(p.m_tiles * (p.n_tiles / NH), p.transposed ? 8 : 1, p.ksplit);
-    hipLaunchKernelGGL((conv_bf16_kernel<TM, KC, HEAD, NH>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_bf16_kernel<SH, TM, KC, HEAD, NH>), grid, dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
 // kc32: the caller forces 32-channel K tiles (tile code + 16); otherwise 64 wherever the layer allows it.
 // NH = 2: 128-cout workgroup tiles (Cout % 128 == 0, no fused head).
-template <int TM, int NH>
+template <int SH, int TM, int NH>
 static hipError_t launch_tm(ConvParamsH p, bool kc32, hipStream_t stream) {
     constexpr int BM = 128 * TM;
     p.m_tiles = (p.Ntotal + BM - 1) / BM;
@@ -1115,10 +1130,10 @@ static hipError_t launch_tm(ConvParamsH p, bool kc32, hipStream_t stream) {
     const bool kc64 = !kc32 && p.Cin % 64 == 0 && (p.Cin / 64) % p.ksplit == 0;
     hipError_t e;
     if constexpr (NH == 2) {
-        e = kc64 ? launch_tm_k<TM, 64, false, 2>(p, stream) : launch_tm_k<TM, 32, false, 2>(p, stream);
+        e = kc64 ? launch_tm_k<SH, TM, 64, false, 2>(p, stream) : launch_tm_k<SH, TM, 32, false, 2>(p, stream);
     } else {
-        e = kc64 ? (head ? launch_tm_k<TM, 64, true, 1>(p, stream) : launch_tm_k<TM, 64, false, 1>(p, stream))
-                 : (head ? launch_tm_k<TM, 32, true, 1>(p, stream) : launch_tm_k<TM, 32, false, 1>(p, stream));
+        e = kc64 ? (head ? launch_tm_k<SH, TM, 64, true, 1>(p, stream) : launch_tm_k<SH, TM, 64, false, 1>(p, stream))
+                 : (head ? launch_tm_k<SH, TM, 32, true, 1>(p, stream) : launch_tm_k<SH, TM, 32, false, 1>(p, stream));
     }
     if (e == hipSuccess && p.ksplit > 1) {
         const long long total = (long long)p.Ntotal * (p.CoutPad >> 1);
@@ -1130,6 +1145,26 @@ static hipError_t launch_tm(ConvParamsH p, bool kc32, hipStream_t stream) {
     return e;
 }
 
+template <int SH>
+static hipError_t launch_shape(const ConvParamsH& p, int tm, hipStream_t stream) {
+    // tm = 1, 2, 4: per-tap gather (conv_bf16_kernel; + 16: 32-channel K tiles even where 64 are possible);
+    // tm = 9, 10: row-reuse gather (conv_bf16r_kernel) with TM 1, 2
+    switch (tm) {
+        case 1: case 17: return launch_tm<SH, 1, 1>(p, tm > 16, stream);
+        case 2: case 18: return launch_tm<SH, 2, 1>(p, tm > 16, stream);
+        case 4: case 20: return launch_tm<SH, 4, 1>(p, tm > 16, stream);
+        case 3: case 19: return launch_tm<SH, 1, 2>(p, tm > 16, stream);      // 128 positions x 128 couts
+        case 5: return launch_tm_plane<SH, 1, 64>(p, stream);
+        case 6: return launch_tm_plane<SH, 2, 64>(p, stream);
+        case 21: return launch_tm_plane<SH, 1, 32>(p, stream);
+        case 22: return launch_tm_plane<SH, 2, 32>(p, stream);
+        case 23: return launch_tm_plane<SH, 2, 32, 2>(p, stream);            // 256 positions x 128 couts
+        case 9: return launch_tm_rowreuse<SH, 1>(p, stream);
+        case 10: return launch_tm_rowreuse<SH, 2>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_conv_bf16(const ConvParamsH& pin, int tm, hipStream_t stream) {
     ConvParamsH p = pin;
 #ifdef S3R_ABLATE
@@ -1138,31 +1173,20 @@ hipError_t launch_conv_bf16(const ConvParamsH& pin, int tm, hipStream_t stream) 
     if (p.Cin % HKC != 0 || p.CoutPad % HBN != 0 || p.ksplit < 1 || (p.Cin / HKC) % p.ksplit != 0 ||
         (p.ksplit > 1 && !p.part))
         return hipErrorInvalidValue;
-    // tm = 1, 2, 4: per-tap gather (conv_bf16_kernel; + 16: 32-channel K tiles even where 64 are possible);
-    // tm = 9, 10: row-reuse gather (conv_bf16r_kernel) with TM 1, 2
-    switch (tm) {
-        case 1: case 17: return launch_tm<1, 1>(p, tm > 16, stream);
-        case 2: case 18: return launch_tm<2, 1>(p, tm > 16, stream);
-        case 4: case 20: return launch_tm<4, 1>(p, tm > 16, stream);
-        case 3: case 19: return launch_tm<1, 2>(p, tm > 16, stream);      // 128 positions x 128 couts
-        case 5: return launch_tm_plane<1, 64>(p, stream);
-        case 6: return launch_tm_plane<2, 64>(p, stream);
-        case 21: return launch_tm_plane<1, 32>(p, stream);
-        case 22: return launch_tm_plane<2, 32>(p, stream);
-        case 23: return launch_tm_plane<2, 32, 2>(p, stream);            // 256 positions x 128 couts
-        case 9: return launch_tm_rowreuse<1>(p, stream);
-        case 10: return launch_tm_rowreuse<2>(p, stream);
-        default: return hipErrorInvalidValue;
-    }
+    return conv_bf16_shape() == 16 ? launch_shape<16>(p, tm, stream) : launch_shape<32>(p, tm, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight packing for the bf16 kernel (fp32 torch layout -> bf16, K-tile major, pre-swizzled):
-//   wp[cls][kt = chunk*T + tap][cout tile][row = tn*32 + c][slot][8]   (64 B per row)
-//     cout = tile*64 + tn*32 + 16*((c>>2)&1) + (c&3) + 4*(c>>3)  (MFMA output row c of half h = (c>>2)&1 is the
-//     lane-half's register r = (c&3) + 4*(c>>3): 16 consecutive couts per lane),   slot holds channel group kg = slot ^ ((row >> 2) & 3),  cin = chunk*32 + kg*8 + e
+// weight packing for the bf16 kernels (fp32 torch layout -> bf16, K-tile major, pre-swizzled):
+//   wp[cls][kt = chunk*T + tap][cout tile][row 0..63][slot][8]   (64 B per row)
+//     slot holds channel group kg = slot ^ swz<32>(row),  cin = chunk*32 + kg*8 + e
+//     row -> cout of the 64-cout tile, so that the couts a lane ends up holding are consecutive (epilogue_h):
+//       SH = 32: row = tn*32 + c; MFMA output row c sits in lane half h = (c>>2)&1, register r = (c&3) + 4*(c>>3):
+//                cout = tn*32 + 16*h + r
+//       SH = 16: row = ct*16 + i; MFMA output row i sits in lane group g = i>>2, register r = i&3:
+//                cout = 16*g + 4*ct + r
 __global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout,
-                                 int CoutPad, int T, int transposed) {
+                                 int CoutPad, int T, int transposed, int sh) {
     const size_t per_cls = (size_t)T * Cin * CoutPad;
     const size_t total = (transposed ? 8 : 1) * per_cls;
     const int n_tiles = CoutPad / 64;
@@ -1175,9 +1199,15 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __
         const int tile = (int)(r % n_tiles); r /= n_tiles;
         const int tap = (int)(r % T);
         const int cc = (int)(r / T);
-        const int tn = row >> 5, c = row & 31;
-        const int co = tile * 64 + tn * 32 + 16 * ((c >> 2) & 1) + (c & 3) + 4 * (c >> 3);
-        const int kg = slot ^ ((row >> 2) & 3);
+        int co;
+        if (sh == 32) {
+            const int tn = row >> 5, c = row & 31;
+            co = tile * 64 + tn * 32 + 16 * ((c >> 2) & 1) + (c & 3) + 4 * (c >> 3);
+        } else {
+            const int ct = row >> 4, ii = row & 15;
+            co = tile * 64 + 16 * (ii >> 2) + 4 * ct + (ii & 3);
+        }
+        const int kg = slot ^ swz<32>(row);
         const int cin = cc * 32 + kg * 8 + e;
         float v = 0.f;
         if (co < Cout) {
@@ -1197,7 +1227,7 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __
 hipError_t launch_pack_bf16(const float* w, void* wp, int Cin, int Cout, int CoutPad, int T, int transposed,
                             hipStream_t s) {
     hipLaunchKernelGGL(pack_bf16_kernel, dim3(1024), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wp), Cin, Cout,
-                       CoutPad, T, transposed);
+                       CoutPad, T, transposed, conv_bf16_shape());
     return hipGetLastError();
 }
 

@@ -139,6 +139,7 @@ int64_t linear_scratch_elems(int B, int Cin, int Cout);
 // ---- bf16 channels-last path
 hipError_t launch_conv_bf16(const ConvParamsH& p, int tm, hipStream_t stream);
 int conv_bf16_pick_tm(const ConvParamsH& p);
+int conv_bf16_shape();              // 16 | 32: the bf16 matrix instruction in use (S3R_BF16_MFMA, else the build's default)
 int conv_bf16_pick_ksplit(const ConvParamsH& p);
 int64_t conv_bf16_scratch_elems(const ConvParamsH& p, int tm);
 hipError_t launch_pack_bf16(const float* w, void* wp, int Cin, int Cout, int CoutPad, int T, int transposed, hipStream_t s);

@@ -9,9 +9,14 @@ File layout as the reference's config documents it (/root/reference/README.md:73
     VOLUME_PATH           <root>/ShapeNetVox32/<taxonomy>/<model>.mat
 
 The reference's own transforms (crop / background / normalisation constants) are on unmounted branches
-(SURVEY.md §0), so the ones here are build-specified and stated: RGBA renders are composited over a white
-background, scaled to [0,1], resized to 224x224 (bilinear) when they are not already.  Decoding is host
-work; batches are handed to the GPU through graph.PrefetchingLoader so the copy overlaps the forward.
+(SURVEY.md §0).  What is EVIDENCED by the mount: the five path templates above and the file types.  What is
+INVENTED by this build (each a constant of this file, to be overwritten from the reference the day it is mounted —
+tools/resurvey.py lists the reference's own): compositing RGBA renders over a WHITE background; scaling to [0,1]
+with NO mean / std normalisation; BILINEAR resize to 224x224 when a render has another size (no crop); `volume > 0`
+as the occupancy rule for the .mat grids; taking the first of Z / V / Y / disparity / R as the EXR disparity channel
+(exr.disparity_channel) with "finite and >= 0" as its validity rule; block-mean pooling of the 224x224 maps to the
+28x28 read-out resolution (downsample_disparity).  Decoding is host work; batches are handed to the GPU through
+graph.PrefetchingLoader so the copy overlaps the forward.
 """
 from __future__ import annotations
 

@@ -160,7 +160,8 @@ class _HipChain(nn.Module):
 
     # -- weight packing cache ------------------------------------------------------------------
     def _cache_key(self, device):
-        items = [str(device), self.precision]
+        # (the bf16 weight image depends on the matrix instruction the library packs for: S3R_BF16_MFMA, an A/B switch)
+        items = [str(device), self.precision, os.environ.get("S3R_BF16_MFMA", "")]
         for t in list(self.parameters()) + list(self.buffers()):
             items.append((id(t), t._version, t.device.type))
         return tuple(items)

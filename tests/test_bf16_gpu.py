@@ -28,8 +28,16 @@ def _layer_cases(spec):
     return cases
 
 
+@pytest.fixture(params=[32, 16], ids=["mfma32x32x16", "mfma16x16x32"])
+def mfma_shape(request, monkeypatch):
+    """Both matrix instructions the kernels are built for (S3R_BF16_MFMA; the library's default is whichever is the
+    faster by wall on random data, s3r_conv_bf16.hip): every per-layer / per-tile check runs under each."""
+    monkeypatch.setenv("S3R_BF16_MFMA", str(request.param))
+    return request.param
+
+
 @pytest.mark.parametrize("idx", range(18))
-def test_each_layer_bf16_vs_oracle(s3r, oracle, idx):
+def test_each_layer_bf16_vs_oracle(s3r, oracle, idx, mfma_shape):
     spec = s3r.arch_spec
     layer, n_in = _layer_cases(spec)[idx]
     B = 2
@@ -74,7 +82,7 @@ def test_each_layer_bf16_vs_oracle(s3r, oracle, idx):
 @pytest.mark.parametrize("kind", ["conv3d_s1", "conv3d_s2", "deconv", "conv2d_s2", "conv3d_k4_valid_ks2", "cout32",
                                   "conv2d_s1_w28", "conv3d_s1_w14", "conv3d_s1_c64", "deconv_c64", "deconv_c128_w8",
                                   "conv3d_k4_valid_c128_ks2", "conv2d_s1_c128_w9", "cout36_narrow_stores", "cout100_s2", "c128_cout128_ks2"])
-def test_bf16_tiles_and_split_k(s3r, oracle, tm, kind):
+def test_bf16_tiles_and_split_k(s3r, oracle, tm, kind, mfma_shape):
     Layer = s3r.arch_spec.Layer
     layer, n_in, B, ks = {
         "conv3d_s1": (Layer("t", "conv3d", 32, 96, 3, 1, 1), 7, 3, 0),
@@ -145,7 +153,7 @@ def test_cost_volume_bf16_bit_exact(s3r, oracle):
     assert border.abs().max().item() == 0
 
 
-def test_stereo2voxel_bf16_vs_fp32_oracle(s3r, oracle):
+def test_stereo2voxel_bf16_vs_fp32_oracle(s3r, oracle, mfma_shape):
     hip = s3r.Stereo2Voxel(precision="bf16")
     s3r.seed_module(hip, 0)
     ref = oracle.OracleStereo2Voxel().eval()
@@ -166,6 +174,33 @@ def test_stereo2voxel_bf16_vs_fp32_oracle(s3r, oracle):
     assert torch.equal(one[0], got[2])
 
 
+def test_bf16_mfma_layout_exact_integers(s3r, mfma_shape):
+    """A 1x1 conv on small-integer data is exact in bf16 x bf16 -> fp32: a swapped lane / register / cout-permutation
+    map of either matrix instruction shows up as a mismatch (asymmetric weights, asymmetric input; 96 couts = one
+    full and one half 64-cout tile; K = 64 = two 32-channel chunks)."""
+    import torch.nn.functional as F
+    L = s3r.arch_spec.Layer("t", "conv2d", 64, 96, 1, 1, 0, bn=False, act="none")
+    ch = s3r.modules._HipChain([L], 9, precision="bf16")
+    w = (torch.arange(96 * 64, dtype=torch.float32).reshape(96, 64, 1, 1) % 7) - 3
+    w[5, 3] = 11
+    w[70, 40] = -9
+    ch.t.conv.weight.data.copy_(w)
+    ch.t.conv.bias.data.copy_(torch.arange(96, dtype=torch.float32) % 5)
+    x = (torch.arange(3 * 64 * 81, dtype=torch.float32).reshape(3, 64, 9, 9) % 5) - 2
+    x[1, 2, 3, 4] = 9
+    want = F.conv2d(x, w, ch.t.conv.bias.data)               # |values| < 2^8 * small: exact in bf16 after rounding? keep small
+    assert float(want.abs().max()) < 256 and torch.equal(want.to(torch.bfloat16).float(), want)
+    ch.to(DEV)
+    xin = x.to(DEV).to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
+    for tm in (1, 2, 17, 21, 22):
+        ch.tile_override["t"] = tm
+        try:
+            got = ch._run(xin)
+        except s3r.S3RError:
+            continue                                         # (plane codes refuse 1x1 shapes they cannot tile)
+        assert torch.equal(got.float().cpu(), want), tm
+
+
 def test_bf16_odd_empty_and_chunked_batches(s3r):
     """Ragged sizes on the bf16 path: an odd batch equals its samples run one by one (bitwise), an empty batch is an
     empty result, and the disparity read-out works from the bf16 encoder's features."""
@@ -183,7 +218,7 @@ def test_bf16_odd_empty_and_chunked_batches(s3r):
 
 
 @pytest.mark.parametrize("n", [2, 7, 16, 33, 64, 100])
-def test_bf16_results_do_not_depend_on_the_batch_size(s3r, n):
+def test_bf16_results_do_not_depend_on_the_batch_size(s3r, n, mfma_shape):
     """The library switches tiles with the batch (plane-reuse <-> row-reuse / per-tap, 128 x 128 <-> 128 x 64) but never
     the K summation order of a layer: sample 0 is bitwise the same alone and inside any batch."""
     hip = s3r.Stereo2Voxel(precision="bf16")

@@ -81,6 +81,18 @@ def test_zip_chunk_written_by_hand(s3r, tmp_path):
     assert np.array_equal(s3r.exr.read_exr(str(p))["Z"], img)
 
 
+def test_committed_zip_half_fixture_from_an_independent_encoder(s3r, golden_dir):
+    """tests/golden/disp_zip_half.exr was assembled by tests/golden/make_exr_fixture.py, which shares no code with exr.py
+    (struct + zlib + byte loops): two channels (FLOAT `A`, HALF `Z`), ZIP compression in 16-scan-line blocks (16 + 5
+    lines), infinities as the dataset's background marker.  The decoder must reproduce the stored arrays exactly."""
+    back = s3r.exr.read_exr(os.path.join(golden_dir, "disp_zip_half.exr"))
+    want = np.load(os.path.join(golden_dir, "disp_zip_half.npz"))
+    assert sorted(back) == ["A", "Z"]
+    for k in ("A", "Z"):
+        assert back[k].dtype == np.float32 and back[k].shape == (21, 13) and np.array_equal(back[k], want[k]), k
+    assert s3r.exr.disparity_channel(back) is back["Z"] and np.isinf(back["Z"][2, 3:9]).all()
+
+
 def test_rle_file(s3r, tmp_path):
     """compression 1: signed run lengths (n >= 0: n + 1 copies of the next byte; n < 0: -n literal bytes) over the same
     predicted / split byte stream as ZIP.  Encoded here with an independent greedy run-length encoder."""
