@@ -2,6 +2,7 @@
 // shift-and-diff cost volume, the 1x1x1 occupancy head (+sigmoid), the point-head linear layers,
 // and the on-device thresholded IoU.  All are priced against the HBM roof.
 #include "s3r_kernels.h"
+#include <cstdlib>
 
 namespace s3r {
 
@@ -235,77 +236,105 @@ hipError_t launch_head(const float* x, const float* w, const float* scale, const
 
 // ------------------------------------------------------------------------------------------------
 // Point-head linear layer  y[b][o] = act(scale[o] * sum_i x[b][i] * w[o][i] + bias[o]).
-// HBM-bound weight streaming (p1 alone is 134 MB of fp32 weights for 2 GFLOP at B=32), so the design
-// goal is "every weight byte crosses HBM once, in whole 128-byte lines, with enough loads in flight":
-//   * one WAVE owns 32 output rows x one K slice x 32*TM batch rows and feeds the fp32 matrix core
-//     straight from registers: A = x (lane (i,h): batch row i), B = w (lane (j,h): output row j), both
-//     operands loaded as 4 x float4 per lane = 64 contiguous bytes of "their" row per 32-deep K step
-//     (the two lane halves take adjacent 64-byte halves of a 128-byte line), no LDS, no barrier;
-//   * v_mfma_f32_32x32x2_f32 at 16 MFMAs per 2 KiB of weights keeps the matrix pipe far below
-//     saturation (9.8 TB/s equivalent), so the kernel stays memory-bound;
-//   * split-K over waves for parallelism; partial slabs [kz][b][o] are reduced in kz order by
+// HBM-bound weight streaming (p1 alone is 134 MB of fp32 weights for 2 GFLOP at B=32), so the design goal is "every
+// weight byte crosses HBM once, in whole 128-byte lines, with enough of them in flight":
+//   * a workgroup owns 128 output rows x 32 batch rows x one K slice and walks the slice in blocks of 32 k = one
+//     128-byte line per row; per block the 128 weight lines (16 KiB) and the 32 activation lines (4 KiB, shared by the
+//     four waves: x is re-read from L2 once per 128 outputs instead of once per 32) arrive by LDS-DMA, 16 bytes per
+//     lane, EIGHT WHOLE LINES per wave-instruction (r01 loaded fragment-shaped: 16 bytes of each of 32 rows per
+//     instruction, 1.5 TB/s), into a 4-deep LDS ring: three blocks = 60 KiB per workgroup stay in flight behind a
+//     counted vmcnt and a raw s_barrier (a barrier the compiler knows about drains vmcnt);
+//   * LDS rows are 128 bytes; the 16-byte chunk c of row r sits at slot c ^ ((r >> 1) & 7) (applied on the DMA's
+//     per-lane SOURCE address: LDS-DMA destinations are lane-linear), which makes the fragment reads — 32 consecutive
+//     rows at one chunk per lane half — conflict-free;
+//   * wave w multiplies its 32 output rows: v_mfma_f32_32x32x2_f32, A = x (lane (i,h): batch row i), B = w (lane (j,h):
+//     output row j), both as ds_read_b128 of chunk 2t + h: 16 MFMAs (1024 cycles) per 4 KiB of weights per wave keeps
+//     the matrix pipe at a 9.8 TB/s equivalent, so the kernel stays memory-bound;
+//   * split-K over workgroups for parallelism; partial slabs [kz][b][o] are reduced in kz order by
 //     linear_finish_kernel (deterministic: no atomics).
 typedef float f32x16_l __attribute__((ext_vector_type(16)));
+#define S3R_LDS_PTR_PW(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int TM>
-__global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          float* __restrict__ part, int B, int Cin, int Cout, int kper,
-                                                          int ksplit) {
+constexpr int LIN_NS = 4;                     // ring slots
+constexpr int LIN_STAGE = (128 + 32) * 128;   // bytes per slot: 128 weight rows + 32 activation rows of 128 B
+
+template <bool NT>
+__global__ __launch_bounds__(256, 2) void linear_stream_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               float* __restrict__ part, int B, int Cin, int Cout, int kper,
+                                                               int ksplit) {
+    extern __shared__ __attribute__((aligned(16))) char lin_smem[];       // [LIN_NS][160 rows][128 B]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const int o0 = blockIdx.x * 32;
-    const int kz = blockIdx.y * 4 + wave;
-    const int b0 = blockIdx.z * 32 * TM;
-    if (kz >= ksplit) return;
+    const int o0 = blockIdx.x * 128;
+    const int kz = blockIdx.y;
+    const int b0 = blockIdx.z * 32;
     const int kbeg = kz * kper;
-    const int kend = min(Cin, kbeg + kper);
-    const int niter = (kend - kbeg) >> 5;
-    const float* __restrict__ wp = w + (size_t)min(o0 + j, Cout - 1) * Cin + kbeg + 16 * h;
-    const float* __restrict__ xp[TM];
+    const int nblk = (min(Cin, kbeg + kper) - kbeg) >> 5;
+
+    // ---- loop-invariant DMA source offsets (bytes): a piece = 8 rows x 128 B; lane l fills slot l & 7 of row l >> 3
+    //      with source chunk (l & 7) ^ ((row >> 1) & 7); rows past the tensor re-read its last row (never stored)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, (int)0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)0x7fffffff, 0x00020000);
+    int wvoff[4], xvoff;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) xp[tm] = x + (size_t)min(b0 + tm * 32 + j, B - 1) * Cin + kbeg + 16 * h;
-    f32x16_l acc[TM];
+    for (int q = 0; q < 4; ++q) {
+        const int r = (wave * 4 + q) * 8 + (lane >> 3);                  // row of the workgroup's 128-row weight tile
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        wvoff[q] = (int)(((long long)min(o0 + r, Cout - 1) * Cin + kbeg) * 4 + c * 16);      // (< 2^31: checked by the launcher)
+    }
+    {
+        const int r = wave * 8 + (lane >> 3);                            // row of the 32-row activation tile
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        xvoff = (int)(((long long)min(b0 + r, B - 1) * Cin + kbeg) * 4 + c * 16);
+    }
+    auto issue = [&](int blk) {
+        char* st = lin_smem + (blk & (LIN_NS - 1)) * LIN_STAGE;
+        const int so = blk * 128;                                        // 32 floats further along every row
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, S3R_LDS_PTR_PW(st + (wave * 4 + q) * 1024), 16, wvoff[q], so, 0,
+                                                     NT ? 2 : 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, S3R_LDS_PTR_PW(st + 128 * 128 + wave * 1024), 16, xvoff, so, 0, 0);
+    };
+
+    f32x16_l acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
-    v4f wv[2][4], xv[2][TM][4];
-#define S3R_LIN_LOAD(S, IT)                                                                          \
-    {                                                                                                \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                              \
-            wv[S][q] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(wp + (IT) * 32 + q * 4)); \
-            _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                        \
-                xv[S][tm][q] = *reinterpret_cast<const v4f*>(xp[tm] + (IT) * 32 + q * 4);            \
-        }                                                                                            \
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // fragment offsets inside a slot: row * 128 + ((2t + h) ^ ((row >> 1) & 7)) * 16; t toggles bits 5..6
+    const int wrow = wave * 32 + j;
+    const int w_off = wrow * 128 + ((h ^ ((wrow >> 1) & 7)) << 4);
+    const int x_off = 128 * 128 + j * 128 + ((h ^ ((j >> 1) & 7)) << 4);
+
+    for (int s0 = 0; s0 < LIN_NS - 1; ++s0)
+        if (s0 < nblk) issue(s0);
+    for (int blk = 0; blk < nblk; ++blk) {
+        // block `blk` has landed when at most the DMAs of the (up to two) later blocks in flight are outstanding
+        const int later = min(nblk - 1 - blk, LIN_NS - 2);
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");           // every wave's part of it has; slot (blk - 1) & 3 is free
+        if (blk + LIN_NS - 1 < nblk) issue(blk + LIN_NS - 1);
+        const char* st = lin_smem + (blk & (LIN_NS - 1)) * LIN_STAGE;
+        v4f xv[4], wv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            xv[t] = *reinterpret_cast<const v4f*>(st + (x_off ^ (t << 5)));
+            wv[t] = *reinterpret_cast<const v4f*>(st + (w_off ^ (t << 5)));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[t][e], wv[t][e], acc, 0, 0, 0);
     }
-#define S3R_LIN_MMA(S)                                                                               \
-    {                                                                                                \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                            \
-                _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                    \
-                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[S][tm][q][e], wv[S][q][e], acc[tm], 0, 0, 0); \
-    }
-    if (niter > 0) S3R_LIN_LOAD(0, 0);
-    int it = 0;
-    for (; it + 2 <= niter; it += 2) {
-        S3R_LIN_LOAD(1, it + 1);
-        S3R_LIN_MMA(0);
-        if (it + 2 < niter) S3R_LIN_LOAD(0, it + 2);
-        S3R_LIN_MMA(1);
-    }
-    if (it < niter) S3R_LIN_MMA(0);
-#undef S3R_LIN_LOAD
-#undef S3R_LIN_MMA
-    const int o = o0 + j;
+    const int o = o0 + wave * 32 + j;
     if (o < Cout) {
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int b = b0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (b < B) part[((size_t)kz * B + b) * Cout + o] = acc[tm][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int b = b0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (b < B) part[((size_t)kz * B + b) * Cout + o] = acc[r];
+        }
     }
 }
 
@@ -320,26 +349,41 @@ __global__ __launch_bounds__(256) void linear_naive_kernel(const float* __restri
     part[i] = s;
 }
 
-__global__ void linear_finish_kernel(const float* __restrict__ part, float* __restrict__ y,
-                                     const float* __restrict__ scale, const float* __restrict__ bias, int Cout,
-                                     long long total, int ksplit, int act) {
+// one thread per output; the ksplit partial slabs are summed in kz order (a fixed order: deterministic) with eight loads
+// in flight per thread (a one-load-at-a-time loop is a chain of ksplit L2 round trips: 64 of them for p1)
+__global__ __launch_bounds__(256) void linear_finish_kernel(const float* __restrict__ part, float* __restrict__ y,
+                                                            const float* __restrict__ scale, const float* __restrict__ bias,
+                                                            int Cout, long long total, int ksplit, int act) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) {
-        const int o = (int)(i % Cout);
-        float s = part[i];
-        for (int z = 1; z < ksplit; ++z) s += part[(size_t)z * total + i];     // fixed order: deterministic
-        y[i] = apply_act(fmaf(s, scale ? scale[o] : 1.f, bias ? bias[o] : 0.f), act);
+    if (i >= total) return;
+    const int o = (int)(i % Cout);
+    float s = part[i];
+    int z = 1;
+    for (; z + 8 <= ksplit; z += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(z + u) * total + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
     }
+    for (; z < ksplit; ++z) s += part[(size_t)z * total + i];
+    y[i] = apply_act(fmaf(s, scale ? scale[o] : 1.f, bias ? bias[o] : 0.f), act);
 }
 
-// split of the K axis: enough waves to cover HBM latency on 256 CUs, K slices of >= 128, multiples of 32
+// split of the K axis: about two workgroups per CU (512) so that every CU streams, K slices of whole 32-k blocks, >= 128
 static void linear_split(int B, int Cin, int Cout, int* ksplit, int* kper) {
-    if (Cin % 32 != 0) { *ksplit = 1; *kper = Cin; return; }
-    const int otiles = (Cout + 31) / 32, btiles = (B + 31) / 32;
+    if (Cin % 32 != 0 || (long long)Cin * Cout * 4 >= (1ll << 31) || (long long)B * Cin * 4 >= (1ll << 31)) {
+        *ksplit = 1; *kper = Cin; return;            // (the streaming kernel addresses its tensors with 32-bit byte offsets)
+    }
+    const int otiles = (Cout + 127) / 128, btiles = (B + 31) / 32;
     int ks = 1;
-    while (otiles * btiles * ks < 2048 && Cin / (2 * ks) >= 128 && (Cin / (2 * ks)) % 32 == 0) ks *= 2;
+    while (otiles * btiles * ks < 512 && Cin / (2 * ks) >= 128 && (Cin / (2 * ks)) % 32 == 0) ks *= 2;
     *ksplit = ks;
     *kper = Cin / ks;
+}
+
+static bool linear_streams(int B, int Cin, int Cout) {
+    return Cin % 32 == 0 && (long long)Cin * Cout * 4 < (1ll << 31) && (long long)B * Cin * 4 < (1ll << 31);
 }
 
 int64_t linear_scratch_elems(int B, int Cin, int Cout) {
@@ -353,12 +397,22 @@ hipError_t launch_linear(const float* x, const float* w, const float* scale, con
     int ks, kper;
     linear_split(B, Cin, Cout, &ks, &kper);
     const long long total = (long long)B * Cout;
-    if (Cin % 32 != 0) {
+    if (!linear_streams(B, Cin, Cout)) {
         hipLaunchKernelGGL(linear_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, scratch, B,
                            Cin, Cout);
     } else {
-        const dim3 grid((Cout + 31) / 32, (ks + 3) / 4, (B + 31) / 32);
-        hipLaunchKernelGGL(linear_mfma_kernel<1>, grid, dim3(256), 0, s, x, w, scratch, B, Cin, Cout, kper, ks);
+        // weights are read once per forward; whether the non-temporal hint pays depends on what else runs between two
+        // forwards (MI355X_MICROARCH.md nt-weights): S3R_LINEAR_NT=0|1 overrides the measured default
+        static const int nt_env = getenv("S3R_LINEAR_NT") ? atoi(getenv("S3R_LINEAR_NT")) : -1;
+        const bool nt = nt_env >= 0 ? nt_env != 0 : true;
+        const size_t lds = (size_t)LIN_NS * LIN_STAGE;
+        static LdsAttr attr_nt, attr_pl;
+        hipError_t e = nt ? attr_nt.ensure(reinterpret_cast<const void*>(&linear_stream_kernel<true>), (int)lds)
+                          : attr_pl.ensure(reinterpret_cast<const void*>(&linear_stream_kernel<false>), (int)lds);
+        if (e != hipSuccess) return e;
+        const dim3 grid((Cout + 127) / 128, ks, (B + 31) / 32);
+        if (nt) hipLaunchKernelGGL(linear_stream_kernel<true>, grid, dim3(256), lds, s, x, w, scratch, B, Cin, Cout, kper, ks);
+        else hipLaunchKernelGGL(linear_stream_kernel<false>, grid, dim3(256), lds, s, x, w, scratch, B, Cin, Cout, kper, ks);
     }
     hipLaunchKernelGGL(linear_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, scratch, y, scale,
                        bias, Cout, total, ks, act);

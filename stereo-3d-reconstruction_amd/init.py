@@ -19,10 +19,9 @@ def seeded_state_dict(module: torch.nn.Module, seed: int = 0, randomize_bn: bool
     out = {}
     for key, ref in module.state_dict().items():
         shape, leaf = tuple(ref.shape), key.rsplit(".", 1)[-1]
-        parent = key.rsplit(".", 2)[-2] if key.count(".") >= 1 else ""
         if leaf == "num_batches_tracked":
             t = torch.zeros(shape, dtype=ref.dtype)
-        elif parent == "bn":
+        elif _is_batchnorm(module, key):          # (by module TYPE, not by name: any key layout, tools/resurvey.py)
             if not randomize_bn:
                 t = torch.ones(shape) if leaf in ("weight", "running_var") else torch.zeros(shape)
             elif leaf == "weight":
@@ -45,6 +44,17 @@ def seeded_state_dict(module: torch.nn.Module, seed: int = 0, randomize_bn: bool
             raise KeyError(f"unexpected state_dict key {key}")
         out[key] = t.to(ref.dtype)
     return out
+
+
+def _owner(module, key):
+    sub = module
+    for part in key.split(".")[:-1]:
+        sub = getattr(sub, part)
+    return sub
+
+
+def _is_batchnorm(module, key):
+    return isinstance(_owner(module, key), torch.nn.modules.batchnorm._BatchNorm)
 
 
 def _is_transposed(module, key):
