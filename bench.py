@@ -131,7 +131,7 @@ def pmc_summary(variant, dtype, B, plain_run):
     tools/summarize_profile.py -> profiles/traffic_<tag>.json).  They are emitted only when that file records the
     hash of the kernel sources this run was built from and the run is the profiled configuration (no autotune, no
     tile overrides): otherwise traffic is null — a stale constant is not a measurement."""
-    if not plain_run or variant != "voxel":
+    if not plain_run:
         return None
     want = csrc_sha256()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
@@ -139,7 +139,8 @@ def pmc_summary(variant, dtype, B, plain_run):
             tj = json.load(open(path))
         except Exception:
             continue
-        if tj.get("csrc_sha256") == want and tj.get("dtype") == dtype and tj.get("batch") == B:
+        if tj.get("csrc_sha256") == want and tj.get("dtype") == dtype and tj.get("batch") == B and \
+                tj.get("variant", "voxel") == variant:
             return {"file": os.path.relpath(path, ROOT), "csrc_sha256": want,
                     "hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch"),
                     "mfma_utilisation_pmc": tj.get("mfma_utilisation_pmc"),

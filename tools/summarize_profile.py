@@ -102,6 +102,7 @@ def main():
         "csrc_sha256": prof.get("csrc_sha256"), "bench_args": prof.get("args"),
         "dtype": bargs[bargs.index("--dtype") + 1] if "--dtype" in bargs else "f32",
         "batch": int(bargs[bargs.index("--batch") + 1]) if "--batch" in bargs else 32,
+        "variant": bargs[bargs.index("--variant") + 1] if "--variant" in bargs else "voxel",
         "fetch_bytes_per_step_raw": fetch / steps,
         "fetch_bytes_per_step_x2": 2 * fetch / steps,
         "write_bytes_per_step": write / steps,
