@@ -410,12 +410,25 @@ def main():
         elapsed = t.item()
 
     records = []
-    if profiling:
-        if graphed is not None:      # per-kernel HIP events: the same K steps again, launched eagerly (untimed)
-            records = eager_records(s3r, torch, model, left, right, gt_cloud, args.steps)
-        else:
-            records = s3r.profile_read(64 * args.steps + 64)
-            s3r.profile_enable(0)
+    if profiling and graphed is None:                     # eager launches: the timed region's own kernel events
+        records = s3r.profile_read(64 * args.steps + 64)
+        s3r.profile_enable(0)
+
+    # per-step spread (untimed for `value`): the same K steps once more, each bracketed by its own pair of events on
+    # the launch stream — the timed region above is one interval, this shows what it averages over
+    spread = None
+    if world == 1:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a, b in evs:
+            a.record()
+            step()
+            b.record()
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        spread = {"min": round(ts[0], 4), "median": round(ts[len(ts) // 2], 4), "max": round(ts[-1], 4)}
+
+    if profiling and graphed is not None:                 # per-kernel HIP events: the same K steps again, eagerly (untimed)
+        records = eager_records(s3r, torch, model, left, right, gt_cloud, args.steps)
 
     if rank == 0:
         pairs = world * B * args.steps
@@ -435,7 +448,7 @@ def main():
             "metric": f"stereo pairs/s forward (batch {B}, 224x224 -> 32^3 voxel)" if args.variant == "voxel"
                       else f"stereo pairs/s forward (batch {B}, 224x224 -> 2048-pt cloud)",
             "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "step_ms_spread": spread, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic" + (" (host->device copy of every batch inside the step)" if args.include_h2d else ""),
             "config": {"workload": f"Stereo2{'Voxel' if args.variant == 'voxel' else 'Point'} forward, batch={B} per GPU, "

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define S3R_ABI_VERSION 3
+#define S3R_ABI_VERSION 4
 
 typedef enum s3r_status {
     S3R_OK = 0,
@@ -60,6 +60,18 @@ typedef enum s3r_dtype {
 
 typedef enum s3r_act { S3R_ACT_NONE = 0, S3R_ACT_RELU = 1, S3R_ACT_SIGMOID = 2 } s3r_act;
 
+/* Memory layout of an activation buffer (beyond NCHW vs channels-last, which the dtype fixes):
+ *   S3R_LAYOUT_PLAIN  the (halo-padded) tensor as described under "Halos" below;
+ *   S3R_LAYOUT_S2D    bf16 path only, even edge n, halo 1: PARITY-SPLIT ("space to depth") — 2^ndim sub-tensors, one per
+ *                     parity class of the position (class = 4*(d&1) + 2*(h&1) + (w&1); d = 0 for 2D), each the
+ *                     (n/2 + 2)^ndim x C channels-last tensor of the positions of that parity with a zero halo of 1:
+ *                     (B, 2^ndim, [n/2+2,] n/2+2, n/2+2, C).  It is what a stride-2 3x3[x3] convolution wants to read:
+ *                     every tap then walks ONE sub-tensor at stride 1, so the kernel that reuses a gathered input plane
+ *                     for all taps of a group serves stride-2 layers as well (the input crosses L2 -> LDS once per 9/4
+ *                     taps instead of once per tap).  s3r_chain_forward plans it between a convolution and a
+ *                     stride-2 consumer by itself; the fields exist so that single layers can be driven and tested. */
+typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_S2D = 1 } s3r_layout;
+
 /* One layer's geometry.  Spatial sizes are cubic/square: `in_size` per axis, `ndim` axes.
  *
  * Halos.  The MFMA convolution kernels read their zero padding from memory: an activation may be
@@ -81,11 +93,13 @@ typedef struct s3r_conv_desc {
     int32_t tile;      /* -1: library picks; >=0 (tuning): S3R_F32: MFMA tile cfg 0..7 + 16*gather_width;
                           S3R_BF16: 1,2,4 per-tap gather x128 positions (3: 128x128 couts; +16: 32-channel K tiles),
                           9,10 row-reuse gather, 5,6 / 21,22 plane-reuse gather (64- / 32-channel K tiles),
-                          23 plane-reuse 256x128 couts */
+                          23 plane-reuse 256x128 couts; 30, 31 plane-reuse over a parity-split input (x64 / x128 couts) */
     int32_t in_halo;   /* zero halo of the input buffer  (elements per spatial axis side) */
     int32_t out_halo;  /* zero halo of the output buffer */
     int32_t ksplit;    /* 0: library picks; >=1: force the split-K factor (must divide cin/16; bf16: cin/32) */
     int32_t dtype;     /* s3r_dtype: which path (layout + matrix instruction) the layer runs on */
+    int32_t in_layout; /* s3r_layout of the input buffer  (S2D: stride-2 k3 p1 convolutions on the bf16 path only) */
+    int32_t out_layout;/* s3r_layout of the output buffer (S2D: bf16 MFMA convolutions, out_halo must be 1) */
 } s3r_conv_desc;
 
 /* One layer of a stage: geometry + its packed weights + folded epilogue vectors (device pointers). */

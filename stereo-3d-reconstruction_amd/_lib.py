@@ -18,13 +18,13 @@ DTYPE = {"fp32": 0, "bf16": 1}
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}
 FAMILY = {0: "conv_mfma", 1: "stem", 2: "head", 3: "cost_volume", 4: "linear", 5: "chamfer", 6: "iou", 7: "pack",
           8: "pad_copy", 9: "disparity"}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("op", "ndim", "batch", "cin", "cout", "in_size", "k", "stride", "pad", "act", "tag", "tile",
-                 "in_halo", "out_halo", "ksplit", "dtype")]
+                 "in_halo", "out_halo", "ksplit", "dtype", "in_layout", "out_layout")]
 
 
 class Layer(C.Structure):
@@ -111,12 +111,15 @@ def check(rc, what=""):
     return rc
 
 
-def make_desc(layer, batch, in_size, tag=0, tile=-1, in_halo=0, out_halo=0, ksplit=0, dtype=0):
+LAYOUT_PLAIN, LAYOUT_S2D = 0, 1
+
+
+def make_desc(layer, batch, in_size, tag=0, tile=-1, in_halo=0, out_halo=0, ksplit=0, dtype=0, in_layout=0, out_layout=0):
     """arch_spec.Layer -> ConvDesc."""
     op = {"conv2d": OP_CONV, "conv3d": OP_CONV, "deconv3d": OP_DECONV, "linear": OP_LINEAR}[layer.op]
     nd = {"conv2d": 2, "conv3d": 3, "deconv3d": 3, "linear": 0}[layer.op]
     return ConvDesc(op, nd, batch, layer.cin, layer.cout, in_size, layer.k, layer.s, layer.p, ACT[layer.act], tag,
-                    tile, in_halo, out_halo, ksplit, dtype)
+                    tile, in_halo, out_halo, ksplit, dtype, in_layout, out_layout)
 
 
 def profile_enable(max_records):

@@ -106,6 +106,18 @@ int conv_bf16_shape() {
 constexpr int HKC = 32;    // channels per K tile
 constexpr int HBN = 64;    // couts per workgroup
 
+// element offset of output position (b, pd, ph, pw) [of parity class (rd, rh, rw) for a transposed conv] in p.y
+__device__ __forceinline__ int out_offset(const ConvParamsH& p, int b, int pd, int ph, int pw, int rd, int rh, int rw) {
+    if (p.y_s2d) {              // parity-split output (S3R_LAYOUT_S2D): the position's class sub-tensor, at half its index
+        const int cls = ((pd & 1) << 2) | ((ph & 1) << 1) | (pw & 1);
+        return b * p.y_bs + cls * p.y_cs + p.y_org + (pd >> 1) * p.y_ds + (ph >> 1) * p.y_hs + (pw >> 1) * p.y_ws;
+    }
+    const int ostep = p.transposed ? 2 : 1;
+    int ye = b * p.y_bs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw * p.y_ws) * ostep;
+    if (p.transposed) ye += rd * p.y_ds + rh * p.y_hs + rw * p.y_ws;
+    return ye;
+}
+
 // Epilogue shared by the bf16 kernels.  D is [cout][position]: lane (li, lk) owns position row
 // wave*32*TM + pt*MT + li of the tile for each position tile pt, and per 64-cout block the 16-cout groups of
 // group_cout() (the pack kernel permutes the weight rows to make them consecutive).  A lane therefore stores 32
@@ -380,12 +392,8 @@ __global__ __launch_bounds__(256, NH == 2 ? (KC == 64 ? 2 : 3) : min_waves_h(TM,
         const int ph = p.dW.div(rem);
         const int pw = rem - ph * p.Nw;
         int xe = b * p.x_bs + p.x_org + (pd * p.x_ds + ph * p.x_hs + pw * p.x_ws) * p.stride;
-        const int ostep = p.transposed ? 2 : 1;
-        int ye = b * p.y_bs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw * p.y_ws) * ostep;
-        if (p.transposed) {
-            xe += (rd - 1) * p.x_ds + (rh - 1) * p.x_hs + (rw - 1) * p.x_ws;
-            ye += rd * p.y_ds + rh * p.y_hs + rw * p.y_ws;
-        }
+        if (p.transposed) xe += (rd - 1) * p.x_ds + (rh - 1) * p.x_hs + (rw - 1) * p.x_ws;
+        const int ye = out_offset(p, b, pd, ph, pw, rd, rh, rw);
         xoff[t] = xe * 2;
         yoff[t] = ok ? ye : -1;
     }
@@ -566,9 +574,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p,
         rem -= pd * p.Nh * p.Nw;
         const int ph = p.dW.div(rem);
         const int pw = rem - ph * p.Nw;
-        const int ostep = p.transposed ? 2 : 1;
-        int ye = b * p.y_bs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw * p.y_ws) * ostep;
-        if (p.transposed) ye += rd * p.y_ds + rh * p.y_hs + rw * p.y_ws;
+        const int ye = out_offset(p, b, pd, ph, pw, rd, rh, rw);
         yoff[t] = ok ? ye : -1;
         const int k = (b * p.Nd + pd) * p.Nh + ph - rowid0;
         lrow[t] = k == 0 ? p.stride * (pw - pw0) : seg0 + (k - 1) * segw + p.stride * pw;
@@ -692,8 +698,13 @@ constexpr int PL_NB = 3;       // weight ring slots
 // KC = 64: 128-byte image rows (whole lines), two workgroups per CU; KC = 32: 64-byte rows, half the LDS, three
 // workgroups per CU (and the only form for Cin = 32).
 // NH = 64-cout halves per workgroup (2: a 256 x 128 tile, the image serves twice the couts; two workgroups per CU).
-template <int SH, int TM, int KC, int NH>
+// S2D: the input is PARITY-SPLIT (S3R_LAYOUT_S2D) and the layer a stride-2 k3 p1 convolution: the kernel walks the output
+// grid at stride 1 over one class sub-tensor at a time, following p.tab: a group = (32-channel chunk, class, depth tap),
+// its image = that class's plane, its taps = the class's (kh, kw) pairs (1, 2, 2 or 4 of them) — the input crosses
+// L2 -> LDS once per 9/4 taps (27/12 in 3D) in contiguous runs, where the per-tap kernel gathers it once per tap.
+template <int SH, int TM, int KC, int NH, bool S2D = false>
 __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p_kernel(const ConvParamsH p, int r_max) {
+    static_assert(!S2D || KC == 32, "the parity-split schedule is built for 32-channel chunks");
     typedef Mf<SH> M;
     constexpr int MT = M::MT;
     constexpr int NPT = 32 * TM / MT, NCT = 64 / MT, NKS = KC / M::KS;
@@ -736,11 +747,12 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
     const int T = p.T, kh = p.kh, kw = p.kw;
     const int taps_g = kh * kw;
     const int chunks = (p.Cin / KC) / p.ksplit;
-    const int ngroups = S3R_ABLH(p, 2) ? 1 : chunks * p.kd;
-    const int total = ngroups * taps_g;
+    const int gpc = S2D ? p.tab.ngroups : p.kd;              // groups (image loads) per chunk
+    const int ngroups = S3R_ABLH(p, 2) ? 1 : chunks * gpc;
+    const int total = S2D ? (S3R_ABLH(p, 2) ? p.tab.g_ntaps[0] : chunks * T) : ngroups * taps_g;
     const int cls_x = p.transposed ? (rd - 1) * p.x_ds + (rh - 1) * p.x_hs + (rw - 1) * p.x_ws : 0;
     const int in_p = p.x_hs / p.x_ws;                        // padded input row length, in positions
-    const int halo = (kh - 1) * in_p + kw - 1;
+    const int halo = S2D ? in_p + 1 : (kh - 1) * in_p + kw - 1;
     const int umax = (p.Nh - 1) * in_p + p.Nw - 1;
     const int LP = umax + 1 + halo;                          // image rows of a whole plane
 
@@ -781,7 +793,8 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
         (int)((unsigned)T * (unsigned)(p.Cin / HKC) * (unsigned)w_tile), 0x00020000);
     int b_cc = kz * chunks, b_tap = 0, b_slot = 0;            // cursor of the NEXT weight tile to fetch
     auto issue_b = [&]() {
-        const int b_base = ((b_cc * (KC / 32) * T + b_tap) * p.n_tiles + n_tile) * 4096;
+        const int wt = S2D ? (int)p.tab.tap_w[b_tap] : b_tap;     // (S2D: b_tap counts the chunk's taps in schedule order)
+        const int b_base = ((b_cc * (KC / 32) * T + wt) * p.n_tiles + n_tile) * 4096;
 #pragma unroll
         for (int q = 0; q < NPB; ++q) dma16(wrsrc, Bs + b_slot * B_BYTES + ((wave + 4 * q) << 10), bvoff[q], b_base);
         if (++b_tap == T) { b_tap = 0; ++b_cc; }
@@ -800,9 +813,7 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
         rem -= pd * P;
         const int ph = p.dW.div(rem);
         const int pw = rem - ph * p.Nw;
-        const int ostep = p.transposed ? 2 : 1;
-        int ye = b * p.y_bs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw * p.y_ws) * ostep;
-        if (p.transposed) ye += rd * p.y_ds + rh * p.y_hs + rw * p.y_ws;
+        const int ye = out_offset(p, b, pd, ph, pw, rd, rh, rw);
         yoff[t] = ok ? ye : -1;
         const int sgm = b * p.Nd + pd - pl0, u = ph * in_p + pw;
         lrow[t] = sgm == 0 ? u - u0 : len0 + (sgm - 1) * LP + u;
@@ -842,11 +853,11 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     int a_cc = kz * chunks, a_td = 0;                         // cursor of the NEXT image to fetch
     auto issue_a = [&]() {
-        const int a_base = (a_cc * KC + a_td * p.x_ds) * 2;
+        const int a_base = (a_cc * KC + (S2D ? p.tab.g_xoff[a_td] : a_td * p.x_ds)) * 2;
 #pragma unroll
         for (int q = 0; q < NPA_CAP; ++q)
             if ((wave + 4 * q) * RPP < r_max) dma16(xrsrc, smem + ((wave + 4 * q) << 10), avoff[q], a_base);
-        if (++a_td == p.kd) { a_td = 0; ++a_cc; }
+        if (++a_td == gpc) { a_td = 0; ++a_cc; }
     };
     typename M::acc_t acc[NH][NPT][NCT];
 #pragma unroll
@@ -861,10 +872,14 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
     issue_a();                                                // (asrc aliases the LAST ring slot, first filled
                                                               //  behind the loop's first barrier)
 
-    int tt = 0, c_slot = 0;
+    int tt = 0, c_slot = 0, gi = 0;
     for (int g = 0; g < ngroups; ++g) {
         int tapoff = 0, c_tw = 0;
-        for (int t = 0; t < taps_g; ++t, ++tt) {
+        const int ntaps = S2D ? (int)p.tab.g_ntaps[gi] : taps_g;
+        const int tfirst = S2D ? (int)p.tab.g_first[gi] : 0;
+        if (++gi == gpc) gi = 0;
+        for (int t = 0; t < ntaps; ++t, ++tt) {
+            if constexpr (S2D) tapoff = p.tab.tap_off[tfirst + t];
             // this tap's weights (and, at t == 0, the image) have landed; the next tap's may still be in flight.
             // (s_barrier as inline asm: the compiler drains vmcnt before every barrier it knows about, which
             // would cut the weight prefetch back to one tap)
@@ -916,8 +931,10 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
                 __builtin_amdgcn_sched_group_barrier(0x008, NCT * NH * NPT, 0);
             }
             if (++c_slot == PL_NB) c_slot = 0;
-            ++tapoff;
-            if (++c_tw == kw) { c_tw = 0; tapoff += in_p - kw; }
+            if constexpr (!S2D) {
+                ++tapoff;
+                if (++c_tw == kw) { c_tw = 0; tapoff += in_p - kw; }
+            }
         }
         asm volatile("s_barrier" ::: "memory");               // every wave is done with this image
         if (g + 1 < ngroups && !S3R_ABLH(p, 3)) issue_a();
@@ -942,7 +959,6 @@ __global__ __launch_bounds__(256) void conv_finish_bf16_kernel(const ConvParamsH
     const int rd = (cls >> 2) & 1, rh = (cls >> 1) & 1, rw = cls & 1;
     const int half = p.CoutPad >> 1;
     const long long total = (long long)p.Ntotal * half;
-    const int ostep = p.transposed ? 2 : 1;
     unsigned short* __restrict__ y = reinterpret_cast<unsigned short*>(p.y);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int n = (int)(i / half);
@@ -960,8 +976,7 @@ __global__ __launch_bounds__(256) void conv_finish_bf16_kernel(const ConvParamsH
         rem -= pd * p.Nh * p.Nw;
         const int ph = p.dW.div(rem);
         const int pw = rem - ph * p.Nw;
-        int ye = b * p.y_bs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw * p.y_ws) * ostep;
-        if (p.transposed) ye += rd * p.y_ds + rh * p.y_hs + rw * p.y_ws;
+        const int ye = out_offset(p, b, pd, ph, pw, rd, rh, rw);
         const bool c1 = co + 1 < p.Cout;
         float v0 = fmaf(s.x, p.scale ? p.scale[co] : 1.f, p.shift ? p.shift[co] : 0.f);
         float v1 = c1 ? fmaf(s.y, p.scale ? p.scale[co + 1] : 1.f, p.shift ? p.shift[co + 1] : 0.f) : 0.f;
@@ -990,6 +1005,9 @@ int conv_bf16_pick_tm(const ConvParamsH& p) {
     const long classes = (p.transposed ? 8 : 1) * (long)p.ksplit;
     const long n_tiles = p.CoutPad / HBN;
     auto wgs = [&](int tm) { return ((p.Ntotal + 128 * tm - 1) / (128 * tm)) * n_tiles * classes; };
+    // a parity-split input has ONE reader (and one K order, whatever the batch): the plane kernel's S2D form; its
+    // 128-cout tile where the channel axis allows and the grid stays full
+    if (p.s2d) return (n_tiles % 2 == 0 && wgs(2) / 2 >= 512) ? 31 : 30;
     // The K summation order of a layer must not depend on the batch (a sample's result is batch-invariant): the
     // plane / row-reuse kernels and the 32-channel per-tap kernel accumulate chunk32-major, the 64-channel per-tap
     // kernel chunk64-major.  So the FAMILY is chosen from per-sample geometry, only the tile from the batch.
@@ -1010,7 +1028,16 @@ int conv_bf16_pick_tm(const ConvParamsH& p) {
     return 1;
 }
 
+// can the plane kernel read this (stride-2 k3 p1) layer from a parity-split input?  Decided from per-sample geometry
+// only (the layout of a layer's input must not depend on the batch): the 256-position image fits its LDS budget
+bool conv_bf16_s2d_ok(const ConvParamsH& p) {
+    if (!p.s2d || p.Cin % 32 != 0 || p.ksplit != 1) return false;
+    const int r = plane_rows(p, 256, 32);
+    return r > 0 && r <= 64 * NPA_PL32 && (size_t)r * 64 + PL_NB * HBN * 2 * 64 + 2 * 256 * sizeof(int) + 2 * EP_BYTES <= 160 * 1024;
+}
+
 int conv_bf16_pick_ksplit(const ConvParamsH& p) {
+    if (p.s2d) return 1;
     // per-sample geometry at a nominal batch (batch-invariant, as in the fp32 path); 128 here: this path's
     // named configuration is batch 256, where splitting v5 / v6 / d1 further costs 15-30 % of their time
     const int chunks = p.Cin / HKC;
@@ -1023,7 +1050,7 @@ int conv_bf16_pick_ksplit(const ConvParamsH& p) {
 
 int64_t conv_bf16_scratch_elems(const ConvParamsH& p, int tm) {
     if (p.ksplit <= 1) return 0;
-    const int t0 = tm == 23 ? 2 : tm >= 21 ? tm - 20 : (tm >= 16 ? tm - 16 : (tm >= 9 ? tm - 8 : (tm >= 5 ? tm - 4 : tm)));
+    const int t0 = (tm == 30 || tm == 31) ? 2 : tm == 23 ? 2 : tm >= 21 ? tm - 20 : (tm >= 16 ? tm - 16 : (tm >= 9 ? tm - 8 : (tm >= 5 ? tm - 4 : tm)));
     const int bm = 128 * (t0 == 3 ? 1 : t0);
     const int64_t mpad = (int64_t)((p.Ntotal + bm - 1) / bm) * bm;
     return (int64_t)(p.transposed ? 8 : 1) * p.ksplit * mpad * p.CoutPad;
@@ -1066,7 +1093,7 @@ static hipError_t launch_tm_rowreuse(ConvParamsH p, hipStream_t stream) {
 static int plane_rows(const ConvParamsH& p, int bm, int kc) {
     if (p.stride != 1 || p.Cin % kc != 0 || p.x_hs % p.x_ws != 0) return 0;
     const int in_p = p.x_hs / p.x_ws, P = p.Nh * p.Nw;
-    const int halo = (p.kh - 1) * in_p + p.kw - 1;
+    const int halo = p.s2d ? in_p + 1 : (p.kh - 1) * in_p + p.kw - 1;       // (parity-split input: tap offsets 0 .. in_p + 1)
     // tiles start at multiples of bm: when rows / planes divide bm (or bm divides the plane) they are never straddled
     // (e2: 112^2 = 49 x 256; d3: 16^2 = 256; d2: 4 planes of 64, d1: 16 planes of 16 per tile)
     const int rows_touched = (bm % p.Nw == 0) ? bm / p.Nw : (bm + p.Nw - 2) / p.Nw + 1;
@@ -1076,11 +1103,12 @@ static int plane_rows(const ConvParamsH& p, int bm, int kc) {
     return (r + unit - 1) / unit * unit;
 }
 
-template <int SH, int TM, int KC, int NH = 1>
+template <int SH, int TM, int KC, int NH = 1, bool S2D = false>
 static hipError_t launch_tm_plane(ConvParamsH p, hipStream_t stream) {
     constexpr int BM = 128 * TM;
     p.m_tiles = (p.Ntotal + BM - 1) / BM;
     p.n_tiles = p.CoutPad / HBN;
+    if (S2D != (p.s2d != 0)) return hipErrorInvalidValue;
     const int r_max = plane_rows(p, BM, KC);
     if (r_max == 0 || r_max > (KC == 64 ? 32 * NPA_PL : 64 * NPA_PL32) || (p.Cin / KC) % p.ksplit != 0)
         return hipErrorInvalidValue;
@@ -1088,10 +1116,10 @@ static hipError_t launch_tm_plane(ConvParamsH p, hipStream_t stream) {
     const size_t lds = (size_t)r_max * KC * 2 + PL_NB * HBN * NH * KC * 2 + 2 * BM * sizeof(int) + EP_BYTES * NH;
     if (lds > 160 * 1024 || r_max * 4 > HBN * NH * KC * 2) return hipErrorInvalidValue;
     static LdsAttr lds_attr;
-    const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_bf16p_kernel<SH, TM, KC, NH>), 160 * 1024);
+    const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_bf16p_kernel<SH, TM, KC, NH, S2D>), 160 * 1024);
     if (attr != hipSuccess) return attr;
     dim3 grid(p.m_tiles * (p.n_tiles / NH), p.transposed ? 8 : 1, p.ksplit);
-    hipLaunchKernelGGL((conv_bf16p_kernel<SH, TM, KC, NH>), grid, dim3(256), lds, stream, p, r_max);
+    hipLaunchKernelGGL((conv_bf16p_kernel<SH, TM, KC, NH, S2D>), grid, dim3(256), lds, stream, p, r_max);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && p.ksplit > 1) {
         const long long total = (long long)p.Ntotal * (p.CoutPad >> 1);
@@ -1159,6 +1187,8 @@ static hipError_t launch_shape(const ConvParamsH& p, int tm, hipStream_t stream)
         case 21: return launch_tm_plane<SH, 1, 32>(p, stream);
         case 22: return launch_tm_plane<SH, 2, 32>(p, stream);
         case 23: return launch_tm_plane<SH, 2, 32, 2>(p, stream);            // 256 positions x 128 couts
+        case 30: return launch_tm_plane<SH, 2, 32, 1, true>(p, stream);      // plane-reuse over a parity-split input
+        case 31: return launch_tm_plane<SH, 2, 32, 2, true>(p, stream);      // ... 256 positions x 128 couts
         case 9: return launch_tm_rowreuse<SH, 1>(p, stream);
         case 10: return launch_tm_rowreuse<SH, 2>(p, stream);
         default: return hipErrorInvalidValue;

@@ -26,12 +26,12 @@ def test_header_symbols_all_exported(s3r, lib):
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.s3r_abi_version() == 3
+    assert lib.s3r_abi_version() == 4
 
 
 def test_struct_layouts_match_header(s3r):
-    assert C.sizeof(s3r._lib.ConvDesc) == 16 * 4
-    assert C.sizeof(s3r._lib.Layer) == 16 * 4 + 3 * 8
+    assert C.sizeof(s3r._lib.ConvDesc) == 18 * 4
+    assert C.sizeof(s3r._lib.Layer) == 18 * 4 + 3 * 8
     assert C.sizeof(s3r._lib.ProfRecord) == 32      # 4 x 4 bytes + 2 doubles
 
 
