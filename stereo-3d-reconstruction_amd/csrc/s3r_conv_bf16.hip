@@ -34,12 +34,20 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef S3R_PRIO_EDGE
+#define S3R_PRIO_EDGE 3               // wave priority of the prologue / epilogue phases (the K loops run at 0)
+#endif
 #ifndef S3R_BF16_MFMA_DEFAULT
 #define S3R_BF16_MFMA_DEFAULT 32      // the matrix instruction used when S3R_BF16_MFMA is not set (see conv_bf16_shape)
 #endif
 
 namespace s3r {
 
+#ifdef S3R_ABLATE
+// S3R_ABL=7: per-workgroup timeline stamps of the plane kernel (s_memrealtime, 100 MHz):
+// [cu key, entry, tables done, first image landed, loop end, epilogue issued, stores landed]
+__device__ unsigned long long s3r_timeline_h[8 * 65536];
+#endif
 #ifdef S3R_ABLATE   // diagnostic builds only: S3R_ABL=1 no epilogue stores, 2 one K tile only, 3 no DMA in the loop
 static int abl_mode_h() { static const int m = getenv("S3R_ABL") ? atoi(getenv("S3R_ABL")) : 0; return m; }
 #define S3R_ABLH(p, m) ((p).debug == (m))
@@ -702,9 +710,15 @@ constexpr int PL_NB = 3;       // weight ring slots
 // grid at stride 1 over one class sub-tensor at a time, following p.tab: a group = (32-channel chunk, class, depth tap),
 // its image = that class's plane, its taps = the class's (kh, kw) pairs (1, 2, 2 or 4 of them) — the input crosses
 // L2 -> LDS once per 9/4 taps (27/12 in 3D) in contiguous runs, where the per-tap kernel gathers it once per tap.
-template <int SH, int TM, int KC, int NH, bool S2D = false>
+// HEAD: the fused pointwise-head epilogue is its own instantiation (d3 only).  Compiled into the same kernel behind a
+// run-time test (r01), the two epilogues shared one register allocation at the 168-VGPR cap of three waves per SIMD
+// and every layer's kernel spilled 40 bytes per lane to scratch; now the plain kernel needs 113 VGPRs and none.  The
+// head instantiation still spills its 40 bytes at three waves per SIMD — measured faster (d3 1.32 vs 1.45 ms) than
+// giving it 176 registers at two.
+template <int SH, int TM, int KC, int NH, bool S2D = false, bool HEAD = false>
 __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p_kernel(const ConvParamsH p, int r_max) {
     static_assert(!S2D || KC == 32, "the parity-split schedule is built for 32-channel chunks");
+    static_assert(!HEAD || NH == 1, "the fused head needs the whole channel axis in one 64-cout tile");
     typedef Mf<SH> M;
     constexpr int MT = M::MT;
     constexpr int NPT = 32 * TM / MT, NCT = 64 / MT, NKS = KC / M::KS;
@@ -724,10 +738,19 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
     float* ep = reinterpret_cast<float*>(lrow + BM);                  // [3][64] scale / shift / head weight
     int* asrc = reinterpret_cast<int*>(Bs + (PL_NB - 1) * B_BYTES);  // [r_max] source byte offset of each image row
                                                                       // (prologue only: aliases the last ring slot)
+    // The prologue (tables, first image) and the epilogue are short, latency-bound instruction streams that run beside
+    // two other workgroups' K loops on the same SIMDs; as the YOUNGEST wave of its SIMD this one loses every issue
+    // arbitration (priority, then age) and a timeline showed 3-4 us of tables and 4.4-5.8 us of epilogue per workgroup
+    // (tools/timeline_bf16.py).  Raised priority outside the K loop lets those phases through; the loop runs at 0.
+    __builtin_amdgcn_s_setprio(S3R_PRIO_EDGE);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane % MT, lk = lane / MT;
+#ifdef S3R_ABLATE
+    unsigned long long tl[6] = {0, 0, 0, 0, 0, 0};
+    if (p.debug == 7) tl[0] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
@@ -829,7 +852,10 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
         const int pd = pl - b * p.Nd;
         asrc[j] = (b * p.x_bs + p.x_org + pd * p.x_ds + off * p.x_ws + cls_x) * 2;
     }
-    __syncthreads();
+    // publish the LDS tables.  NOT __syncthreads(): the compiler drains vmcnt before a barrier it knows about, which would
+    // wait out the two weight tiles and the per-cout constants requested above (an L2 / HBM round trip in the prologue
+    // of every workgroup) — they only have to land by the first tap / the epilogue
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     // ---- loop-invariant DMA source offsets
     // A pieces (RPP rows each) are dealt round-robin to the four waves; r_max is a whole number of pieces
@@ -869,9 +895,13 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
 #pragma unroll
                 for (int r = 0; r < M::NACC; ++r) acc[nh][a][b][r] = 0.f;
 
+#ifdef S3R_ABLATE
+    if (p.debug == 7) tl[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     issue_a();                                                // (asrc aliases the LAST ring slot, first filled
                                                               //  behind the loop's first barrier)
 
+    __builtin_amdgcn_s_setprio(0);
     int tt = 0, c_slot = 0, gi = 0;
     for (int g = 0; g < ngroups; ++g) {
         int tapoff = 0, c_tw = 0;
@@ -887,6 +917,9 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
             else if (NPB == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");           // ... for every wave; ring slot (tt+2)%3 is free
+#ifdef S3R_ABLATE
+            if (p.debug == 7 && tt == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
+#endif
             if (tt + 2 < total && !S3R_ABLH(p, 3)) issue_b();
             const char* b = Bs + c_slot * B_BYTES;
             int a_off[NPT];
@@ -940,16 +973,28 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
         if (g + 1 < ngroups && !S3R_ABLH(p, 3)) issue_a();
     }
 
+#ifdef S3R_ABLATE
+    if (p.debug == 7) tl[3] = __builtin_amdgcn_s_memrealtime();
+#endif
+    __builtin_amdgcn_s_setprio(S3R_PRIO_EDGE);
     store_ep(epr, ep, tid, BNW);
-    if constexpr (NH == 1) {
-        if (p.head_w) epilogue_h<SH, TM, true>(p, acc[0], yoff, ep, smem + wave * (32 * ST_ROW), wave, li, lk, m0, n0, cls, kz, BM);
-        else epilogue_h<SH, TM, false>(p, acc[0], yoff, ep, smem + wave * (32 * ST_ROW), wave, li, lk, m0, n0, cls, kz, BM);
-    } else {
 #pragma unroll
-        for (int nh = 0; nh < NH; ++nh)
-            epilogue_h<SH, TM, false>(p, acc[nh], yoff, ep + nh * 192, smem + wave * (32 * ST_ROW), wave, li, lk, m0, n0 + nh * HBN,
-                                      cls, kz, BM);
+    for (int nh = 0; nh < NH; ++nh)
+        epilogue_h<SH, TM, HEAD>(p, acc[nh], yoff, ep + nh * 192, smem + wave * (32 * ST_ROW), wave, li, lk, m0, n0 + nh * HBN,
+                                 cls, kz, BM);
+#ifdef S3R_ABLATE
+    if (p.debug == 7 && tid == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 65536) {
+        tl[4] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tl[5] = __builtin_amdgcn_s_memrealtime();
+        const unsigned hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* t = s3r_timeline_h + 8 * (size_t)blockIdx.x;
+        t[0] = ((unsigned long long)(xcc & 15u) << 8) | ((hw >> 8) & 0xffu);
+        for (int i = 0; i < 6; ++i) t[1 + i] = tl[i];
     }
+#endif
 }
 
 // split-K finish: y[pos][cout] = bf16(act(scale * sum_kz slab + shift)); one thread per (position, cout pair)
@@ -1116,11 +1161,22 @@ static hipError_t launch_tm_plane(ConvParamsH p, hipStream_t stream) {
     const size_t lds = (size_t)r_max * KC * 2 + PL_NB * HBN * NH * KC * 2 + 2 * BM * sizeof(int) + EP_BYTES * NH;
     if (lds > 160 * 1024 || r_max * 4 > HBN * NH * KC * 2) return hipErrorInvalidValue;
     static LdsAttr lds_attr;
-    const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_bf16p_kernel<SH, TM, KC, NH, S2D>), 160 * 1024);
-    if (attr != hipSuccess) return attr;
     dim3 grid(p.m_tiles * (p.n_tiles / NH), p.transposed ? 8 : 1, p.ksplit);
-    hipLaunchKernelGGL((conv_bf16p_kernel<SH, TM, KC, NH, S2D>), grid, dim3(256), lds, stream, p, r_max);
-    hipError_t e = hipGetLastError();
+    hipError_t e;
+    if constexpr (NH == 1 && !S2D) {
+        if (p.head_w && p.ksplit == 1) {
+            static LdsAttr lds_attr_h;
+            const hipError_t ah = lds_attr_h.ensure(reinterpret_cast<const void*>(&conv_bf16p_kernel<SH, TM, KC, NH, S2D, true>), 160 * 1024);
+            if (ah != hipSuccess) return ah;
+            hipLaunchKernelGGL((conv_bf16p_kernel<SH, TM, KC, NH, S2D, true>), grid, dim3(256), lds, stream, p, r_max);
+            return hipGetLastError();
+        }
+    }
+    if (p.head_w) return hipErrorInvalidValue;
+    const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_bf16p_kernel<SH, TM, KC, NH, S2D, false>), 160 * 1024);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((conv_bf16p_kernel<SH, TM, KC, NH, S2D, false>), grid, dim3(256), lds, stream, p, r_max);
+    e = hipGetLastError();
     if (e == hipSuccess && p.ksplit > 1) {
         const long long total = (long long)p.Ntotal * (p.CoutPad >> 1);
         const long long blocks = (total + 255) / 256;
@@ -1262,3 +1318,10 @@ hipError_t launch_pack_bf16(const float* w, void* wp, int Cin, int Cout, int Cou
 }
 
 }  // namespace s3r
+
+#ifdef S3R_ABLATE
+extern "C" int s3r_debug_read_timeline_h(unsigned long long* out, int nblocks) {
+    if (nblocks > 65536) nblocks = 65536;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(s3r::s3r_timeline_h), sizeof(unsigned long long) * 8 * (size_t)nblocks) == hipSuccess ? nblocks : -1;
+}
+#endif
