@@ -72,3 +72,45 @@ def test_shard_bounds_cover_every_sample_once(s3r):
             assert max(sizes) - min(sizes) <= 1 and sizes == s3r.collate.shard_sizes(total, world)
     with pytest.raises(ValueError):
         s3r.collate.shard_bounds(4, 2, 2)
+
+
+def test_bench_and_runner_start_their_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` / `python runner.py --test --gpus N` with no launcher around them (how the driver
+    invokes N = 1, and what it would do for N > 1): the parent starts `torch.distributed.run` with N ranks as a CHILD
+    process — before importing torch — on 127.0.0.1, passes its own arguments through, and returns the child's code."""
+    import importlib
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    for name, argv in (("bench", ["bench.py", "--gpus", "4", "--steps", "7", "--batch", "256"]),
+                       ("runner", ["runner.py", "--test", "--gpus", "4", "--samples", "8"])):
+        mod = importlib.import_module(name)
+        calls = []
+
+        class Done:
+            returncode = 17
+
+        def fake_run(cmd, env=None, **kw):
+            calls.append((cmd, env))
+            return Done()
+        monkeypatch.setattr(mod.subprocess, "run", fake_run)
+        monkeypatch.setattr(sys, "argv", argv)
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            monkeypatch.delenv(k, raising=False)
+        with pytest.raises(SystemExit) as e:
+            mod.main()
+        assert e.value.code == 17                                   # the child's exit code, relayed
+        (cmd, env), = calls
+        assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+        assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+        assert cmd[-len(argv) + 1:] == argv[1:] and cmd[-len(argv)].endswith(argv[0])
+        assert env["MASTER_ADDR"] == "127.0.0.1"
+        # under an external launcher (WORLD_SIZE set) nothing is spawned: the script is one of the ranks
+        monkeypatch.setenv("WORLD_SIZE", "4")
+        calls.clear()
+        try:
+            mod.main()
+        except BaseException:
+            pass                                                    # (no GPU here: it fails later, after NOT spawning)
+        assert not calls
+        monkeypatch.delenv("WORLD_SIZE")
