@@ -2,6 +2,7 @@
 // (fp32 NCHW renders -> bf16 NHWC features), the fused bidirectional cost volume on channels-last bf16
 // features, and the 1x1x1 occupancy head (bf16 NDHWC -> fp32 (B,32,32,32) probabilities).
 #include "s3r_kernels.h"
+#include <cstdlib>
 
 namespace s3r {
 
@@ -94,11 +95,257 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same stem on the matrix cores, rows staged through LDS.  What the VALU form above is bound by is not its 432
+// packed FMAs per pixel but its memory pattern: 27 stride-2 dword gathers per pixel-thread (a diagnostic build with the
+// stores removed still took 142 us at B = 256 for 308 MB of renders: 2.2 TB/s) and a store path that waits behind them
+// (0.21 ms in all, 3.4 TB/s).  Here a workgroup of 7 waves owns 4 output rows of one image:
+//   * the 9 input rows x 3 channels it needs arrive by LDS-DMA, one whole 896-byte row per wave-instruction (56 lanes
+//     x 16 B, contiguous in HBM and in LDS) into 1-KiB LDS slots whose last 128 bytes stay zero — which is also the
+//     zero a tap at column -1 must read (it is the tail of the slot before); the row above the image is zero-filled;
+//     two such slabs: the rows of the next pass are in flight while this one is computed (counted vmcnt, raw barriers);
+//   * a wave computes 32 pixels x 32 couts as D[cout][pixel] with v_mfma_f32_32x32x2_f32 over K = 28: tap k = ci*9 +
+//     kh*3 + kw for k < 27 (weights x folded-BN scale) and a constant-one column whose weight is the folded-BN shift —
+//     exact fp32 FMA chains, no VALU arithmetic at all before the ReLU; lane (j = l & 31, h = l >> 5) feeds pixel j /
+//     cout j at k = 2 s + h, one ds_read_b32 per MFMA;
+//   * the 32 x 64-byte result goes through a wave-private LDS slab so that every store instruction writes 16 whole
+//     pixels = 1 KiB contiguous.
+// 14 MFMAs of 64 cycles per tile: 73 us of matrix time at B = 256 under 145 us of HBM time; measured 156 us (4.6 TB/s,
+// VALU form 210).  tools/timeline_stem.py (diagnostic build) on what is left: a pass takes 6.1 us per workgroup —
+// issuing the next rows 0.7, waiting for this pass's 0.25, barrier 0.3, 28 operand reads 0.4, the two MFMA chains
+// 1.4, ReLU + LDS slab + stores 0.85 per tile, closing barrier 0.3 — with 2 workgroups (14 waves) per CU the matrix
+// pipe is busy 48 % of the time and no unit more than that: what is left is the serial chain inside a pass.
+// ReLU as ONE instruction the compiler knows (so the MFMA -> VALU read hazard is its to cover): fmaxf on an MFMA result
+// gets a canonicalising v_max_f32 x, x in front of it; as signed integers every negative float (and -0) is below zero and
+// every positive float is itself, so v_max_i32(bits, 0) is the same function
+__device__ __forceinline__ float relu1(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
+constexpr int STEM_ROWS = 4;                 // output rows per workgroup pass
+constexpr int STEM_SLOTS = 3 * (2 * STEM_ROWS + 1);
+constexpr int STEM_WAVES = 7;                // 4 rows x 112 pixels = 14 tiles of 32: two per wave
+constexpr int STEM_SLABS = 2;                // row slabs: 2 = the next pass's rows in flight during this one (0.156 ms at B = 256);
+                                             // 1 = this pass's own rows, waited for in full (0.172: registers, not LDS, hold it to 2 workgroups/CU too)
+constexpr int STEM_LDS_BYTES = 1024 + STEM_SLABS * STEM_SLOTS * 1024 + STEM_WAVES * 2048;  // guard + row slabs + store slabs
+
+#ifdef S3R_ABLATE   // diagnostic builds: S3R_ABL = 32 + bits: 1 no global stores, 2 no row DMA (after the first pass), 4 one MFMA per tile
+#define S3R_STEM_DBG_PARAM , int dbg
+#define S3R_STEM_DBG(bit) (dbg >= 32 && (dbg & (bit)))
+#else
+#define S3R_STEM_DBG_PARAM
+#define S3R_STEM_DBG(m) false
+#endif
+#ifdef S3R_ABLATE
+// per workgroup (first 4096), wave 0, pass 5: [pass start, rows issued, rows landed (before barrier), after barrier,
+// tile 1 done, tile 2 done, after the closing barrier, operands read (landed), MFMAs of both tiles issued+done, ...]
+__device__ unsigned long long s3r_stem_timeline[4096 * 16];
+#define S3R_STEM_STAMP(k) do { if (dbg >= 32 && stamp_pass == 5 && lane == 0 && wave == 0 && blockIdx.x < 4096) \
+        s3r_stem_timeline[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define S3R_STEM_STAMP(k) do {} while (0)
+#endif
+__global__ __launch_bounds__(64 * STEM_WAVES) void stem_bf16_mfma_kernel(
+        const float* __restrict__ x, const float* __restrict__ x2, int nsplit, const float* __restrict__ wt,
+        const float* __restrict__ scale, const float* __restrict__ shift, unsigned short* __restrict__ y, int N,
+        int y_bs, int y_hs, int y_org S3R_STEM_DBG_PARAM) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    constexpr int Hi = 224, Wi = 224, Wo = 112, BPI = 112 / STEM_ROWS;       // the network's stem geometry (launcher checks)
+    constexpr int ROWB = Wi * 4;                                              // 896
+    extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
+    unsigned char* slab = slds + 1024;                                        // slot sl at slab + 1024 sl; 1 KiB of zeros before slot 0
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    v2u* sw = reinterpret_cast<v2u*>(slab + STEM_SLABS * STEM_SLOTS * 1024 + wave * 2048);  // [pixel 32][8 x 8 B], 16-B slot g at g ^ ((pixel >> 1) & 3)
+    const v4u* sr = reinterpret_cast<const v4u*>(sw);
+
+    // ---- once: zero guard + slot tails, weight fragments (A operand: cout j, k = 2 s + h), tap offsets (B operand)
+    for (int i = threadIdx.x; i < 256 + STEM_SLABS * STEM_SLOTS * 32; i += 64 * STEM_WAVES) {
+        if (i < 256) reinterpret_cast<unsigned*>(slds)[i] = 0u;
+        else { const int sl = (i - 256) >> 5, w = (i - 256) & 31; reinterpret_cast<unsigned*>(slab + sl * 1024 + ROWB)[w] = 0u; }
+    }
+    float wa[14];
+    int off[14];
+    {
+        const float sc = scale ? scale[j] : 1.f;
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            const int k = 2 * s + h;
+            const int t = k < 27 ? k : 0;
+            const int ci = t / 9, kh = (t - ci * 9) / 3, kw = t - ci * 9 - kh * 3;
+            off[s] = (ci * (2 * STEM_ROWS + 1) + kh) * 1024 + kw * 4;
+            wa[s] = k < 27 ? wt[t * 32 + j] * sc : (shift ? shift[j] : 0.f);
+        }
+    }
+    const int sj = (j >> 1) & 3;
+
+    // ---- rows of pass `blk` into slab `sb`: slot sl = ci*9 + rr holds input row 8 q - 1 + rr of channel ci.  Returns the
+    // number of DMA instructions this wave issued (wave-uniform)
+    auto issue = [&](int blk, unsigned char* sb) -> int {
+        const int n = blk / BPI, q = blk - n * BPI;
+        const float* xn = n < nsplit ? x + (size_t)n * 3 * Hi * Wi : x2 + (size_t)(n - nsplit) * 3 * Hi * Wi;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, 3 * Hi * Wi * 4, 0x00020000);
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int sl = wave * 4 + u;
+            if (sl >= STEM_SLOTS) break;
+            const int ci = sl / (2 * STEM_ROWS + 1), rr = sl - ci * (2 * STEM_ROWS + 1);
+            const int irow = 2 * STEM_ROWS * q - 1 + rr;
+            if (irow < 0) {                                                    // the row above the image
+                if (lane < 56) *reinterpret_cast<v4u*>(sb + sl * 1024 + lane * 16) = (v4u){0u, 0u, 0u, 0u};
+            } else if (!(S3R_STEM_DBG(2) && blk >= (int)gridDim.x)) {
+                if (lane < 56)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(sb + sl * 1024), 16,
+                                                             lane * 16, (ci * Hi + irow) * ROWB, 0, 0);
+                ++cnt;
+            }
+        }
+        return cnt;
+    };
+
+    const int nblk = N * BPI;
+    int blk = blockIdx.x;
+    unsigned char* cur = slab;
+    unsigned char* oth = slab + (STEM_SLABS - 1) * STEM_SLOTS * 1024;
+    if (STEM_SLABS == 2 && blk < nblk) issue(blk, cur);
+#ifdef S3R_ABLATE
+    int stamp_pass = -1;
+#endif
+    for (; blk < nblk; blk += gridDim.x) {
+#ifdef S3R_ABLATE
+        ++stamp_pass;
+#endif
+        S3R_STEM_STAMP(0);
+        // ---- the next pass's rows go into the other slab while this one is computed; then wait for THIS pass's rows.
+        // vmcnt retires in issue order (loads and stores alike), and what was issued after this pass's DMAs is the
+        // previous pass's 4 stores of this wave and the DMAs just issued: they may stay in flight — waiting for the
+        // stores' acknowledgements here cost 5 us per pass
+        const int nxt = blk + gridDim.x;
+        int nn = 0;
+        if (STEM_SLABS == 1) issue(blk, cur);                   // (one slab: this pass's own rows, waited for in full)
+        else nn = (nxt < nblk ? issue(nxt, oth) : 0) + ((blk != (int)blockIdx.x && !S3R_STEM_DBG(1)) ? 4 : 0);
+        S3R_STEM_STAMP(1);
+        switch (nn) {
+            case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
+        }
+        S3R_STEM_STAMP(2);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        S3R_STEM_STAMP(3);
+        const int n = blk / BPI, q = blk - n * BPI;
+        // ---- two tiles per wave.  All 28 operand reads go out before the first MFMA (left to itself the compiler
+        // pairs every ds_read with the MFMA that consumes it: 14 exposed LDS latencies per tile, 1.7 us instead of 0.6)
+        float bv[2][14];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int px = (wave + k * STEM_WAVES) * 32 + j;
+            const int orow = px / Wo, ow = px - orow * Wo;
+            const unsigned char* bp = cur + (2 * orow) * 1024 + (2 * ow - 1) * 4;
+#pragma unroll
+            for (int s = 0; s < 14; ++s) bv[k][s] = *reinterpret_cast<const float*>(bp + off[s]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef S3R_ABLATE
+        if (dbg >= 32) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); S3R_STEM_STAMP(7); }
+#endif
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int tt = wave + k * STEM_WAVES;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 14; ++s) {
+                float b = bv[k][s];
+                if (s == 13) b = h ? 1.f : b;                                  // k = 27: the constant-one column
+                if (S3R_STEM_DBG(4) && s > 0) { acc[s] += b; continue; }
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s], b, acc, 0, 0, 0);
+            }
+#ifdef S3R_ABLATE
+            if (dbg >= 32) { asm volatile("s_nop 0" :: "v"(acc[0])); S3R_STEM_STAMP(8 + 4 * k); }
+#endif
+            // ReLU, bf16: lane (j, h) owns bytes [16 g + 8 h, +8) of pixel j, g = 0..3  (couts 8 g + 4 h + 0..3)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                v2u t;
+                t[0] = pack2(relu1(acc[4 * g]), relu1(acc[4 * g + 1]));
+                t[1] = pack2(relu1(acc[4 * g + 2]), relu1(acc[4 * g + 3]));
+                sw[j * 8 + ((g ^ sj) << 1) + h] = t;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef S3R_ABLATE
+            if (dbg >= 32) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); S3R_STEM_STAMP(9 + 4 * k); }
+#endif
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pix = 16 * i + (lane >> 2), qq = lane & 3;
+                const int ppx = tt * 32 + pix;
+                const int prow = ppx / Wo, pw = ppx - prow * Wo;
+                const v4u t = sr[pix * 4 + (qq ^ ((pix >> 1) & 3))];
+                const size_t o = (size_t)n * y_bs + y_org + (size_t)(STEM_ROWS * q + prow) * y_hs + pw * 32 + qq * 8;
+                if (!S3R_STEM_DBG(1) || t[0] == 0x12345678u) *reinterpret_cast<v4u*>(y + o) = t;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            S3R_STEM_STAMP(4 + k);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                          // this slab is free for the pass after next
+        asm volatile("" ::: "memory");
+        S3R_STEM_STAMP(6);
+        unsigned char* t = cur; cur = oth; oth = t;
+    }
+}
+
+static bool stem_mfma_enabled() {
+    static const bool on = !(getenv("S3R_STEM_MFMA") && atoi(getenv("S3R_STEM_MFMA")) == 0);   // A/B switch
+    return on;
+}
+
 hipError_t launch_stem_bf16(const float* x, const float* x2, int nsplit, const float* wt, const float* scale,
                             const float* shift, void* y, int N, int Hi, int Wi, int Ho, int Wo, int y_bs, int y_hs, int y_org,
                             hipStream_t s) {
     const long long total = (long long)N * Ho * Wo;
     if (!x2) { x2 = x; nsplit = N; }
+    if (stem_mfma_enabled() && Hi == 224 && Wi == 224 && Ho == 112 && Wo == 112 && N > 0 && N <= (1 << 16)) {
+        // persistent workgroups, every one of them resident at once (as many as the occupancy query says fit)
+        static LdsAttr attr;
+        hipError_t e = attr.ensure(reinterpret_cast<const void*>(&stem_bf16_mfma_kernel), STEM_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        static int resident[16] = {0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+        if (!resident[dev]) {
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stem_bf16_mfma_kernel, 64 * STEM_WAVES, STEM_LDS_BYTES) !=
+                    hipSuccess || per_cu < 1)
+                per_cu = 2;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+            resident[dev] = per_cu * cus;
+        }
+        const int blocks = N * (112 / STEM_ROWS);
+        const int wgs = blocks < resident[dev] ? blocks : resident[dev];
+        hipLaunchKernelGGL(stem_bf16_mfma_kernel, dim3((unsigned)wgs), dim3(64 * STEM_WAVES), STEM_LDS_BYTES, s, x, x2, nsplit,
+                           wt, scale, shift, reinterpret_cast<unsigned short*>(y), N, y_bs, y_hs, y_org
+#ifdef S3R_ABLATE
+                           , getenv("S3R_ABL") ? atoi(getenv("S3R_ABL")) : 0
+#endif
+                           );
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(stem_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x2, nsplit, wt, scale,
                        shift, reinterpret_cast<unsigned short*>(y), N, Hi, Wi, Ho, Wo, y_bs, y_hs, y_org);
     return hipGetLastError();
@@ -209,3 +456,10 @@ hipError_t launch_head_bf16(const void* x, const float* w, const float* scale, c
 }
 
 }  // namespace s3r
+
+#ifdef S3R_ABLATE
+extern "C" int s3r_debug_read_stem_timeline(unsigned long long* out, int nblocks) {
+    if (nblocks > 4096) nblocks = 4096;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(s3r::s3r_stem_timeline), sizeof(unsigned long long) * 16 * (size_t)nblocks) == hipSuccess ? nblocks : -1;
+}
+#endif

@@ -201,6 +201,34 @@ def test_bf16_mfma_layout_exact_integers(s3r, mfma_shape):
         assert torch.equal(got.float().cpu(), want), tm
 
 
+def test_bf16_stem_many_images_against_the_fp32_stem(s3r):
+    """The bf16 stem (fp32 MFMA over rows staged by LDS-DMA, persistent workgroups) on enough images that every
+    workgroup makes several passes over its two row slabs (80 images = 2240 passes on <= 512 resident workgroups),
+    checked against the fp32 path's stem — a different kernel (VALU, NCHW) — rounded to bf16: what may differ is the
+    summation order (1e-6) and hence, rarely, the last bf16 bit.  The image border (top row, left column) must be exact
+    zeros' worth: compare those rows / columns separately."""
+    spec = s3r.arch_spec
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(80, 3, spec.IMG_HW, spec.IMG_HW, generator=g).to(DEV)
+    hb = s3r.modules._HipChain([spec.ENCODER[0]], spec.IMG_HW, precision="bf16")
+    hf = s3r.modules._HipChain([spec.ENCODER[0]], spec.IMG_HW, precision="fp32")
+    s3r.seed_module(hb, 5)
+    hf.load_state_dict(hb.state_dict())
+    hb.to(DEV), hf.to(DEV)
+    got = hb._run(x).float()                                   # logical (80,32,112,112)
+    want32 = hf._run(x)
+    want = want32.to(torch.bfloat16).float()
+    assert got.shape == want.shape
+    ulp = 2.0 ** -7 * want32.abs() + 1e-6                      # one bf16 step at the value's magnitude
+    diff = (got - want).abs()
+    assert (diff <= ulp).all()
+    assert (diff > 0).float().mean().item() < 0.02             # the last bit differs on a per-cent of the elements at most
+    for sl in (got[:, :, 0, :] - want[:, :, 0, :], got[:, :, :, 0] - want[:, :, :, 0]):
+        assert (sl.abs() <= ulp.max()).all()
+    again = hb._run(x).float()
+    assert torch.equal(again, got)                             # deterministic across launches
+
+
 def test_bf16_odd_empty_and_chunked_batches(s3r):
     """Ragged sizes on the bf16 path: an odd batch equals its samples run one by one (bitwise), an empty batch is an
     empty result, and the disparity read-out works from the bf16 encoder's features."""
