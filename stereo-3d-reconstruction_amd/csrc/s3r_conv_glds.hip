@@ -95,7 +95,11 @@ static int abl_mode() { static const int m = getenv("S3R_ABL") ? atoi(getenv("S3
 constexpr int min_waves(int tm, int tn) { return tm * tn >= 8 ? 2 : (tm * tn >= 4 ? 4 : 5); }
 
 // HEAD: the fused pointwise-head epilogue (its own instantiation: the two epilogues never share registers)
-template <int WM, int WN, int TM, int TN, int VEC, bool HEAD = false>
+// NBUF: LDS stages of the K loop.  2 = the DMAs of tile t+1 in flight during tile t (every full launch: several
+// workgroups per CU cover each other's waits); 6 = five tiles in flight, for launches that leave a CU with one small
+// workgroup or none (the remainder of a cut launch, tiny batches): alone, a workgroup pays the whole DMA round trip per
+// K tile with two stages (0.5 us against 0.2 us of MFMAs on the 64 x 64 tile).  The K order is the same either way.
+template <int WM, int WN, int TM, int TN, int VEC, bool HEAD = false, int NBUF = 2>
 __global__ __launch_bounds__(256, min_waves(TM, TN) - (HEAD ? 1 : 0)) void conv_glds_kernel(const ConvParams p) {
     constexpr int BM = 32 * WM * TM;
     constexpr int BN = 32 * WN * TN;
@@ -118,8 +122,10 @@ __global__ __launch_bounds__(256, min_waves(TM, TN) - (HEAD ? 1 : 0)) void conv_
     constexpr int LPR_A = BM / 4;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                  // [2][BK][BM]
-    float* Bs = smem + 2 * BK * BM;    // [2][BK][BN]
+    float* As = smem;                     // [NBUF][BK][BM]
+    float* Bs = smem + NBUF * BK * BM;    // [NBUF][BK][BN]
+    static_assert(NBUF == 2 || NPIECE_A % 4 == 0, "a deeper ring counts DMAs per wave: every wave must issue as many");
+    constexpr int NPD = NPA + NPB;        // DMAs per wave per K tile
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -218,9 +224,21 @@ __global__ __launch_bounds__(256, min_waves(TM, TN) - (HEAD ? 1 : 0)) void conv_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (NBUF == 2) {
+        issue(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
+        // tiles 0 .. NBUF-2 go out; tile 0 has landed once at most NBUF-2 tiles' DMAs are outstanding (vmcnt retires
+        // in issue order)
+#pragma unroll
+        for (int i = 0; i < NBUF - 1; ++i)
+            if (i < nkt) issue(i);
+        if (nkt >= NBUF - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NBUF - 2) * NPD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
 
 #ifdef S3R_ABLATE
     if (p.debug == 7) tl1 = __builtin_amdgcn_s_memrealtime();
@@ -230,9 +248,15 @@ __global__ __launch_bounds__(256, min_waves(TM, TN) - (HEAD ? 1 : 0)) void conv_
     typedef typename FVec<TM>::type AV;
     typedef typename FVec<TN>::type BV;
 
+    int cur = 0;                                   // stage of tile kt (NBUF > 2; kt & 1 otherwise)
     for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt && !S3R_ABL(p, 3)) issue(cur ^ 1);
+        if constexpr (NBUF == 2) {
+            cur = kt & 1;
+            if (kt + 1 < nkt && !S3R_ABL(p, 3)) issue(cur ^ 1);
+        } else {
+            // tile kt+NBUF-1 into the stage tile kt-1 was read from (every wave is past the barrier that ended it)
+            if (kt + NBUF - 1 < nkt) issue(cur == 0 ? NBUF - 1 : cur - 1);
+        }
         const float* a = As + cur * BK * BM + a_off;
         const float* b = Bs + cur * BK * BN + b_off;
 #pragma unroll
@@ -246,9 +270,19 @@ __global__ __launch_bounds__(256, min_waves(TM, TN) - (HEAD ? 1 : 0)) void conv_
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(vget<TM>(av, tm), vget<TN>(bv, tn),
                                                                        acc[tm][tn], 0, 0, 0);
         }
-        if (!S3R_ABL(p, 5)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of tile kt+1 have landed
-        if (S3R_ABL(p, 5)) __builtin_amdgcn_s_barrier(); else
-        __syncthreads();                                    // ... everyone's have, and buffer `cur` is free
+        if constexpr (NBUF == 2) {
+            if (!S3R_ABL(p, 5)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of tile kt+1 have landed
+            if (S3R_ABL(p, 5)) __builtin_amdgcn_s_barrier(); else
+            __syncthreads();                                    // ... everyone's have, and buffer `cur` is free
+        } else {
+            // tile kt+1 has landed when only the NBUF-2 tiles after it are outstanding; in the drain (nothing issued
+            // this iteration) wait for everything
+            if (kt + NBUF - 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NBUF - 2) * NPD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cur = cur + 1 == NBUF ? 0 : cur + 1;
+        }
     }
 
 #ifdef S3R_ABLATE
@@ -579,7 +613,7 @@ int conv_pick_vec(const ConvParams& p) {
     return (p.Nw % 4 == 0) ? 4 : 1;   // (there is no 8-byte LDS-DMA)
 }
 
-template <int WM, int WN, int TM, int TN, int VEC, bool HEAD>
+template <int WM, int WN, int TM, int TN, int VEC, bool HEAD, int NBUF = 2>
 static hipError_t launch_cfg(ConvParams p, hipStream_t stream) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     if constexpr (GBK * BN % (256 * VEC) != 0 || BN > 256 * VEC) {
@@ -587,19 +621,26 @@ static hipError_t launch_cfg(ConvParams p, hipStream_t stream) {
     } else {
         p.m_tiles = (p.Cout + BM - 1) / BM;
         p.n_tiles = (p.n_end - p.n_begin + BN - 1) / BN;
-        const size_t lds = (size_t)2 * GBK * (BM + BN) * sizeof(float);
+        const size_t lds = (size_t)NBUF * GBK * (BM + BN) * sizeof(float);
         if (lds > 48 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation and device
             static LdsAttr lds_attr;
             const hipError_t attr = lds_attr.ensure(
-                reinterpret_cast<const void*>(&conv_glds_kernel<WM, WN, TM, TN, VEC, HEAD>), (int)lds);
+                reinterpret_cast<const void*>(&conv_glds_kernel<WM, WN, TM, TN, VEC, HEAD, NBUF>), (int)lds);
             if (attr != hipSuccess) return attr;
         }
         dim3 grid(p.m_tiles * p.n_tiles, p.transposed ? 8 : 1, p.ksplit);
-        hipLaunchKernelGGL((conv_glds_kernel<WM, WN, TM, TN, VEC, HEAD>), grid, dim3(256), lds, stream, p);
+        hipLaunchKernelGGL((conv_glds_kernel<WM, WN, TM, TN, VEC, HEAD, NBUF>), grid, dim3(256), lds, stream, p);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess && p.ksplit > 1) e = launch_conv_finish(p, p.n_tiles * BN, stream);
         return e;
     }
+}
+
+// the 64 x 64 tile on a launch that leaves CUs with one workgroup or none: six LDS stages (see the kernel's NBUF note)
+static bool sparse_launch(const ConvParams& p, int bm, int bn) {
+    static const bool off = getenv("S3R_DEEP_RING") && atoi(getenv("S3R_DEEP_RING")) == 0;      // A/B switch
+    const long w = (long)((p.Cout + bm - 1) / bm) * ((p.n_end - p.n_begin + bn - 1) / bn) * (p.transposed ? 8 : 1) * p.ksplit;
+    return !off && w <= 384;
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -614,6 +655,15 @@ static hipError_t launch_vec(const ConvParams& p, int vec, hipStream_t stream) {
         }
     } else if (p.head_w) {
         return hipErrorInvalidValue;
+    }
+    if constexpr (WM == 2 && WN == 2 && TM == 1 && TN == 1) {
+        if (sparse_launch(p, 64, 64)) {
+            switch (vec) {
+                case 4: return launch_cfg<WM, WN, TM, TN, 4, false, 6>(p, stream);
+                case 1: return launch_cfg<WM, WN, TM, TN, 1, false, 6>(p, stream);
+                default: return hipErrorInvalidValue;
+            }
+        }
     }
     switch (vec) {
         case 4: return launch_cfg<WM, WN, TM, TN, 4, false>(p, stream);
