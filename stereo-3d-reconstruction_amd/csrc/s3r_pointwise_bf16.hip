@@ -337,7 +337,10 @@ hipError_t launch_stem_bf16(const float* x, const float* x2, int nsplit, const f
             resident[dev] = per_cu * cus;
         }
         const int blocks = N * (112 / STEM_ROWS);
-        const int wgs = blocks < resident[dev] ? blocks : resident[dev];
+        int wgs = blocks < resident[dev] ? blocks : resident[dev];
+#ifdef S3R_ABLATE
+        if (getenv("S3R_STEM_WGS")) wgs = atoi(getenv("S3R_STEM_WGS"));
+#endif
         hipLaunchKernelGGL(stem_bf16_mfma_kernel, dim3((unsigned)wgs), dim3(64 * STEM_WAVES), STEM_LDS_BYTES, s, x, x2, nsplit,
                            wt, scale, shift, reinterpret_cast<unsigned short*>(y), N, y_bs, y_hs, y_org
 #ifdef S3R_ABLATE
