@@ -139,16 +139,22 @@ __global__ __launch_bounds__(256, min_waves(TM, TN) - (HEAD ? 1 : 0)) void conv_
 
     // ---- XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a
     // contiguous run of tiles so neighbouring N tiles find their shared input rows in that XCD's L2.
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
+    // Transposed convolutions: the grid is 8 x as long and an XCD walks its tiles with the 8 output-parity classes of a
+    // tile back to back (they gather from the same input tile: L2 hits instead of eight passes over the input).
+    int bid = blockIdx.x, cls = 0;                    // cls: output parity class (transposed only)
+    if (p.transposed) {
+        const int nwg = gridDim.x >> 3;
+        const int item = (bid & 7) * nwg + (bid >> 3);
+        bid = item >> 3;
+        cls = item & 7;
+    } else {
+        const int nwg = gridDim.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
     const int m_tile = bid % p.m_tiles;
     const int n_tile = bid / p.m_tiles;
     const int m0 = m_tile * BM, n0 = p.n_begin + n_tile * BN;
-    const int cls = blockIdx.y;                       // output parity class (transposed only)
     const int rd = (cls >> 2) & 1, rh = (cls >> 1) & 1, rw = cls & 1;
 
     const int S = p.Nd * p.Nh * p.Nw;
@@ -628,7 +634,7 @@ static hipError_t launch_cfg(ConvParams p, hipStream_t stream) {
                 reinterpret_cast<const void*>(&conv_glds_kernel<WM, WN, TM, TN, VEC, HEAD, NBUF>), (int)lds);
             if (attr != hipSuccess) return attr;
         }
-        dim3 grid(p.m_tiles * p.n_tiles, p.transposed ? 8 : 1, p.ksplit);
+        dim3 grid(p.m_tiles * p.n_tiles * (p.transposed ? 8 : 1), 1, p.ksplit);      // (class inside blockIdx.x)
         hipLaunchKernelGGL((conv_glds_kernel<WM, WN, TM, TN, VEC, HEAD, NBUF>), grid, dim3(256), lds, stream, p);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess && p.ksplit > 1) e = launch_conv_finish(p, p.n_tiles * BN, stream);
