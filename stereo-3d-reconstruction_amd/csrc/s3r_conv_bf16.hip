@@ -340,6 +340,10 @@ __device__ __host__ __forceinline__ int swz(int row) { return KC == 64 ? (row >>
 // NH = 64-cout halves per workgroup: 2 (a 128 x 128 tile; Cout % 128 == 0) gathers the activations once for twice
 // the couts — 1.5x the FLOPs per byte brought into LDS, for the layers this kernel keeps (stride 2), which are
 // bound by exactly that.
+// tap visiting order of stride-2 3x3x3 layers (tap id = (td*3 + th)*3 + tw, 5 bits each, 9 per word): parity classes,
+// each along a Gray path —  0 2 8 6 24 26 20 18 | 1 7 25 19 | 3 5 23 21 | 9 11 17 15 | 4 22 | 10 16 | 12 14 | 13
+constexpr unsigned long long S2_3D_A = 0x19535832040ull, S2_3D_B = 0xb4d6e51cf27ull, S2_3D_C = 0xd7320ab11f1ull;
+
 template <int SH, int TM, int KC, bool HEAD, int NH>
 __global__ __launch_bounds__(256, NH == 2 ? (KC == 64 ? 2 : 3) : min_waves_h(TM, KC, HEAD)) void conv_bf16_kernel(const ConvParamsH p) {
     static_assert(NH == 1 || !HEAD, "the fused head needs the whole channel axis in one 64-cout tile");
@@ -440,6 +444,31 @@ __global__ __launch_bounds__(256, NH == 2 ? (KC == 64 ? 2 : 3) : min_waves_h(TM,
         (int)((unsigned)T * (unsigned)(p.Cin / HKC) * (unsigned)w_tile), 0x00020000);
 
     int c_td = 0, c_th = 0, c_tw = 0, c_tap = 0, c_cc = kz * chunks;
+    // Stride-2 3x3[x3] layers visit their taps by PARITY CLASS.  At stride 2 a tap index 0 and a tap index 2 along an
+    // axis read the same input rows (planes, columns) one output position apart, tap index 1 reads the others: the
+    // taps fall into classes that gather the same pixels — the 4 (8 in 3D) "corner" taps, 2 + 2 (4 + 4 + 4) edge groups,
+    // ..., the centre alone.  In kh-major order the second gather of a pixel comes up to 6 K tiles after the first — of
+    // every workgroup on the XCD, ~10 MB of other gathers against a 4 MB L2 — and e3 / v2 fetched 1.5x / 1.6x their
+    // input.  Walking each class along a Gray path (consecutive taps differ along one axis) puts every re-read one
+    // K tile behind the read it repeats.  The packed weights stay in tap order (c_tap indexes them); the order is a
+    // function of the layer's geometry only, so a sample's K order is the same in every batch.
+    const bool s2_order = p.stride == 2 && !p.transposed && p.kh == 3 && p.kw == 3 && (p.kd == 1 || p.kd == 3);
+    int c_v = 0;                                   // visit index 0 .. T-1 (s2_order)
+    auto visit = [&](int v) {                      // -> c_td, c_th, c_tw, c_tap of visit v
+        // (orders packed in immediates: a table in memory put a load on the path of every K tile's DMA issue)
+        if (p.kd == 1) {
+            c_tap = (int)((0x453716820ull >> (4 * v)) & 15ull);                       // 0 2 8 6 | 1 7 | 3 5 | 4
+        } else {
+            const int g = v / 9, i = v - g * 9;                                       // 27 ids, 5 bits each, 9 per word
+            const unsigned long long w = g == 0 ? S2_3D_A : (g == 1 ? S2_3D_B : S2_3D_C);
+            c_tap = (int)((w >> (5 * i)) & 31ull);
+        }
+        c_td = c_tap / 9;
+        const int r = c_tap - c_td * 9;
+        c_th = r / 3;
+        c_tw = r - c_th * 3;
+    };
+    if (s2_order) visit(0);
 
     auto issue = [&](int buf) {
         const int b_base = ((c_cc * (KC / 32) * T + c_tap) * p.n_tiles + n_tile) * 4096;
@@ -450,8 +479,13 @@ __global__ __launch_bounds__(256, NH == 2 ? (KC == 64 ? 2 : 3) : min_waves_h(TM,
 #pragma unroll
         for (int q = 0; q < NPA; ++q)
             dma16(xrsrc, As + buf * A_BYTES + (wave + 4 * q) * 1024, avoff[q], a_base);
-        if (++c_tw == p.kw) { c_tw = 0; if (++c_th == p.kh) { c_th = 0; ++c_td; } }
-        if (++c_tap == T) { c_tap = 0; c_td = 0; c_th = 0; c_tw = 0; ++c_cc; }
+        if (s2_order) {
+            if (++c_v == T) { c_v = 0; ++c_cc; }
+            visit(c_v);
+        } else {
+            if (++c_tw == p.kw) { c_tw = 0; if (++c_th == p.kh) { c_th = 0; ++c_td; } }
+            if (++c_tap == T) { c_tap = 0; c_td = 0; c_th = 0; c_tw = 0; ++c_cc; }
+        }
     };
 
     typename M::acc_t acc[NH][NPT][NCT];
