@@ -109,7 +109,7 @@ def self_launch(args):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={max(1, args.gpus)}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     log("bench.py: launching " + " ".join(cmd))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
@@ -214,7 +214,17 @@ def eager_records(s3r, torch, model, left, right, gt_cloud, steps):
     return records
 
 
-def secondary_config(s3r, torch, dev, variant, dtype, B, steps, warmup):
+# environment switches that change which kernel (or which variant of one) runs without changing the kernel sources: a run
+# under any of them is not the configuration the committed counter passes were taken on
+_KERNEL_ENV = ("S3R_TILE_", "S3R_KSPLIT_", "S3R_BF16_MFMA", "S3R_STEM_MFMA", "S3R_S2D", "S3R_DEEP_RING", "S3R_LINEAR_NT",
+               "S3R_NO_TAIL_CUT", "S3R_NO_FUSE", "S3R_LIB")
+
+
+def kernel_env_overrides():
+    return sorted(k for k in os.environ if k.startswith(_KERNEL_ENV))
+
+
+def secondary_config(s3r, torch, dev, variant, dtype, B, steps, warmup, plain_run):
     """One more single-GPU configuration of BASELINE.json, measured the way the headline is (graph replay of K
     steps over one resident batch between synchronisations), in this process, after the headline's timed region."""
     spec = s3r.arch_spec
@@ -245,7 +255,7 @@ def secondary_config(s3r, torch, dev, variant, dtype, B, steps, warmup):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     records = eager_records(s3r, torch, model, left, right, gt_cloud, steps)
-    roof, kernels = roofline_of(records, steps, dtype, variant, B, spec, plain_run=True)
+    roof, kernels = roofline_of(records, steps, dtype, variant, B, spec, plain_run=plain_run)
     fl = spec.flops_per_pair(variant)
     out = {"workload": f"Stereo2{'Voxel' if variant == 'voxel' else 'Point'} forward"
                        f"{' + Chamfer distance vs a (B,2048,3) cloud' if variant == 'point' else ''}, batch={B}, "
@@ -282,11 +292,20 @@ def main():
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to exercise the N>1 code on one GPU)")
     ap.add_argument("--same-device", action="store_true",
                     help="testing only: every rank uses cuda:0 (with --backend gloo) so the N>1 path runs on a 1-GPU box")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the N>1 code path (init_process_group, warm-up all-gather, all-reduce, RCCL version query, "
+                         "per-step collation) even with one rank: a world-size-1 RCCL rehearsal on a 1-GPU box")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="pairs per step over ALL ranks (overrides --batch: per-GPU batch = global / N); "
+                         "--global-batch 2048 --gpus 8 is BASELINE configs[4]")
+    ap.add_argument("--renders", default="f32", choices=["f32", "u8"],
+                    help="dtype of the resident input renders: f32 (SURVEY 8d's torch.rand pairs, the headline) or u8 "
+                         "(8-bit renders, scaled by 1/255 inside the first kernel)")
     ap.add_argument("--autotune", action="store_true",
                     help="time tile / split-K candidates per layer in warm-up instead of using the library's table")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))              # nothing has touched the GPU in this process
 
     import torch
@@ -304,7 +323,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist       # (--force-dist: the same code with a communicator of one rank)
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -313,16 +333,23 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     B = args.batch
+    if args.global_batch:
+        if args.global_batch % world:
+            log(f"--global-batch {args.global_batch} does not divide over {world} ranks")
+            sys.exit(2)
+        B = args.global_batch // world
     prec = "bf16" if args.dtype == "bf16" else "fp32"
     model = s3r.Stereo2Voxel(prec) if args.variant == "voxel" else s3r.Stereo2Point(prec)
     s3r.seed_module(model, 0)
     model.to(dev)
     left, right = s3r.synthetic_pairs(B, seed=1000 + rank)      # random data (never zeros: DVFS, rule 25)
+    if args.renders == "u8":                                    # the same pairs quantised to 8 bits
+        left, right = (left * 255.0).round().to(torch.uint8), (right * 255.0).round().to(torch.uint8)
     left, right = left.to(dev), right.to(dev)
     gathered = None
     out_shape = (B, 32, 32, 32) if args.variant == "voxel" else (B, spec.N_POINTS, 3)
     n_ranks_seen = 1
-    if world > 1:
+    if dist_on:
         # eval collation is double-buffered: step k's all-gather (RCCL, its own stream) runs under step k+1's forward
         gathered = [torch.empty((world * B,) + out_shape[1:], dtype=torch.float32, device=dev) for _ in range(2)]
         staged = [torch.empty(out_shape, dtype=torch.float32, device=dev) for _ in range(2)]
@@ -344,7 +371,7 @@ def main():
     graphed = None
     if not args.no_graph:
         try:
-            graphed = s3r.GraphedForward(model, B, dev)
+            graphed = s3r.GraphedForward(model, B, dev, input_dtype=left.dtype)
             graphed.left.copy_(left)
             graphed.right.copy_(right)
         except Exception as e:                       # never lose the measurement to a capture problem
@@ -364,7 +391,7 @@ def main():
         y = graphed() if graphed else model(left, right)
         if gt_cloud is not None:
             s3r.chamfer_distance(y, gt_cloud)
-        if world > 1:
+        if dist_on:
             k = step_no[0] & 1
             step_no[0] += 1
             if pending[k] is not None:
@@ -374,13 +401,13 @@ def main():
         return y
 
     def drain():
-        if world > 1:
+        if dist_on:
             for k in range(2):
                 if pending[k] is not None:
                     pending[k].wait()
                     pending[k] = None
 
-    if world > 1:          # build the RCCL communicator outside the timed region even when --warmup 0
+    if dist_on:            # build the RCCL communicator outside the timed region even when --warmup 0
         dist.all_gather_into_tensor(gathered[0], torch.zeros(out_shape, dtype=torch.float32, device=dev))
         one = torch.ones(1, dtype=torch.int64, device=dev)
         dist.all_reduce(one)                              # every rank the launcher started is really in the job
@@ -393,7 +420,7 @@ def main():
     profiling = not args.no_profile
     if profiling and graphed is None:
         s3r.profile_enable(64 * args.steps + 64)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -401,10 +428,10 @@ def main():
         step()
     drain()                                               # every step's collation has completed inside the timed region
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -417,7 +444,7 @@ def main():
     # per-step spread (untimed for `value`): the same K steps once more, each bracketed by its own pair of events on
     # the launch stream — the timed region above is one interval, this shows what it averages over
     spread = None
-    if world == 1:
+    if not dist_on:
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         for a, b in evs:
             a.record()
@@ -435,11 +462,12 @@ def main():
         value = pairs / elapsed
         ms_per_step = 1e3 * elapsed / args.steps
         fl = spec.flops_per_pair(args.variant)
-        overrides = any(k.startswith(("S3R_TILE_", "S3R_KSPLIT_")) for k in os.environ)
-        plain_run = not args.autotune and not args.no_graph and not overrides and not args.include_h2d
+        overrides = kernel_env_overrides()
+        plain_run = not args.autotune and not args.no_graph and not overrides and not args.include_h2d and \
+            args.renders == "f32"
         roof, kernels = roofline_of(records, args.steps, args.dtype, args.variant, B, spec, plain_run)
         rccl = None
-        if world > 1 and args.backend == "nccl":
+        if dist_on and args.backend == "nccl":
             try:
                 rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
             except Exception:
@@ -452,13 +480,15 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic" + (" (host->device copy of every batch inside the step)" if args.include_h2d else ""),
             "config": {"workload": f"Stereo2{'Voxel' if args.variant == 'voxel' else 'Point'} forward, batch={B} per GPU, "
-                                   f"224x224 RGB stereo pair, {'bf16 MFMA path' if args.dtype == 'bf16' else 'fp32'}, "
+                                   f"224x224 RGB stereo pair ({'8-bit' if args.renders == 'u8' else 'fp32'} renders), "
+                                   f"{'bf16 MFMA path' if args.dtype == 'bf16' else 'fp32'}, "
                                    f"random-init weights, build-specified arch_spec "
                                    f"({fl['total'] / 1e9:.2f} GFLOP/pair)",
                        "per_gpu_batch": B, "global_batch": world * B,
                        "parallelism": f"batch-sharded x{world}, RCCL all-gather of predictions every step (overlapped "
-                                      f"with the next step's forward)" if world > 1 else "single GPU"},
-            "n_ranks_seen": n_ranks_seen, "collective_backend": (args.backend if world > 1 else None),
+                                      f"with the next step's forward)" if dist_on else "single GPU"},
+            "n_ranks_seen": n_ranks_seen, "collective_backend": (args.backend if dist_on else None),
+            "kernel_env_overrides": overrides or None,
             "rccl_version": rccl,
             "end_to_end_tflops": round(value * fl["total"] / 1e12, 3),
             "launch": "eager" if graphed is None else "hipGraph replay (1 launch per step); per-kernel HIP-event timing "
@@ -466,22 +496,24 @@ def main():
             "autotuned": {k: [v["tile"], v["ksplit"]] for k, v in tuned.items()} if tuned else None,
             "roofline": roof, "kernels": kernels,
         }
-        if world == 1 and not args.no_secondary and args.variant == "voxel" and args.dtype == "f32" and not args.include_h2d:
+        if not dist_on and not args.no_secondary and args.variant == "voxel" and args.dtype == "f32" and \
+                not args.include_h2d and args.renders == "f32":
             # BASELINE.json configs[2] and configs[3], measured in the same process (never part of `value`)
             graphed = None                           # (its buffers stay with the model; the secondaries build their own)
             sec = {}
             k2 = max(5, min(args.steps, 10))
             for name, (v, d, b) in {"bf16_b256": ("voxel", "bf16", 256), "point_b32": ("point", "f32", 32)}.items():
                 try:
-                    sec[name] = secondary_config(s3r, torch, dev, v, d, b, k2, max(2, min(args.warmup, 3)))
+                    sec[name] = secondary_config(s3r, torch, dev, v, d, b, k2, max(2, min(args.warmup, 3)),
+                                                 plain_run=not overrides)
                 except Exception as e:
                     log(f"secondary {name} failed: {type(e).__name__}: {e}")
                     sec[name] = {"error": f"{type(e).__name__}: {e}"}
             out["secondary"] = sec
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.force_dist:
             out["cpu_baseline"] = cpu_baseline(32)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -7,6 +7,8 @@
  *
  *   s3r_conv_forward, s3r_encoder_forward   the torch conv2d+BatchNorm+ReLU calls inside the stereo
  *                                           feature encoder's nn.Module.forward        (README.md:5,73-74)
+ *   s3r_encoder_forward_u8                  the same fed with the 8-bit renders the PNG decode yields: replaces the
+ *                                           dataset transform's uint8 -> float32 / 255 as well (requirements.txt:5)
  *   s3r_cost_volume_forward                 the per-disparity shift/subtract Python loop that builds the
  *                                           disparity cost volume                       (README.md:75-76)
  *   s3r_decoder_forward (+conv/deconv/head) the torch conv3d / ConvTranspose3d + BN + ReLU + sigmoid
@@ -36,7 +38,7 @@
 extern "C" {
 #endif
 
-#define S3R_ABI_VERSION 4
+#define S3R_ABI_VERSION 5
 
 typedef enum s3r_status {
     S3R_OK = 0,
@@ -149,6 +151,18 @@ int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* imag
                         void* features, float* ws, int64_t ws_elems, int ws_fresh, void* stream);
 int s3r_decoder_forward(const s3r_layer* layers, int n_layers, const void* volume, float* occupancy, float* ws,
                         int64_t ws_elems, int ws_fresh, void* stream);
+
+/* The encoder on 8-BIT renders: (B,3,224,224) uint8 NCHW, as the reference's PNG decode yields them (OpenCV,
+ * /root/reference/requirements.txt:5; README.md:73-74) — a quarter of the bytes across PCIe and into the first kernel.
+ * The stem scales a sample by 1/255 as it reads it, with the single rounding of the host conversion
+ * float32(u) / float32(255) it replaces: the features equal, bit for bit, those of s3r_encoder_forward on renders
+ * converted that way on the host.  Everything else as s3r_encoder_forward (both precisions; images_right may be NULL). */
+int s3r_encoder_forward_u8(const s3r_layer* layers, int n_layers, const uint8_t* images_left, const uint8_t* images_right,
+                           void* features, float* ws, int64_t ws_elems, int ws_fresh, void* stream);
+
+/* Hand-off from the bf16 path to an fp32 consumer (s3r_linear_forward on the latent, s3r_disparity_wta on the features):
+ * x channels-last bf16 (batch, positions, channels) -> y fp32 (batch, channels, positions), exact. */
+int s3r_channels_last_to_f32(const void* x, float* y, int batch, int channels, int64_t positions, void* stream);
 
 /* vol[b,c,d,h,w] = L[b,c,h,w]-R[b,c,h,w-d] (w>=d), vol[b,C+c,d,h,w] = R[b,c,h,w]-L[b,c,h,w+d] (w+d<W), else 0.
  * `out_halo` > 0 writes the interior of a (B,2C,D+2h,H+2h,W+2h) buffer whose halo the caller zeroed. */

@@ -49,17 +49,24 @@ def main():
     ap.add_argument("--workers", type=int, default=0, help="with --dataset-root: DataLoader decode workers (PNG / MAT / EXR "
                                                            "decoding is host work: ~300 pairs/s per worker)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--renders", default="u8", choices=["u8", "f32"],
+                    help="dtype of the renders handed to the model: u8 (default: 8-bit, as the PNG decode yields them; the "
+                         "first kernel scales by 1/255) or f32 (converted on the host: 4x the bytes across PCIe, same result)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-rank code path (init_process_group, metric all-gather) even with one rank: a "
+                         "world-size-1 RCCL rehearsal on a 1-GPU box")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--gpus", type=int, default=1,
                     help="evaluate on N GPUs of this node: the eval list is sharded over one process per GPU (RCCL "
                          "all-gather of the per-sample metrics); runner.py starts the ranks itself")
     args = ap.parse_args()
-    if args.test and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.test and (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         # single-process entry point (README.md:85,91) kept: the ranks are a CHILD process started before anything
         # here touches the GPU (never exec from a process that has); rank 0's JSON line reaches our stdout
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={max(1, args.gpus)}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")).returncode)
     if args.suggest_keymap:
@@ -85,10 +92,14 @@ def main():
         sys.exit("runner.py --test needs an MI355X: this path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     model = s3r.Stereo2Voxel(args.precision) if args.variant == "voxel" else s3r.Stereo2Point(args.precision)
     if args.weights:
@@ -101,7 +112,11 @@ def main():
     import time
     with torch.no_grad():          # one-time work (weight packing, the batch-size layout of the activation arena,
         wb = max(1, min(args.batch, 256))                          # library init) stays out of the rate
-        model(torch.rand(wb, 3, 224, 224, device=dev), torch.rand(wb, 3, 224, 224, device=dev))
+        if args.renders == "u8":
+            model(torch.randint(0, 256, (wb, 3, 224, 224), dtype=torch.uint8, device=dev),
+                  torch.randint(0, 256, (wb, 3, 224, 224), dtype=torch.uint8, device=dev))
+        else:
+            model(torch.rand(wb, 3, 224, 224, device=dev), torch.rand(wb, 3, 224, 224, device=dev))
     torch.cuda.synchronize()
     clock = {"t": 0.0}
 
@@ -116,47 +131,72 @@ def main():
     def rate(n):
         return round(n / max(clock["t"], 1e-9), 1)
 
+    rdt = "uint8" if args.renders == "u8" else "float32"
+
+    def renders(a):                 # an .npz array of renders in the requested dtype (uint8 arrays are 8-bit renders)
+        t = torch.from_numpy(a)
+        if t.dtype == torch.uint8:
+            return t if args.renders == "u8" else s3r.data.renders_to_float(t)
+        return t.float()            # already scaled to [0,1]: stays fp32 whatever --renders says
+
+    def dist_info():
+        if not dist_on:
+            return {}
+        rccl = None
+        if args.backend == "nccl":
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rccl = None
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one)
+        return {"collective_backend": args.backend, "rccl_version": rccl, "n_ranks_seen": int(one.item())}
+
     if args.variant == "point":
         if args.dataset_root:
             sys.exit("runner.py --variant point reads an .npz (left, right, points) or synthetic data, not a dataset tree")
         if args.data:
             z = np.load(args.data)
-            left, right, clouds = (torch.from_numpy(z[k]).float() for k in ("left", "right", "points"))
+            left, right, clouds = renders(z["left"]), renders(z["right"]), torch.from_numpy(z["points"]).float()
         else:
-            left, right, _ = s3r.evaluate.synthetic_eval_set(args.samples, args.seed)
+            left, right, _ = s3r.evaluate.synthetic_eval_set(args.samples, args.seed, rdt)
             clouds = torch.rand(args.samples, 2048, 3, generator=torch.Generator().manual_seed(args.seed)) - 0.5
         res = timed(s3r.evaluate.test_point_net, model, left, right, clouds, batch=args.batch, device=dev)
+        info = dist_info()
         if rank == 0:
-            print(json.dumps({"samples": res["samples"], "n_gpus": world, "mean_chamfer": round(res["mean_chamfer"], 8),
-                              "precision": args.precision, "eval_pairs_per_s": rate(res["samples"]),
-                              "weights": args.weights or f"seeded random init (seed {args.seed})",
-                              "data": args.data or "synthetic"}))
-        if world > 1:
+            print(json.dumps(dict({"samples": res["samples"], "n_gpus": world, "mean_chamfer": round(res["mean_chamfer"], 8),
+                                   "precision": args.precision, "eval_pairs_per_s": rate(res["samples"]),
+                                   "renders": str(left.dtype).replace("torch.", ""),
+                                   "weights": args.weights or f"seeded random init (seed {args.seed})",
+                                   "data": args.data or "synthetic"}, **info)))
+        if dist_on:
             dist.destroy_process_group()
         return
 
     disp = None
     if args.dataset_root:
-        ds = s3r.data.StereoShapeNet(args.dataset_root, with_disparity=args.disparity)
+        ds = s3r.data.StereoShapeNet(args.dataset_root, with_disparity=args.disparity, render_dtype=rdt)
         res = timed(s3r.evaluate.test_dataset, model, ds, batch=args.batch, device=dev, workers=args.workers)
         left = None
         if args.disparity:
             disp = {"epe_left": res["epe_left"], "epe_right": res["epe_right"]}
     elif args.data:
         z = np.load(args.data)
-        left, right, gt = (torch.from_numpy(z[k]).float() for k in ("left", "right", "volume"))
+        left, right, gt = renders(z["left"]), renders(z["right"]), torch.from_numpy(z["volume"]).float()
     else:
-        left, right, gt = s3r.evaluate.synthetic_eval_set(args.samples, args.seed)
+        left, right, gt = s3r.evaluate.synthetic_eval_set(args.samples, args.seed, rdt)
     if left is not None:
         res = timed(s3r.evaluate.test_net, model, left, right, gt, batch=args.batch, device=dev)
         if args.data and "disp_left" in z.files and "disp_right" in z.files:
             # (N,28,28) ground-truth disparity at feature resolution, render pixels; inf / negative = invalid
             disp = s3r.evaluate.test_disparity(model, left, right, torch.from_numpy(z["disp_left"]).float(),
                                                torch.from_numpy(z["disp_right"]).float(), batch=args.batch, device=dev)
+    info = dist_info()
     if rank == 0:
         out = {"samples": res["samples"], "n_gpus": world, "thresholds": res["thresholds"],
                "mean_iou": [round(x, 6) for x in res["mean_iou"]],
                "precision": args.precision, "eval_pairs_per_s": rate(res["samples"]),
+               "renders": rdt if left is None else str(left.dtype).replace("torch.", ""),
                "weights": args.weights or f"seeded random init (seed {args.seed})",
                "data": args.dataset_root or args.data or "synthetic"}
         if "per_taxonomy" in res:
@@ -164,8 +204,9 @@ def main():
                                    for k, v in res["per_taxonomy"].items()}
         if disp is not None:
             out.update({"disparity_epe_left_px": round(disp["epe_left"], 4), "disparity_epe_right_px": round(disp["epe_right"], 4)})
+        out.update(info)
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

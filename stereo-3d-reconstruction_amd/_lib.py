@@ -18,7 +18,7 @@ DTYPE = {"fp32": 0, "bf16": 1}
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}
 FAMILY = {0: "conv_mfma", 1: "stem", 2: "head", 3: "cost_volume", 4: "linear", 5: "chamfer", 6: "iou", 7: "pack",
           8: "pad_copy", 9: "disparity"}
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ConvDesc(C.Structure):
@@ -58,6 +58,9 @@ SIGNATURES = {
                                     C.c_int, C.c_void_p]),
     "s3r_encoder_forward": (C.c_int, [C.POINTER(Layer), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.c_int, C.c_void_p]),
+    "s3r_encoder_forward_u8": (C.c_int, [C.POINTER(Layer), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int64, C.c_int, C.c_void_p]),
+    "s3r_channels_last_to_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "s3r_decoder_forward": (C.c_int, [C.POINTER(Layer), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_int, C.c_void_p]),
     "s3r_cost_volume_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

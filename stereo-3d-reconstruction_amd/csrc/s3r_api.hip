@@ -607,7 +607,8 @@ int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d) {
 namespace {
 // s3r_conv_forward with an optional SECOND input tensor for the stem: images [0, nsplit) are read from xv, images
 // [nsplit, batch) from x2v (left / right renders of a stereo batch: no concatenation copy)
-int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, int nsplit, const void* packed_wv,
+// x_u8 != 0 (stem only): xv / x2v are 8-bit renders, scaled by 1/255 inside the stem kernel
+int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, int nsplit, int x_u8, const void* packed_wv,
                       const float* scale, const float* shift, void* yv, float* scratch, int64_t scratch_elems, void* stream);
 }
 
@@ -615,14 +616,14 @@ extern "C" {
 
 int s3r_conv_forward(const s3r_conv_desc* d, const void* xv, const void* packed_wv, const float* scale,
                      const float* shift, void* yv, float* scratch, int64_t scratch_elems, void* stream) {
-    return conv_forward_impl(d, xv, nullptr, 0, packed_wv, scale, shift, yv, scratch, scratch_elems, stream);
+    return conv_forward_impl(d, xv, nullptr, 0, 0, packed_wv, scale, shift, yv, scratch, scratch_elems, stream);
 }
 
 }  // extern "C"
 
 namespace {
 
-int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, int nsplit, const void* packed_wv,
+int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, int nsplit, int x_u8, const void* packed_wv,
                       const float* scale, const float* shift, void* yv, float* scratch, int64_t scratch_elems, void* stream) {
     const float* x = static_cast<const float*>(xv);
     const float* x2 = static_cast<const float*>(x2v);
@@ -635,6 +636,8 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
     if ((rc = check_halos(d, r))) return rc;
     if (!x || !packed_w || !y) return fail(S3R_ERR_INVALID, "null tensor pointer");
     if (x2 && r != R_STEM) return fail(S3R_ERR_INVALID, "only the stem convolution takes a second input tensor");
+    if (x_u8 && r != R_STEM) return fail(S3R_ERR_INVALID, "only the stem convolution reads 8-bit renders");
+    const double u8_saved = x_u8 ? 3.0 * d->batch * d->cin * (double)g.in_sp : 0.0;      // algorithmic bytes: 1 instead of 4 per sample
     if (x2 && (nsplit <= 0 || nsplit >= d->batch)) return fail(S3R_ERR_INVALID, "split %d outside (0, batch=%d)", nsplit, d->batch);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipSuccess;
@@ -644,8 +647,8 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
         switch (r) {
             case R_STEM: {
                 if (!scale || !shift) return fail(S3R_ERR_INVALID, "stem needs scale and shift");
-                ProfScope ps(s, F_STEM, d->tag, g.flops, g.bytes);
-                e = s3r::launch_stem_bf16(x, x2, nsplit, packed_w, scale, shift, yv, d->batch, g.in, g.in, g.out, g.out,
+                ProfScope ps(s, F_STEM, d->tag, g.flops, g.bytes - u8_saved);
+                e = s3r::launch_stem_bf16(xv, x2v, x_u8, nsplit, packed_w, scale, shift, yv, d->batch, g.in, g.in, g.out, g.out,
                                           g.out_p * g.out_p * 32, g.out_p * 32, d->out_halo * (g.out_p + 1) * 32, s);
                 break;
             }
@@ -680,8 +683,8 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
     switch (r) {
         case R_STEM: {
             if (!scale || !shift) return fail(S3R_ERR_INVALID, "stem needs scale and shift");
-            ProfScope ps(s, F_STEM, d->tag, g.flops, g.bytes);
-            e = s3r::launch_stem(x, x2, nsplit, packed_w, scale, shift, y, d->batch, g.in, g.in, g.out, g.out, g.out_p * g.out_p,
+            ProfScope ps(s, F_STEM, d->tag, g.flops, g.bytes - u8_saved);
+            e = s3r::launch_stem(xv, x2v, x_u8, nsplit, packed_w, scale, shift, y, d->batch, g.in, g.in, g.out, g.out, g.out_p * g.out_p,
                                  g.out_p, d->out_halo * (g.out_p + 1), s);
             break;
         }
@@ -722,8 +725,8 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
     return S3R_OK;
 }
 
-int chain_forward_impl(const s3r_layer* layers, int n_layers, const void* x, const void* x2, int nsplit, void* y, float* ws,
-                       int64_t ws_elems, int ws_fresh, void* stream);
+int chain_forward_impl(const s3r_layer* layers, int n_layers, const void* x, const void* x2, int nsplit, int x_u8, void* y,
+                       float* ws, int64_t ws_elems, int ws_fresh, void* stream);
 
 }  // namespace
 
@@ -738,15 +741,15 @@ int64_t s3r_chain_workspace_elems(const s3r_layer* layers, int n_layers) {
 
 int s3r_chain_forward(const s3r_layer* layers, int n_layers, const void* x, void* y, float* ws, int64_t ws_elems,
                       int ws_fresh, void* stream) {
-    return chain_forward_impl(layers, n_layers, x, nullptr, 0, y, ws, ws_elems, ws_fresh, stream);
+    return chain_forward_impl(layers, n_layers, x, nullptr, 0, 0, y, ws, ws_elems, ws_fresh, stream);
 }
 
 }  // extern "C"
 
 namespace {
 
-int chain_forward_impl(const s3r_layer* layers, int n_layers, const void* x, const void* x2, int nsplit, void* y, float* ws,
-                       int64_t ws_elems, int ws_fresh, void* stream) {
+int chain_forward_impl(const s3r_layer* layers, int n_layers, const void* x, const void* x2, int nsplit, int x_u8, void* y,
+                       float* ws, int64_t ws_elems, int ws_fresh, void* stream) {
     Plan pl;
     int rc = plan_chain(layers, n_layers, &pl);
     if (rc) return rc;
@@ -760,8 +763,8 @@ int chain_forward_impl(const s3r_layer* layers, int n_layers, const void* x, con
         if (e != hipSuccess) return hip_fail(e, "workspace memset");
     }
     const void* cur = x;
-    if (x2 && (pl.pad_input || pl.r[0] != R_STEM))
-        return fail(S3R_ERR_INVALID, "a second input tensor needs a chain that starts with the stem convolution");
+    if ((x2 || x_u8) && (pl.pad_input || pl.r[0] != R_STEM))
+        return fail(S3R_ERR_INVALID, "a second input tensor / 8-bit renders need a chain that starts with the stem convolution");
     if (pl.pad_input) {
         const s3r_conv_desc& d0 = pl.d[0];
         const int hl = d0.in_halo, is3 = d0.ndim == 3;
@@ -795,7 +798,7 @@ int chain_forward_impl(const s3r_layer* layers, int n_layers, const void* x, con
             continue;
         }
         void* out = (i == n_layers - 1) ? y : static_cast<void*>(ws + pl.off[i]);
-        rc = conv_forward_impl(&pl.d[i], cur, i == 0 ? x2 : nullptr, nsplit, L.packed_w, L.scale, L.shift, out,
+        rc = conv_forward_impl(&pl.d[i], cur, i == 0 ? x2 : nullptr, nsplit, i == 0 ? x_u8 : 0, L.packed_w, L.scale, L.shift, out,
                                pl.scratch_elems ? ws + pl.scratch_off : nullptr, pl.scratch_elems, stream);
         if (rc) return rc;
         cur = out;
@@ -807,8 +810,8 @@ int chain_forward_impl(const s3r_layer* layers, int n_layers, const void* x, con
 
 extern "C" {
 
-int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* images_left, const float* images_right,
-                        void* features, float* ws, int64_t ws_elems, int ws_fresh, void* stream) {
+static int encoder_forward(const s3r_layer* layers, int n_layers, const void* images_left, const void* images_right, int u8,
+                           void* features, float* ws, int64_t ws_elems, int ws_fresh, void* stream) {
     if (!layers || n_layers <= 0) return fail(S3R_ERR_INVALID, "empty encoder");
     const s3r_conv_desc& f = layers[0].desc;
     if (f.op != S3R_OP_CONV || f.ndim != 2 || f.cin != 3)
@@ -818,7 +821,31 @@ int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* imag
             return fail(S3R_ERR_INVALID, "encoder layer %d is not a 2D convolution", i);
     if (images_right && (f.batch < 2 || (f.batch & 1)))
         return fail(S3R_ERR_INVALID, "a (left, right) pair of tensors needs an even image count N = 2B (got %d)", f.batch);
-    return chain_forward_impl(layers, n_layers, images_left, images_right, f.batch / 2, features, ws, ws_elems, ws_fresh, stream);
+    return chain_forward_impl(layers, n_layers, images_left, images_right, f.batch / 2, u8, features, ws, ws_elems, ws_fresh,
+                              stream);
+}
+
+int s3r_encoder_forward(const s3r_layer* layers, int n_layers, const float* images_left, const float* images_right,
+                        void* features, float* ws, int64_t ws_elems, int ws_fresh, void* stream) {
+    return encoder_forward(layers, n_layers, images_left, images_right, 0, features, ws, ws_elems, ws_fresh, stream);
+}
+
+int s3r_encoder_forward_u8(const s3r_layer* layers, int n_layers, const uint8_t* images_left, const uint8_t* images_right,
+                           void* features, float* ws, int64_t ws_elems, int ws_fresh, void* stream) {
+    return encoder_forward(layers, n_layers, images_left, images_right, 1, features, ws, ws_elems, ws_fresh, stream);
+}
+
+int s3r_channels_last_to_f32(const void* x, float* y, int batch, int channels, int64_t positions, void* stream) {
+    if (!x || !y) return fail(S3R_ERR_INVALID, "null tensor pointer");
+    if (batch <= 0 || channels <= 0 || positions <= 0) return fail(S3R_ERR_INVALID, "dims must be positive");
+    if (batch > 65535 || (int64_t)channels * positions >= kMaxElems)
+        return fail(S3R_ERR_INVALID, "tensor too large for one call: split the batch");
+    hipStream_t s = (hipStream_t)stream;
+    const double n = (double)batch * channels * (double)positions;
+    ProfScope ps(s, F_PAD, 1, 0.0, 6.0 * n);
+    hipError_t e = s3r::launch_cl_bf16_to_f32(x, y, batch, positions, channels, s);
+    if (e != hipSuccess) return hip_fail(e, "channels-last to fp32 launch");
+    return S3R_OK;
 }
 
 int s3r_decoder_forward(const s3r_layer* layers, int n_layers, const void* volume, float* occupancy, float* ws,

@@ -38,6 +38,21 @@ struct FastDiv {
 #endif
 };
 
+#if defined(__HIPCC__)
+// A render sample as the fp32 value the network computes on.  8-bit renders (what the reference's PNG decode yields,
+// /root/reference/requirements.txt:5, README.md:73-74) are scaled by 1/255 HERE, with the one rounding of the host
+// conversion `float32(u) / float32(255)` it replaces: q = u * rcp, then one Newton correction through the exact
+// residual u - 255 q, is the correctly rounded quotient for every u in 0..255 (checked exhaustively against exact
+// rational arithmetic in tests/test_data_cpu.py::test_u8_scale_formula_is_the_correctly_rounded_quotient).
+__device__ __forceinline__ float render_f32(float v) { return v; }
+__device__ __forceinline__ float render_f32(unsigned char u) {
+    const float f = (float)u;
+    const float rcp = 1.f / 255.f;                 // (compile-time constant: the nearest fp32 to 1/255)
+    const float q = __fmul_rn(f, rcp);
+    return fmaf(fmaf(-q, 255.f, f), rcp, q);
+}
+#endif
+
 // Kernel-side view of one convolution launch.  All tensors are fp32 NC(D)HW; activations may carry a
 // zero halo of `halo` elements on every spatial axis (padded edge = edge + 2*halo), described here
 // purely by element strides and origin offsets.
@@ -136,9 +151,11 @@ hipError_t launch_pack_conv(const float* w, float* wp, int Cin, int Cout, int Co
                             hipStream_t s);
 // y (N,32,Ho+2h,Wo+2h) <- stem conv of x (N,3,Hi,Wi); y_hs / y_cs / y_org describe the padded output.
 // Images [0, nsplit) are read from x, images [nsplit, N) from x2 (the left / right renders of a stereo batch live in
-// two tensors: no concatenation copy); nsplit = N, x2 = null: one tensor.
-hipError_t launch_stem(const float* x, const float* x2, int nsplit, const float* w, const float* scale, const float* shift,
-                       float* y, int N, int Hi, int Wi, int Ho, int Wo, int y_cs, int y_hs, int y_org, hipStream_t s);
+// two tensors: no concatenation copy); nsplit = N, x2 = null: one tensor.  u8 != 0: x / x2 are 8-bit renders (N,3,Hi,Wi)
+// uint8, scaled by 1/255 inside the kernel (render_f32); otherwise fp32.
+hipError_t launch_stem(const void* x, const void* x2, int u8, int nsplit, const float* w, const float* scale,
+                       const float* shift, float* y, int N, int Hi, int Wi, int Ho, int Wo, int y_cs, int y_hs, int y_org,
+                       hipStream_t s);
 hipError_t launch_cost_volume(const float* fl, const float* fr, float* vol, int B, int C, int D, int H, int W,
                               int halo, hipStream_t s);
 hipError_t launch_pad_copy(const float* x, float* y, int64_t planes, int D, int H, int W, int hd, int hh, int hw,
@@ -160,13 +177,14 @@ int conv_bf16_pick_ksplit(const ConvParamsH& p);
 bool conv_bf16_s2d_ok(const ConvParamsH& p);   // parity-split input readable by the plane kernel (per-sample geometry only)
 int64_t conv_bf16_scratch_elems(const ConvParamsH& p, int tm);
 hipError_t launch_pack_bf16(const float* w, void* wp, int Cin, int Cout, int CoutPad, int T, int transposed, hipStream_t s);
-hipError_t launch_stem_bf16(const float* x, const float* x2, int nsplit, const float* wt, const float* scale,
+hipError_t launch_stem_bf16(const void* x, const void* x2, int u8, int nsplit, const float* wt, const float* scale,
                             const float* shift, void* y, int N, int Hi, int Wi, int Ho, int Wo, int y_bs, int y_hs, int y_org,
                             hipStream_t s);
 hipError_t launch_cost_volume_bf16(const void* fl, const void* fr, void* vol, int B, int C, int D, int H, int W, int halo,
                                    hipStream_t s);
 hipError_t launch_head_bf16(const void* x, const float* w, const float* scale, const float* shift, float* y, int C,
                             int64_t voxels, int act, hipStream_t s);
+hipError_t launch_cl_bf16_to_f32(const void* x, float* y, int N, int64_t S, int C, hipStream_t s);
 hipError_t launch_iou(const float* pred, const float* gt, float th, float* iou, int B, int64_t S, hipStream_t s);
 hipError_t launch_disparity_wta(const float* fl, const float* fr, float* dl, float* dr, int B, int C, int D, int H, int W,
                                 hipStream_t s);

@@ -21,7 +21,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // store a 256-byte coalesced row segment.
 //   wt: packed [27][32] (k-major, cout fastest)
 //   images [0, nsplit) come from x, images [nsplit, N) from x2 (left / right renders: no concatenation copy)
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ x2, int nsplit,
+//   TI = float: fp32 renders in [0,1]; TI = unsigned char: 8-bit renders, scaled by 1/255 on the way in (render_f32)
+template <typename TI>
+__global__ __launch_bounds__(256) void stem_kernel(const TI* __restrict__ x, const TI* __restrict__ x2, int nsplit,
                                                    const float* __restrict__ wt,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    float* __restrict__ y, int N, int Hi, int Wi, int Ho, int Wo,
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     const int sp = (int)(gid - (long long)n * HWo);
     const int oh = sp / Wo, ow = sp - oh * Wo;
     const int ih0 = oh * 2 - 1, iw0 = ow * 2 - 1;
-    const float* __restrict__ xn = n < nsplit ? x + (size_t)n * 3 * Hi * Wi : x2 + (size_t)(n - nsplit) * 3 * Hi * Wi;
+    const TI* __restrict__ xn = n < nsplit ? x + (size_t)n * 3 * Hi * Wi : x2 + (size_t)(n - nsplit) * 3 * Hi * Wi;
 
     // accumulators in pairs: the channel loop compiles to v_pk_fma_f32 (two exact fp32 FMAs per lane per instruction,
     // the weight pair straight from SGPRs) — half the VALU instructions of the scalar form, same bits
@@ -51,13 +53,13 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
         for (int kh = 0; kh < 3; ++kh) {
             const int ih = ih0 + kh;
             const bool vh = (unsigned)ih < (unsigned)Hi;
-            const float* __restrict__ xrow = xn + ((size_t)ci * Hi + ih) * Wi;
+            const TI* __restrict__ xrow = xn + ((size_t)ci * Hi + ih) * Wi;
             const float* __restrict__ wrow = wt + (ci * 3 + kh) * 96;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int iw = iw0 + kw;
                 const bool v = vh && ((unsigned)iw < (unsigned)Wi);
-                const float xv = v ? xrow[iw] : 0.f;
+                const float xv = v ? render_f32(xrow[iw]) : 0.f;
                 const f32x2 xv2 = {xv, xv};
 #pragma unroll
                 for (int c = 0; c < 16; ++c)
@@ -81,12 +83,18 @@ __global__ void pack_stem_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-hipError_t launch_stem(const float* x, const float* x2, int nsplit, const float* wt, const float* scale, const float* shift,
-                       float* y, int N, int Hi, int Wi, int Ho, int Wo, int y_cs, int y_hs, int y_org, hipStream_t s) {
+hipError_t launch_stem(const void* x, const void* x2, int u8, int nsplit, const float* wt, const float* scale,
+                       const float* shift, float* y, int N, int Hi, int Wi, int Ho, int Wo, int y_cs, int y_hs, int y_org,
+                       hipStream_t s) {
     const long long total = (long long)N * Ho * Wo;
     if (!x2) { x2 = x; nsplit = N; }
-    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x2, nsplit, wt, scale, shift,
-                       y, N, Hi, Wi, Ho, Wo, y_cs, y_hs, y_org);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (u8)
+        hipLaunchKernelGGL(stem_kernel<unsigned char>, grid, dim3(256), 0, s, static_cast<const unsigned char*>(x),
+                           static_cast<const unsigned char*>(x2), nsplit, wt, scale, shift, y, N, Hi, Wi, Ho, Wo, y_cs, y_hs, y_org);
+    else
+        hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(x),
+                           static_cast<const float*>(x2), nsplit, wt, scale, shift, y, N, Hi, Wi, Ho, Wo, y_cs, y_hs, y_org);
     return hipGetLastError();
 }
 

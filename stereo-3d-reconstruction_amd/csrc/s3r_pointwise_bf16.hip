@@ -25,13 +25,15 @@ __device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(f
 // lines: store-issue bound, 2.7 TB/s in r01); instead the workgroup's 256 x 64 B go through LDS and every store
 // instruction writes 16 CONSECUTIVE pixels = 1 KiB contiguous (whole 128-byte lines).
 //   images [0, nsplit) come from x, images [nsplit, N) from x2 (left / right renders: no concatenation copy)
-__global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict__ x, const float* __restrict__ x2, int nsplit,
+//   TI = float | unsigned char (8-bit renders, scaled by 1/255 on the way in: render_f32)
+template <typename TI>
+__global__ __launch_bounds__(256) void stem_bf16_kernel(const TI* __restrict__ x, const TI* __restrict__ x2, int nsplit,
                                                         const float* __restrict__ wt,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         unsigned short* __restrict__ y, int N, int Hi, int Wi, int Ho, int Wo,
                                                         int y_bs, int y_hs, int y_org) {
     __shared__ __attribute__((aligned(16))) v4u st[256 * 4];      // [pixel][4 x 16 B], part q at slot q ^ ((pixel >> 1) & 3)
-    __shared__ int yo[256];                                        // output element offset of each pixel, -1 = none
+    __shared__ long long yo[256];                                  // output element offset of each pixel, -1 = none
     const int HWo = Ho * Wo;
     const int tid = threadIdx.x;
     const long long gid = (long long)blockIdx.x * 256 + tid;
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
     const int sp = (int)(g - (long long)n * HWo);
     const int oh = sp / Wo, ow = sp - oh * Wo;
     const int ih0 = oh * 2 - 1, iw0 = ow * 2 - 1;
-    const float* __restrict__ xn = n < nsplit ? x + (size_t)n * 3 * Hi * Wi : x2 + (size_t)(n - nsplit) * 3 * Hi * Wi;
+    const TI* __restrict__ xn = n < nsplit ? x + (size_t)n * 3 * Hi * Wi : x2 + (size_t)(n - nsplit) * 3 * Hi * Wi;
     // accumulators in pairs: the channel loop compiles to v_pk_fma_f32 (two exact fp32 FMAs per lane per instruction,
     // the weight pair straight from SGPRs) — half the VALU instructions of the scalar form, same bits
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -55,13 +57,13 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
         for (int kh = 0; kh < 3; ++kh) {
             const int ih = ih0 + kh;
             const bool vh = (unsigned)ih < (unsigned)Hi;
-            const float* __restrict__ xrow = xn + ((size_t)ci * Hi + ih) * Wi;
+            const TI* __restrict__ xrow = xn + ((size_t)ci * Hi + ih) * Wi;
             const float* __restrict__ wrow = wt + (ci * 3 + kh) * 96;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int iw = iw0 + kw;
                 const bool v = vh && ((unsigned)iw < (unsigned)Wi);
-                const float xv = v ? xrow[iw] : 0.f;
+                const float xv = v ? render_f32(xrow[iw]) : 0.f;
                 const f32x2 xv2 = {xv, xv};
 #pragma unroll
                 for (int c = 0; c < 16; ++c)
@@ -71,7 +73,8 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
     float acc[32];
 #pragma unroll
     for (int c = 0; c < 16; ++c) { acc[2 * c] = acc2[c].x; acc[2 * c + 1] = acc2[c].y; }
-    yo[tid] = live ? (int)((size_t)n * y_bs + y_org + ((size_t)oh * y_hs + (size_t)ow * 32)) : -1;
+    // (64-bit: n * y_bs passes 2^31 elements beyond ~5160 images, and this form has no image-count limit of its own)
+    yo[tid] = live ? (long long)((size_t)n * y_bs + y_org + ((size_t)oh * y_hs + (size_t)ow * 32)) : -1ll;
     const int sw = (tid >> 1) & 3;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int pix = wbase + 16 * j + (lane >> 2), q = lane & 3;
-        const int off = yo[pix];
+        const long long off = yo[pix];
         const v4u t = st[pix * 4 + (q ^ ((pix >> 1) & 3))];
         if (off >= 0) *reinterpret_cast<v4u*>(y + (size_t)off + q * 8) = t;       // 64-byte pixels: 16-byte aligned
     }
@@ -146,25 +149,35 @@ __device__ unsigned long long s3r_stem_timeline[4096 * 16];
 #else
 #define S3R_STEM_STAMP(k) do {} while (0)
 #endif
+// U8: the renders are 8-bit (N,3,224,224) uint8 — what the reference's PNG decode yields and a quarter of the bytes: a row
+// is 224 bytes = 14 lanes x 16 B per DMA, slots are 256 B apart (32 zero bytes behind each row), and an operand is read as
+// one byte and scaled by 1/255 in registers (render_f32: the same single rounding as the host's float32(u) / 255, so
+// the result is bit-identical to the fp32 entry on renders converted on the host).
+template <bool U8>
 __global__ __launch_bounds__(64 * STEM_WAVES) void stem_bf16_mfma_kernel(
-        const float* __restrict__ x, const float* __restrict__ x2, int nsplit, const float* __restrict__ wt,
+        const void* __restrict__ xv, const void* __restrict__ x2v, int nsplit, const float* __restrict__ wt,
         const float* __restrict__ scale, const float* __restrict__ shift, unsigned short* __restrict__ y, int N,
         int y_bs, int y_hs, int y_org S3R_STEM_DBG_PARAM) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
     constexpr int Hi = 224, Wi = 224, Wo = 112, BPI = 112 / STEM_ROWS;       // the network's stem geometry (launcher checks)
-    constexpr int ROWB = Wi * 4;                                              // 896
+    constexpr int ES = U8 ? 1 : 4;                                            // bytes per render sample
+    constexpr int ROWB = Wi * ES;                                             // 896 | 224
+    constexpr int SLOT = U8 ? 256 : 1024;                                     // bytes between row slots (tail: zeros)
+    const unsigned char* x = static_cast<const unsigned char*>(xv);
+    const unsigned char* x2 = static_cast<const unsigned char*>(x2v);
     extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
-    unsigned char* slab = slds + 1024;                                        // slot sl at slab + 1024 sl; 1 KiB of zeros before slot 0
+    unsigned char* slab = slds + 1024;                                        // slot sl at slab + SLOT sl; 1 KiB of zeros before slot 0
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    v2u* sw = reinterpret_cast<v2u*>(slab + STEM_SLABS * STEM_SLOTS * 1024 + wave * 2048);  // [pixel 32][8 x 8 B], 16-B slot g at g ^ ((pixel >> 1) & 3)
+    v2u* sw = reinterpret_cast<v2u*>(slab + STEM_SLABS * STEM_SLOTS * SLOT + wave * 2048);  // [pixel 32][8 x 8 B], 16-B slot g at g ^ ((pixel >> 1) & 3)
     const v4u* sr = reinterpret_cast<const v4u*>(sw);
 
     // ---- once: zero guard + slot tails, weight fragments (A operand: cout j, k = 2 s + h), tap offsets (B operand)
-    for (int i = threadIdx.x; i < 256 + STEM_SLABS * STEM_SLOTS * 32; i += 64 * STEM_WAVES) {
+    constexpr int TAILW = (SLOT - ROWB) / 4;                                  // zero words behind each row: 32 | 8
+    for (int i = threadIdx.x; i < 256 + STEM_SLABS * STEM_SLOTS * TAILW; i += 64 * STEM_WAVES) {
         if (i < 256) reinterpret_cast<unsigned*>(slds)[i] = 0u;
-        else { const int sl = (i - 256) >> 5, w = (i - 256) & 31; reinterpret_cast<unsigned*>(slab + sl * 1024 + ROWB)[w] = 0u; }
+        else { const int sl = (i - 256) / TAILW, w = (i - 256) % TAILW; reinterpret_cast<unsigned*>(slab + sl * SLOT + ROWB)[w] = 0u; }
     }
     float wa[14];
     int off[14];
@@ -175,7 +188,7 @@ __global__ __launch_bounds__(64 * STEM_WAVES) void stem_bf16_mfma_kernel(
             const int k = 2 * s + h;
             const int t = k < 27 ? k : 0;
             const int ci = t / 9, kh = (t - ci * 9) / 3, kw = t - ci * 9 - kh * 3;
-            off[s] = (ci * (2 * STEM_ROWS + 1) + kh) * 1024 + kw * 4;
+            off[s] = (ci * (2 * STEM_ROWS + 1) + kh) * SLOT + kw * ES;
             wa[s] = k < 27 ? wt[t * 32 + j] * sc : (shift ? shift[j] : 0.f);
         }
     }
@@ -185,8 +198,8 @@ __global__ __launch_bounds__(64 * STEM_WAVES) void stem_bf16_mfma_kernel(
     // number of DMA instructions this wave issued (wave-uniform)
     auto issue = [&](int blk, unsigned char* sb) -> int {
         const int n = blk / BPI, q = blk - n * BPI;
-        const float* xn = n < nsplit ? x + (size_t)n * 3 * Hi * Wi : x2 + (size_t)(n - nsplit) * 3 * Hi * Wi;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, 3 * Hi * Wi * 4, 0x00020000);
+        const unsigned char* xn = n < nsplit ? x + (size_t)n * 3 * Hi * Wi * ES : x2 + (size_t)(n - nsplit) * 3 * Hi * Wi * ES;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(xn), 0, 3 * Hi * Wi * ES, 0x00020000);
         int cnt = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -195,10 +208,10 @@ __global__ __launch_bounds__(64 * STEM_WAVES) void stem_bf16_mfma_kernel(
             const int ci = sl / (2 * STEM_ROWS + 1), rr = sl - ci * (2 * STEM_ROWS + 1);
             const int irow = 2 * STEM_ROWS * q - 1 + rr;
             if (irow < 0) {                                                    // the row above the image
-                if (lane < 56) *reinterpret_cast<v4u*>(sb + sl * 1024 + lane * 16) = (v4u){0u, 0u, 0u, 0u};
+                if (lane < ROWB / 16) *reinterpret_cast<v4u*>(sb + sl * SLOT + lane * 16) = (v4u){0u, 0u, 0u, 0u};
             } else if (!(S3R_STEM_DBG(2) && blk >= (int)gridDim.x)) {
-                if (lane < 56)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(sb + sl * 1024), 16,
+                if (lane < ROWB / 16)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(sb + sl * SLOT), 16,
                                                              lane * 16, (ci * Hi + irow) * ROWB, 0, 0);
                 ++cnt;
             }
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(64 * STEM_WAVES) void stem_bf16_mfma_kernel(
     const int nblk = N * BPI;
     int blk = blockIdx.x;
     unsigned char* cur = slab;
-    unsigned char* oth = slab + (STEM_SLABS - 1) * STEM_SLOTS * 1024;
+    unsigned char* oth = slab + (STEM_SLABS - 1) * STEM_SLOTS * SLOT;
     if (STEM_SLABS == 2 && blk < nblk) issue(blk, cur);
 #ifdef S3R_ABLATE
     int stamp_pass = -1;
@@ -251,9 +264,17 @@ __global__ __launch_bounds__(64 * STEM_WAVES) void stem_bf16_mfma_kernel(
         for (int k = 0; k < 2; ++k) {
             const int px = (wave + k * STEM_WAVES) * 32 + j;
             const int orow = px / Wo, ow = px - orow * Wo;
-            const unsigned char* bp = cur + (2 * orow) * 1024 + (2 * ow - 1) * 4;
+            const unsigned char* bp = cur + (2 * orow) * SLOT + (2 * ow - 1) * ES;
+            if constexpr (U8) {
+                unsigned char raw[14];
 #pragma unroll
-            for (int s = 0; s < 14; ++s) bv[k][s] = *reinterpret_cast<const float*>(bp + off[s]);
+                for (int s = 0; s < 14; ++s) raw[s] = bp[off[s]];
+#pragma unroll
+                for (int s = 0; s < 14; ++s) bv[k][s] = render_f32(raw[s]);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 14; ++s) bv[k][s] = *reinterpret_cast<const float*>(bp + off[s]);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #ifdef S3R_ABLATE
@@ -315,42 +336,55 @@ static bool stem_mfma_enabled() {
     return on;
 }
 
-hipError_t launch_stem_bf16(const float* x, const float* x2, int nsplit, const float* wt, const float* scale,
+template <bool U8>
+static hipError_t launch_stem_bf16_mfma(const void* x, const void* x2, int nsplit, const float* wt, const float* scale,
+                                        const float* shift, void* y, int N, int y_bs, int y_hs, int y_org, hipStream_t s) {
+    // persistent workgroups, every one of them resident at once (as many as the occupancy query says fit)
+    static LdsAttr attr;
+    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&stem_bf16_mfma_kernel<U8>), STEM_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    static int resident[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    if (!resident[dev]) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stem_bf16_mfma_kernel<U8>, 64 * STEM_WAVES, STEM_LDS_BYTES) !=
+                hipSuccess || per_cu < 1)
+            per_cu = 2;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        resident[dev] = per_cu * cus;
+    }
+    const int blocks = N * (112 / STEM_ROWS);
+    int wgs = blocks < resident[dev] ? blocks : resident[dev];
+#ifdef S3R_ABLATE
+    if (getenv("S3R_STEM_WGS")) wgs = atoi(getenv("S3R_STEM_WGS"));
+#endif
+    hipLaunchKernelGGL(stem_bf16_mfma_kernel<U8>, dim3((unsigned)wgs), dim3(64 * STEM_WAVES), STEM_LDS_BYTES, s, x, x2, nsplit,
+                       wt, scale, shift, reinterpret_cast<unsigned short*>(y), N, y_bs, y_hs, y_org
+#ifdef S3R_ABLATE
+                       , getenv("S3R_ABL") ? atoi(getenv("S3R_ABL")) : 0
+#endif
+                       );
+    return hipGetLastError();
+}
+
+hipError_t launch_stem_bf16(const void* x, const void* x2, int u8, int nsplit, const float* wt, const float* scale,
                             const float* shift, void* y, int N, int Hi, int Wi, int Ho, int Wo, int y_bs, int y_hs, int y_org,
                             hipStream_t s) {
     const long long total = (long long)N * Ho * Wo;
     if (!x2) { x2 = x; nsplit = N; }
-    if (stem_mfma_enabled() && Hi == 224 && Wi == 224 && Ho == 112 && Wo == 112 && N > 0 && N <= (1 << 16)) {
-        // persistent workgroups, every one of them resident at once (as many as the occupancy query says fit)
-        static LdsAttr attr;
-        hipError_t e = attr.ensure(reinterpret_cast<const void*>(&stem_bf16_mfma_kernel), STEM_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        static int resident[16] = {0};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-        if (!resident[dev]) {
-            int per_cu = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stem_bf16_mfma_kernel, 64 * STEM_WAVES, STEM_LDS_BYTES) !=
-                    hipSuccess || per_cu < 1)
-                per_cu = 2;
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-            resident[dev] = per_cu * cus;
-        }
-        const int blocks = N * (112 / STEM_ROWS);
-        int wgs = blocks < resident[dev] ? blocks : resident[dev];
-#ifdef S3R_ABLATE
-        if (getenv("S3R_STEM_WGS")) wgs = atoi(getenv("S3R_STEM_WGS"));
-#endif
-        hipLaunchKernelGGL(stem_bf16_mfma_kernel, dim3((unsigned)wgs), dim3(64 * STEM_WAVES), STEM_LDS_BYTES, s, x, x2, nsplit,
-                           wt, scale, shift, reinterpret_cast<unsigned short*>(y), N, y_bs, y_hs, y_org
-#ifdef S3R_ABLATE
-                           , getenv("S3R_ABL") ? atoi(getenv("S3R_ABL")) : 0
-#endif
-                           );
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL(stem_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x2, nsplit, wt, scale,
-                       shift, reinterpret_cast<unsigned short*>(y), N, Hi, Wi, Ho, Wo, y_bs, y_hs, y_org);
+    if (stem_mfma_enabled() && Hi == 224 && Wi == 224 && Ho == 112 && Wo == 112 && N > 0 && N <= (1 << 16))
+        return u8 ? launch_stem_bf16_mfma<true>(x, x2, nsplit, wt, scale, shift, y, N, y_bs, y_hs, y_org, s)
+                  : launch_stem_bf16_mfma<false>(x, x2, nsplit, wt, scale, shift, y, N, y_bs, y_hs, y_org, s);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (u8)
+        hipLaunchKernelGGL(stem_bf16_kernel<unsigned char>, grid, dim3(256), 0, s, static_cast<const unsigned char*>(x),
+                           static_cast<const unsigned char*>(x2), nsplit, wt, scale, shift, reinterpret_cast<unsigned short*>(y),
+                           N, Hi, Wi, Ho, Wo, y_bs, y_hs, y_org);
+    else
+        hipLaunchKernelGGL(stem_bf16_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(x),
+                           static_cast<const float*>(x2), nsplit, wt, scale, shift, reinterpret_cast<unsigned short*>(y),
+                           N, Hi, Wi, Ho, Wo, y_bs, y_hs, y_org);
     return hipGetLastError();
 }
 
@@ -455,6 +489,37 @@ hipError_t launch_head_bf16(const void* x, const float* w, const float* scale, c
     const long long waves = (voxels + 64 / lanes_per - 1) / (64 / lanes_per);
     hipLaunchKernelGGL(head_bf16_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s,
                        reinterpret_cast<const unsigned short*>(x), w, scale, shift, y, C, (long long)voxels, act);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hand-off from the bf16 path to an fp32 consumer (the point head's linear layers, the disparity read-out): channels-last
+// bf16 (N, S, C) -> fp32 NC(S) (N, C, S), exact (a bf16 is the top half of an fp32).  32 x 32 tiles through LDS: reads are
+// 64-byte channel runs, writes 128-byte position runs.
+__global__ __launch_bounds__(256) void cl_bf16_to_f32_kernel(const unsigned short* __restrict__ x, float* __restrict__ y,
+                                                             int S, int C) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, s0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const unsigned short* __restrict__ xn = x + (size_t)n * S * C;
+    float* __restrict__ yn = y + (size_t)n * C * S;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int s = s0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (s < S && c < C) ? __builtin_bit_cast(float, (unsigned)xn[(size_t)s * C + c] << 16) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, sp = s0 + tx;
+        if (sp < S && c < C) yn[(size_t)c * S + sp] = tile[tx][ty + 8 * i];
+    }
+}
+
+hipError_t launch_cl_bf16_to_f32(const void* x, float* y, int N, int64_t S, int C, hipStream_t s) {
+    if (N <= 0 || S <= 0 || C <= 0 || N > 65535 || (C + 31) / 32 > 65535) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((S + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
+    hipLaunchKernelGGL(cl_bf16_to_f32_kernel, grid, dim3(256), 0, s, reinterpret_cast<const unsigned short*>(x), y, (int)S, C);
     return hipGetLastError();
 }
 

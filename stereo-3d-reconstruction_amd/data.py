@@ -11,12 +11,18 @@ File layout as the reference's config documents it (/root/reference/README.md:73
 The reference's own transforms (crop / background / normalisation constants) are on unmounted branches
 (SURVEY.md §0).  What is EVIDENCED by the mount: the five path templates above and the file types.  What is
 INVENTED by this build (each a constant of this file, to be overwritten from the reference the day it is mounted —
-tools/resurvey.py lists the reference's own): compositing RGBA renders over a WHITE background; scaling to [0,1]
-with NO mean / std normalisation; BILINEAR resize to 224x224 when a render has another size (no crop); `volume > 0`
+tools/resurvey.py lists the reference's own): compositing RGBA renders over a WHITE background IN 8 BITS (rounded
+integer blend, as an image library composites); scaling to [0,1] by 1/255 with NO mean / std normalisation; BILINEAR
+resize to 224x224 when a render has another size (no crop); `volume > 0`
 as the occupancy rule for the .mat grids; taking the first of Z / V / Y / disparity / R as the EXR disparity channel
 (exr.disparity_channel) with "finite and >= 0" as its validity rule; block-mean pooling of the 224x224 maps to the
 28x28 read-out resolution (downsample_disparity).  Decoding is host work; batches are handed to the GPU through
 graph.PrefetchingLoader so the copy overlaps the forward.
+
+Renders stay 8-BIT all the way to the first kernel (render_dtype="uint8", the default): the PNGs are 8-bit, a uint8 batch
+is a quarter of the bytes across PCIe, and the stem scales by 1/255 as it reads (`s3r_encoder_forward_u8`) with the same
+single rounding as the host conversion — render_dtype="float32" yields exactly `uint8 / 255` computed here, and both
+give bit-identical predictions.
 """
 from __future__ import annotations
 
@@ -32,7 +38,23 @@ RENDER_DIR, VOLUME_DIR = "ShapeNetStereoRendering", "ShapeNetVox32"
 _VIEW = re.compile(r"render_(\d+)_l\.png$")
 
 
+def composite_over_white_u8(rgba: np.ndarray) -> np.ndarray:
+    """(H,W,4) uint8 RGBA -> (H,W,3) uint8 over a white background: round((c * a + 255 * (255 - a)) / 255) in integers."""
+    c = rgba[..., :3].astype(np.uint32)
+    a = rgba[..., 3:4].astype(np.uint32)
+    return ((c * a + 255 * (255 - a) + 127) // 255).astype(np.uint8)
+
+
+def renders_to_float(u8) :
+    """The host form of the stem's 1/255 scaling: float32(u) / float32(255), one correctly rounded division per sample
+    (numpy array or torch tensor).  `model(renders_to_float(x))` == `model(x)` bit for bit for uint8 x."""
+    if isinstance(u8, torch.Tensor):
+        return u8.to(torch.float32) / 255.0
+    return u8.astype(np.float32) / np.float32(255.0)
+
+
 def _load_png(path: str) -> np.ndarray:
+    """One render as (3,224,224) uint8, composited over white."""
     try:
         from PIL import Image
     except ImportError as e:                              # pragma: no cover
@@ -41,9 +63,8 @@ def _load_png(path: str) -> np.ndarray:
         im = im.convert("RGBA")
         if im.size != (IMG, IMG):
             im = im.resize((IMG, IMG), Image.BILINEAR)
-        a = np.asarray(im, dtype=np.float32) / 255.0
-    rgb, alpha = a[..., :3], a[..., 3:4]
-    return (rgb * alpha + (1.0 - alpha)).transpose(2, 0, 1).copy()          # white background, CHW
+        rgba = np.asarray(im, dtype=np.uint8)
+    return composite_over_white_u8(rgba).transpose(2, 0, 1).copy()          # white background, CHW
 
 
 def _load_volume(path: str) -> np.ndarray:
@@ -80,13 +101,16 @@ def downsample_disparity(d: torch.Tensor, size: int = 28) -> torch.Tensor:
 
 
 class StereoShapeNet(torch.utils.data.Dataset):
-    """One item per (taxonomy, model, view): left, right (3,224,224) float32 in [0,1], volume (32,32,32) {0,1};
+    """One item per (taxonomy, model, view): left, right (3,224,224) uint8 (render_dtype="uint8", default: the modules
+    take them as they are) or float32 in [0,1] (render_dtype="float32": uint8 / 255), volume (32,32,32) {0,1};
     with_disparity=True appends the left / right ground-truth disparity maps (224,224) float32 (render pixels; the
     files' own invalid markers — inf / negative — are kept) and lists only the views that have both EXR files."""
 
     def __init__(self, root: str, taxonomies: Optional[Sequence[str]] = None, views: Optional[Sequence[int]] = None,
-                 with_disparity: bool = False):
-        self.with_disparity = with_disparity
+                 with_disparity: bool = False, render_dtype: str = "uint8"):
+        if render_dtype not in ("uint8", "float32"):
+            raise ValueError("render_dtype must be 'uint8' or 'float32'")
+        self.with_disparity, self.render_dtype = with_disparity, render_dtype
         rdir = os.path.join(root, RENDER_DIR)
         if not os.path.isdir(rdir):
             raise FileNotFoundError(f"{rdir} not found (expected the layout of README.md:73-77 under {root})")
@@ -120,6 +144,8 @@ class StereoShapeNet(torch.utils.data.Dataset):
         mdir = os.path.join(self.root, RENDER_DIR, tax, model)
         left = _load_png(os.path.join(mdir, "render_%02d_l.png" % view))
         right = _load_png(os.path.join(mdir, "render_%02d_r.png" % view))
+        if self.render_dtype == "float32":
+            left, right = renders_to_float(left), renders_to_float(right)
         vol = _load_volume(os.path.join(self.root, VOLUME_DIR, tax, model + ".mat"))
         if self.with_disparity:
             dl = _load_disparity(os.path.join(mdir, "disp_%02d_l.exr" % view))

@@ -42,11 +42,16 @@ def _device_batches(tensors: Sequence[torch.Tensor], b0: int, e0: int, batch: in
             rt.cudaHostUnregister(t.data_ptr())
 
 
-def synthetic_eval_set(n: int, seed: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+def synthetic_eval_set(n: int, seed: int = 0, render_dtype: str = "float32") -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """n synthetic (left, right, ground-truth 32^3 occupancy) triples: there is no dataset in this
-    container (README.md:29 is a download link).  GT is a random axis-aligned box per sample."""
+    container (README.md:29 is a download link).  GT is a random axis-aligned box per sample.
+    render_dtype="uint8": 8-bit renders (uniform 0..255), what a decoded PNG list looks like."""
     g = torch.Generator().manual_seed(seed)
-    left, right = torch.rand(n, 3, 224, 224, generator=g), torch.rand(n, 3, 224, 224, generator=g)
+    if render_dtype == "uint8":
+        left = torch.randint(0, 256, (n, 3, 224, 224), generator=g, dtype=torch.uint8)
+        right = torch.randint(0, 256, (n, 3, 224, 224), generator=g, dtype=torch.uint8)
+    else:
+        left, right = torch.rand(n, 3, 224, 224, generator=g), torch.rand(n, 3, 224, 224, generator=g)
     gt = torch.zeros(n, 32, 32, 32)
     lo = torch.randint(0, 12, (n, 3), generator=g)
     hi = lo + torch.randint(8, 20, (n, 3), generator=g)

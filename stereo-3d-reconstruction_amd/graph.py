@@ -23,10 +23,11 @@ class GraphedForward:
     and initialised by the warm-up calls made before capture, so the captured region only launches kernels.
     """
 
-    def __init__(self, model, batch: int, device, warmup: int = 2):
+    def __init__(self, model, batch: int, device, warmup: int = 2, input_dtype=torch.float32):
+        """input_dtype: torch.float32 renders in [0,1], or torch.uint8 (8-bit renders: the stem scales by 1/255)."""
         self.model, self.batch, self.device = model, batch, torch.device(device)
-        self.left = torch.zeros(batch, 3, 224, 224, device=self.device)
-        self.right = torch.zeros(batch, 3, 224, 224, device=self.device)
+        self.left = torch.zeros(batch, 3, 224, 224, device=self.device, dtype=input_dtype)
+        self.right = torch.zeros(batch, 3, 224, 224, device=self.device, dtype=input_dtype)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):                 # warm-up on the capture stream: arenas, packing, fresh memsets
@@ -52,8 +53,10 @@ class GraphedForward:
         none given the static inputs are used as they are (fill `.left` / `.right` yourself).  The returned
         tensor is the graph's static output: it is overwritten by the next replay."""
         if left is not None:
-            if left.shape != self.left.shape or right is None or right.shape != self.right.shape:
-                raise RuntimeError(f"graph was captured for batch {self.batch}; got {tuple(left.shape)}")
+            if left.shape != self.left.shape or right is None or right.shape != self.right.shape or \
+                    left.dtype != self.left.dtype or right.dtype != self.right.dtype:
+                raise RuntimeError(f"graph was captured for batch {self.batch} of {self.left.dtype} renders; got "
+                                   f"{tuple(left.shape)} {left.dtype}")
             self.left.copy_(left, non_blocking=True)
             self.right.copy_(right, non_blocking=True)
         self.graph.replay()

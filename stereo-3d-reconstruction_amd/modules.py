@@ -68,6 +68,26 @@ def _check_input(x: torch.Tensor, name: str, shape_tail: Sequence[int], dtype=to
     return x.contiguous()
 
 
+def _check_render(x: torch.Tensor, name: str) -> torch.Tensor:
+    """A batch of renders, (B,3,224,224): float32 in [0,1], or uint8 as a PNG decode yields them (the stem scales by
+    1/255 as it reads, bit-identical to `x.float() / 255` on the host: `s3r_encoder_forward_u8`)."""
+    dt = x.dtype if isinstance(x, torch.Tensor) and x.dtype == torch.uint8 else torch.float32
+    return _check_input(x, name, (3, spec.IMG_HW, spec.IMG_HW), dt)
+
+
+@torch.no_grad()
+def channels_last_to_f32(x: torch.Tensor) -> torch.Tensor:
+    """Hand-off from the bf16 path to an fp32 consumer: a logical (B,C,...) bfloat16 tensor in channels-last memory (what
+    the bf16 modules return) -> contiguous fp32 (B,C,...), exact, by `s3r_channels_last_to_f32` (no torch kernel)."""
+    phys = _check_input_cl(x, "x", x.shape[1:])
+    B, Cc = x.shape[0], x.shape[1]
+    y = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
+    if B and y.numel():
+        _lib.check(_lib.load().s3r_channels_last_to_f32(phys.data_ptr(), y.data_ptr(), B, Cc, y[0, 0].numel(),
+                                                        _stream_ptr(x.device)), "channels_last_to_f32")
+    return y
+
+
 class _Workspace:
     """A chain's activation arena.  Every intermediate of the chain has its own region in it, stored with
     the zero halo the next layer's gather reads; the kernels write interiors only, so the
@@ -262,11 +282,15 @@ class _HipChain(nn.Module):
         # re-zeroes the arena (fresh), so no region is ever read with another plan's bytes in its halo.
         cfg = tuple((arr[i].desc.tile, arr[i].desc.ksplit) for i in range(n)) + (in_layout, out_layout)
         ws, fresh = self._ws.get(device, need, (batch, n, in_halo, need, cfg))
-        if x2 is not None:
-            if upto is not None or self._entry != "s3r_encoder_forward":
-                raise RuntimeError("a (left, right) tensor pair is an input of the whole encoder only")
-            _lib.check(lib.s3r_encoder_forward(arr, n, x.data_ptr(), x2.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(),
-                                               fresh, _stream_ptr(device)), type(self).__name__)
+        u8 = x.dtype == torch.uint8
+        if (u8 or x2 is not None) and self._entry != "s3r_encoder_forward":
+            raise RuntimeError("8-bit renders / a (left, right) tensor pair are inputs of the encoder only")
+        if x2 is not None and x2.dtype != x.dtype:
+            raise RuntimeError("left and right renders must share one dtype")
+        if x2 is not None or u8:                 # (any prefix of the tower: the entry takes a chain that starts with the stem)
+            enc = lib.s3r_encoder_forward_u8 if u8 else lib.s3r_encoder_forward
+            _lib.check(enc(arr, n, x.data_ptr(), x2.data_ptr() if x2 is not None else None, y.data_ptr(), ws.data_ptr(),
+                           ws.numel(), fresh, _stream_ptr(device)), type(self).__name__)
         elif upto is None and self._entry == "s3r_encoder_forward":
             _lib.check(lib.s3r_encoder_forward(arr, n, x.data_ptr(), None, y.data_ptr(), ws.data_ptr(), ws.numel(), fresh,
                                                _stream_ptr(device)), type(self).__name__)
@@ -281,8 +305,10 @@ class _HipChain(nn.Module):
 
     # -- measured per-layer configuration ----------------------------------------------------------
     _TUNE_TILES = (1, 2, 3, 7, 0)               # fp32 tile configurations (s3r_conv_glds.hip)
-    _TUNE_TILES_BF16 = (1, 3, 9, 17, 22, 23, 30, 31)    # bf16: per-tap (128 / 128x128 / 32-ch K), row-reuse, plane-reuse,
-                                                        # plane-reuse over a parity-split input (stride-2 layers)
+    _TUNE_TILES_BF16 = (1, 3, 9, 17, 22, 23)    # bf16: per-tap (128 / 128x128 / 32-ch K), row-reuse, plane-reuse.  (30 / 31,
+                                                # plane-reuse over a parity-split input, are not candidates: forcing them
+                                                # also switches the PRODUCER's output layout, a cost these per-layer
+                                                # timings would not count; the hand-off measured slower)
     _TUNE_KSPLITS = (1, 2, 4, 8)
 
     def _mfma_layers(self):
@@ -344,18 +370,19 @@ class Encoder(_HipChain):
 
     def forward(self, images: torch.Tensor, upto: Optional[str] = None) -> torch.Tensor:
         """fp32: (N,32,28,28) contiguous.  bf16: (N,32,28,28) bfloat16 in channels_last memory format.
+        `images`: float32 in [0,1] or uint8 (`_check_render`).
         `upto`: stop after the named layer (stage-by-stage checks), as on Decoder.forward."""
-        x = _check_input(images, "images", (3, spec.IMG_HW, spec.IMG_HW))
+        x = _check_render(images, "images")
         return self._run(x, upto)
 
     def forward_pair(self, left: torch.Tensor, right: torch.Tensor) -> torch.Tensor:
         """The tower over the B left and the B right renders in ONE pass, read from their two tensors (the first
         kernel picks its source by image index): features (2B,32,28,28), left batch first.  Equal, bit for bit, to
         `forward(torch.cat([left, right]))` — without the concatenation copy."""
-        left = _check_input(left, "left", (3, spec.IMG_HW, spec.IMG_HW))
-        right = _check_input(right, "right", (3, spec.IMG_HW, spec.IMG_HW))
-        if left.shape[0] != right.shape[0] or left.device != right.device:
-            raise RuntimeError("left and right must be two batches of one size on one device")
+        left = _check_render(left, "left")
+        right = _check_render(right, "right")
+        if left.shape[0] != right.shape[0] or left.device != right.device or left.dtype != right.dtype:
+            raise RuntimeError("left and right must be two batches of one size and dtype on one device")
         if left.shape[0] == 0:
             return self._run(left)
         return self._run(left, None, 0, right)
@@ -500,15 +527,17 @@ class _DisparityMixin:
         """Predicted (left, right) disparity maps, (B,28,28) each: the winner-take-all read-out of the cost volume's
         shift-and-diff costs on this model's encoder features (`disparity_wta`).  in_pixels scales feature-resolution
         disparities to 224x224 render pixels (x8), the unit of the dataset's EXR ground truth."""
-        left = _check_input(left, "left", (3, spec.IMG_HW, spec.IMG_HW))
-        right = _check_input(right, "right", (3, spec.IMG_HW, spec.IMG_HW))
+        left = _check_render(left, "left")
+        right = _check_render(right, "right")
         if left.shape[0] != right.shape[0]:
             raise RuntimeError("left and right batch sizes differ")
         dls, drs = [], []
         for s in range(0, max(left.shape[0], 1), MAX_CHUNK):
             l, r = left[s:s + MAX_CHUNK], right[s:s + MAX_CHUNK]
             b = l.shape[0]
-            feats = self.encoder.forward_pair(l, r).float().contiguous()        # (bf16 path: back to fp32 NCHW)
+            feats = self.encoder.forward_pair(l, r)
+            if feats.dtype != torch.float32:                     # bf16 path: channels-last bf16 -> fp32 NCHW (HIP kernel)
+                feats = channels_last_to_f32(feats)
             dl, dr = disparity_wta(feats[:b], feats[b:], self.cost_volume.max_disp)
             dls.append(dl), drs.append(dr)
         dl = dls[0] if len(dls) == 1 else torch.cat(dls, 0)
@@ -539,8 +568,9 @@ class Stereo2Voxel(_DisparityMixin, nn.Module):
 
     @torch.no_grad()
     def forward(self, left: torch.Tensor, right: torch.Tensor) -> torch.Tensor:
-        left = _check_input(left, "left", (3, spec.IMG_HW, spec.IMG_HW))
-        right = _check_input(right, "right", (3, spec.IMG_HW, spec.IMG_HW))
+        """left, right: (B,3,224,224) float32 in [0,1] or uint8 (8-bit renders: scaled by 1/255 inside the first kernel)."""
+        left = _check_render(left, "left")
+        right = _check_render(right, "right")
         if left.shape[0] != right.shape[0]:
             raise RuntimeError("left and right batch sizes differ")
         outs = []
@@ -587,8 +617,8 @@ class Stereo2Point(_DisparityMixin, nn.Module):
 
     @torch.no_grad()
     def forward(self, left: torch.Tensor, right: torch.Tensor) -> torch.Tensor:
-        left = _check_input(left, "left", (3, spec.IMG_HW, spec.IMG_HW))
-        right = _check_input(right, "right", (3, spec.IMG_HW, spec.IMG_HW))
+        left = _check_render(left, "left")
+        right = _check_render(right, "right")
         if left.shape[0] != right.shape[0]:
             raise RuntimeError("left and right batch sizes differ")
         outs = []
@@ -598,8 +628,8 @@ class Stereo2Point(_DisparityMixin, nn.Module):
             feats = self.encoder.forward_pair(l, r)
             vol = self.cost_volume.forward_padded(feats[:b], feats[b:])
             latent = self.decoder.forward_padded(vol)
-            if latent.dtype != torch.float32:                      # bf16 channels-last view -> fp32 (B,512,4,4,4)
-                latent = latent.float().contiguous()
+            if latent.dtype != torch.float32:                      # bf16 channels-last view -> fp32 (B,512,4,4,4): HIP kernel
+                latent = channels_last_to_f32(latent)
             outs.append(self.point_head(latent))
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 

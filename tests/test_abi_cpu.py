@@ -26,7 +26,7 @@ def test_header_symbols_all_exported(s3r, lib):
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.s3r_abi_version() == 4
+    assert lib.s3r_abi_version() == 5
 
 
 def test_struct_layouts_match_header(s3r):

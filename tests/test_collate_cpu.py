@@ -105,12 +105,24 @@ def test_bench_and_runner_start_their_own_ranks(monkeypatch):
         assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
         assert cmd[-len(argv) + 1:] == argv[1:] and cmd[-len(argv)].endswith(argv[0])
         assert env["MASTER_ADDR"] == "127.0.0.1"
-        # under an external launcher (WORLD_SIZE set) nothing is spawned: the script is one of the ranks
+        # under an external launcher (WORLD_SIZE set) nothing is spawned: the script is one of the ranks.  The first thing
+        # a rank does is pick its device: stop it THERE with a sentinel (nothing of the GPU or of torch.distributed is
+        # initialised in this process, with or without a GPU / MASTER_PORT in the environment)
+        import torch
+
+        class _Reached(Exception):
+            pass
+
+        def stop(*a, **k):
+            raise _Reached()
+        monkeypatch.setattr(torch.cuda, "set_device", stop)
+        monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+        monkeypatch.setattr(torch.distributed, "init_process_group", stop)
         monkeypatch.setenv("WORLD_SIZE", "4")
+        monkeypatch.delenv("MASTER_ADDR", raising=False)
+        monkeypatch.delenv("MASTER_PORT", raising=False)
         calls.clear()
-        try:
+        with pytest.raises(_Reached):
             mod.main()
-        except BaseException:
-            pass                                                    # (no GPU here: it fails later, after NOT spawning)
         assert not calls
         monkeypatch.delenv("WORLD_SIZE")
