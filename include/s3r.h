@@ -71,7 +71,14 @@ typedef enum s3r_act { S3R_ACT_NONE = 0, S3R_ACT_RELU = 1, S3R_ACT_SIGMOID = 2 }
  *                     every tap then walks ONE sub-tensor at stride 1, so the kernel that reuses a gathered input plane
  *                     for all taps of a group serves stride-2 layers as well (the input crosses L2 -> LDS once per 9/4
  *                     taps instead of once per tap).  s3r_chain_forward plans it between a convolution and a
- *                     stride-2 consumer by itself; the fields exist so that single layers can be driven and tested. */
+ *                     stride-2 consumer by itself; the fields exist so that single layers can be driven and tested.
+ *                     fp32 path (NC(D)HW), even edge n, halo 1: W-PARITY-SPLIT ROWS — the same (B, C, [n+2,] n+2, n+2)
+ *                     buffer, every padded row of n+2 elements stored as its (n+2)/2 even columns followed by its (n+2)/2
+ *                     odd columns.  Tap kw of a stride-2 k3 p1 convolution then reads, for consecutive output columns,
+ *                     CONSECUTIVE dwords of one half (columns 2 ow + kw): the gather is as wide as a stride-1 layer's
+ *                     (16-byte LDS-DMA where the output width is a multiple of 4) instead of every other dword.  Planned
+ *                     by s3r_chain_forward between a convolution and its stride-2 consumer; the K order does not change,
+ *                     so results are bit-identical to the plain layout. */
 typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_S2D = 1 } s3r_layout;
 
 /* One layer's geometry.  Spatial sizes are cubic/square: `in_size` per axis, `ndim` axes.
@@ -100,8 +107,8 @@ typedef struct s3r_conv_desc {
     int32_t out_halo;  /* zero halo of the output buffer */
     int32_t ksplit;    /* 0: library picks; >=1: force the split-K factor (must divide cin/16; bf16: cin/32) */
     int32_t dtype;     /* s3r_dtype: which path (layout + matrix instruction) the layer runs on */
-    int32_t in_layout; /* s3r_layout of the input buffer  (S2D: stride-2 k3 p1 convolutions on the bf16 path only) */
-    int32_t out_layout;/* s3r_layout of the output buffer (S2D: bf16 MFMA convolutions, out_halo must be 1) */
+    int32_t in_layout; /* s3r_layout of the input buffer  (S2D: stride-2 k3 p1 convolutions, in_halo must be 1) */
+    int32_t out_layout;/* s3r_layout of the output buffer (S2D: MFMA convolutions, out_halo must be 1) */
 } s3r_conv_desc;
 
 /* One layer of a stage: geometry + its packed weights + folded epilogue vectors (device pointers). */

@@ -112,8 +112,8 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
     if ((d->in_layout != S3R_LAYOUT_PLAIN && d->in_layout != S3R_LAYOUT_S2D) ||
         (d->out_layout != S3R_LAYOUT_PLAIN && d->out_layout != S3R_LAYOUT_S2D))
         return fail(S3R_ERR_INVALID, "unknown layout");
-    if ((d->in_layout || d->out_layout) && (d->dtype != S3R_BF16 || d->op == S3R_OP_LINEAR))
-        return fail(S3R_ERR_INVALID, "the parity-split layout exists on the bf16 convolution path only");
+    if ((d->in_layout || d->out_layout) && d->op == S3R_OP_LINEAR)
+        return fail(S3R_ERR_INVALID, "the parity-split layout exists on the convolution paths only");
     if (d->op == S3R_OP_LINEAR) {
         if (d->in_halo || d->out_halo) return fail(S3R_ERR_INVALID, "linear layers take no halo");
         g->nd = 0; g->in = g->out = g->in_p = g->out_p = 1; g->in_sp = 1; g->out_sp = 1;
@@ -141,14 +141,16 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
     g->out_sp = ipow(g->out, g->nd);
     g->x_elems = (int64_t)d->batch * d->cin * ipow(g->in_p, g->nd);
     g->y_elems = (int64_t)d->batch * d->cout * ipow(g->out_p, g->nd);
-    if (d->in_layout == S3R_LAYOUT_S2D) {        // (B, 2^nd, (n/2 + 2)^nd, C): what a stride-2 k3 p1 convolution reads
+    if (d->in_layout == S3R_LAYOUT_S2D) {        // what a stride-2 k3 p1 convolution reads
         if (d->op != S3R_OP_CONV || d->stride != 2 || d->k != 3 || d->pad != 1 || (g->in & 1) || d->in_halo != 1)
             return fail(S3R_ERR_INVALID, "a parity-split input serves Conv k=3 s=2 p=1 over an even edge, in_halo = 1");
-        g->x_elems = (int64_t)d->batch * d->cin * ipow(2, g->nd) * ipow(g->in / 2 + 2, g->nd);
+        // bf16: (B, 2^nd, (n/2 + 2)^nd, C); fp32: the plain padded tensor with every row stored even columns first
+        if (d->dtype == S3R_BF16) g->x_elems = (int64_t)d->batch * d->cin * ipow(2, g->nd) * ipow(g->in / 2 + 2, g->nd);
     }
     if (d->out_layout == S3R_LAYOUT_S2D) {
         if ((g->out & 1) || d->out_halo != 1) return fail(S3R_ERR_INVALID, "a parity-split output needs an even edge and out_halo = 1");
-        g->y_elems = (int64_t)d->batch * d->cout * ipow(2, g->nd) * ipow(g->out / 2 + 2, g->nd);
+        if (d->dtype == S3R_BF16) g->y_elems = (int64_t)d->batch * d->cout * ipow(2, g->nd) * ipow(g->out / 2 + 2, g->nd);
+        else if (d->op != S3R_OP_CONV) return fail(S3R_ERR_INVALID, "fp32 path: a parity-split output is written by convolutions only");
     }
     g->w_elems = (int64_t)d->cin * d->cout * ipow(d->k, g->nd);
     if (d->op == S3R_OP_DECONV)
@@ -290,7 +292,7 @@ int resolve_launch_h(const s3r_conv_desc* d, s3r::ConvParamsH* p, LaunchH* L) {
     p->ksplit = L->ksplit;
     if (d->tile >= 0 && d->tile != 1 && d->tile != 2 && d->tile != 3 && d->tile != 19 && d->tile != 4 && d->tile != 5 && d->tile != 6 && d->tile != 9 &&
         d->tile != 10 && d->tile != 17 && d->tile != 18 && d->tile != 20 && d->tile != 21 && d->tile != 22 && d->tile != 23 &&
-        d->tile != 30 && d->tile != 31)
+        d->tile != 30 && d->tile != 31 && d->tile != 40)
         return fail(S3R_ERR_INVALID, "bf16 path: tile must be -1 (auto), 1, 2, 4 (x128 positions, per-tap gather), 3 (128 x 128 couts), 5, 6 "
                     "(x128 positions = 1, 2, plane-reuse gather) or 9, 10 (row-reuse gather); per-tap / plane + 16 = "
                     "32-channel K tiles");
@@ -333,6 +335,9 @@ s3r::ConvParams make_params(const s3r_conv_desc* d, const Geo& g) {
     p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
     p.dW = s3r::FastDiv((unsigned)p.Nw);
     p.ksplit = 1;
+    // W-parity-split rows (fp32 form of S3R_LAYOUT_S2D): same strides, columns rearranged inside every padded row
+    if (d->in_layout == S3R_LAYOUT_S2D) { p.x_wsplit = 1; p.x_wh = g.in_p / 2; }
+    if (d->out_layout == S3R_LAYOUT_S2D) { p.y_wsplit = 1; p.y_wh = g.out_p / 2; }
     return p;
 }
 
@@ -404,6 +409,37 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
         if (geometry(&t, &tg) != S3R_OK) continue;
         const s3r::ConvParamsH tp = make_params_h(&t, tg);
         if (!s3r::conv_bf16_s2d_ok(tp)) continue;
+        pr.out_layout = S3R_LAYOUT_S2D;
+        c.in_layout = S3R_LAYOUT_S2D;
+    }
+    // W-parity-split hand-off (fp32 path): a convolution whose consumer is a stride-2 k3 p1 convolution writes every padded
+    // row as its even columns followed by its odd ones; the consumer's taps then read consecutive dwords for consecutive
+    // output positions, like a stride-1 layer (16-byte LDS-DMA gathers where Nw % 4 == 0; whole lines instead of every
+    // other dword everywhere).  The K order is unchanged: results are bit-identical to the plain layout.  Decided from
+    // per-sample geometry only.
+    // MEASURED NO GAIN (r03, B = 32, three A/B pairs of bench.py on one device): alone, the consumers are 2-8 % faster
+    // (e3 0.149 -> 0.138 ms, e5 0.145 -> 0.133, v2 0.326 -> 0.310, v4 0.179 -> 0.176: tools/layer_bench.py --wsplit), but
+    // inside the forward they are not (e3 0.1353 -> 0.1358, e5 0.134 -> 0.141, v4 0.179 -> 0.183: their input is then
+    // served from the Infinity Cache and what bounds a 64 x 64-tile, K = 576 layer is its per-workgroup fixed cost, not
+    // the width of its gathers), while the producers' split stores cost e2 +0.012 and v1 +0.008 ms: 5.98 -> 6.01 ms per
+    // step.  So the hand-off is planned only on request (S3R_WSPLIT=1); the plain layout stays the default.
+    static const bool wsplit_off = !(getenv("S3R_WSPLIT") && atoi(getenv("S3R_WSPLIT")) != 0);
+    for (int i = 0; i + 1 < n && !wsplit_off; ++i) {
+        s3r_conv_desc& pr = pl->d[i];
+        s3r_conv_desc& c = pl->d[i + 1];
+        if (pr.dtype != S3R_F32 || c.dtype != S3R_F32 || pl->r[i] != R_MFMA || pl->r[i + 1] != R_MFMA) continue;
+        if (pr.op != S3R_OP_CONV || c.op != S3R_OP_CONV || pr.ndim != c.ndim || pr.cout != c.cin) continue;
+        if (c.stride != 2 || c.k != 3 || c.pad != 1 || (c.in_size & 1)) continue;
+        if (pr.stride <= 0 || pr.k <= 0 || out_size(&pr) != c.in_size) continue;
+        {   // the producer's split-K finish kernel writes the plain layout only
+            s3r_conv_desc t = pr;
+            t.in_halo = need_halo(&pr, R_MFMA); t.out_halo = 1;
+            Geo tg;
+            if (geometry(&t, &tg) != S3R_OK) continue;
+            s3r::ConvParams tp = make_params(&t, tg);
+            Launch tl;
+            if (resolve_launch(&t, &tp, &tl) != S3R_OK || tl.ksplit != 1) continue;
+        }
         pr.out_layout = S3R_LAYOUT_S2D;
         c.in_layout = S3R_LAYOUT_S2D;
     }
@@ -715,6 +751,8 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                                 (long long)need, (long long)(scratch ? scratch_elems : 0));
                 else p.ksplit = L.ksplit = 1;     // no scratch offered: run unsplit (same result up to rounding order)
             }
+            if (p.y_wsplit && L.ksplit > 1)
+                return fail(S3R_ERR_INVALID, "fp32 path: a parity-split output cannot be combined with split-K (ksplit=%d)", L.ksplit);
             ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
             e = s3r::launch_conv_mfma(p, L.cfg + 16 * L.vec, s);
             ps.launches = s3r::conv_last_launch_count();

@@ -163,10 +163,12 @@ __device__ __forceinline__ void store_ep(const EpRegs& e, float* ep, int tid, in
 }
 
 // acc: the wave's accumulators of ONE 64-cout block: [position tile][cout tile of MT].
-template <int SH, int TM, bool HEAD>
+// NOSIG: the caller guarantees p.act != sigmoid (the per-element test of the wave-uniform flag compiles to a branch per
+// value: 64 of them per unit)
+template <int SH, int TM, bool HEAD, bool NOSIG = false>
 __device__ __forceinline__ void epilogue_h(const ConvParamsH& p, typename Mf<SH>::acc_t (&acc)[32 * TM / Mf<SH>::MT][64 / Mf<SH>::MT],
                                            const int* yoff, const float* ep, char* stage, int wave, int li, int lk, int m0,
-                                           int n0, int cls, int kz, int bm) {
+                                           int n0, int cls, int kz, int bm, int ybase = 0) {
     constexpr int MT = Mf<SH>::MT;
     constexpr int NPT = 32 * TM / MT;             // position tiles per wave
     constexpr int PPU = 32 / MT;                  // position tiles per 32-row staging unit (1 or 2)
@@ -224,7 +226,7 @@ __device__ __forceinline__ void epilogue_h(const ConvParamsH& p, typename Mf<SH>
     }
     // ReLU / identity as ONE v_max against a wave-uniform floor; sigmoid (rare) behind a wave-uniform flag
     const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
-    const bool sig = p.act == ACT_SIGMOID;
+    const bool sig = !NOSIG && p.act == ACT_SIGMOID;
     if constexpr (HEAD) {
         int ye[NPT];
 #pragma unroll
@@ -298,7 +300,7 @@ __device__ __forceinline__ void epilogue_h(const ConvParamsH& p, typename Mf<SH>
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = i * 8 + srow;
-            const int ye = yoff[wave * 32 * TM + u * 32 + r];
+            const int ye = yoff[wave * 32 * TM + u * 32 + r] + ybase;     // (ybase: a persistent kernel's per-step offset)
             const int co = n0 + 8 * spiece;
             const uint4 pk = *reinterpret_cast<const uint4*>(stage + r * ST_ROW + spiece * 16);
             if (ye < 0 || co >= p.Cout) continue;
@@ -1048,6 +1050,147 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-persistent variant for the shallow front layer (e2: Conv2d 32 -> 64, k3 s1 p1 over 112 x 112; K = 288).  In the
+// plane kernel above such a layer is all fixed cost: 11.6 us of tables, first image, epilogue and store tail per
+// workgroup around 1.2 us of MFMAs, its input fetched 1.9 times over (every tile reloads its halo rows), its output
+// stored in 32-position pieces (tools/timeline_bf16.py).  Here a workgroup of SEVEN waves owns a strip
+// of output rows of one image and slides down it FOUR output rows (448 positions = 7 waves x 2 tiles of 32) per step:
+//   * the layer's weights (9 taps x 4 KiB per 64 couts) are fetched ONCE per workgroup and stay in LDS;
+//   * input rows live in a ring of ten 8-KiB slots (a padded row is 114 x 64 B; slot = padded row mod 10); a step
+//     reads six of them and, at its start, requests the four NEW rows of the next step — one contiguous 29 KB run of the
+//     channels-last input, each row as eight whole 1-KiB LDS-DMA pieces — so every input row crosses HBM -> LDS once;
+//   * ONE workgroup barrier per step (rows landed for everyone / everyone done with the rows about to be replaced),
+//     none inside it: 72 MFMAs per wave straight through, operands from LDS only;
+//   * the position -> (row, column) tables are computed once per workgroup: a step moves two scalar offsets;
+//   * the four output rows of a step are 448 x 128 B = 56 KB contiguous in the channels-last output.
+// The K order (tap-major, two 16-channel k-steps per tap) is the plane kernel's, so the two produce the same bits and
+// the library is free to pick by batch size (the rows kernel needs >= 256 strips to fill the chip).
+constexpr int RW_WAVES = 7;
+constexpr int RW_R = 4;                          // output rows per step
+constexpr int RW_NS = 10;                        // ring slots (input rows)
+constexpr int RW_SLOT = 128 * 64;                // bytes per slot: 128 positions x 32 channels (114 used)
+constexpr int RW_LDS = RW_NS * RW_SLOT + 9 * 4096 + RW_WAVES * 32 * ST_ROW + 448 * 4 + EP_BYTES;
+
+template <int SH>
+__global__ __launch_bounds__(64 * RW_WAVES) void conv_bf16w_kernel(const ConvParamsH p, int strips, int units) {
+    typedef Mf<SH> M;
+    constexpr int MT = M::MT;
+    constexpr int NPT = 64 / MT, NCT = 64 / MT, NKS = HKC / M::KS;
+    constexpr int W = 112, WP = 114;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;                                               // [RW_NS][128][64 B]
+    char* wts = smem + RW_NS * RW_SLOT;                              // [9 taps][64 rows][64 B] (pre-swizzled by the pack kernel)
+    char* stage = wts + 9 * 4096 + 0;                                // [RW_WAVES][32][ST_ROW]
+    int* yoff = reinterpret_cast<int*>(stage + RW_WAVES * 32 * ST_ROW);   // [448] output element offset inside a step
+    float* ep = reinterpret_cast<float*>(yoff + 448);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane % MT, lk = lane / MT;
+    const int n_tile = blockIdx.y, n0 = n_tile * HBN;
+
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.w), 0, (int)(9u * (unsigned)p.n_tiles * 4096u), 0x00020000);
+
+    // ---- once per workgroup: the weights, the per-cout constants, the position tables
+    for (int pc = wave; pc < 36; pc += RW_WAVES) {                   // 36 pieces of 1 KiB: tap = pc >> 2
+        const int tap = pc >> 2;
+        dma16(wrsrc, wts + pc * 1024, lane * 16, ((tap * p.n_tiles + n_tile) * 4 + (pc & 3)) * 1024);
+    }
+    const EpRegs epr = load_ep(p, tid, n0);
+    for (int t = tid; t < RW_R * W; t += 64 * RW_WAVES) {
+        const int dr = t / W, c = t - dr * W;
+        yoff[t] = dr * p.y_hs + c * p.y_ws;
+    }
+    store_ep(epr, ep, tid);                                          // (__syncthreads inside: also publishes yoff)
+
+    // per lane: the two position tiles' (row in step, column), and per tw the byte offset inside a slot
+    int dr[NPT], colpart[NPT][3];
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) {
+        const int n = wave * 64 + pt * MT + li;
+        dr[pt] = n / W;
+        const int c = n - dr[pt] * W;
+#pragma unroll
+        for (int tw = 0; tw < 3; ++tw) colpart[pt][tw] = (c + tw) * 64 + ((lk ^ swz<32>(c + tw)) << 4);
+    }
+    int b_off[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int row = ct * MT + li;
+        b_off[ct] = row * 64 + ((lk ^ swz<32>(row)) << 4);
+    }
+    // DMA source offset of this lane inside a 16-position piece: position l >> 2, channel group (l & 3) ^ swz(position).
+    // A slot starts at a multiple of 128 LDS rows and a piece at a multiple of 16, so the swizzle of an LDS row depends
+    // on the lane only: ONE loop-invariant offset, the piece's 1 KiB goes into the scalar offset.
+    const int pvoff = (lane >> 2) * 64 + (((lane & 3) ^ swz<32>(lane >> 2)) << 4);
+    // rows [r0, r0 + nr) of the padded image at byte offset `img` -> their ring slots; 8 pieces per row
+    auto issue_rows = [&](int img, int r0, int nr) {
+        for (int pc = wave; pc < nr * 8; pc += RW_WAVES) {
+            const int rr = pc >> 3, i = pc & 7;
+            const int prow = r0 + rr;
+            const int slot = prow % RW_NS;
+            dma16(xrsrc, ring + slot * RW_SLOT + i * 1024, pvoff, img + prow * (WP * 64) + i * 1024);
+        }
+    };
+
+    const int rows_per_strip = W / strips;                           // (launcher: a multiple of RW_R)
+    const int steps = rows_per_strip / RW_R;
+    for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
+        const int b = unit / strips, st = unit - b * strips;
+        const int img = (b * p.x_bs) * 2;                            // byte offset of the padded image (x_org = 0: halo 1, pad 1)
+        const int row0 = st * rows_per_strip;                        // first output row = first padded input row of the strip
+        __syncthreads();                                             // every wave is done with the previous unit's rows
+        issue_rows(img, row0, RW_R + 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int s = 0; s < steps; ++s) {
+            const int p0 = row0 + s * RW_R;                          // padded input row of tap row 0 of the step's first output row
+            __builtin_amdgcn_s_barrier();                            // this step's rows have landed for every wave; the rows of
+            asm volatile("" ::: "memory");                           // step s - 1 that the next request replaces are free
+            if (s + 1 < steps) issue_rows(img, p0 + RW_R + 2, RW_R);
+            int slotoff[NPT][3];
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+                for (int th = 0; th < 3; ++th) slotoff[pt][th] = ((p0 + dr[pt] + th) % RW_NS) * RW_SLOT;
+            typename M::acc_t acc[NPT][NCT];
+#pragma unroll
+            for (int a = 0; a < NPT; ++a)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                    for (int r = 0; r < M::NACC; ++r) acc[a][c][r] = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int th = tap / 3, tw = tap - th * 3;
+                const char* b = wts + tap * 4096;
+#pragma unroll
+                for (int q = 0; q < NKS; ++q) {
+                    bf16x8 av[NPT], bv[NCT];
+#pragma unroll
+                    for (int pt = 0; pt < NPT; ++pt)
+                        av[pt] = *reinterpret_cast<const bf16x8*>(ring + ((slotoff[pt][th] + colpart[pt][tw]) ^ (q * M::NK * 16)));
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) bv[ct] = *reinterpret_cast<const bf16x8*>(b + (b_off[ct] ^ (q * M::NK * 16)));
+#pragma unroll
+                    for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) acc[pt][ct] = mma<SH>(bv[ct], av[pt], acc[pt][ct]);
+                }
+            }
+            const int ybase = b * p.y_bs + p.y_org + (row0 + s * RW_R) * p.y_hs;
+            epilogue_h<SH, 2, false, true>(p, acc, yoff, ep, stage + wave * (32 * ST_ROW), wave, li, lk, 0, n0, 0, 0, 0, ybase);
+            // the rows of step s + 1 were requested BEFORE this step's 8 stores: they have landed once at most those 8
+            // are outstanding (vmcnt retires in issue order, loads and stores alike)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+    }
+}
+
 // split-K finish: y[pos][cout] = bf16(act(scale * sum_kz slab + shift)); one thread per (position, cout pair)
 __global__ __launch_bounds__(256) void conv_finish_bf16_kernel(const ConvParamsH p, int mpad) {
     const int S = p.Nd * p.Nh * p.Nw;
@@ -1086,6 +1229,7 @@ __global__ __launch_bounds__(256) void conv_finish_bf16_kernel(const ConvParamsH
 
 static int rowreuse_rows(const ConvParamsH& p, int bm);
 static int plane_rows(const ConvParamsH& p, int bm, int kc);
+static int rows_strips(const ConvParamsH& p);
 
 // Tile / gather choice (tools/layer_bench.py --dtype bf16, B = 256, MI355X):
 //   * stride-1 layers with 4+ taps per plane and K >= 256 whose 256-position plane image leaves room for THREE
@@ -1112,6 +1256,7 @@ int conv_bf16_pick_tm(const ConvParamsH& p) {
                               (long)p.Cin * p.T >= 256;      // (e2, K = 288: -12 % once its planes tile exactly)
     // (transposed classes have only 4 taps per image: its 256 x 128-cout form, code 23, amortises the image over twice
     //  the couts — d1 -10 %, d2 -6 %; the 9-tap layers are level or slower with it)
+    if (plane_family && rows_strips(p)) return 40;           // (same K order as the plane kernel: a per-batch choice)
     if (plane_family && wgs(2) >= 512) return (p.transposed && n_tiles % 2 == 0 && wgs(2) / 2 >= 512) ? 23 : 22;
     // row-reuse (32-channel K order, like the plane kernel): small batches of deep plane-family layers (v5 at B = 32)
     const bool deep = !p.transposed && p.kw >= 3 && (long)p.Cin * p.T >= 64 * 27;
@@ -1280,6 +1425,41 @@ static hipError_t launch_tm(ConvParamsH p, bool kc32, hipStream_t stream) {
     return e;
 }
 
+// can the row-persistent kernel serve this layer, and in how many row strips per image?  (0 = no.)  Geometry: e2's.  The
+// kernel is bit-identical to the plane family, so — unlike the choice of family — this may depend on the batch: it needs
+// >= 512 strips of >= 28 rows to fill 256 CUs with two work units each.
+static int rows_strips(const ConvParamsH& p) {
+    static const bool off = getenv("S3R_ROWS") && atoi(getenv("S3R_ROWS")) == 0;                   // A/B switch
+    if (off || p.transposed || p.stride != 1 || p.kd != 1 || p.kh != 3 || p.kw != 3 || p.Cin != 32 || p.Nd != 1 ||
+        p.Nh != 112 || p.Nw != 112 || p.x_ws != 32 || p.x_hs != 114 * 32 || p.x_org != 0 || p.ksplit != 1 || p.head_w ||
+        p.y_s2d || p.s2d || (p.Cout & 7) != 0 || p.act == ACT_SIGMOID)
+        return 0;
+    for (int strips = 1; strips <= 4; strips *= 2)
+        if ((long)p.B * strips >= 512) return strips;
+    return 0;
+}
+
+template <int SH>
+static hipError_t launch_rows(ConvParamsH p, hipStream_t stream) {
+    const int strips = rows_strips(p);
+    if (!strips) return hipErrorInvalidValue;
+    p.n_tiles = p.CoutPad / HBN;
+    p.m_tiles = 0;
+    static LdsAttr lds_attr;
+    const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_bf16w_kernel<SH>), RW_LDS);
+    if (attr != hipSuccess) return attr;
+    static int cus[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    if (!cus[dev] && (hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus[dev] < 1))
+        cus[dev] = 256;
+    const int units = p.B * strips;
+    const int per_tile = cus[dev] / p.n_tiles > 0 ? cus[dev] / p.n_tiles : 1;       // one workgroup per CU in all
+    dim3 grid(units < per_tile ? units : per_tile, p.n_tiles, 1);
+    hipLaunchKernelGGL((conv_bf16w_kernel<SH>), grid, dim3(64 * RW_WAVES), RW_LDS, stream, p, strips, units);
+    return hipGetLastError();
+}
+
 template <int SH>
 static hipError_t launch_shape(const ConvParamsH& p, int tm, hipStream_t stream) {
     // tm = 1, 2, 4: per-tap gather (conv_bf16_kernel; + 16: 32-channel K tiles even where 64 are possible);
@@ -1298,6 +1478,7 @@ static hipError_t launch_shape(const ConvParamsH& p, int tm, hipStream_t stream)
         case 31: return launch_tm_plane<SH, 2, 32, 2, true>(p, stream);      // ... 256 positions x 128 couts
         case 9: return launch_tm_rowreuse<SH, 1>(p, stream);
         case 10: return launch_tm_rowreuse<SH, 2>(p, stream);
+        case 40: return launch_rows<SH>(p, stream);                          // row-persistent (e2 at large batches)
         default: return hipErrorInvalidValue;
     }
 }

@@ -89,6 +89,13 @@ struct ConvParams {
     const float* head_scale;   // [1] or null
     const float* head_shift;   // [1] or null
     int head_act;
+    // W-parity-split rows (include/s3r.h, S3R_LAYOUT_S2D on the fp32 path): every padded row of Wp elements is stored as
+    // its Wp/2 even columns followed by its Wp/2 odd columns.  x_wsplit: the input of a stride-2 k3 p1 layer is stored
+    // that way (tap tw of output column ow then reads element (tw & 1) * x_wh + (tw >> 1) + ow of the row: consecutive
+    // output positions are consecutive dwords, so the gather is as wide as a stride-1 layer's); y_wsplit: the output is
+    // written that way (out_halo = 1).
+    int x_wsplit, x_wh;
+    int y_wsplit, y_wh;
 };
 
 // Tap schedule of a stride-2 k3 p1 convolution over a PARITY-SPLIT input (include/s3r.h, S3R_LAYOUT_S2D), per 32-channel

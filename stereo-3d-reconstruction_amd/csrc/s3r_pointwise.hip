@@ -357,6 +357,39 @@ __global__ __launch_bounds__(256) void linear_naive_kernel(const float* __restri
     part[i] = s;
 }
 
+// The same for deep splits (ksplit % 4 == 0, >= 16): a workgroup owns 64 outputs and its four waves a quarter of the slabs
+// each (wave w: kz in [w q, (w+1) q), q = ksplit / 4, summed in kz order), combined as ((s0 + s1) + s2) + s3 through LDS —
+// a fixed order, and a quarter of the dependent L2 round trips per thread (p1: 64 slabs, 6.5 us with one thread per output).
+__global__ __launch_bounds__(256) void linear_finish4_kernel(const float* __restrict__ part, float* __restrict__ y,
+                                                             const float* __restrict__ scale, const float* __restrict__ bias,
+                                                             int Cout, long long total, int ksplit, int act) {
+    __shared__ float red[3][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + lane;
+    const int q = ksplit >> 2;
+    float s = 0.f;
+    if (i < total) {
+        const float* __restrict__ src = part + (size_t)w * q * total + i;
+        s = src[0];
+        int z = 1;
+        for (; z + 8 <= q; z += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(z + u) * total];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; z < q; ++z) s += src[(size_t)z * total];
+    }
+    if (w) red[w - 1][lane] = s;
+    __syncthreads();
+    if (w == 0 && i < total) {
+        s = ((s + red[0][lane]) + red[1][lane]) + red[2][lane];
+        const int o = (int)(i % Cout);
+        y[i] = apply_act(fmaf(s, scale ? scale[o] : 1.f, bias ? bias[o] : 0.f), act);
+    }
+}
+
 // one thread per output; the ksplit partial slabs are summed in kz order (a fixed order: deterministic) with eight loads
 // in flight per thread (a one-load-at-a-time loop is a chain of ksplit L2 round trips: 64 of them for p1)
 __global__ __launch_bounds__(256) void linear_finish_kernel(const float* __restrict__ part, float* __restrict__ y,
@@ -378,6 +411,108 @@ __global__ __launch_bounds__(256) void linear_finish_kernel(const float* __restr
     y[i] = apply_act(fmaf(s, scale ? scale[o] : 1.f, bias ? bias[o] : 0.f), act);
 }
 
+// Small-K layers (p2, p3: Cin = 1024) in ONE launch.  Their activations are tiny (131 KB), so a workgroup can afford to
+// own just 32 output rows (Cout / 32 workgroups: 32 for p2, 192 for p3) and split K over its FOUR WAVES instead of over
+// workgroups: wave w streams k in [w Cin/4, (w+1) Cin/4) — its own 32 x 128-byte weight lines and 32 x 128-byte
+// activation lines per block of 32 k, by LDS-DMA into a wave-private 3-slot ring behind a counted vmcnt (no barrier in
+// the loop: a wave reads only what it fetched itself) — and the four 32 x 32 partial tiles are added through LDS as
+// ((a0 + a1) + a2) + a3 with scale / bias / activation applied on the way out.  No slab round trip through HBM, no
+// finish launch, and a summation order that depends on nothing but Cin.  (Split over workgroups, p2 and p3 took
+// 6.4 + 4.5 and 10 + 4.6 us: launch-latency bound.)
+constexpr int WGK_W = 4;                       // waves along K
+constexpr int WGK_NS = 3;                      // ring slots per wave
+constexpr int WGK_SLOT = 64 * 128;             // 32 weight rows + 32 activation rows of 128 B
+
+__global__ __launch_bounds__(64 * WGK_W) void linear_wgk_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ scale, const float* __restrict__ bias,
+                                                                float* __restrict__ y, int B, int Cin, int Cout, int act) {
+    extern __shared__ __attribute__((aligned(16))) char wgk_smem[];       // [WGK_W][WGK_NS][64 rows][128 B]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int o0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int kq = Cin / WGK_W, kbeg = wave * kq, nblk = kq >> 5;
+    char* ring = wgk_smem + wave * (WGK_NS * WGK_SLOT);
+
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, (int)0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)0x7fffffff, 0x00020000);
+    // a piece = 8 rows x 128 B; lane l fills slot l & 7 of row l >> 3 with source chunk (l & 7) ^ ((row >> 1) & 7)
+    int wvoff[4], xvoff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = q * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        wvoff[q] = (int)(((long long)min(o0 + r, Cout - 1) * Cin + kbeg) * 4 + c * 16);
+        xvoff[q] = (int)(((long long)min(b0 + r, B - 1) * Cin + kbeg) * 4 + c * 16);
+    }
+    auto issue = [&](int blk) {
+        char* st = ring + (blk % WGK_NS) * WGK_SLOT;
+        const int so = blk * 128;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, S3R_LDS_PTR_PW(st + q * 1024), 16, wvoff[q], so, 0, 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, S3R_LDS_PTR_PW(st + 4096 + q * 1024), 16, xvoff[q], so, 0, 0);
+    };
+    f32x16_l acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int w_off = j * 128 + ((h ^ ((j >> 1) & 7)) << 4);
+    const int x_off = 4096 + w_off;
+    for (int s0 = 0; s0 < WGK_NS - 1; ++s0)
+        if (s0 < nblk) issue(s0);
+    for (int blk = 0; blk < nblk; ++blk) {
+        // slot (blk + 2) % 3 was read in iteration blk - 1 (its ds_reads retired before those MFMAs issued): refill it,
+        // then wait until only the DMAs of the blocks after `blk` are outstanding (8 per block)
+        if (blk + WGK_NS - 1 < nblk) issue(blk + WGK_NS - 1);
+        const int later = min(nblk - 1 - blk, WGK_NS - 1);
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const char* st = ring + (blk % WGK_NS) * WGK_SLOT;
+        v4f xv[4], wv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            xv[t] = *reinterpret_cast<const v4f*>(st + (x_off ^ (t << 5)));
+            wv[t] = *reinterpret_cast<const v4f*>(st + (w_off ^ (t << 5)));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[t][e], wv[t][e], acc, 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the reads above are done before this slot is refilled)
+    }
+    // ---- the four K quarters: ((a0 + a1) + a2) + a3 through LDS (each wave's ring is idle now; its first 4 KiB hold its tile)
+    float* mine = reinterpret_cast<float*>(ring);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[r * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wave == 0) {
+        const int o = o0 + j;
+        const float sc = (scale && o < Cout) ? scale[o] : 1.f, bi = (bias && o < Cout) ? bias[o] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float sum = acc[r];
+#pragma unroll
+            for (int q = 1; q < WGK_W; ++q)
+                sum += reinterpret_cast<const float*>(wgk_smem + q * (WGK_NS * WGK_SLOT))[r * 64 + lane];
+            const int b = b0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (b < B && o < Cout) y[(size_t)b * Cout + o] = apply_act(fmaf(sum, sc, bi), act);
+        }
+    }
+}
+
+// which layers the one-launch form serves: K small enough that a wave's quarter is a handful of blocks, tensors within
+// 32-bit byte offsets
+static bool linear_wgk_ok(int B, int Cin, int Cout) {
+    static const bool off = getenv("S3R_LINEAR_WGK") && atoi(getenv("S3R_LINEAR_WGK")) == 0;      // A/B switch
+    // (>= 128 workgroups: p3's 192 take 14.5 us against 17.7 split over workgroups + finish; p2's 32 would take 12.6
+    //  against 11.5 — too few waves in flight for a latency-bound stream of 4 MB: tools/point_bench.py, cold caches)
+    return !off && Cin % (32 * WGK_W) == 0 && Cin <= 4096 && (long long)Cin * Cout * 4 < (1ll << 31) &&
+           (long long)B * Cin * 4 < (1ll << 31) && (long)((Cout + 31) / 32) * ((B + 31) / 32) >= 128;
+}
+
 // split of the K axis: about two workgroups per CU (512) so that every CU streams, K slices of whole 32-k blocks, >= 128
 static void linear_split(int B, int Cin, int Cout, int* ksplit, int* kper) {
     if (Cin % 32 != 0 || (long long)Cin * Cout * 4 >= (1ll << 31) || (long long)B * Cin * 4 >= (1ll << 31)) {
@@ -395,6 +530,7 @@ static bool linear_streams(int B, int Cin, int Cout) {
 }
 
 int64_t linear_scratch_elems(int B, int Cin, int Cout) {
+    if (linear_wgk_ok(B, Cin, Cout)) return 1;            // (no slabs; a non-empty scratch keeps the ABI's contract simple)
     int ks, kper;
     linear_split(B, Cin, Cout, &ks, &kper);
     return (int64_t)ks * B * Cout;
@@ -402,6 +538,15 @@ int64_t linear_scratch_elems(int B, int Cin, int Cout) {
 
 hipError_t launch_linear(const float* x, const float* w, const float* scale, const float* bias, float* y, int B,
                          int Cin, int Cout, int act, float* scratch, hipStream_t s) {
+    if (linear_wgk_ok(B, Cin, Cout)) {
+        const size_t lds = (size_t)WGK_W * WGK_NS * WGK_SLOT;
+        static LdsAttr attr;
+        hipError_t e = attr.ensure(reinterpret_cast<const void*>(&linear_wgk_kernel), (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(linear_wgk_kernel, dim3((Cout + 31) / 32, (B + 31) / 32), dim3(64 * WGK_W), lds, s, x, w, scale, bias,
+                           y, B, Cin, Cout, act);
+        return hipGetLastError();
+    }
     int ks, kper;
     linear_split(B, Cin, Cout, &ks, &kper);
     const long long total = (long long)B * Cout;
@@ -422,8 +567,12 @@ hipError_t launch_linear(const float* x, const float* w, const float* scale, con
         if (nt) hipLaunchKernelGGL(linear_stream_kernel<true>, grid, dim3(256), lds, s, x, w, scratch, B, Cin, Cout, kper, ks);
         else hipLaunchKernelGGL(linear_stream_kernel<false>, grid, dim3(256), lds, s, x, w, scratch, B, Cin, Cout, kper, ks);
     }
-    hipLaunchKernelGGL(linear_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, scratch, y, scale,
-                       bias, Cout, total, ks, act);
+    if (ks >= 16 && ks % 4 == 0)
+        hipLaunchKernelGGL(linear_finish4_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, scratch, y, scale, bias,
+                           Cout, total, ks, act);
+    else
+        hipLaunchKernelGGL(linear_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, scratch, y, scale,
+                           bias, Cout, total, ks, act);
     return hipGetLastError();
 }
 

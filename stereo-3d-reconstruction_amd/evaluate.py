@@ -19,27 +19,53 @@ THRESHOLDS = (0.2, 0.3, 0.4, 0.5)
 
 
 def _device_batches(tensors: Sequence[torch.Tensor], b0: int, e0: int, batch: int, device):
-    """[b0, e0) of a host-resident eval list as device batches.  The list is page-locked IN PLACE for the duration
-    (hipHostRegister: 3 ms for 150 MB, no copy), so every slice is DMA-able at PCIe rate (~50 GB/s here against 4.6 GB/s
-    from pageable memory) and the next batch crosses on a side stream while the current one runs
-    (graph.PrefetchingLoader).  A plain `.to(device)` per batch made this loop 10x slower than the forward."""
+    """[b0, e0) of a host-resident eval list as device batches.  Each batch's slices are page-locked IN PLACE
+    (hipHostRegister, no copy), so they are DMA-able at PCIe rate (~55 GB/s here against 4.6 GB/s from pageable memory)
+    and the next batch crosses on a side stream while the current one runs (graph.PrefetchingLoader).  A plain
+    `.to(device)` per batch made this loop 10x slower than the forward.  Page-locking costs ~0.04 ms per MB — 0.12 s for a
+    4 GB list of fp32 renders when done for the whole list before the first kernel starts (r02) — so it is done PER BATCH,
+    one registration per slice (a copy must lie inside ONE registration: tools/reg_debug.py), by the loader's look-ahead:
+    the pages of batch i+1 are locked while batch i-1 runs on the GPU."""
     from .graph import PrefetchingLoader
     if torch.device(device).type != "cuda" or any(t.is_cuda for t in tensors):
         for s in range(b0, e0, batch):
             yield tuple(t[s:min(e0, s + batch)].to(device) for t in tensors)
         return
-    rt, registered = torch.cuda.cudart(), []
+    rt = torch.cuda.cudart()
+    locked = []                                               # addresses registered so far
+    lockable = [bool(t.numel()) and t.is_contiguous() and not t.is_pinned() for t in tensors]
+
+    def host():
+        for s in range(b0, e0, batch):
+            e = min(e0, s + batch)
+            out = []
+            for i, t in enumerate(tensors):
+                sl = t[s:e]
+                if lockable[i] and sl.numel():
+                    if int(rt.cudaHostRegister(sl.data_ptr(), sl.numel() * sl.element_size(), 0)) == 0:
+                        locked.append(sl.data_ptr())
+                    else:                                     # not lockable: the loader stages this tensor through its ring
+                        lockable[i] = False
+                        _clear_hip_error()
+                out.append(sl)
+            yield tuple(out)
+
     try:
-        for t in tensors:
-            if t.numel() and t.is_contiguous() and not t.is_pinned():
-                if int(rt.cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)) == 0:
-                    registered.append(t)
-        host = (tuple(t[s:min(e0, s + batch)] for t in tensors) for s in range(b0, e0, batch))
-        yield from PrefetchingLoader(host, device)
+        yield from PrefetchingLoader(host(), device)
     finally:
         torch.cuda.synchronize(device)
-        for t in registered:
-            rt.cudaHostUnregister(t.data_ptr())
+        for ptr in locked:
+            rt.cudaHostUnregister(ptr)
+
+
+def _clear_hip_error():
+    """A failed hipHostRegister leaves its code in the runtime's sticky last-error slot, where the next unrelated torch
+    call would find (and raise) it: read it out."""
+    try:
+        import ctypes
+        ctypes.CDLL("libamdhip64.so").hipGetLastError()
+    except OSError:                                           # pragma: no cover
+        pass
 
 
 def synthetic_eval_set(n: int, seed: int = 0, render_dtype: str = "float32") -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:

@@ -269,7 +269,9 @@ class _HipChain(nn.Module):
             return torch.empty(shape, dtype=torch.float32, device=device)
         arr, n = self._layer_array(batch, device, upto, in_halo, in_layout, out_layout, 1 if out_layout else 0)
         shape = self._out_shape(batch, n)
-        if out_layout:                # (tests) parity-split output: (B, 2^nd, (m/2+2)^nd, C) bf16, zeroed (halo) here
+        if out_layout and self.precision != "bf16":   # (tests) fp32: the padded (B,C,m+2,..) tensor, rows W-parity-split
+            y = torch.zeros(shape[:2] + tuple(m + 2 for m in shape[2:]), dtype=torch.float32, device=device)
+        elif out_layout:              # (tests) parity-split output: (B, 2^nd, (m/2+2)^nd, C) bf16, zeroed (halo) here
             nd = len(shape) - 2
             y = torch.zeros((shape[0], 2 ** nd) + (shape[2] // 2 + 2,) * nd + (shape[1],), dtype=torch.bfloat16, device=device)
         elif self._out_is_bf16(n):    # physical channels-last (B,...,C) bf16; handed back as a logical (B,C,...) view

@@ -457,3 +457,38 @@ def test_chain_plans_the_parity_split_handoff(s3r, oracle, mfma_shape):
     ch.tile_override.pop("b")
     plain = ch._run(xin)                                      # default: plain layout, per-tap family
     assert rel_l2(plain.cpu(), want) < 4e-3 and not torch.equal(plain, got)
+
+
+def test_rows_kernel_equals_the_plane_kernel_bitwise(s3r, oracle, mfma_shape):
+    """e2 at large image counts runs the row-persistent kernel (tile code 40: seven waves slide down a strip of rows,
+    weights resident in LDS, input rows in a ten-slot ring).  Its K order is the plane kernel's, so the two must agree
+    BIT FOR BIT (which is what lets the library choose between them by batch size); 1, 2 and 4 strips per image."""
+    spec = s3r.arch_spec
+    L = spec.ENCODER[1]
+    ch = s3r.modules._HipChain([L], 112, precision="bf16")
+    s3r.seed_module(ch, 3)
+    ch.to(DEV)
+    g = torch.Generator().manual_seed(5)
+    for n_img in (128, 256, 512):                                   # 4, 2, 1 strips per image
+        x = torch.randn((n_img, 112, 112, 32), generator=g).to(torch.bfloat16).to(DEV)   # physical channels-last
+        x = x.permute(0, 3, 1, 2)                                                         # logical (N,32,112,112) view
+        ch.tile_override["e2"] = 22
+        want = ch._run(s3r.modules._check_input_cl(x, "x", (32, 112, 112)))
+        ch.tile_override["e2"] = 40
+        got = ch._run(s3r.modules._check_input_cl(x, "x", (32, 112, 112)))
+        assert torch.equal(got, want), n_img
+        del ch.tile_override["e2"]
+        assert torch.equal(ch._run(s3r.modules._check_input_cl(x, "x", (32, 112, 112))), want)   # the library's own pick
+    # against the oracle on a few images (bf16-rounded operands, fp32 accumulation, one bf16 rounding at the end)
+    blk = oracle._Block(L).eval()
+    sd = {k: (_bf(v) if k.endswith("conv.weight") else v) for k, v in ch.e2.state_dict().items()}
+    blk.load_state_dict(sd)
+    xs = x[:2].float().cpu()
+    with torch.no_grad():
+        ref = blk(xs)
+    ch.tile_override["e2"] = 40
+    got = ch._run(s3r.modules._check_input_cl(x, "x", (32, 112, 112)))[:2].float().cpu()
+    assert rel_l2(got, ref) < 6e-3
+    # a batch too small for it is refused under a forced code (the library then picks the plane kernel itself)
+    with pytest.raises(s3r.S3RError):
+        ch._run(s3r.modules._check_input_cl(x[:8], "x", (32, 112, 112)))

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--shapes", default="", help="bf16: MFMA shapes to A/B, e.g. 32,16 (S3R_BF16_MFMA; weights are re-packed per shape)")
+    ap.add_argument("--wsplit", action="store_true", help="fp32 stride-2 k3 p1 layers: feed the halo-padded input with "
+                    "W-parity-split rows (S3R_LAYOUT_S2D), as the chain hands it over")
     ap.add_argument("--zeros", action="store_true", help="all-zero inputs and weights (how much of the rate is power: the\n"
                     "chip holds a higher clock on zeros, MI355X_MICROARCH.md DVFS notes)")
     args = ap.parse_args()
@@ -66,6 +68,11 @@ def main():
                     prm.zero_()
         if args.dtype == "bf16":
             x = x.to(torch.bfloat16).permute(0, *range(2, x.dim()), 1).contiguous()
+        run_kw = {}
+        if args.wsplit and args.dtype == "fp32" and l.s == 2 and l.k == 3 and l.p == 1:
+            xp = torch.nn.functional.pad(x, (1,) * (2 * spec.ndim(l)))
+            x = torch.cat([xp[..., 0::2], xp[..., 1::2]], -1).contiguous()
+            run_kw = dict(in_halo=1, in_layout=1)
         flops = 2.0 * spec.layer_macs(l, n_in) * B
         res = {}
         clk = {}
@@ -85,7 +92,7 @@ def main():
                     ch.ksplit_override[l.name] = ks
                     s3r.profile_enable(8)
                     try:
-                        y = ch._run(x)
+                        y = ch._run(x, None, **run_kw)
                     except s3r.S3RError:
                         s3r.profile_enable(0)
                         continue
