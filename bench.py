@@ -179,6 +179,14 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False)
     c = fam.get("conv_mfma")
     if not c or c["ms"] <= 0:
         return None, kernels
+    # the family's kernel time step by step (records arrive in launch order, the same number per step): what the
+    # average launch duration below averages over
+    conv = [r["ms"] for r in records if r["family"] == "conv_mfma"]
+    per = len(conv) // steps if steps else 0
+    step_sums = [sum(conv[i * per:(i + 1) * per]) for i in range(steps)] if per and per * steps == len(conv) else []
+    if step_sums and not quiet:
+        log("conv_mfma kernel ms per eager step, in order: " + " ".join(f"{v:.3f}" for v in step_sums))
+    step_sums.sort()
     achieved = c["flops"] / c["ms"] / 1e9            # TFLOP/s
     # §8d's formulas count the taps that multiply padding zeros; without them (arch_spec.layer_macs_interior)
     ratio = spec.mfma_flops_per_pair(variant, interior=True) / spec.mfma_flops_per_pair(variant)
@@ -197,17 +205,28 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False)
             "algorithmic_gflop_per_launch": round(c["flops"] / c["launches"] / 1e9, 3),
             "avg_launch_ms": round(c["ms"] / c["launches"], 5),
             "algorithmic_gflop_per_step": round(c["flops"] / steps / 1e9, 3),
-            "kernel_ms_per_step": round(c["ms"] / steps, 4)}
+            "kernel_ms_per_step": round(c["ms"] / steps, 4),
+            "kernel_ms_per_step_spread": ({"min": round(step_sums[0], 4), "median": round(step_sums[len(step_sums) // 2], 4),
+                                           "max": round(step_sums[-1], 4)} if step_sums else None)}
     return roof, kernels
 
 
 def eager_records(s3r, torch, model, left, right, gt_cloud, steps):
-    """Per-kernel HIP events cannot bracket kernels inside a graph replay: run the same K steps eagerly (untimed)."""
-    s3r.profile_enable(64 * steps + 64)
-    for _ in range(steps):
+    """Per-kernel HIP events cannot bracket kernels inside a graph replay: run the same K steps eagerly (untimed).
+    The chip needs a few steps of uninterrupted work to settle after the host-side pause that precedes this pass (the
+    first three or four eager steps' kernels ran 2-14 % longer than the rest: clocks ramping back up), so six steps go
+    first and the recording starts behind them WITHOUT draining the queue — what is averaged is the steady state the
+    timed region runs in."""
+    def one():
         yy = model(left, right)
         if gt_cloud is not None:
             s3r.chamfer_distance(yy, gt_cloud)
+    s3r.profile_enable(64 * steps + 64)
+    for _ in range(6):
+        one()
+    s3r.profile_reset()                              # (host-side only: the queue stays full)
+    for _ in range(steps):
+        one()
     torch.cuda.synchronize()
     records = s3r.profile_read(64 * steps + 64)
     s3r.profile_enable(0)
