@@ -99,8 +99,12 @@ constexpr int min_waves(int tm, int tn) { return tm * tn >= 8 ? 2 : (tm * tn >= 
 // workgroups per CU cover each other's waits); 6 = five tiles in flight, for launches that leave a CU with one small
 // workgroup or none (the remainder of a cut launch, tiny batches): alone, a workgroup pays the whole DMA round trip per
 // K tile with two stages (0.5 us against 0.2 us of MFMAs on the 64 x 64 tile).  The K order is the same either way.
-template <int WM, int WN, int TM, int TN, int VEC, bool HEAD = false, int NBUF = 2>
-__global__ __launch_bounds__(256, min_waves(TM, TN) - (HEAD ? 1 : 0)) void conv_glds_kernel(const ConvParams p) {
+// The kernel's body as a device function of (workgroup id, workgroup count, position range): conv_glds_kernel below runs
+// it over its whole grid; conv_glds_dual_kernel runs TWO tile shapes in one launch (a layer's bulk and its re-tiled
+// remainder).
+template <int WM, int WN, int TM, int TN, int VEC, bool HEAD, int NBUF>
+__device__ __forceinline__ void conv_glds_body(const ConvParams& p, const int bid_in, const int nwg_in, const int n_begin,
+                                               const int n_end, const int kz, float* smem) {
     constexpr int BM = 32 * WM * TM;
     constexpr int BN = 32 * WN * TN;
     constexpr int BK = GBK;
@@ -121,7 +125,6 @@ __global__ __launch_bounds__(256, min_waves(TM, TN) - (HEAD ? 1 : 0)) void conv_
     static_assert(BM <= 256 && 256 % BM == 0, "BM");
     constexpr int LPR_A = BM / 4;
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                     // [NBUF][BK][BM]
     float* Bs = smem + NBUF * BK * BM;    // [NBUF][BK][BN]
     static_assert(NBUF == 2 || NPIECE_A % 4 == 0, "a deeper ring counts DMAs per wave: every wave must issue as many");
@@ -141,27 +144,27 @@ __global__ __launch_bounds__(256, min_waves(TM, TN) - (HEAD ? 1 : 0)) void conv_
     // contiguous run of tiles so neighbouring N tiles find their shared input rows in that XCD's L2.
     // Transposed convolutions: the grid is 8 x as long and an XCD walks its tiles with the 8 output-parity classes of a
     // tile back to back (they gather from the same input tile: L2 hits instead of eight passes over the input).
-    int bid = blockIdx.x, cls = 0;                    // cls: output parity class (transposed only)
+    int bid = bid_in, cls = 0;                        // cls: output parity class (transposed only)
     if (p.transposed) {
-        const int nwg = gridDim.x >> 3;
+        const int nwg = nwg_in >> 3;
         const int item = (bid & 7) * nwg + (bid >> 3);
         bid = item >> 3;
         cls = item & 7;
     } else {
-        const int nwg = gridDim.x;
+        const int nwg = nwg_in;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    const int m_tile = bid % p.m_tiles;
-    const int n_tile = bid / p.m_tiles;
-    const int m0 = m_tile * BM, n0 = p.n_begin + n_tile * BN;
+    const int m_tiles = (p.Cout + BM - 1) / BM;       // (of THIS tile shape: a dual launch runs two)
+    const int m_tile = bid % m_tiles;
+    const int n_tile = bid / m_tiles;
+    const int m0 = m_tile * BM, n0 = n_begin + n_tile * BN;
     const int rd = (cls >> 2) & 1, rh = (cls >> 1) & 1, rw = cls & 1;
 
     const int S = p.Nd * p.Nh * p.Nw;
     const int T = p.T;
     // split-K: blockIdx.z owns a contiguous range of 16-channel chunks (all taps of each)
     const int chunks = (p.Cin / BK) / p.ksplit;
-    const int kz = blockIdx.z;
     const int nkt = S3R_ABL(p, 2) ? 1 : T * chunks;
 
     // ---- per-lane loop-invariant DMA offsets (bytes)
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256, min_waves(TM, TN) - (HEAD ? 1 : 0)) void conv_
         if (B_WIDE) { col = (wave % PPR) * PB + lane * VEC; lrow = 0; }
         else        { col = (lane % LPR_B) * VEC;           lrow = lane / LPR_B; }
         int n = n0 + col;
-        if (n >= p.n_end) n = p.n_end - VEC;            // tail tile: fetch a valid group, never stored
+        if (n >= n_end) n = n_end - VEC;                // tail tile: fetch a valid group, never stored
         const int b = p.dS.div(n);
         int rem = n - b * S;
         const int pd = p.dHW.div(rem);
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(256, min_waves(TM, TN) - (HEAD ? 1 : 0)) void conv_
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int n = nl + tn;
-        yok[tn] = n < p.n_end;
+        yok[tn] = n < n_end;
         const int nn = yok[tn] ? n : 0;
         const int b = p.dS.div(nn);
         int rem = nn - b * S;
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(256, min_waves(TM, TN) - (HEAD ? 1 : 0)) void conv_
     // 2m + 1 the two neighbouring EVEN ones: one 8-byte store per lane and row, as in the plain layout (two dword stores
     // per row made the producers e2 / e4 / v1 slower than the stride-2 consumers gained: 5.97 -> 5.99 ms per step).
     // Needs whole groups of 4 columns per row and per launch range (wave-uniform).
-    const bool lane_swap = TN == 2 && vec_ok && p.y_wsplit && (p.Nw & 3) == 0 && ((p.n_end | p.n_begin) & 3) == 0;
+    const bool lane_swap = TN == 2 && vec_ok && p.y_wsplit && (p.Nw & 3) == 0 && ((n_end | n_begin) & 3) == 0;
     const int mbase = wm * TM * 32 + 4 * h * TM;
     const int mlimit = p.Cout - (m0 + mbase);                  // rows dm >= mlimit are padding
     // buffer stores: per-lane 32-bit byte offset in a VGPR (computed once), the row's cout offset in the SGPR
@@ -503,6 +506,28 @@ __global__ __launch_bounds__(256, min_waves(TM, TN) - (HEAD ? 1 : 0)) void conv_
             }
     };
     if (p.act == ACT_SIGMOID) rows(std::true_type{}); else rows(std::false_type{});
+}
+
+template <int WM, int WN, int TM, int TN, int VEC, bool HEAD = false, int NBUF = 2>
+__global__ __launch_bounds__(256, min_waves(TM, TN) - (HEAD ? 1 : 0)) void conv_glds_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    conv_glds_body<WM, WN, TM, TN, VEC, HEAD, NBUF>(p, blockIdx.x, gridDim.x, p.n_begin, p.n_end, blockIdx.z, smem);
+}
+
+// A layer's bulk and its remainder in ONE launch (see plan_tail_cut): workgroups [0, p.big_wgs) run the layer's own tile
+// over positions [n_begin, n_cut), the rest run the 64 x 64 tile over [n_cut, n_end).  As a launch of its own the remainder
+// — a few dozen small workgroups — had the chip to itself for 68 / 36 / 18 us after e7 / e6 / e4 at B = 32 (a workgroup
+// alone on a CU pays every DMA round trip in full); inside the bulk's launch its workgroups take the fourth slot of a
+// CU beside three bulk workgroups and their MFMAs fill the pipe time the others leave.  Same K order per output whatever
+// the tile, so nothing changes bitwise (tests/test_quantization_gpu.py).
+template <int WM, int WN, int TM, int TN, int VEC>
+__global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_dual_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < p.big_wgs)
+        conv_glds_body<WM, WN, TM, TN, VEC, false, 2>(p, blockIdx.x, p.big_wgs, p.n_begin, p.n_cut, 0, smem);
+    else
+        conv_glds_body<2, 2, 1, 1, VEC, false, 2>(p, (int)blockIdx.x - p.big_wgs, (int)gridDim.x - p.big_wgs, p.n_cut, p.n_end, 0,
+                                                  smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -680,6 +705,47 @@ static hipError_t launch_cfg(ConvParams p, hipStream_t stream) {
     }
 }
 
+template <int WM, int WN, int TM, int TN, int VEC>
+static hipError_t launch_dual_cfg(ConvParams p, int n_cut, hipStream_t stream) {
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    if constexpr (GBK * BN % (256 * VEC) != 0 || BN > 256 * VEC || GBK * 64 % (256 * VEC) != 0) {
+        return hipErrorInvalidValue;
+    } else {
+        p.n_cut = n_cut;
+        p.big_wgs = ((p.Cout + BM - 1) / BM) * ((n_cut - p.n_begin + BN - 1) / BN);
+        const int small = ((p.Cout + 63) / 64) * ((p.n_end - n_cut + 63) / 64);
+        p.m_tiles = 0; p.n_tiles = 0;                  // (unused: the body derives its own; no split-K here)
+        const size_t lds = (size_t)2 * GBK * (BM + BN) * sizeof(float);      // >= the 64 x 64 tile's
+        if (lds > 48 * 1024) {
+            static LdsAttr lds_attr;
+            const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_glds_dual_kernel<WM, WN, TM, TN, VEC>), (int)lds);
+            if (attr != hipSuccess) return attr;
+        }
+        hipLaunchKernelGGL((conv_glds_dual_kernel<WM, WN, TM, TN, VEC>), dim3(p.big_wgs + small), dim3(256), lds, stream, p);
+        return hipGetLastError();
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+static hipError_t launch_dual_vec(const ConvParams& p, int n_cut, int vec, hipStream_t stream) {
+    switch (vec) {
+        case 4: return launch_dual_cfg<WM, WN, TM, TN, 4>(p, n_cut, stream);
+        case 1: return launch_dual_cfg<WM, WN, TM, TN, 1>(p, n_cut, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// bulk tile `cfg` over [0, n_cut) + 64 x 64 tiles over the rest, one launch
+static hipError_t launch_dual(const ConvParams& p, int cfg, int n_cut, int vec, hipStream_t stream) {
+    switch (cfg) {
+        case 0: return launch_dual_vec<2, 2, 2, 2>(p, n_cut, vec, stream);
+        case 1: return launch_dual_vec<1, 4, 2, 2>(p, n_cut, vec, stream);
+        case 4: return launch_dual_vec<2, 2, 2, 4>(p, n_cut, vec, stream);
+        case 7: return launch_dual_vec<1, 4, 2, 1>(p, n_cut, vec, stream);
+        default: return hipErrorNotSupported;          // (the caller then issues the two launches)
+    }
+}
+
 // the 64 x 64 tile on a launch that leaves CUs with one workgroup or none: six LDS stages (see the kernel's NBUF note)
 static bool sparse_launch(const ConvParams& p, int bm, int bn) {
     static const bool off = getenv("S3R_DEEP_RING") && atoi(getenv("S3R_DEEP_RING")) == 0;      // A/B switch
@@ -737,10 +803,11 @@ static hipError_t launch_tile(const ConvParams& p, int cfg, int vec, hipStream_t
 // Workgroup-count quantisation.  The four waves of a workgroup sit on the four SIMDs of a CU, so a CU that
 // hosts n workgroups takes n workgroup-times: a launch of W equal workgroups costs ceil(W / 256) of them
 // (measured: tools/quant_exp.py — e7 with 128x128 tiles runs 135 TFLOP/s at W = 1018 and 104 at W = 1030).
-// When W is a little over a multiple of 256 the launch is cut in two along the position axis: the bulk —
+// When W is a little over a multiple of 256 the layer is cut in two along the position axis: the bulk —
 // a whole number of 256-workgroup rounds — keeps its tile, and the remainder is re-tiled 64 x 64 so that it
 // spreads over all CUs in a fraction of a round.  Any tile shape produces the same bits (the K order is
-// fixed), so the cut never changes a result.
+// fixed), so the cut never changes a result.  Both parts go out as ONE launch where the dual kernel is built for the
+// bulk's tile (conv_glds_dual_kernel), as two otherwise.
 static bool plan_tail_cut(const ConvParams& p, int cfg, int* n_cut) {
     if (p.ksplit != 1 || p.Cout <= 32 || cfg == 3) return false;
     const int classes = p.transposed ? 8 : 1;
@@ -788,6 +855,13 @@ hipError_t launch_conv_mfma(const ConvParams& pin, int code, hipStream_t stream)
     int n_cut = 0;
     static const bool no_cut = getenv("S3R_NO_TAIL_CUT") != nullptr;      // tuning / A-B switch
     if (!p.head_w && !no_cut && plan_tail_cut(p, cfg, &n_cut)) {
+        static const bool no_dual = getenv("S3R_NO_DUAL") != nullptr;         // A/B switch: bulk and remainder as two launches
+        if (!no_dual && !p.transposed && p.Cout > 32) {
+            g_launch_count += 1;
+            const hipError_t ed = launch_dual(p, cfg, n_cut, vec, stream);
+            if (ed != hipErrorNotSupported) return ed;
+            g_launch_count -= 1;
+        }
         p.n_end = n_cut;
         hipError_t e = launch_tile(p, cfg, vec, stream);
         if (e != hipSuccess) return e;

@@ -80,6 +80,8 @@ struct ConvParams {
     int Ntotal;           // B*Nd*Nh*Nw
     int n_begin, n_end;   // position range [n_begin, n_end) this launch covers (a layer may be cut in two launches)
     int n_tiles, m_tiles;
+    int n_cut, big_wgs;   // dual launch (bulk + re-tiled remainder in one grid): positions [n_begin, n_cut) by workgroups
+                          // [0, big_wgs) with the layer's tile, [n_cut, n_end) by the rest with 64 x 64 tiles
     int ksplit;           // split-K factor (divides Cin/16); > 1: partial slabs to `part`, then conv_finish
     float* part;          // split-K scratch: [cls][ksplit][Cout][n_tiles*BN]
     int debug;            // diagnostic builds (-DS3R_ABLATE) only

@@ -14,28 +14,36 @@ _CHILD = r"""
 import sys, torch
 sys.path.insert(0, %r)
 import s3r
-L = s3r.arch_spec.Layer("t", "conv2d", 64, 128, 3, 1, 1)
-ch = s3r.modules._HipChain([L], 28)
-s3r.seed_module(ch, 3)
-ch.to("cuda:0")
-ch.tile_override["t"] = 0                      # 128x128 tiles: B*784/128 workgroups
 outs = []
-for B in (42, 43, 50):                          # 258, 264, 307 workgroups: just over one 256-workgroup round
-    x = torch.randn(B, 64, 28, 28, generator=torch.Generator().manual_seed(B)).cuda()
-    outs.append(ch._run(x).cpu())
+# every tile shape the dual launch is built for (0, 1, 4, 7), 16-byte gathers (28-wide rows) and dword gathers (14-wide
+# rows, 3D), workgroup counts just over one or two 256-workgroup rounds
+for op, n, tile, batches in (("conv2d", 28, 0, (42, 43, 50)), ("conv2d", 28, 1, (42, 85)), ("conv2d", 28, 4, (84, 90)),
+                             ("conv2d", 28, 7, (22, 43)), ("conv3d", 14, 0, (12, 13)), ("conv3d", 14, 7, (7, 13))):
+    L = s3r.arch_spec.Layer("t", op, 64, 128, 3, 1, 1)
+    ch = s3r.modules._HipChain([L], n)
+    s3r.seed_module(ch, 3)
+    ch.to("cuda:0")
+    ch.tile_override["t"] = tile
+    nd = s3r.arch_spec.ndim(L)
+    for B in batches:
+        x = torch.randn((B, 64) + (n,) * nd, generator=torch.Generator().manual_seed(B)).cuda()
+        outs.append(ch._run(x).cpu())
 torch.save(outs, sys.argv[1])
 """
 
 
 def test_tail_cut_is_bitwise_neutral(tmp_path):
+    """"cut": the default — bulk and re-tiled remainder in ONE launch (conv_glds_dual_kernel); "two": the same cut as two
+    launches (S3R_NO_DUAL); "nocut": one launch of the layer's own tile.  All three give the same bits."""
     res = {}
-    for tag, env in (("cut", {}), ("nocut", {"S3R_NO_TAIL_CUT": "1"})):
+    for tag, env in (("cut", {}), ("two", {"S3R_NO_DUAL": "1"}), ("nocut", {"S3R_NO_TAIL_CUT": "1"})):
         out = tmp_path / f"{tag}.pt"
         e = dict(os.environ, **env)
         subprocess.run([sys.executable, "-c", _CHILD % ROOT, str(out)], check=True, env=e)
         res[tag] = torch.load(out)
-    for a, b in zip(res["cut"], res["nocut"]):
-        assert torch.equal(a, b)
+    assert len(res["cut"]) == 13
+    for a, b, c in zip(res["cut"], res["two"], res["nocut"]):
+        assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, c)
 
 
 _RING_CHILD = r"""
