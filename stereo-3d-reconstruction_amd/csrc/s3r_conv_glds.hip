@@ -618,15 +618,15 @@ struct Tuned { int cin, cout, T, stride, S, transposed, tile, ksplit; };
 static const Tuned kTuned[] = {
     //  cin cout   T  s       S  tr  tile ks
     {32,  64,  9, 1, 12544, 0, 7, 1},   // e2  112^2   (r03 re-tune, three A/B pairs of bench.py: e2 1 -> 7, e4 2 -> 4, d1 2 -> 7: -0.5 % per step)
-    {64,  64,  9, 2,  3136, 0, 3, 1},   // e3  -> 56^2
+    {64,  64,  9, 2,  3136, 0, 1, 1},   // e3  -> 56^2  (with the remainder inside the bulk's launch, r03: e3 3 -> 1, v2 / v3 3 -> 7: -0.7 %)
     {64, 128,  9, 1,  3136, 0, 4, 1},   // e4
     {128, 128, 9, 2,   784, 0, 3, 1},   // e5  -> 28^2
     {128, 256, 9, 1,   784, 0, 1, 1},   // e6  (64x256 bulk + 64x64 remainder, see plan_tail_cut)
     {256, 256, 9, 1,   784, 0, 1, 1},   // e7
     {256, 32,  1, 1,   784, 0, 2, 1},   // e8
     {64,  64, 27, 1, 21952, 0, 1, 1},   // v1  28^3
-    {64, 128, 27, 2,  2744, 0, 3, 1},   // v2  -> 14^3
-    {128, 128, 27, 1, 2744, 0, 3, 1},   // v3
+    {64, 128, 27, 2,  2744, 0, 7, 1},   // v2  -> 14^3
+    {128, 128, 27, 1, 2744, 0, 7, 1},   // v3
     {128, 256, 27, 2,  343, 0, 3, 4},   // v4  -> 7^3
     {256, 256, 27, 1,  343, 0, 3, 4},   // v5
     {256, 512, 64, 1,   64, 0, 7, 8},   // v6  k4 valid -> 4^3
@@ -815,15 +815,22 @@ static bool plan_tail_cut(const ConvParams& p, int cfg, int* n_cut) {
     const long m_tiles = (p.Cout + bm - 1) / bm, n_tiles = (p.Ntotal + bn - 1) / bn;
     const long W = m_tiles * n_tiles * classes;
     const long rounds = W / 256, rem = W % 256;
-    if (rounds < 1 || rounds >= 16 || rem == 0) return false;
+    // where both parts share ONE launch (launch_dual) the remainder's small workgroups run beside the bulk's last round
+    // instead of after it: its cost is its share of a round, not a round of its own, and the cut pays for longer launches
+    static const int dual_model = getenv("S3R_DUAL_MODEL") ? atoi(getenv("S3R_DUAL_MODEL")) : 1;      // A/B switch
+    const bool dual = dual_model && !p.transposed && (cfg == 0 || cfg == 1 || cfg == 4 || cfg == 7) &&
+                      getenv("S3R_NO_DUAL") == nullptr;
+    if (rounds < 1 || rounds >= (dual ? 64 : 16) || rem == 0) return false;
     const long n_main = (rounds * 256) / (m_tiles * classes);          // whole N tiles in the bulk
     if (n_main < 1 || n_main >= n_tiles) return false;
     const long pos_tail = p.Ntotal - n_main * bn;
     const long W_tail = ((pos_tail + 63) / 64) * ((p.Cout + 63) / 64) * classes;
     const double before = (double)((W + 255) / 256);
     const double bulk = (double)((n_main * m_tiles * classes + 255) / 256);
-    const double after = bulk + (double)((W_tail + 255) / 256) * (64.0 * 64.0) / (double)(bm * bn) / 0.8;
-    if (after > 0.97 * before) return false;
+    const double small = (64.0 * 64.0) / (double)(bm * bn);
+    const double after = dual ? bulk + (double)W_tail / 256.0 * small / 0.85
+                              : bulk + (double)((W_tail + 255) / 256) * small / 0.8;
+    if (after > (dual ? 0.99 : 0.97) * before) return false;
     *n_cut = (int)(n_main * bn);
     return true;
 }
