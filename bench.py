@@ -194,7 +194,8 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False)
     roof = {"bound": "mfma",
             "kernel": "conv_bf16{,r,p}_kernel (bf16 MFMA implicit-GEMM conv, channels-last, LDS-DMA; "
                       "per-tap / row-reuse / plane-reuse gathers)" if bf
-            else "conv_glds_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv, LDS-DMA operand staging)",
+            else "conv_glds_kernel / conv_glds_dual_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv, LDS-DMA operand "
+                 "staging; dual = a layer's bulk and its re-tiled remainder in one launch)",
             "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
             "frac_border_excluded": round(achieved / peak * ratio, 4),

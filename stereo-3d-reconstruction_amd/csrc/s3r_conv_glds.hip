@@ -545,9 +545,32 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(const ConvParams p, in
         const int n = (int)(i - (long long)m * nq) * 4;
         if (n >= p.Ntotal) continue;
         const float* __restrict__ src = p.part + ((size_t)cls * p.ksplit * p.Cout + m) * npad + n;
-        v4f sum = *reinterpret_cast<const v4f*>(src);
-        for (int z = 1; z < p.ksplit; ++z) {
-            const v4f t = *reinterpret_cast<const v4f*>(src + (size_t)z * p.Cout * npad);
+        const size_t zs = (size_t)p.Cout * npad;
+        // (the slabs are added in kz order either way; four loads in flight instead of a chain of dependent round trips)
+        v4f sum;
+        int z;
+        if (p.ksplit >= 4) {
+            const v4f t0 = *reinterpret_cast<const v4f*>(src);
+            const v4f t1 = *reinterpret_cast<const v4f*>(src + zs);
+            const v4f t2 = *reinterpret_cast<const v4f*>(src + 2 * zs);
+            const v4f t3 = *reinterpret_cast<const v4f*>(src + 3 * zs);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum[k] = ((t0[k] + t1[k]) + t2[k]) + t3[k];
+            z = 4;
+        } else {
+            sum = *reinterpret_cast<const v4f*>(src);
+            z = 1;
+        }
+        for (; z + 4 <= p.ksplit; z += 4) {
+            const v4f t0 = *reinterpret_cast<const v4f*>(src + (size_t)z * zs);
+            const v4f t1 = *reinterpret_cast<const v4f*>(src + (size_t)(z + 1) * zs);
+            const v4f t2 = *reinterpret_cast<const v4f*>(src + (size_t)(z + 2) * zs);
+            const v4f t3 = *reinterpret_cast<const v4f*>(src + (size_t)(z + 3) * zs);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum[k] = (((sum[k] + t0[k]) + t1[k]) + t2[k]) + t3[k];
+        }
+        for (; z < p.ksplit; ++z) {
+            const v4f t = *reinterpret_cast<const v4f*>(src + (size_t)z * zs);
             sum[0] += t[0]; sum[1] += t[1]; sum[2] += t[2]; sum[3] += t[3];
         }
         const float sc = p.scale ? p.scale[m] : 1.f, sf = p.shift ? p.shift[m] : 0.f;

@@ -16,7 +16,7 @@ import sys
 from collections import defaultdict
 
 
-FAMILY = "conv_glds_kernel"     # third argument overrides it (bf16 path: "conv_bf16", matching all three kernels)
+FAMILY = "conv_glds"            # conv_glds_kernel + conv_glds_dual_kernel; third argument overrides it (bf16 path: "conv_bf16", all three kernels)
 
 
 def rows(path):
