@@ -373,6 +373,21 @@ def test_batch32_matches_per_sample_bitwise(s3r, models):
     assert torch.equal(again, full)            # deterministic (no atomics on the voxel path)
 
 
+@pytest.mark.parametrize("n", [2, 5, 11, 21, 33, 47, 64, 100])
+def test_results_do_not_depend_on_the_batch_size(s3r, models, n):
+    """The library changes tiles, cuts layers into a bulk and a re-tiled remainder (one launch or two) and re-plans both
+    with the workgroup count — i.e. with the batch — but never a layer's K order or split-K factor: the first and the last
+    sample are bitwise the same alone and inside any batch (workgroup counts just under / over whole 256-workgroup rounds
+    included: the batch sizes walk the remainder logic through cut / no-cut decisions on different layers)."""
+    hip, _ = models
+    left, right = s3r.synthetic_pairs(n, seed=23)
+    left, right = left.to(DEV), right.to(DEV)
+    got = hip(left, right).clone()
+    assert torch.equal(hip(left[:1], right[:1])[0], got[0])
+    assert torch.equal(hip(left[n - 1:], right[n - 1:])[0], got[n - 1])
+    assert torch.equal(hip(left, right), got)
+
+
 def test_batch32_sample_vs_oracle(s3r, models):
     hip, ref = models
     left, right = s3r.synthetic_pairs(32, seed=3)
