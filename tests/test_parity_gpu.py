@@ -755,6 +755,38 @@ def test_dataset_eval_matches_tensor_eval(s3r, models, tmp_path):
     assert a["per_taxonomy"]["02691156"]["mean_iou"] == pytest.approx(a["mean_iou"])
 
 
+def test_dataset_eval_vs_oracle_on_an_independent_decode(s3r, oracle, models, tmp_path):
+    """The same chain against the ORACLE, with the files decoded here and not by data.py: Pillow -> float RGBA composited
+    over white in float64, rounded to the 8-bit code, / 255; scipy.io for the volume; the oracle's CPU forward and a
+    plain-torch IoU.  (test_dataset_eval_matches_tensor_eval above is HIP against HIP.)"""
+    import os
+    import numpy as np
+    from PIL import Image
+    from scipy.io import loadmat
+    from tests.test_data_cpu import _make_tree
+    hip, ref = models
+    _make_tree(str(tmp_path), n_models=3, views=(0,), size=224)
+    got = s3r.evaluate.test_dataset(hip, s3r.data.StereoShapeNet(str(tmp_path)), batch=2, device=DEV)
+    lefts, rights, vols = [], [], []
+    for m in range(3):
+        rdir = os.path.join(str(tmp_path), "ShapeNetStereoRendering", "02691156", f"model{m:02d}")
+        for side, dst in (("l", lefts), ("r", rights)):
+            rgba = np.asarray(Image.open(os.path.join(rdir, f"render_00_{side}.png")).convert("RGBA"), dtype=np.float64)
+            al = rgba[..., 3:4] / 255.0
+            rgb = np.rint(rgba[..., :3] * al + 255.0 * (1.0 - al))              # over white, to the nearest 8-bit code
+            dst.append(torch.from_numpy((rgb / 255.0).astype(np.float32).transpose(2, 0, 1).copy()))
+        vols.append(torch.from_numpy(loadmat(os.path.join(str(tmp_path), "ShapeNetVox32", "02691156",
+                                                          f"model{m:02d}.mat"))["Volume"].astype(np.float32)))
+    left, right, gt = torch.stack(lefts), torch.stack(rights), torch.stack(vols)
+    with torch.no_grad():
+        pred = ref(left, right)
+    for j, t in enumerate(got["thresholds"]):
+        p_, g_ = pred > t, gt > 0.5
+        want = (p_ & g_).flatten(1).sum(1).float() / (p_ | g_).flatten(1).sum(1).float().clamp(min=1)
+        assert (got["per_sample"][:, j].cpu() - want).abs().max().item() < 1e-3          # north_star: IoU within 1e-3
+        assert abs(got["mean_iou"][j] - want.mean().item()) < 1e-3
+
+
 def test_dataset_eval_with_exr_disparity(s3r, models, tmp_path):
     """The whole next-row chain: PNG / MAT / EXR decode -> prefetch -> forward + IoU, disparity read-out + end-point error
     against the EXR ground truth (block-averaged to the read-out's resolution) — equal to the tensor-level drivers."""
