@@ -292,10 +292,10 @@ int resolve_launch_h(const s3r_conv_desc* d, s3r::ConvParamsH* p, LaunchH* L) {
     p->ksplit = L->ksplit;
     if (d->tile >= 0 && d->tile != 1 && d->tile != 2 && d->tile != 3 && d->tile != 19 && d->tile != 4 && d->tile != 5 && d->tile != 6 && d->tile != 9 &&
         d->tile != 10 && d->tile != 17 && d->tile != 18 && d->tile != 20 && d->tile != 21 && d->tile != 22 && d->tile != 23 &&
-        d->tile != 30 && d->tile != 31 && d->tile != 40)
+        d->tile != 30 && d->tile != 31 && d->tile != 40 && d->tile != 42 && d->tile != 43)
         return fail(S3R_ERR_INVALID, "bf16 path: tile must be -1 (auto), 1, 2, 4 (x128 positions, per-tap gather), 3 (128 x 128 couts), 5, 6 "
                     "(x128 positions = 1, 2, plane-reuse gather) or 9, 10 (row-reuse gather); per-tap / plane + 16 = "
-                    "32-channel K tiles");
+                    "32-channel K tiles; 40 (row-persistent e2), 42, 43 (persistent plane kernel, transposed)");
     L->tm = d->tile >= 0 ? d->tile : s3r::conv_bf16_pick_tm(*p);
     if (d->in_layout == S3R_LAYOUT_S2D && L->tm != 30 && L->tm != 31)
         return fail(S3R_ERR_INVALID, "a parity-split input is read by tile codes 30 / 31 only");

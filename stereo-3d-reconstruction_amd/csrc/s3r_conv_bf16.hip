@@ -230,7 +230,7 @@ __device__ __forceinline__ void epilogue_h(const ConvParamsH& p, typename Mf<SH>
     if constexpr (HEAD) {
         int ye[NPT];
 #pragma unroll
-        for (int pt = 0; pt < NPT; ++pt) ye[pt] = yoff[wave * 32 * TM + pt * MT + li];
+        for (int pt = 0; pt < NPT; ++pt) ye[pt] = yoff[wave * 32 * TM + pt * MT + li] + ybase;   // (-1 + 0: still 'none')
         // fused pointwise head (conv -> 1x1x1 conv to ONE channel + activation; the workgroup's 64-cout tile
         // is the whole channel axis): 16 * GL FMAs in the lane, an exchange per lane-group bit, one fp32 store per
         // position.  The conv's own bf16 output — the largest activation of the network — is never written.
@@ -1051,6 +1051,249 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
 }
 
 // ------------------------------------------------------------------------------------------------
+// Persistent form of the plane-reuse kernel for the transposed convolutions (d1, d2, d3 with its fused head).  Their tiles
+// are ALIGNED: 256 positions of one output-parity class are a whole number of (sample, depth) planes (d3: one 16 x 16
+// plane; d2: four 8 x 8; d1: sixteen 4 x 4, i.e. four samples), so the three position tables of the plane kernel — LDS row
+// of a tile position, output offset of a tile position, source of an image row — are the same for EVERY tile up to one
+// scalar base each.  In the plane kernel a d3 workgroup lives 38.6 us around 26.9 us of K loop (tables 3.9, first image
+// 1.8, epilogue 5.8: tools/timeline_bf16.py) and the layer launches 32 768 of them.  Here a workgroup
+//   * builds the tables ONCE, then walks its XCD's run of work items (tile, class) — the same class-adjacent order;
+//   * requests the NEXT item's first two weight tiles and its image right behind the last barrier of the current K loop,
+//     i.e. under the current epilogue (the epilogue stages through its own LDS, not through the idle operand buffers);
+//   * moves two scalars per item (image base, output base) and rebuilds the weight descriptor of the item's class.
+// The K order is the plane kernel's (chunk-major, depth tap, then the 4 in-plane taps; two 16-channel k-steps per tap), so
+// the two are bit-identical (tests/test_bf16_gpu.py::test_persistent_deconv_kernel_equals_the_plane_kernel_bitwise).
+// MEASURED SLOWER, ON REQUEST ONLY (tile codes 42 / 43; never the library's own pick).  B = 256, same device, inside the
+// forward: d3 + head 1.153 vs 1.024 ms, d2 0.479 vs 0.465, d1 0.241 vs 0.239 (plane kernel codes 22 / 23); alone (no head):
+// d3 1.41 vs 1.04, d2 0.505 vs 0.491, d1 0.252 vs 0.248; delaying the k-th round of co-resident workgroups by 3 - 15 us
+// changes nothing.  A CU that hosts two or three plane-kernel workgroups already hides one's tables, first image and
+// epilogue behind the others' K loops as far as the matrix pipe allows; what persistence adds is its
+// cost: the invariants live across the epilogue (148 VGPRs against 113; the fused-head form spills 55 registers per item
+// where the plane kernel spills 10), a grid that must be resident at once (sized by the occupancy query below), and the
+// hardware's dynamic balancing of 32 768 short workgroups replaced by a static split.
+template <int SH, int NH, bool HEAD>
+__global__ __launch_bounds__(256, NH == 2 ? 2 : 3) void conv_bf16d_kernel(const ConvParamsH p, int r_max) {
+    static_assert(!HEAD || NH == 1, "the fused head needs the whole channel axis in one 64-cout tile");
+    typedef Mf<SH> M;
+    constexpr int MT = M::MT, TM = 2, KC = 32;
+    constexpr int NPT = 32 * TM / MT, NCT = 64 / MT, NKS = KC / M::KS;
+    constexpr int BM = 128 * TM, BNW = HBN * NH, ROWB = KC * 2;
+    constexpr int B_BYTES = BNW * ROWB, NPB = B_BYTES / 4096;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int a_bytes = r_max * ROWB;
+    char* Bs = smem + a_bytes;                                        // [PL_NB][BNW][ROWB]
+    int* yoff = reinterpret_cast<int*>(Bs + PL_NB * B_BYTES);         // [BM] output offset of a tile position, tile-relative
+    int* lrow = yoff + BM;                                            // [BM] LDS row of a tile position (tap 0,0)
+    float* ep = reinterpret_cast<float*>(lrow + BM);                  // [NH][3][64]
+    int* asrc = reinterpret_cast<int*>(ep + 192 * NH);                // [r_max] source byte offset of each image row, tile-relative
+    int* ctab = asrc + r_max;                                         // [8][2] per class: image base (bytes), output base (elements)
+    char* stage = reinterpret_cast<char*>(ctab + 16);                 // [4][32][ST_ROW] (plain epilogue only)
+
+    const int xcd = blockIdx.x & 7, wgs_x = gridDim.x >> 3;           // (launcher: gridDim.x % 8 == 0, wgs_x <= run)
+    const int run = p.m_tiles;                                        // items (tile, class) per XCD: 8 * m_tiles / 8
+    int idx = blockIdx.x >> 3;                                        // this workgroup's position in its XCD's run
+    if (idx >= run) return;
+
+    __builtin_amdgcn_s_setprio(S3R_PRIO_EDGE);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane % MT, lk = lane / MT;
+    const int n_tile = blockIdx.y * NH, n0 = n_tile * HBN;
+
+    const int P = p.Nh * p.Nw;
+    const int T = p.T, kh = p.kh, kw = p.kw;
+    const int taps_g = kh * kw, chunks = p.Cin / KC, gpc = p.kd;
+    const int ngroups = chunks * gpc, total = ngroups * taps_g;
+    const int in_p = p.x_hs / p.x_ws;
+    const int halo = (kh - 1) * in_p + kw - 1;
+    const int LP = (p.Nh - 1) * in_p + p.Nw + halo;                   // image rows of a whole plane
+    const int ppt = BM / P;                                           // planes per tile
+
+    const EpRegs epr = load_ep(p, tid, n0, BNW);
+    for (int t = tid; t < BM; t += 256) {
+        const int dpl = p.dHW.div(t);
+        const int rem = t - dpl * P;
+        const int ph = p.dW.div(rem), pw = rem - ph * p.Nw;
+        const int db = p.dS.div(t), dpd = dpl - db * p.Nd;            // (ppt divides Nd: db = 0; Nd divides ppt: whole samples)
+        yoff[t] = db * p.y_bs + (dpd * p.y_ds + ph * p.y_hs + pw * p.y_ws) * 2;
+        lrow[t] = dpl * LP + ph * in_p + pw;
+    }
+    for (int j = tid; j < r_max; j += 256) {
+        int sgm = j / LP, off = j - sgm * LP;
+        if (sgm >= ppt) { sgm = 0; off = 0; }                        // past the image: any valid address, never read
+        const int db = sgm / p.Nd, dpd = sgm - db * p.Nd;
+        asrc[j] = (db * p.x_bs + dpd * p.x_ds + off * p.x_ws) * 2;
+    }
+    if (tid < 8) {                                                    // what an item's class adds to its two bases
+        const int rd = (tid >> 2) & 1, rh = (tid >> 1) & 1, rw = tid & 1;
+        ctab[2 * tid] = (p.x_org + (rd - 1) * p.x_ds + (rh - 1) * p.x_hs + (rw - 1) * p.x_ws) * 2;
+        ctab[2 * tid + 1] = p.y_org + rd * p.y_ds + rh * p.y_hs + rw * p.y_ws;
+    }
+    store_ep(epr, ep, tid, BNW);                                      // (__syncthreads inside: also publishes the tables)
+
+    // The per-lane loop invariants (image-piece sources, LDS rows of the lane's positions, weight-fragment offsets) are
+    // re-read from LDS at the top of every item instead of being kept across the epilogue: held live there they push the
+    // kernel past its register budget (168 VGPRs at three workgroups per CU) into scratch.
+    int avoff[NPA_PL32], lr[NPT], b_off[NCT * NH];
+    auto load_invariants = [&]() {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                                  // (opaque: keeps the ALU halves from being hoisted out of the
+        const int l_i = ln % MT, l_k = ln / MT;                       //  item loop and held in registers across the epilogue)
+#pragma unroll
+        for (int q = 0; q < NPA_PL32; ++q) {
+            const int j = (wave + 4 * q) * 16 + (ln >> 2);
+            avoff[q] = (j < r_max ? asrc[j] : 0) + (((ln & 3) ^ swz<KC>(j)) << 4);
+        }
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) lr[pt] = lrow[wave * 32 * TM + pt * MT + l_i];
+#pragma unroll
+        for (int ct = 0; ct < NCT * NH; ++ct) {
+            const int row = ct * MT + l_i;
+            b_off[ct] = row * ROWB + ((l_k ^ swz<KC>(row)) << 4);
+        }
+    };
+    load_invariants();
+    const int bvoff0 = wave * 1024 + lane * 16;                       // weight pieces are stored pre-swizzled for 64-byte rows
+
+    const int w_tile = p.n_tiles * 4096;
+    const unsigned w_bytes = (unsigned)T * (unsigned)(p.Cin / HKC) * (unsigned)w_tile;
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+
+    // ---- per item: class, image base (bytes), output base (elements), weight descriptor of the class.  The strides are
+    // re-read from the kernel arguments' LDS copy (ctab) / recomputed per item rather than held in scalar registers across
+    // the K loop: the kernel is short of those (the compiler otherwise spills them to VGPR lanes and moves loop counters
+    // into vector registers, which turns every LDS-DMA into a waterfall loop).
+    const int lg_nd = 31 - __builtin_clz((unsigned)p.Nd);             // (launcher: Nd is a power of two)
+    int cls = 0, a_item = 0, ybase = 0;
+    __amdgpu_buffer_rsrc_t wrsrc;
+    auto setup = [&](int i) {
+        const int item = xcd * run + i;
+        const int tile = item >> 3;
+        cls = item & 7;
+        const int pl0 = tile * ppt, b0 = pl0 >> lg_nd, pd0 = pl0 & (p.Nd - 1);
+        const int2 ct = *reinterpret_cast<const int2*>(ctab + 2 * cls);
+        a_item = __builtin_amdgcn_readfirstlane((b0 * p.x_bs + pd0 * p.x_ds) * 2 + ct.x);
+        ybase = __builtin_amdgcn_readfirstlane(b0 * p.y_bs + pd0 * p.y_ds * 2 + ct.y);
+        wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(p.w) + (size_t)cls * w_bytes), 0, (int)w_bytes, 0x00020000);
+    };
+    int b_cc = 0, b_tap = 0, b_slot = 0;                              // cursor of the NEXT weight tile to fetch
+    auto issue_b = [&]() {
+        const int b_base = __builtin_amdgcn_readfirstlane(((b_cc * T + b_tap) * p.n_tiles + n_tile) * 4096);
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) dma16(wrsrc, Bs + b_slot * B_BYTES + ((wave + 4 * q) << 10), bvoff0, b_base + q * 4096);
+        if (++b_tap == T) { b_tap = 0; ++b_cc; }
+        if (++b_slot == PL_NB) b_slot = 0;
+    };
+    int a_cc = 0, a_td = 0;                                           // cursor of the NEXT image to fetch
+    const int npa = (r_max / 16 - wave + 3) >> 2;                     // this wave's 16-row image pieces (dealt round-robin)
+    auto issue_a = [&]() {
+        const int a_base = __builtin_amdgcn_readfirstlane(a_item + (a_cc * KC + a_td * p.x_ds) * 2);   // (a counter the compiler
+                                                              //  moved to a vector register must not make each DMA a waterfall loop)
+        int n = npa;
+        asm volatile("" : "+s"(n));                                   // (opaque: twelve hoisted lane masks cost 24 scalar registers)
+#pragma unroll
+        for (int q = 0; q < NPA_PL32; ++q)
+            if (q < n) dma16(xrsrc, smem + ((wave + 4 * q) << 10), avoff[q], a_base);
+        if (++a_td == gpc) { a_td = 0; ++a_cc; }
+    };
+    auto begin_item = [&](int i) {
+        setup(i);
+        b_cc = 0; b_tap = 0; b_slot = 0; a_cc = 0; a_td = 0;
+        issue_b();
+        if (total > 1) issue_b();
+        issue_a();
+    };
+    begin_item(idx);
+
+    for (;;) {
+        typename M::acc_t acc[NH][NPT][NCT];
+#pragma unroll
+        for (int nh = 0; nh < NH; ++nh)
+#pragma unroll
+            for (int a = 0; a < NPT; ++a)
+#pragma unroll
+                for (int b = 0; b < NCT; ++b)
+#pragma unroll
+                    for (int r = 0; r < M::NACC; ++r) acc[nh][a][b][r] = 0.f;
+        if (idx != (int)(blockIdx.x >> 3)) load_invariants();        // (first item: just loaded)
+        __builtin_amdgcn_s_setprio(0);
+        int tt = 0, c_slot = 0;
+        for (int g = 0; g < ngroups; ++g) {
+            int tapoff = 0, c_tw = 0;
+            for (int t = 0; t < taps_g; ++t, ++tt) {
+                // this tap's weights (and, at t == 0, the image) have landed; the next tap's may still be in flight.  (At
+                // the first tap of an item the count also covers the previous item's epilogue stores, issued after them.)
+                if (t == 0 || tt + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (NPB == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");           // ... for every wave; ring slot (tt+2)%3 is free
+                if (tt + 2 < total) issue_b();
+                const char* b = Bs + c_slot * B_BYTES;
+                int a_off[NPT];
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) {
+                    const int row = lr[pt] + tapoff;
+                    a_off[pt] = row * ROWB + ((lk ^ swz<KC>(row)) << 4);
+                }
+                bf16x8 av[2][NPT], bv[2][NCT * NH];
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) av[0][pt] = *reinterpret_cast<const bf16x8*>(smem + a_off[pt]);
+#pragma unroll
+                for (int ct = 0; ct < NCT * NH; ++ct) bv[0][ct] = *reinterpret_cast<const bf16x8*>(b + b_off[ct]);
+#pragma unroll
+                for (int q = 0; q < NKS; ++q) {
+                    if (q < NKS - 1) {
+#pragma unroll
+                        for (int pt = 0; pt < NPT; ++pt)
+                            av[(q + 1) & 1][pt] = *reinterpret_cast<const bf16x8*>(smem + (a_off[pt] ^ ((q + 1) * M::NK * 16)));
+#pragma unroll
+                        for (int ct = 0; ct < NCT * NH; ++ct)
+                            bv[(q + 1) & 1][ct] = *reinterpret_cast<const bf16x8*>(b + (b_off[ct] ^ ((q + 1) * M::NK * 16)));
+                    }
+#pragma unroll
+                    for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+                        for (int ct = 0; ct < NCT * NH; ++ct)
+                            acc[ct / NCT][pt][ct % NCT] = mma<SH>(bv[q & 1][ct], av[q & 1][pt], acc[ct / NCT][pt][ct % NCT]);
+                }
+                if constexpr (NKS > 1) {                          // (issue order pinned as in the plane kernel)
+                    __builtin_amdgcn_sched_group_barrier(0x100, NPT + NCT * NH, 0);
+#pragma unroll
+                    for (int q = 0; q < NKS - 1; ++q)
+#pragma unroll
+                        for (int i = 0; i < NCT * NH * NPT; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            if (i < NPT + NCT * NH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                    __builtin_amdgcn_sched_group_barrier(0x008, NCT * NH * NPT, 0);
+                }
+                if (++c_slot == PL_NB) c_slot = 0;
+                ++tapoff;
+                if (++c_tw == kw) { c_tw = 0; tapoff += in_p - kw; }
+            }
+            asm volatile("s_barrier" ::: "memory");               // every wave is done with this image
+            if (g + 1 < ngroups) issue_a();
+        }
+        // every wave is past the last barrier: the image and the whole weight ring are free.  The next item's first
+        // operands go out now and land under this item's epilogue.
+        __builtin_amdgcn_s_setprio(S3R_PRIO_EDGE);
+        const int ybase_cur = ybase, cls_cur = cls;
+        const int nidx = idx + wgs_x;
+        const bool more = nidx < run;
+        if (more) begin_item(nidx);
+#pragma unroll
+        for (int nh = 0; nh < NH; ++nh)
+            epilogue_h<SH, TM, HEAD>(p, acc[nh], yoff, ep + nh * 192, stage + wave * (32 * ST_ROW), wave, li, lk, 0, n0 + nh * HBN,
+                                     cls_cur, 0, BM, ybase_cur);
+        if (!more) break;
+        idx = nidx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Row-persistent variant for the shallow front layer (e2: Conv2d 32 -> 64, k3 s1 p1 over 112 x 112; K = 288).  In the
 // plane kernel above such a layer is all fixed cost: 11.6 us of tables, first image, epilogue and store tail per
 // workgroup around 1.2 us of MFMAs, its input fetched 1.9 times over (every tile reloads its halo rows), its output
@@ -1230,6 +1473,7 @@ __global__ __launch_bounds__(256) void conv_finish_bf16_kernel(const ConvParamsH
 static int rowreuse_rows(const ConvParamsH& p, int bm);
 static int plane_rows(const ConvParamsH& p, int bm, int kc);
 static int rows_strips(const ConvParamsH& p);
+static bool persist_ok(const ConvParamsH& p, int nh);
 
 // Tile / gather choice (tools/layer_bench.py --dtype bf16, B = 256, MI355X):
 //   * stride-1 layers with 4+ taps per plane and K >= 256 whose 256-position plane image leaves room for THREE
@@ -1294,7 +1538,7 @@ int conv_bf16_pick_ksplit(const ConvParamsH& p) {
 
 int64_t conv_bf16_scratch_elems(const ConvParamsH& p, int tm) {
     if (p.ksplit <= 1) return 0;
-    const int t0 = (tm == 30 || tm == 31) ? 2 : tm == 23 ? 2 : tm >= 21 ? tm - 20 : (tm >= 16 ? tm - 16 : (tm >= 9 ? tm - 8 : (tm >= 5 ? tm - 4 : tm)));
+    const int t0 = (tm == 30 || tm == 31 || tm == 42 || tm == 43) ? 2 : tm == 23 ? 2 : tm >= 21 ? tm - 20 : (tm >= 16 ? tm - 16 : (tm >= 9 ? tm - 8 : (tm >= 5 ? tm - 4 : tm)));
     const int bm = 128 * (t0 == 3 ? 1 : t0);
     const int64_t mpad = (int64_t)((p.Ntotal + bm - 1) / bm) * bm;
     return (int64_t)(p.transposed ? 8 : 1) * p.ksplit * mpad * p.CoutPad;
@@ -1463,6 +1707,65 @@ static hipError_t launch_rows(ConvParamsH p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// can the persistent plane kernel serve this layer?  Transposed, tiles aligned to whole planes (see the kernel), no split-K.
+static bool persist_ok(const ConvParamsH& p, int nh) {
+    const int P = p.Nh * p.Nw;
+    if (!p.transposed || p.stride != 1 || p.ksplit != 1 || p.s2d || p.y_s2d || p.Cin % 32 != 0 || P < 1 || 256 % P != 0 ||
+        p.Ntotal % 256 != 0 || p.x_hs % p.x_ws != 0)
+        return false;
+    const int ppt = 256 / P;
+    if ((p.Nd & (p.Nd - 1)) != 0 || (p.Nd % ppt != 0 && ppt % p.Nd != 0)) return false;
+    if (nh == 2 && ((p.CoutPad / HBN) % 2 != 0 || p.head_w)) return false;
+    const int r_max = plane_rows(p, 256, 32);
+    return r_max > 0 && r_max <= 64 * NPA_PL32;
+}
+
+template <int SH, int NH>
+static hipError_t launch_persist(ConvParamsH p, hipStream_t stream) {
+    if (!persist_ok(p, NH)) return hipErrorInvalidValue;
+    p.m_tiles = p.Ntotal / 256;
+    p.n_tiles = p.CoutPad / HBN;
+    const int r_max = plane_rows(p, 256, 32);
+    const bool head = p.head_w != nullptr;
+    const size_t lds = (size_t)r_max * 64 + PL_NB * HBN * NH * 64 + 2 * 256 * sizeof(int) + EP_BYTES * NH + (size_t)r_max * 4 + 64 +
+                       (head ? 0 : 4 * 32 * ST_ROW);
+    static int cus[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    if (!cus[dev] && (hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus[dev] < 8))
+        cus[dev] = 256;
+    // A persistent grid must be RESIDENT all at once (a workgroup that starts after another has finished its run doubles
+    // the launch): workgroups per CU from the runtime's occupancy calculation for this instantiation and LDS size.
+    const void* fn = head ? reinterpret_cast<const void*>(&conv_bf16d_kernel<SH, 1, true>)
+                          : reinterpret_cast<const void*>(&conv_bf16d_kernel<SH, NH, false>);
+    static LdsAttr lds_attr[2];
+    const hipError_t attr = lds_attr[head].ensure(fn, 160 * 1024);
+    if (attr != hipSuccess) return attr;
+    static std::atomic<int> occ[2][16];                               // (queried once per device: r_max, hence lds, is the layer's)
+    static std::atomic<unsigned> occ_lds[2][16];
+    int per_cu = occ_lds[head][dev].load() == (unsigned)lds ? occ[head][dev].load() : 0;
+    if (per_cu < 1) {
+        const hipError_t oe = head ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_bf16d_kernel<SH, 1, true>, 256, lds)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_bf16d_kernel<SH, NH, false>, 256, lds);
+        if (oe != hipSuccess || per_cu < 1) return oe != hipSuccess ? oe : hipErrorInvalidValue;
+        occ[head][dev].store(per_cu);
+        occ_lds[head][dev].store((unsigned)lds);
+    }
+    // workgroups per XCD and cout column: the XCD's CUs x their resident workgroups, shared by the columns
+    const int cols = p.n_tiles / NH;
+    int wgs_x = (cus[dev] / 8) * per_cu / cols;
+    if (wgs_x < 1) wgs_x = 1;
+    if (wgs_x > p.m_tiles) wgs_x = p.m_tiles;
+    dim3 grid(8 * wgs_x, cols, 1);
+    if (head) {
+        if constexpr (NH == 1) hipLaunchKernelGGL((conv_bf16d_kernel<SH, 1, true>), grid, dim3(256), lds, stream, p, r_max);
+        else return hipErrorInvalidValue;
+    } else {
+        hipLaunchKernelGGL((conv_bf16d_kernel<SH, NH, false>), grid, dim3(256), lds, stream, p, r_max);
+    }
+    return hipGetLastError();
+}
+
 template <int SH>
 static hipError_t launch_shape(const ConvParamsH& p, int tm, hipStream_t stream) {
     // tm = 1, 2, 4: per-tap gather (conv_bf16_kernel; + 16: 32-channel K tiles even where 64 are possible);
@@ -1482,6 +1785,8 @@ static hipError_t launch_shape(const ConvParamsH& p, int tm, hipStream_t stream)
         case 9: return launch_tm_rowreuse<SH, 1>(p, stream);
         case 10: return launch_tm_rowreuse<SH, 2>(p, stream);
         case 40: return launch_rows<SH>(p, stream);                          // row-persistent (e2 at large batches)
+        case 42: return launch_persist<SH, 1>(p, stream);                    // persistent plane kernel (aligned transposed classes)
+        case 43: return launch_persist<SH, 2>(p, stream);                    // ... 256 positions x 128 couts
         default: return hipErrorInvalidValue;
     }
 }

@@ -459,6 +459,39 @@ def test_chain_plans_the_parity_split_handoff(s3r, oracle, mfma_shape):
     assert rel_l2(plain.cpu(), want) < 4e-3 and not torch.equal(plain, got)
 
 
+@pytest.mark.parametrize("name", ["d1", "d2", "d3", "d3+head"])
+def test_persistent_deconv_kernel_equals_the_plane_kernel_bitwise(s3r, oracle, mfma_shape, name):
+    """The PERSISTENT plane kernel for the transposed convolutions (tile codes 42 / 43, on request only — measured slower
+    than the plane kernel, DESIGN.md §4.4: position tables built once per workgroup, a workgroup walks its XCD's run of
+    (tile, class) items and requests the next item's operands under the current epilogue).  Same K order as the plane
+    kernel (22 / 23): bit-identical at every batch — few items per workgroup, many, a run that does not divide by the
+    workgroups of an XCD — and with the fused head."""
+    spec = s3r.arch_spec
+    layers = {l.name: (l, n_in) for l, n_in, _ in spec.trace(spec.DECODER, spec.MAX_DISP)}
+    base = name.split("+")[0]
+    L, n_in = layers[base]
+    chain = [L] + ([layers["d4"][0]] if name.endswith("head") else [])
+    ch = s3r.modules._HipChain(chain, n_in, precision="bf16")
+    s3r.seed_module(ch, 11)
+    ch.to(DEV)
+    g = torch.Generator().manual_seed(13)
+    codes = [(22, 42)] + ([(23, 43)] if L.cout % 128 == 0 else [])
+    for B in {"d1": (4, 36, 256), "d2": (1, 7, 64), "d3": (1, 5, 24), "d3+head": (1, 5, 24)}[name]:
+        x = torch.randn((B,) + (n_in,) * 3 + (L.cin,), generator=g).to(torch.bfloat16).to(DEV)      # physical channels-last
+        for plane, persistent in codes:
+            ch.tile_override[base] = plane
+            want = ch._run(x).clone()
+            ch.tile_override[base] = persistent
+            got = ch._run(x)
+            assert got.dtype == want.dtype and torch.equal(got, want), (B, persistent)
+        del ch.tile_override[base]
+        assert torch.equal(ch._run(x), want)                                   # the library's own pick, whichever it is
+    if name == "d1":                                  # tiles are whole planes of whole samples: B * 64 positions % 256
+        ch.tile_override[base] = 43
+        with pytest.raises(s3r.S3RError):
+            ch._run(x[:5])
+
+
 def test_rows_kernel_equals_the_plane_kernel_bitwise(s3r, oracle, mfma_shape):
     """e2 at large image counts runs the row-persistent kernel (tile code 40: seven waves slide down a strip of rows,
     weights resident in LDS, input rows in a ten-slot ring).  Its K order is the plane kernel's, so the two must agree
