@@ -139,6 +139,8 @@ def pmc_summary(variant, dtype, B, plain_run):
             tj = json.load(open(path))
         except Exception:
             continue
+        if "--renders u8" in tj.get("bench_args", ""):          # (a plain run has fp32 renders: not the 8-bit-entry pass)
+            continue
         if tj.get("csrc_sha256") == want and tj.get("dtype") == dtype and tj.get("batch") == B and \
                 tj.get("variant", "voxel") == variant:
             return {"file": os.path.relpath(path, ROOT), "csrc_sha256": want,
