@@ -44,6 +44,30 @@ def test_arch_spec_shapes_and_budget(s3r):
         assert l.cin % 16 == 0, l
 
 
+def test_arch_spec_is_the_frozen_table_the_golden_fixtures_were_made_under(s3r):
+    """The oracle builds its modules FROM arch_spec (oracle/s2v_oracle.py), so an accidental edit of the table would move
+    both sides of every parity test together.  This is the table, written out: (name, op, cin, cout, k, stride, pad, bn,
+    act) of every layer and the constants around it; tests/golden/*.npz were generated under it."""
+    spec = s3r.arch_spec
+    frozen = [
+        ("e1", "conv2d", 3, 32, 3, 2, 1, True, "relu"), ("e2", "conv2d", 32, 64, 3, 1, 1, True, "relu"),
+        ("e3", "conv2d", 64, 64, 3, 2, 1, True, "relu"), ("e4", "conv2d", 64, 128, 3, 1, 1, True, "relu"),
+        ("e5", "conv2d", 128, 128, 3, 2, 1, True, "relu"), ("e6", "conv2d", 128, 256, 3, 1, 1, True, "relu"),
+        ("e7", "conv2d", 256, 256, 3, 1, 1, True, "relu"), ("e8", "conv2d", 256, 32, 1, 1, 0, True, "relu"),
+        ("v1", "conv3d", 64, 64, 3, 1, 1, True, "relu"), ("v2", "conv3d", 64, 128, 3, 2, 1, True, "relu"),
+        ("v3", "conv3d", 128, 128, 3, 1, 1, True, "relu"), ("v4", "conv3d", 128, 256, 3, 2, 1, True, "relu"),
+        ("v5", "conv3d", 256, 256, 3, 1, 1, True, "relu"), ("v6", "conv3d", 256, 512, 4, 1, 0, True, "relu"),
+        ("d1", "deconv3d", 512, 256, 4, 2, 1, True, "relu"), ("d2", "deconv3d", 256, 128, 4, 2, 1, True, "relu"),
+        ("d3", "deconv3d", 128, 64, 4, 2, 1, True, "relu"), ("d4", "conv3d", 64, 1, 1, 1, 0, False, "sigmoid"),
+        ("p1", "linear", 32768, 1024, 1, 1, 0, False, "relu"), ("p2", "linear", 1024, 1024, 1, 1, 0, False, "relu"),
+        ("p3", "linear", 1024, 6144, 1, 1, 0, False, "none"),
+    ]
+    got = [(l.name, l.op, l.cin, l.cout, l.k, l.s, l.p, l.bn, l.act) for l in spec.ENCODER + spec.DECODER + spec.POINT_HEAD]
+    assert got == frozen
+    assert (spec.IMG_HW, spec.FEAT_C, spec.FEAT_HW, spec.MAX_DISP, spec.VOX, spec.N_POINTS, spec.LATENT_C, spec.BN_EPS) == \
+        (224, 32, 28, 28, 32, 2048, 512, 1e-5)
+
+
 def test_arch_spec_flops_match_parameter_count(s3r, oracle):
     spec = s3r.arch_spec
     m = oracle.OracleStereo2Voxel()
