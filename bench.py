@@ -150,6 +150,26 @@ def pmc_summary(variant, dtype, B, plain_run):
     return None
 
 
+def executed_ratio(variant):
+    """MFMA multiply-adds the fp32 path EXECUTES over the algorithmic count the roofline is quoted on: the layers the library
+    runs through Winograd F(2,3) along H (S3R_WINO policy: v1, v3) execute 2/3 of theirs."""
+    import s3r
+    spec = s3r.arch_spec
+    mode = int(os.environ.get("S3R_WINO", "1"))
+    tot = exe = 0.0
+    layers = list(spec.trace(spec.ENCODER, spec.IMG_HW)) + \
+        list(spec.trace(spec.DECODER if variant == "voxel" else spec.DECODER_DOWN, spec.MAX_DISP))
+    for l, n_in, _ in layers:
+        if l.name in ("e1", "d4"):
+            continue
+        m = spec.layer_macs(l, n_in) * (2 if l.name.startswith("e") else 1)
+        wino = mode > 0 and l.op in ("conv2d", "conv3d") and l.k == 3 and l.s == 1 and l.p == 1 and \
+            (mode == 2 or (l.op == "conv3d" and n_in >= 14))
+        tot += m
+        exe += m * (2.0 / 3.0 if wino else 1.0)
+    return round(exe / tot, 4)
+
+
 def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False):
     """Roofline of the dominant kernel family (the MFMA implicit-GEMM convolution): algorithmic FLOPs of its launches
     / their HIP-event durations (events recorded by the library on the stream it launches on)."""
@@ -197,7 +217,10 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False)
             "kernel": "conv_bf16{,r,p}_kernel (bf16 MFMA implicit-GEMM conv, channels-last, LDS-DMA; "
                       "per-tap / row-reuse / plane-reuse gathers)" if bf
             else "conv_glds_kernel / conv_glds_dual_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv, LDS-DMA operand "
-                 "staging; dual = a layer's bulk and its re-tiled remainder in one launch)",
+                 "staging; dual = a layer's bulk and its re-tiled remainder in one launch) + conv_wino_kernel / wino_input_kernel "
+                 "(v1, v3: Winograd F(2,3) along H, 2/3 of the direct form's multiplications — `achieved` counts the DIRECT "
+                 "form's algorithmic FLOPs for every layer)",
+            "executed_over_algorithmic_mfma_flops": executed_ratio(variant) if not bf else 1.0,
             "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
             "frac_border_excluded": round(achieved / peak * ratio, 4),
@@ -239,7 +262,8 @@ def eager_records(s3r, torch, model, left, right, gt_cloud, steps):
 # environment switches that change which kernel (or which variant of one) runs without changing the kernel sources: a run
 # under any of them is not the configuration the committed counter passes were taken on
 _KERNEL_ENV = ("S3R_TILE_", "S3R_KSPLIT_", "S3R_BF16_MFMA", "S3R_STEM_MFMA", "S3R_S2D", "S3R_DEEP_RING", "S3R_LINEAR_NT",
-               "S3R_NO_TAIL_CUT", "S3R_NO_FUSE", "S3R_LIB")
+               "S3R_NO_TAIL_CUT", "S3R_NO_FUSE", "S3R_LIB", "S3R_WINO", "S3R_WSPLIT", "S3R_ROWS", "S3R_NO_DUAL", "S3R_DUAL_MODEL",
+               "S3R_LINEAR_WGK")
 
 
 def kernel_env_overrides():

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define S3R_ABI_VERSION 5
+#define S3R_ABI_VERSION 6
 
 typedef enum s3r_status {
     S3R_OK = 0,
@@ -125,7 +125,11 @@ const char* s3r_last_error(void);
 /* output edge of a layer: conv (n+2p-k)/s+1, deconv (n-1)s-2p+k, linear 1 */
 int s3r_conv_out_size(const s3r_conv_desc* d);
 /* size of the packed weight buffer for a layer IN 4-BYTE UNITS (>= the torch weight's numel on the fp32
- * path: couts are padded; about half of it on the bf16 path) */
+ * path: couts are padded; about half of it on the bf16 path).  ABI 6: an fp32 3 x 3 [x 3] stride-1 pad-1 convolution packs
+ * two forms, the direct slab and the four Winograd F(2,3)-along-H class slabs (csrc/s3r_conv_wino.hip); which kernel a
+ * forward runs is decided per call (environment S3R_WINO: unset / 1 = the layers it measured faster on, 0 = never, 2 =
+ * every eligible layer; a tile / split-K override, a non-plain layout or too little scratch select the direct kernel).
+ * The two kernels agree to fp32 rounding (another summation order), not bit for bit. */
 int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems);
 /* repack a torch-layout weight (Conv: [cout][cin][k..]; ConvTranspose: [cin][cout][k..]; Linear:
  * [cout][cin]) into the kernel's K-major layout.  Device to device, on `stream`. */

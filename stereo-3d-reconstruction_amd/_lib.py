@@ -18,7 +18,7 @@ DTYPE = {"fp32": 0, "bf16": 1}
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}
 FAMILY = {0: "conv_mfma", 1: "stem", 2: "head", 3: "cost_volume", 4: "linear", 5: "chamfer", 6: "iou", 7: "pack",
           8: "pad_copy", 9: "disparity"}
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class ConvDesc(C.Structure):

@@ -203,6 +203,47 @@ int check_halos(const s3r_conv_desc* d, Route r) {
 }
 
 int cout_pad(int cout) { return (cout + 127) / 128 * 128; }
+
+// Winograd F(2,3) along H (s3r_conv_wino.hip) for the fp32 3 x 3 [x 3] stride-1 pad-1 convolutions: 2/3 of the matrix work,
+// another summation order (not bit-identical to the direct kernels, same fp32 accuracy).  Such a layer's packed weights
+// hold BOTH forms — the direct slab, then the four Winograd class slabs — so which kernel runs is decided per call:
+//   S3R_WINO unset / 1: the layers it measured faster on (3D, >= 14 rows: v1, v3 — DESIGN.md §4.1);  0: never;  2: every
+//   eligible layer (experiments).  A call with a tile / split-K override, a non-plain layout, no halo or too little
+//   scratch runs the direct kernel.
+int wino_mode() {
+    const char* e = getenv("S3R_WINO");                  // (read per call: the A/B tools flip it in-process)
+    return e ? atoi(e) : 1;
+}
+// structural: the layer has a Winograd form (decides the packed layout; independent of any switch)
+bool wino_layer(const s3r_conv_desc* d) {
+    return d->dtype != S3R_BF16 && d->op == S3R_OP_CONV && (d->ndim == 2 || d->ndim == 3) && d->k == 3 && d->stride == 1 &&
+           d->pad == 1 && d->cin % 16 == 0 && d->cout > 1 && d->in_size >= 4;
+}
+// this call takes it (scratch is checked by the caller)
+bool wino_ok(const s3r_conv_desc* d) {
+    const int mode = wino_mode();
+    if (mode <= 0 || !wino_layer(d) || d->act == S3R_ACT_SIGMOID) return false;
+    if (mode == 1 && !(d->ndim == 3 && d->in_size >= 14)) return false;
+    return d->in_halo == 1 && d->in_layout == S3R_LAYOUT_PLAIN && d->out_layout == S3R_LAYOUT_PLAIN && d->tile < 0 && d->ksplit <= 1;
+}
+// samples per Winograd call (the transformed input of a call stays below 2 GiB) and the scratch that takes, in floats
+int wino_bmax(const s3r_conv_desc* d);
+int64_t wino_need(const s3r_conv_desc* d);
+int64_t wino_w_elems(const s3r_conv_desc* d) {       // the four class slabs behind the direct slab
+    return 4 * ipow(3, d->ndim - 1) * d->cin * (int64_t)cout_pad(d->cout);
+}
+int64_t wino_v_elems(const s3r_conv_desc* d) {       // the four transformed plane sets: [4][B][Cin][Dp][ceil(H/2)][Wp]
+    const int64_t dp = d->ndim == 3 ? d->in_size + 2 : 1, h2 = (d->in_size + 1) / 2, wp = d->in_size + 2;
+    return 4 * (int64_t)d->batch * d->cin * dp * h2 * wp;
+}
+int wino_bmax(const s3r_conv_desc* d) {
+    const int64_t v_sample = wino_v_elems(d) / (d->batch > 0 ? d->batch : 1);
+    const int64_t m = v_sample > 0 ? (((int64_t)1 << 31) - 1) / (4 * v_sample) : 0;
+    return (int)(m < d->batch ? m : d->batch);
+}
+int64_t wino_need(const s3r_conv_desc* d) {
+    return d->batch > 0 ? wino_v_elems(d) / d->batch * wino_bmax(d) : 0;
+}
 int cout_pad_h(int cout) { return (cout + 63) / 64 * 64; }
 
 // bf16 channels-last twin of make_params: strides are in elements of (B, Dp, Hp, Wp, C)
@@ -469,6 +510,7 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
     for (int i = 0; i + 1 < n; ++i) {
         if (pl->r[i] != R_MFMA || pl->r[i + 1] != R_HEAD || pl->d[i].cout > 64) continue;
         if (pl->d[i + 1].cin != pl->d[i].cout || pl->d[i].out_halo != 0 || pl->d[i].act == S3R_ACT_SIGMOID) continue;
+        if (wino_ok(&pl->d[i])) continue;                   // (the Winograd kernel has no fused-head epilogue)
         if (pl->d[i].dtype == S3R_BF16) {
             s3r::ConvParamsH ph = make_params_h(&pl->d[i], pl->g[i]);
             LaunchH Lh;
@@ -585,7 +627,7 @@ int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems) {
         case R_MFMA: {
             const int64_t taps = d->op == S3R_OP_DECONV ? 64 : ipow(d->k, g.nd);
             if (d->dtype == S3R_BF16) *elems = (taps * d->cin * cout_pad_h(d->cout) + 1) / 2;   // bf16, in float units
-            else *elems = taps * d->cin * cout_pad(d->cout);
+            else *elems = taps * d->cin * cout_pad(d->cout) + (wino_layer(d) ? wino_w_elems(d) : 0);
             break;
         }
     }
@@ -610,9 +652,13 @@ int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, void* packedv,
             if (d->dtype == S3R_BF16)
                 e = s3r::launch_pack_bf16(w, packed, d->cin, d->cout, cout_pad_h(d->cout),
                                           d->op == S3R_OP_DECONV ? 8 : (int)ipow(d->k, g.nd), d->op == S3R_OP_DECONV, s);
-            else
+            else {
                 e = s3r::launch_pack_conv(w, packed, d->cin, d->cout, cout_pad(d->cout),
                                           d->op == S3R_OP_DECONV ? 8 : (int)ipow(d->k, g.nd), d->op == S3R_OP_DECONV, s);
+                if (e == hipSuccess && wino_layer(d))
+                    e = s3r::launch_pack_wino(w, packed + ipow(d->k, g.nd) * d->cin * cout_pad(d->cout), d->cin, d->cout,
+                                              cout_pad(d->cout), g.nd == 3 ? 3 : 1, 3, s);
+            }
             break;
     }
     if (e != hipSuccess) return hip_fail(e, "pack weights");
@@ -635,7 +681,9 @@ int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d) {
     s3r::ConvParams p = make_params(d, g);
     Launch L;
     if ((rc = resolve_launch(d, &p, &L))) return rc;
-    return s3r::conv_scratch_elems(p, L.cfg);
+    const int64_t direct = s3r::conv_scratch_elems(p, L.cfg);
+    const int64_t wino = wino_ok(d) ? wino_need(d) : 0;         // (a caller that offers less gets the direct kernel)
+    return wino > direct ? wino : direct;
 }
 
 }  // extern "C"
@@ -741,6 +789,41 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
         case R_MFMA: {
             s3r::ConvParams p = make_params(d, g);
             p.x = x; p.w = packed_w; p.scale = scale; p.shift = shift; p.y = y;
+            // Winograd F(2,3) along H.  The transformed input must stay inside 32-bit byte offsets: larger batches go through in
+            // sub-batches (a sample's result does not depend on the batch it is computed in, so neither does it on this split)
+            if (wino_ok(d) && scratch && scratch_elems >= wino_need(d) && wino_need(d) > 0) {
+                const int is3 = d->ndim == 3, n = d->in_size, wp = n + 2, h2 = (n + 1) / 2, dp = is3 ? n + 2 : 1;
+                const int64_t v_sample = wino_v_elems(d) / d->batch, x_sample = g.x_elems / d->batch;
+                const int bmax = wino_bmax(d);
+                ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
+                ps.launches = 0;
+                p.w = packed_w + ipow(3, g.nd) * d->cin * cout_pad(d->cout);        // the class slabs sit behind the direct slab
+                p.x = scratch;
+                p.Nh = h2; p.kh = 1; p.T = p.kd * p.kw;
+                p.x_hs = wp; p.x_ds = is3 ? h2 * wp : 0; p.x_cs = dp * h2 * wp;
+                p.x_org = 0;
+                p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
+                p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
+                p.dW = s3r::FastDiv((unsigned)p.Nw);
+                p.Hout = n;
+                p.ksplit = 1;
+                for (int b0 = 0; b0 < d->batch; b0 += bmax) {
+                    const int nb = d->batch - b0 < bmax ? d->batch - b0 : bmax;
+                    e = s3r::launch_wino_input(x + (int64_t)b0 * x_sample, scratch, (long long)nb * d->cin * dp, n + 2, wp, h2, s);
+                    if (e != hipSuccess) return hip_fail(e, "Winograd input transform launch");
+                    p.B = nb;
+                    p.x_cls = nb * d->cin * p.x_cs;
+                    p.x_bytes = (unsigned)(4 * (int64_t)nb * v_sample);
+                    p.Ntotal = nb * p.Nd * p.Nh * p.Nw;
+                    p.n_begin = 0; p.n_end = p.Ntotal;
+                    p.y = y + (int64_t)b0 * p.y_bs;
+                    p.y_bytes = (unsigned)(4 * (int64_t)nb * p.y_bs);
+                    e = s3r::launch_conv_wino(p, s);
+                    if (e != hipSuccess) return hip_fail(e, "Winograd conv launch");
+                    ps.launches += 2;
+                }
+                return S3R_OK;
+            }
             Launch L;
             if ((rc = resolve_launch(d, &p, &L))) return rc;
             if (L.ksplit > 1) {

@@ -1,0 +1,284 @@
+// fp32 3 x 3 [x 3] stride-1 convolutions with FEWER multiplications: Winograd F(2, 3) along the H axis only.
+//
+// Two output rows (2q, 2q + 1) of a column need input rows r0..r3 = 2q .. 2q + 3 of the padded input and the three
+// kernel rows g0, g1, g2:
+//     v0 = r0 - r2      u0 = g0                 m_i = sum over (cin, kd, kw) of u_i * v_i        (4 products, not 6)
+//     v1 = r1 + r2      u1 = (g0 + g1 + g2) / 2
+//     v2 = r2 - r1      u2 = (g0 - g1 + g2) / 2      y(2q)     = (m0 + m1) + m2
+//     v3 = r1 - r3      u3 = g2                      y(2q + 1) = (m1 - m2) - m3
+// so the layer becomes FOUR convolutions with a (kd x 1 x kw) kernel — 9 taps instead of 27 in 3D, 3 instead of 9 in 2D,
+// each over its own transformed input plane set V_i and its own transformed weights U_i — whose results are combined in
+// registers: 2/3 of the matrix work of the direct form for the same outputs.  Why only one axis: every further axis
+// doubles the transform-domain accumulators per output again (4 per 2 outputs here; 64 per 8 for F(2,3)^3 — a whole CU's
+// register file for a 32 x 32 tile) and shortens each GEMM's K to Cin; along H alone K stays Cin x 9 (or x 3), the
+// W axis stays contiguous (16-byte gathers where W % 4 == 0, whole-row stores), and the kernel below is the implicit
+// GEMM of s3r_conv_glds.hip with a class loop around its K loop.  fp32 F(2, 3) is as accurate as the direct fp32 sum
+// here (3-5e-7 relative to fp64 over 64-256 input channels; north_star allows 1e-4), but it is a DIFFERENT summation:
+// results are not bit-identical to the direct kernels', so the path is taken only on request (S3R_WINO=1) this round.
+//
+//   wino_input_kernel   x (padded NC(D)HW, halo 1) -> V[4][B][C][Dp][H/2][Wp]      (HBM-bound: reads x once, writes 2 x)
+//   pack_wino_kernel    w[Cout][Cin][kd][3][kw]    -> Up[4][(chunk*T' + tap')*16 + c][CoutPad],  T' = kd*kw
+//   conv_wino_kernel    64 couts x 128 positions per workgroup (positions = (b, d, row pair q, w)), 4 waves of 64 x 32,
+//                       4 classes x 2 MFMA tiles of accumulators per wave, 3-stage LDS ring behind counted vmcnt
+#include "s3r_kernels.h"
+#include <cstdlib>
+
+namespace s3r {
+
+typedef float wf32x16 __attribute__((ext_vector_type(16)));
+typedef float wv2f __attribute__((ext_vector_type(2)));
+
+#define S3R_LDS_PTR_W(p) ((__attribute__((address_space(3))) void*)(p))
+
+constexpr int WBM = 64, WBN = 128, WBK = 16, WNB = 3;
+
+template <int BYTES>
+__device__ __forceinline__ void wdma(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, int voffset, int soffset) {
+    static_assert(BYTES == 16 || BYTES == 4, "LDS-DMA width");
+    if constexpr (BYTES == 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, S3R_LDS_PTR_W(lds_dst), 16, voffset, soffset, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, S3R_LDS_PTR_W(lds_dst), 4, voffset, soffset, 0, 0);
+}
+
+// ---- input transform: one thread per (plane row of V, column); rows r0..r3 of the padded input plane
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, long long planes,
+                                                         int Hp, int Wp, int H2, long long cls_stride) {
+    const long long total = planes * H2 * Wp;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long row = i / Wp;                     // (plane, q)
+        const int w = (int)(i - row * Wp);
+        const long long pl = row / H2;
+        const int q = (int)(row - pl * H2);
+        const float* __restrict__ src = x + (pl * Hp + 2 * q) * Wp + w;
+        const float r0 = src[0], r1 = src[Wp], r2 = src[2 * (long long)Wp];
+        const float r3 = (2 * q + 3 < Hp) ? src[3 * (long long)Wp] : 0.f;        // (odd H: the row below the halo is zero)
+        V[i] = r0 - r2;
+        V[i + cls_stride] = r1 + r2;
+        V[i + 2 * cls_stride] = r2 - r1;
+        V[i + 3 * cls_stride] = r1 - r3;
+    }
+}
+
+hipError_t launch_wino_input(const float* x, float* V, long long planes, int Hp, int Wp, int H2, hipStream_t s) {
+    const long long total = planes * H2 * Wp;
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, x, V, planes, Hp, Wp,
+                       H2, total);
+    return hipGetLastError();
+}
+
+// ---- weights: w[Cout][Cin][kd][3][kw] (torch layout, 2D: kd = 1) -> 4 class slabs in the conv kernel's packed K order
+__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int CoutPad, int kd,
+                                 int kw) {
+    const int T = kd * kw;
+    const size_t per_cls = (size_t)T * Cin * CoutPad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < 4 * per_cls; i += (size_t)gridDim.x * blockDim.x) {
+        const int cls = (int)(i / per_cls);
+        size_t r = i % per_cls;
+        const int co = (int)(r % CoutPad);
+        r /= CoutPad;
+        const int c = (int)(r & 15);
+        r >>= 4;
+        const int tap = (int)(r % T);
+        const int cc = (int)(r / T);
+        const int cin = cc * 16 + c;
+        float v = 0.f;
+        if (co < Cout) {
+            const int td = tap / kw, tw = tap - td * kw;
+            const float* g = w + (((size_t)co * Cin + cin) * kd + td) * 3 * kw + tw;       // g[kh * kw]
+            const float g0 = g[0], g1 = g[kw], g2 = g[2 * kw];
+            v = cls == 0 ? g0 : cls == 1 ? ((g0 + g1) + g2) * 0.5f : cls == 2 ? ((g0 - g1) + g2) * 0.5f : g2;
+        }
+        wp[i] = v;
+    }
+}
+
+hipError_t launch_pack_wino(const float* w, float* wp, int Cin, int Cout, int CoutPad, int kd, int kw, hipStream_t s) {
+    hipLaunchKernelGGL(pack_wino_kernel, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CoutPad, kd, kw);
+    return hipGetLastError();
+}
+
+// ---- the four class convolutions and their combination.  p describes the CLASS convolution: p.x = V, x_cs / x_ds / x_hs
+// its strides (x_hs = one V row per row pair), p.x_cls the class stride, Nh = row pairs per plane, kh = 1, T = kd * kw,
+// x_org = 0; p.y the layer's padded output, p.Hout its true height (odd: the last pair's second row is not stored).
+template <int VEC>
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wsmem[];
+    float* As = wsmem;                                   // [WNB][16][64]
+    float* Bs = wsmem + WNB * WBK * WBM;                 // [WNB][16][128]
+    constexpr int PB = 64 * VEC;                         // floats per B piece
+    constexpr int NPIECE_B = WBK * WBN / PB;
+    constexpr int NPB = NPIECE_B / 4;
+    constexpr bool B_WIDE = WBN >= PB;
+    constexpr int PPR = B_WIDE ? WBN / PB : 1;
+    constexpr int RPP = B_WIDE ? 1 : PB / WBN;
+    constexpr int LPR_B = WBN / VEC;
+    constexpr int NPD = 1 + NPB;                         // DMAs per wave per K tile (one 1 KiB weight piece + NPB gathers)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    int bid = blockIdx.x;
+    {   // XCD-aware tile order (as conv_glds_kernel)
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int m_tile = bid % p.m_tiles, n_tile = bid / p.m_tiles;
+    const int m0 = m_tile * WBM, n0 = n_tile * WBN;
+    const int S = p.Nd * p.Nh * p.Nw;
+    const int T = p.T;
+    const int chunks = p.Cin / WBK;
+    const int nkt = T * chunks;                          // K tiles per class
+    const int total = 4 * nkt;
+
+    int bvoff;
+    {
+        int col, lrow;
+        if (B_WIDE) { col = (wave % PPR) * PB + lane * VEC; lrow = 0; }
+        else        { col = (lane % LPR_B) * VEC;           lrow = lane / LPR_B; }
+        int n = n0 + col;
+        if (n >= p.Ntotal) n = p.Ntotal - VEC;
+        const int b = p.dS.div(n);
+        int rem = n - b * S;
+        const int pd = p.dHW.div(rem);
+        rem -= pd * p.Nh * p.Nw;
+        const int q = p.dW.div(rem);
+        const int pw = rem - q * p.Nw;
+        bvoff = (b * p.Cin * p.x_cs + p.x_org + pd * p.x_ds + q * p.x_hs + pw + lrow * p.x_cs) * 4;
+    }
+    const int avoff = ((lane >> 4) * p.CoutPad + (lane & 15) * 4) * 4;
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w), 0, (int)(4u * (unsigned)T * (unsigned)p.Cin * (unsigned)p.CoutPad * 4u), 0x00020000);
+    const int b_row0 = B_WIDE ? wave / PPR : wave * RPP;
+    constexpr int B_ROW_STEP = B_WIDE ? 4 / PPR : 4 * RPP;
+    const int b_lds0 = B_WIDE ? b_row0 * WBN + (wave % PPR) * PB : wave * PB;
+    constexpr int B_LDS_STEP = B_WIDE ? B_ROW_STEP * WBN : 4 * PB;
+    const int cs4 = p.x_cs * 4;
+
+    int c_cls = 0, c_cc = 0, c_td = 0, c_tw = 0, c_tap = 0, c_kt = 0;      // cursor of the NEXT K tile to fetch (scalar)
+    auto issue = [&](int buf) {
+        wdma<16>(wrsrc, As + buf * WBK * WBM + wave * 256, avoff, (c_kt * WBK * p.CoutPad + m0) * 4 + wave * 4 * p.CoutPad * 4);
+        float* sb = Bs + buf * WBK * WBN + b_lds0;
+        const int b_base = (c_cls * p.x_cls + (c_cc * WBK + b_row0) * p.x_cs + c_td * p.x_ds + c_tw) * 4;
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) wdma<4 * VEC>(xrsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
+        ++c_kt;
+        if (++c_tw == p.kw) { c_tw = 0; ++c_td; }
+        if (++c_tap == T) {
+            c_tap = 0; c_td = 0; c_tw = 0;
+            if (++c_cc == chunks) { c_cc = 0; ++c_cls; }
+        }
+    };
+
+    wf32x16 acc[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
+
+    // tiles 0 .. WNB-2 go out; tile 0 has landed once at most WNB-2 tiles' DMAs are outstanding
+#pragma unroll
+    for (int i = 0; i < WNB - 1; ++i)
+        if (i < total) issue(i);
+    if (total >= WNB - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((WNB - 2) * NPD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    const int a_off = h * WBM + j * 2;
+    const int b_off = h * WBN + wave * 32 + j;
+    int cur = 0, g = 0;
+    auto run_class = [&](wf32x16 (&ac)[2]) {
+        for (int kt = 0; kt < nkt; ++kt, ++g) {
+            const bool more = g + WNB - 1 < total;
+            if (more) issue(cur == 0 ? WNB - 1 : cur - 1);        // into the stage tile g - 1 was read from
+            const float* a = As + cur * WBK * WBM + a_off;
+            const float* b = Bs + cur * WBK * WBN + b_off;
+#pragma unroll
+            for (int ks = 0; ks < WBK / 2; ++ks) {
+                const wv2f av = *reinterpret_cast<const wv2f*>(a + ks * 2 * WBM);
+                const float bv = b[ks * 2 * WBN];
+                ac[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv, ac[0], 0, 0, 0);
+                ac[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv, ac[1], 0, 0, 0);
+            }
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((WNB - 2) * NPD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cur = cur + 1 == WNB ? 0 : cur + 1;
+        }
+    };
+    run_class(acc[0]);
+    run_class(acc[1]);
+    run_class(acc[2]);
+    run_class(acc[3]);
+
+    // ---- epilogue: per-cout constants through LDS (every wave is past the last barrier: the ring is idle)
+    float* ep_sc = wsmem;
+    float* ep_sf = wsmem + WBM;
+    if (tid < WBM) {
+        const int m = m0 + tid;
+        ep_sc[tid] = (p.scale && m < p.Cout) ? p.scale[m] : 1.f;
+        ep_sf[tid] = (p.shift && m < p.Cout) ? p.shift[m] : 0.f;
+    }
+    __syncthreads();
+    const int n = n0 + wave * 32 + j;
+    const bool ok = n < p.Ntotal;
+    int e0, row1;
+    {
+        const int nn = ok ? n : 0;
+        const int b = p.dS.div(nn);
+        int rem = nn - b * S;
+        const int pd = p.dHW.div(rem);
+        rem -= pd * p.Nh * p.Nw;
+        const int q = p.dW.div(rem);
+        const int pw = rem - q * p.Nw;
+        e0 = b * p.y_bs + p.y_org + pd * p.y_ds + 2 * q * p.y_hs + pw;
+        row1 = 2 * q + 1 < p.Hout;
+    }
+    const int mbase = 8 * h;                             // rows of this lane: mbase + ((r & 3) + 8 (r >> 2)) * 2 + tm
+    const int mlimit = p.Cout - (m0 + mbase);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
+    const int yvo0 = (e0 + (m0 + mbase) * p.y_cs) * 4;
+    const int yvo1 = yvo0 + p.y_hs * 4;
+    const int row_bytes = p.y_cs * 4;
+    const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dm = ((r & 3) + 8 * (r >> 2)) * 2 + tm;
+            if (dm >= mlimit) continue;
+            const float sc = ep_sc[mbase + dm], sf = ep_sf[mbase + dm];
+            const float y0 = (acc[0][tm][r] + acc[1][tm][r]) + acc[2][tm][r];
+            const float y1 = (acc[1][tm][r] - acc[2][tm][r]) - acc[3][tm][r];
+            const float v0 = fmaxf(fmaf(y0, sc, sf), lo), v1 = fmaxf(fmaf(y1, sc, sf), lo);
+            const int so = dm * row_bytes;
+            if (ok) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), yrsrc, yvo0, so, 0);
+                if (row1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), yrsrc, yvo1, so, 0);
+            }
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+// p: see the kernel.  vec: 4 where Nw % 4 == 0, else 1.
+hipError_t launch_conv_wino(ConvParams p, hipStream_t stream) {
+    if (p.Cin % WBK != 0 || p.kh != 1 || p.stride != 1 || p.transposed || p.ksplit != 1 || p.head_w || p.act == ACT_SIGMOID)
+        return hipErrorInvalidValue;
+    p.m_tiles = (p.Cout + WBM - 1) / WBM;
+    p.n_tiles = (p.Ntotal + WBN - 1) / WBN;
+    const size_t lds = (size_t)WNB * WBK * (WBM + WBN) * sizeof(float);
+    const dim3 grid(p.m_tiles * p.n_tiles);
+    if (p.Nw % 4 == 0) hipLaunchKernelGGL(conv_wino_kernel<4>, grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL(conv_wino_kernel<1>, grid, dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace s3r

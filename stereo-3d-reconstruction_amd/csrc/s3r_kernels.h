@@ -98,6 +98,9 @@ struct ConvParams {
     // written that way (out_halo = 1).
     int x_wsplit, x_wh;
     int y_wsplit, y_wh;
+    // Winograd F(2,3) along H (s3r_conv_wino.hip): x = the four transformed input plane sets, x_cls elements apart; Nh = row
+    // pairs per plane; Hout = the output's true height
+    int x_cls, Hout;
 };
 
 // Tap schedule of a stride-2 k3 p1 convolution over a PARITY-SPLIT input (include/s3r.h, S3R_LAYOUT_S2D), per 32-channel
@@ -158,6 +161,10 @@ int conv_last_launch_count();     // kernel launches the calling thread's last l
 void conv_tile_dims(int tile_cfg, int* bm, int* bn);
 hipError_t launch_pack_conv(const float* w, float* wp, int Cin, int Cout, int CoutPad, int T, int transposed,
                             hipStream_t s);
+// Winograd F(2,3) along H for 3 x 3 [x 3] stride-1 pad-1 convolutions (s3r_conv_wino.hip)
+hipError_t launch_wino_input(const float* x, float* V, long long planes, int Hp, int Wp, int H2, hipStream_t s);
+hipError_t launch_pack_wino(const float* w, float* wp, int Cin, int Cout, int CoutPad, int kd, int kw, hipStream_t s);
+hipError_t launch_conv_wino(ConvParams p, hipStream_t stream);
 // y (N,32,Ho+2h,Wo+2h) <- stem conv of x (N,3,Hi,Wi); y_hs / y_cs / y_org describe the padded output.
 // Images [0, nsplit) are read from x, images [nsplit, N) from x2 (the left / right renders of a stereo batch live in
 // two tensors: no concatenation copy); nsplit = N, x2 = null: one tensor.  u8 != 0: x / x2 are 8-bit renders (N,3,Hi,Wi)

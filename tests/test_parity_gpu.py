@@ -135,7 +135,8 @@ def test_chain_plans_the_wsplit_handoff_bitwise(s3r, tmp_path):
     for flag in ("1", "0"):
         path = str(tmp_path / f"wsplit_{flag}.pt")
         r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=300, cwd=root,
-                           env=dict(os.environ, S3R_WSPLIT=flag))
+                           env=dict(os.environ, S3R_WSPLIT=flag, S3R_WINO="0"))     # (a W-split OUTPUT selects the direct kernel:
+                                                                                    #  compare like with like)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(torch.load(path))
     assert torch.equal(outs[0], outs[1])

@@ -1,0 +1,90 @@
+"""Winograd F(2,3)-along-H path of the fp32 3 x 3 [x 3] stride-1 convolutions (csrc/s3r_conv_wino.hip).  S3R_WINO: unset / 1 =
+the library's policy (v1 and v3, where it measured faster), 0 = never, 2 = every eligible layer; each setting runs in its
+own child process.  It computes the same convolution with 2/3 of the multiplications in a different summation order, so
+the bar is the oracle at the path's fp32 tolerance (north_star: 1e-4 relative; measured here ~1e-6), not bit-equality with
+the direct kernels; what must stay bitwise are the properties that do not depend on the algorithm: determinism and batch
+invariance."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+_CHILD = r'''
+import sys, json, torch
+sys.path.insert(0, %(root)r)
+import s3r
+from oracle import s2v_oracle as oracle
+dev = torch.device("cuda:0")
+spec = s3r.arch_spec
+out = {"layers": {}, "ok": True}
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+# ---- every eligible layer alone, two batch sizes, against the oracle's block
+cases = []
+for layers, n0 in ((spec.ENCODER, spec.IMG_HW), (spec.DECODER, spec.MAX_DISP)):
+    for l, n_in, _ in spec.trace(layers, n0):
+        if l.op in ("conv2d", "conv3d") and l.k == 3 and l.s == 1 and l.p == 1 and l.cin %% 16 == 0:
+            cases.append((l, n_in))
+for l, n_in in cases:
+    ch = s3r.modules._HipChain([l], n_in, precision="fp32")
+    s3r.seed_module(ch, 7)
+    blk = oracle._Block(l).eval()
+    blk.load_state_dict(getattr(ch, l.name).state_dict())
+    ch.to(dev)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((3, l.cin) + (n_in,) * spec.ndim(l), generator=g)
+    with torch.no_grad():
+        want = blk(x)
+    got = ch._run(x.to(dev))
+    again = ch._run(x.to(dev))
+    one = ch._run(x[1:2].to(dev))
+    out["layers"][l.name] = {"rel": rel_l2(got.cpu(), want), "deterministic": bool(torch.equal(got, again)),
+                             "batch_invariant": bool(torch.equal(one[0], got[1])),
+                             "launches": None}
+# ---- the whole forward against the oracle, and batch invariance of the whole forward
+m = s3r.Stereo2Voxel(); s3r.seed_module(m, 0); m.to(dev)
+ref = oracle.OracleStereo2Voxel(); ref.load_state_dict(m.state_dict()); ref.eval()
+l, r = s3r.synthetic_pairs(3, seed=71)
+with torch.no_grad():
+    want = ref(l, r)
+got = m(l.to(dev), r.to(dev)).clone()
+out["model_rel"] = rel_l2(got.cpu(), want)
+out["model_max"] = float((got.cpu() - want).abs().max())
+out["model_batch_invariant"] = bool(torch.equal(m(l[2:3].to(dev), r[2:3].to(dev))[0], got[2]))
+torch.save(got.cpu(), sys.argv[1])
+print("RESULT " + json.dumps(out))
+'''
+
+
+def _run_child(tmp_path, flag):
+    path = str(tmp_path / f"wino_{flag}.pt")
+    r = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT}, path], capture_output=True, text=True, timeout=600,
+                       cwd=ROOT, env=dict(os.environ, S3R_WINO=flag))
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    return json.loads(line[7:]), torch.load(path)
+
+
+def test_winograd_path_vs_oracle_and_invariants(tmp_path):
+    res, out2 = _run_child(tmp_path, "2")                       # every eligible layer on the Winograd kernel
+    assert set(res["layers"]) == {"e2", "e4", "e6", "e7", "v1", "v3", "v5"}
+    for name, r in res["layers"].items():
+        assert r["rel"] < 1e-5, (name, r)                       # north_star: 1e-4 relative
+        assert r["deterministic"] and r["batch_invariant"], (name, r)
+    assert res["model_rel"] < 1e-5 and res["model_max"] < 1e-4 and res["model_batch_invariant"]
+    res1, out1 = _run_child(tmp_path, "1")                      # the library's policy (the default)
+    assert res1["model_rel"] < 1e-5 and res1["model_batch_invariant"]
+    res0, out0 = _run_child(tmp_path, "0")                      # direct kernels only
+    assert res0["model_rel"] < 1e-5
+    # the switch does something: same convolution, other summation — other bits within the same bar
+    for a, b in ((out0, out1), (out0, out2), (out1, out2)):
+        assert not torch.equal(a, b)
+        assert float((a.double() - b.double()).norm() / a.double().norm()) < 1e-5

@@ -16,12 +16,17 @@ import sys
 from collections import defaultdict
 
 
-FAMILY = "conv_glds"            # conv_glds_kernel + conv_glds_dual_kernel; third argument overrides it (bf16 path: "conv_bf16", all three kernels)
+FAMILY = "conv_glds,conv_wino,wino_input"   # the fp32 conv family: conv_glds_kernel, conv_glds_dual_kernel and the Winograd pair
+                                            # (input transform + class kernel); third argument overrides it (bf16: "conv_bf16")
 
 
 def rows(path):
     with open(path) as f:
         return list(csv.DictReader(f))
+
+
+def in_family(name):
+    return any(f in name for f in FAMILY.split(","))
 
 
 def short(name):
@@ -38,14 +43,14 @@ def main():
     os.makedirs(out, exist_ok=True)
     # ---- --stats summary
     st = rows(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0])
-    fam_calls = sum(int(r["Calls"]) for r in st if FAMILY in r["Name"])
-    fam_ns = sum(int(r["TotalDurationNs"]) for r in st if FAMILY in r["Name"])
+    fam_calls = sum(int(r["Calls"]) for r in st if in_family(r["Name"]))
+    fam_ns = sum(int(r["TotalDurationNs"]) for r in st if in_family(r["Name"]))
     with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         # the dominant kernel is ONE template (conv_glds_kernel) launched 16x per step in several tile
         # instantiations: its family row is what bench.py's roofline (avg launch duration) is checked against
-        w.writerow([FAMILY + "<*> (all instantiations)", fam_calls, fam_ns, f"{fam_ns / max(fam_calls, 1):.1f}", "", "", ""])
+        w.writerow([FAMILY.split(",")[0] + "<*> (all instantiations" + (" + " + " + ".join(FAMILY.split(",")[1:]) if "," in FAMILY else "") + ")", fam_calls, fam_ns, f"{fam_ns / max(fam_calls, 1):.1f}", "", "", ""])
         for r in st:
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                         r["MinNs"], r["MaxNs"]])
@@ -80,7 +85,7 @@ def main():
             w.writerow([k, i] + [v.get(c, "") for c in names])
     # ---- traffic per forward pass; the PMC passes' forward count = number of stem_kernel dispatches
     steps = max(1, sum(1 for (k, _), v in per.items() if k.startswith("stem_") and "FETCH_SIZE" in v))
-    fam = [v for (k, _), v in per.items() if k.startswith(FAMILY)]
+    fam = [v for (k, _), v in per.items() if in_family(k)]
     launches = len(fam)
     fetch = sum(v.get("FETCH_SIZE", 0) for v in fam) * 1024
     write = sum(v.get("WRITE_SIZE", 0) for v in fam) * 1024
