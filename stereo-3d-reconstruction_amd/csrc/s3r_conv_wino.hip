@@ -30,7 +30,10 @@ typedef float wv2f __attribute__((ext_vector_type(2)));
 
 #define S3R_LDS_PTR_W(p) ((__attribute__((address_space(3))) void*)(p))
 
-constexpr int WBM = 64, WBN = 128, WBK = 16, WNB = 3;
+#ifndef S3R_WNB
+#define S3R_WNB 3
+#endif
+constexpr int WBM = 64, WBN = 128, WBK = 16, WNB = S3R_WNB;
 
 template <int BYTES>
 __device__ __forceinline__ void wdma(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, int voffset, int soffset) {
