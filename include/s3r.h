@@ -79,7 +79,12 @@ typedef enum s3r_act { S3R_ACT_NONE = 0, S3R_ACT_RELU = 1, S3R_ACT_SIGMOID = 2 }
  *                     (16-byte LDS-DMA where the output width is a multiple of 4) instead of every other dword.  Planned
  *                     by s3r_chain_forward between a convolution and its stride-2 consumer; the K order does not change,
  *                     so results are bit-identical to the plain layout. */
-typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_S2D = 1 } s3r_layout;
+/*   S3R_LAYOUT_WINO_H  fp32 path, INPUT of a 3 x 3 [x 3] stride-1 pad-1 convolution only, even edge n, in_halo 1: the four
+ *                      Winograd F(2,3)-along-H plane sets of the halo-padded tensor, (4, B, C, [n+2,] n/2, n+2) — set i, row q
+ *                      = r(2q) - r(2q+2), r(2q+1) + r(2q+2), r(2q+2) - r(2q+1), r(2q+1) - r(2q+3) of the padded rows r.  What
+ *                      s3r_cost_volume_forward_wino writes: the consumer then skips its input transform.  The batch of such a
+ *                      call is bounded: s3r_conv_wino_input_elems returns 0 when the layer / batch cannot take it. */
+typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_S2D = 1, S3R_LAYOUT_WINO_H = 2 } s3r_layout;
 
 /* One layer's geometry.  Spatial sizes are cubic/square: `in_size` per axis, `ndim` axes.
  *
@@ -179,6 +184,15 @@ int s3r_channels_last_to_f32(const void* x, float* y, int batch, int channels, i
  * `out_halo` > 0 writes the interior of a (B,2C,D+2h,H+2h,W+2h) buffer whose halo the caller zeroed. */
 int s3r_cost_volume_forward(const float* feat_left, const float* feat_right, float* volume, int batch, int channels,
                             int max_disp, int height, int width, int out_halo, void* stream);
+
+/* The volume written directly as the S3R_LAYOUT_WINO_H input of the 3D convolution that consumes it (halo 1):
+ * (4, B, 2C, D+2, H/2, W+2) floats, bit-identical to the input transform of the padded volume; the caller zeroed the buffer
+ * once (the depth-halo planes are never written).  height even. */
+int s3r_cost_volume_forward_wino(const float* feat_left, const float* feat_right, float* planes, int batch, int channels,
+                                 int max_disp, int height, int width, void* stream);
+/* floats of the S3R_LAYOUT_WINO_H input of layer `d` (in_halo = 1) if a forward of it would run the Winograd kernel under the
+ * library's current policy (S3R_WINO) and the batch fits one call; 0 otherwise (hand the layer its plain input then). */
+int64_t s3r_conv_wino_input_elems(const s3r_conv_desc* d);
 
 /* the same on channels-last bf16 features (B,H,W,C) -> volume (B,D+2h,H+2h,W+2h,2C); channels % 8 == 0 */
 int s3r_cost_volume_forward_bf16(const void* feat_left, const void* feat_right, void* volume, int batch, int channels,

@@ -109,7 +109,7 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
     if (d->in_halo < 0 || d->out_halo < 0 || d->in_halo > 8 || d->out_halo > 8)
         return fail(S3R_ERR_INVALID, "halo must be in [0, 8]");
     if (d->dtype != S3R_F32 && d->dtype != S3R_BF16) return fail(S3R_ERR_INVALID, "unknown dtype %d", d->dtype);
-    if ((d->in_layout != S3R_LAYOUT_PLAIN && d->in_layout != S3R_LAYOUT_S2D) ||
+    if ((d->in_layout != S3R_LAYOUT_PLAIN && d->in_layout != S3R_LAYOUT_S2D && d->in_layout != S3R_LAYOUT_WINO_H) ||
         (d->out_layout != S3R_LAYOUT_PLAIN && d->out_layout != S3R_LAYOUT_S2D))
         return fail(S3R_ERR_INVALID, "unknown layout");
     if ((d->in_layout || d->out_layout) && d->op == S3R_OP_LINEAR)
@@ -141,6 +141,12 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
     g->out_sp = ipow(g->out, g->nd);
     g->x_elems = (int64_t)d->batch * d->cin * ipow(g->in_p, g->nd);
     g->y_elems = (int64_t)d->batch * d->cout * ipow(g->out_p, g->nd);
+    if (d->in_layout == S3R_LAYOUT_WINO_H) {     // the four F(2,3)-along-H plane sets a 3 x 3 [x 3] stride-1 pad-1 convolution reads
+        if (d->dtype != S3R_F32 || d->op != S3R_OP_CONV || d->stride != 1 || d->k != 3 || d->pad != 1 || (g->in & 1) || d->in_halo != 1 ||
+            d->cin % 16 != 0 || d->cout <= 1)
+            return fail(S3R_ERR_INVALID, "a Winograd-transformed input serves an fp32 Conv k=3 s=1 p=1 over an even edge, in_halo = 1");
+        g->x_elems = 4 * (int64_t)d->batch * d->cin * (g->nd == 3 ? g->in_p : 1) * (g->in / 2) * g->in_p;
+    }
     if (d->in_layout == S3R_LAYOUT_S2D) {        // what a stride-2 k3 p1 convolution reads
         if (d->op != S3R_OP_CONV || d->stride != 2 || d->k != 3 || d->pad != 1 || (g->in & 1) || d->in_halo != 1)
             return fail(S3R_ERR_INVALID, "a parity-split input serves Conv k=3 s=2 p=1 over an even edge, in_halo = 1");
@@ -682,6 +688,7 @@ int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d) {
     Launch L;
     if ((rc = resolve_launch(d, &p, &L))) return rc;
     const int64_t direct = s3r::conv_scratch_elems(p, L.cfg);
+    if (d->in_layout == S3R_LAYOUT_WINO_H) return 0;
     const int64_t wino = wino_ok(d) ? wino_need(d) : 0;         // (a caller that offers less gets the direct kernel)
     return wino > direct ? wino : direct;
 }
@@ -791,6 +798,30 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
             p.x = x; p.w = packed_w; p.scale = scale; p.shift = shift; p.y = y;
             // Winograd F(2,3) along H.  The transformed input must stay inside 32-bit byte offsets: larger batches go through in
             // sub-batches (a sample's result does not depend on the batch it is computed in, so neither does it on this split)
+            if (d->in_layout == S3R_LAYOUT_WINO_H) {      // the producer wrote the transformed planes: the class kernel alone
+                if (!wino_layer(d) || d->act == S3R_ACT_SIGMOID || d->out_layout != S3R_LAYOUT_PLAIN || d->tile >= 0 || d->ksplit > 1 ||
+                    wino_bmax(d) < d->batch)
+                    return fail(S3R_ERR_INVALID, "a Winograd-transformed input runs the Winograd kernel only: no tile / split-K "
+                                "override, a plain output, at most %d samples per call here (s3r_conv_wino_input_elems)", wino_bmax(d));
+                const int is3 = d->ndim == 3, n = d->in_size, wp = n + 2, h2 = n / 2, dp = is3 ? n + 2 : 1;
+                ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
+                p.w = packed_w + ipow(3, g.nd) * d->cin * cout_pad(d->cout);
+                p.Nh = h2; p.kh = 1; p.T = p.kd * p.kw;
+                p.x_hs = wp; p.x_ds = is3 ? h2 * wp : 0; p.x_cs = dp * h2 * wp;
+                p.x_cls = d->batch * d->cin * p.x_cs;
+                p.x_org = 0;
+                p.x_bytes = (unsigned)(4 * g.x_elems);
+                p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
+                p.n_begin = 0; p.n_end = p.Ntotal;
+                p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
+                p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
+                p.dW = s3r::FastDiv((unsigned)p.Nw);
+                p.Hout = n;
+                p.ksplit = 1;
+                e = s3r::launch_conv_wino(p, s);
+                if (e != hipSuccess) return hip_fail(e, "Winograd conv launch");
+                return S3R_OK;
+            }
             if (wino_ok(d) && scratch && scratch_elems >= wino_need(d) && wino_need(d) > 0) {
                 const int is3 = d->ndim == 3, n = d->in_size, wp = n + 2, h2 = (n + 1) / 2, dp = is3 ? n + 2 : 1;
                 const int64_t v_sample = wino_v_elems(d) / d->batch, x_sample = g.x_elems / d->batch;
@@ -996,6 +1027,32 @@ int s3r_cost_volume_forward(const float* fl, const float* fr, float* vol, int ba
     hipError_t e = s3r::launch_cost_volume(fl, fr, vol, batch, channels, max_disp, height, width, out_halo, s);
     if (e != hipSuccess) return hip_fail(e, "cost volume launch");
     return S3R_OK;
+}
+
+int s3r_cost_volume_forward_wino(const float* fl, const float* fr, float* planes, int batch, int channels, int max_disp,
+                                 int height, int width, void* stream) {
+    if (!fl || !fr || !planes) return fail(S3R_ERR_INVALID, "null tensor pointer");
+    if (batch <= 0 || channels <= 0 || max_disp <= 0 || height < 4 || width <= 0 || (height & 1))
+        return fail(S3R_ERR_INVALID, "bad cost-volume shape for the Winograd layout (even height >= 4)");
+    if (max_disp > width) return fail(S3R_ERR_INVALID, "max_disp %d exceeds the feature width %d", max_disp, width);
+    if ((size_t)2 * height * width * sizeof(float) > 64 * 1024)
+        return fail(S3R_ERR_INVALID, "feature plane %dx%d does not fit the kernel's 64 KiB of LDS", height, width);
+    const int64_t elems = 4 * (int64_t)batch * 2 * channels * (max_disp + 2) * (height / 2) * (width + 2);
+    if (elems * 4 >= ((int64_t)1 << 31)) return fail(S3R_ERR_INVALID, "Winograd planes of %lld floats exceed 2 GiB: split the batch", (long long)elems);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(s, F_COSTVOL, 0, 2.0 * batch * channels * (double)max_disp * height * width,
+                 4.0 * batch * channels * (2.0 * height * width) + 4.0 * (double)elems);
+    hipError_t e = s3r::launch_cost_volume_wino(fl, fr, planes, batch, channels, max_disp, height, width, s);
+    if (e != hipSuccess) return hip_fail(e, "cost volume (Winograd layout) launch");
+    return S3R_OK;
+}
+
+int64_t s3r_conv_wino_input_elems(const s3r_conv_desc* d) {
+    if (!d) return fail(S3R_ERR_INVALID, "null descriptor");
+    s3r_conv_desc t = *d;
+    t.in_layout = S3R_LAYOUT_PLAIN;
+    if (!wino_ok(&t) || (t.in_size & 1) || wino_bmax(&t) < t.batch) return 0;
+    return wino_v_elems(&t);
 }
 
 int s3r_cost_volume_forward_bf16(const void* fl, const void* fr, void* vol, int batch, int channels, int max_disp,

@@ -174,6 +174,8 @@ hipError_t launch_stem(const void* x, const void* x2, int u8, int nsplit, const 
                        hipStream_t s);
 hipError_t launch_cost_volume(const float* fl, const float* fr, float* vol, int B, int C, int D, int H, int W,
                               int halo, hipStream_t s);
+// the same volume written as the Winograd F(2,3)-along-H plane sets of its halo-1 padded form: V[4][B][2C][D+2][H/2][W+2]
+hipError_t launch_cost_volume_wino(const float* fl, const float* fr, float* V, int B, int C, int D, int H, int W, hipStream_t s);
 hipError_t launch_pad_copy(const float* x, float* y, int64_t planes, int D, int H, int W, int hd, int hh, int hw,
                            hipStream_t s);
 hipError_t launch_pack_stem(const float* w, float* wt, hipStream_t s);

@@ -243,6 +243,17 @@ class _HipChain(nn.Module):
             arr[i].shift = shift.data_ptr() if shift is not None else None
         return arr, n_layers
 
+    def takes_wino_input(self, batch: int) -> bool:
+        """Would the chain's first layer run the Winograd kernel on a halo-1 input of this batch (library policy: S3R_WINO)?
+        Then its producer may write the transformed planes directly (CostVolume.forward_wino, S3R_LAYOUT_WINO_H)."""
+        if self.precision != "fp32" or batch <= 0:
+            return False
+        l, (n_in, _) = self._layers[0], self._sizes()[0]
+        tile = int(os.environ.get(f"S3R_TILE_{l.name}", self.tile_override.get(l.name, -1)))
+        ksplit = int(os.environ.get(f"S3R_KSPLIT_{l.name}", self.ksplit_override.get(l.name, 0)))
+        desc = _lib.make_desc(l, batch, n_in, tile=tile, in_halo=1, ksplit=ksplit, dtype=self._dtype)
+        return _lib.load().s3r_conv_wino_input_elems(C.byref(desc)) > 0
+
     def _out_shape(self, batch: int, n_layers: int):
         l = self._layers[n_layers - 1]
         m = self._sizes()[n_layers - 1][1]
@@ -261,6 +272,8 @@ class _HipChain(nn.Module):
         x2 (encoder only): a second tensor of as many images — the chain runs over x's images, then x2's."""
         lib = _lib.load()
         device, batch = x.device, x.shape[0] + (x2.shape[0] if x2 is not None else 0)
+        if in_layout == _lib.LAYOUT_WINO_H:                 # (4, B, C, ...): the four transformed plane sets of the padded input
+            batch = x.shape[1]
         if batch == 0:                 # same dtype / layout contract as a non-empty batch
             n0 = len(self._layers) if upto is None else self.names.index(upto) + 1
             shape = self._out_shape(0, n0)
@@ -398,6 +411,7 @@ class CostVolume(nn.Module):
         self.max_disp = max_disp
         self.precision = precision
         self._padded: Optional[torch.Tensor] = None      # resident halo-padded volume (internal hand-off)
+        self._planes: Optional[torch.Tensor] = None      # ... or its Winograd-transformed planes (forward_wino)
 
     def _bf16(self, feat_left, feat_right, halo, resident):
         """bf16 path: logical (B,C,H,W) channels_last features -> physical (B,D+2h,H+2h,W+2h,2C) volume."""
@@ -445,6 +459,23 @@ class CostVolume(nn.Module):
         return self._padded
 
     @torch.no_grad()
+    def forward_wino(self, feat_left: torch.Tensor, feat_right: torch.Tensor) -> torch.Tensor:
+        """fp32 internal hand-off to a decoder whose first 3D conv runs the Winograd kernel (`takes_wino_input`): the volume
+        written directly as the four F(2,3)-along-H plane sets of its halo-1 padded form, (4,B,2C,D+2,H/2,W+2) — bit-identical
+        to the consumer's own input transform, without the volume's round trip through HBM."""
+        fl = _check_input(feat_left, "feat_left", feat_left.shape[1:])
+        fr = _check_input(feat_right, "feat_right", feat_left.shape[1:])
+        B, Cc, H, W = fl.shape
+        shape = (4, B, 2 * Cc, self.max_disp + 2, H // 2, W + 2)
+        if self._planes is None or tuple(self._planes.shape) != shape or self._planes.device != fl.device:
+            if getattr(self, "_pinned", False):
+                raise RuntimeError("the padded cost volume of this module is captured in a HIP graph for another shape")
+            self._planes = torch.zeros(shape, dtype=torch.float32, device=fl.device)
+        _lib.check(_lib.load().s3r_cost_volume_forward_wino(fl.data_ptr(), fr.data_ptr(), self._planes.data_ptr(), B, Cc,
+                                                            self.max_disp, H, W, _stream_ptr(fl.device)), "cost_volume (wino)")
+        return self._planes
+
+    @torch.no_grad()
     def forward(self, feat_left: torch.Tensor, feat_right: torch.Tensor) -> torch.Tensor:
         if self.precision == "bf16":      # logical (B,2C,D,H,W) view of the channels-last volume
             return _to_logical(self._bf16(feat_left, feat_right, 0, resident=False))
@@ -460,6 +491,14 @@ class CostVolume(nn.Module):
         _lib.check(_lib.load().s3r_cost_volume_forward(fl.data_ptr(), fr.data_ptr(), vol.data_ptr(), B, Cc,
                                                        self.max_disp, H, W, 0, _stream_ptr(fl.device)), "cost_volume")
         return vol
+
+
+def _check_wino_planes(v: torch.Tensor) -> torch.Tensor:
+    want = (2 * spec.FEAT_C, spec.MAX_DISP + 2, spec.FEAT_HW // 2, spec.FEAT_HW + 2)
+    if not isinstance(v, torch.Tensor) or not v.is_cuda or v.dtype != torch.float32 or v.dim() != 6 or v.shape[0] != 4 or \
+            tuple(v.shape[2:]) != want or not v.is_contiguous():
+        raise RuntimeError(f"transformed volume must be a contiguous float32 HIP tensor (4, B, {', '.join(map(str, want))})")
+    return v
 
 
 class Decoder(_HipChain):
@@ -478,8 +517,11 @@ class Decoder(_HipChain):
         y = self._run(x, upto)
         return y.squeeze(1) if upto is None or upto == self.names[-1] else y
 
-    def forward_padded(self, volume_padded: torch.Tensor, halo: int = 1) -> torch.Tensor:
-        """Decoder on the halo-padded volume CostVolume.forward_padded produced (no pad copy)."""
+    def forward_padded(self, volume_padded: torch.Tensor, halo: int = 1, in_layout: int = 0) -> torch.Tensor:
+        """Decoder on the halo-padded volume CostVolume.forward_padded produced (no pad copy), or (in_layout =
+        LAYOUT_WINO_H) on the transformed planes CostVolume.forward_wino produced."""
+        if in_layout == _lib.LAYOUT_WINO_H:
+            return self._run(_check_wino_planes(volume_padded), None, in_halo=1, in_layout=in_layout).squeeze(1)
         n = (spec.MAX_DISP + 2 * halo, spec.FEAT_HW + 2 * halo, spec.FEAT_HW + 2 * halo)
         if self.precision == "bf16":
             x = _check_input(volume_padded, "volume_padded", n + (2 * spec.FEAT_C,), torch.bfloat16)
@@ -501,7 +543,9 @@ class VolumeEncoder(_HipChain):
             return self._run(_check_input_cl(volume, "volume", tail))
         return self._run(_check_input(volume, "volume", tail))
 
-    def forward_padded(self, volume_padded: torch.Tensor, halo: int = 1) -> torch.Tensor:
+    def forward_padded(self, volume_padded: torch.Tensor, halo: int = 1, in_layout: int = 0) -> torch.Tensor:
+        if in_layout == _lib.LAYOUT_WINO_H:
+            return self._run(_check_wino_planes(volume_padded), None, in_halo=1, in_layout=in_layout)
         n = (spec.MAX_DISP + 2 * halo, spec.FEAT_HW + 2 * halo, spec.FEAT_HW + 2 * halo)
         if self.precision == "bf16":            # physical (B,D+2h,H+2h,W+2h,2C) bf16 -> logical (B,512,4,4,4) bf16
             x = _check_input(volume_padded, "volume_padded", n + (2 * spec.FEAT_C,), torch.bfloat16)
@@ -580,6 +624,10 @@ class Stereo2Voxel(_DisparityMixin, nn.Module):
             l, r = left[s:s + MAX_CHUNK], right[s:s + MAX_CHUNK]
             b = l.shape[0]
             feats = self.encoder.forward_pair(l, r)          # (2b,32,28,28): left batch, then right batch
+            if self.decoder.takes_wino_input(b):             # v1 on the Winograd kernel: the volume goes over transformed
+                vol = self.cost_volume.forward_wino(feats[:b], feats[b:])
+                outs.append(self.decoder.forward_padded(vol, in_layout=_lib.LAYOUT_WINO_H))
+                continue
             vol = self.cost_volume.forward_padded(feats[:b], feats[b:])
             outs.append(self.decoder.forward_padded(vol))
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
@@ -628,8 +676,11 @@ class Stereo2Point(_DisparityMixin, nn.Module):
             l, r = left[s:s + MAX_CHUNK], right[s:s + MAX_CHUNK]
             b = l.shape[0]
             feats = self.encoder.forward_pair(l, r)
-            vol = self.cost_volume.forward_padded(feats[:b], feats[b:])
-            latent = self.decoder.forward_padded(vol)
+            if self.decoder.takes_wino_input(b):
+                latent = self.decoder.forward_padded(self.cost_volume.forward_wino(feats[:b], feats[b:]),
+                                                     in_layout=_lib.LAYOUT_WINO_H)
+            else:
+                latent = self.decoder.forward_padded(self.cost_volume.forward_padded(feats[:b], feats[b:]))
             if latent.dtype != torch.float32:                      # bf16 channels-last view -> fp32 (B,512,4,4,4): HIP kernel
                 latent = channels_last_to_f32(latent)
             outs.append(self.point_head(latent))
