@@ -216,6 +216,9 @@ int cout_pad(int cout) { return (cout + 127) / 128 * 128; }
 //   S3R_WINO unset / 1: the layers it measured faster on (3D, >= 14 rows: v1, v3 — DESIGN.md §4.1);  0: never;  2: every
 //   eligible layer (experiments).  A call with a tile / split-K override, a non-plain layout, no halo or too little
 //   scratch runs the direct kernel.
+#ifndef S3R_DWINO_MIN_EDGE
+#define S3R_DWINO_MIN_EDGE 8      // library policy: transposed layers with an input edge >= this (d2, d3)
+#endif
 int wino_mode() {
     const char* e = getenv("S3R_WINO");                  // (read per call: the A/B tools flip it in-process)
     return e ? atoi(e) : 1;
@@ -249,6 +252,42 @@ int wino_bmax(const s3r_conv_desc* d) {
 }
 int64_t wino_need(const s3r_conv_desc* d) {
     return d->batch > 0 ? wino_v_elems(d) / d->batch * wino_bmax(d) : 0;
+}
+
+// The transposed convolutions (k4 s2 p1): Winograd F(2,2) along H inside each output-parity class — 3/4 of the matrix work
+// (s3r_conv_wino.hip).  Same scheme: both weight forms packed (direct: 8 classes x 8 taps; then 24 (class, F) slabs x 4
+// taps), kernel chosen per call; the transformed input is the padded input plus its row differences (scratch: one more
+// tensor of the input's size).
+bool dwino_layer(const s3r_conv_desc* d) {
+    return d->dtype != S3R_BF16 && d->op == S3R_OP_DECONV && d->ndim == 3 && d->k == 4 && d->stride == 2 && d->pad == 1 &&
+           d->cin % 16 == 0 && d->in_size >= 2 && (d->in_size & 1) == 0;
+}
+bool dwino_ok(const s3r_conv_desc* d) {
+    const int mode = wino_mode();
+    if (mode <= 0 || !dwino_layer(d) || d->act == S3R_ACT_SIGMOID) return false;
+    if (mode == 1 && d->in_size < S3R_DWINO_MIN_EDGE) return false;
+    return d->in_halo == 1 && d->in_layout == S3R_LAYOUT_PLAIN && d->out_layout == S3R_LAYOUT_PLAIN && d->tile < 0 && d->ksplit <= 1;
+}
+int64_t dwino_w_elems(const s3r_conv_desc* d) { return 24 * 4 * (int64_t)d->cin * cout_pad(d->cout); }
+int64_t dwino_d_elems(const s3r_conv_desc* d) { return (int64_t)d->batch * d->cin * ipow(d->in_size + 2, 3); }
+// fills the transposed-convolution parameters for the Winograd kernel and runs transform + kernel
+int dwino_run(const s3r_conv_desc* d, s3r::ConvParams p, const float* x, const float* packed_w, float* scratch, hipStream_t s) {
+    const int n = d->in_size;
+    hipError_t e = s3r::launch_wino_rowdiff(x, scratch, (long long)d->batch * d->cin * (n + 2), n + 2, n + 2, s);
+    if (e != hipSuccess) return hip_fail(e, "Winograd row-difference launch");
+    p.x = x;
+    p.part = scratch;
+    p.w = packed_w + 64 * (int64_t)d->cin * cout_pad(d->cout);          // behind the direct slab (8 classes x 8 taps)
+    p.Nh = n / 2;
+    p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
+    p.n_begin = 0; p.n_end = p.Ntotal;
+    p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
+    p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
+    p.dW = s3r::FastDiv((unsigned)p.Nw);
+    p.ksplit = 1;
+    e = s3r::launch_deconv_wino(p, s);
+    if (e != hipSuccess) return hip_fail(e, "Winograd transposed-conv launch");
+    return S3R_OK;
 }
 int cout_pad_h(int cout) { return (cout + 63) / 64 * 64; }
 
@@ -554,7 +593,7 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
 
 // MFMA conv with the following 1x1 single-channel head folded into its epilogue (plan_chain decides)
 int conv_head_fused(const s3r_conv_desc* d, const Geo& g, const s3r_conv_desc* hd, const Geo& hg, const float* x,
-                    const s3r_layer& L, const s3r_layer& H, float* out, hipStream_t s) {
+                    const s3r_layer& L, const s3r_layer& H, float* out, float* scratch, int64_t scratch_elems, hipStream_t s) {
     s3r::ConvParams p = make_params(d, g);
     p.x = x; p.w = static_cast<const float*>(L.packed_w); p.scale = L.scale; p.shift = L.shift; p.y = out;
     // y_* now describe the head's (B, 1, n[, n], n) output
@@ -564,6 +603,12 @@ int conv_head_fused(const s3r_conv_desc* d, const Geo& g, const s3r_conv_desc* h
     p.y_org = hd->out_halo * (p.y_ds + p.y_hs + 1);
     p.y_bytes = (unsigned)(hg.y_elems * 4);
     p.head_w = static_cast<const float*>(H.packed_w); p.head_scale = H.scale; p.head_shift = H.shift; p.head_act = hd->act;
+    if (dwino_ok(d) && d->cout <= 64 && scratch && scratch_elems >= dwino_d_elems(d)) {
+        ProfScope ps(s, F_MFMA, d->tag, g.flops + hg.flops, g.bytes - 4.0 * d->batch * d->cout * (double)g.out_sp +
+                     4.0 * d->batch * (double)hg.out_sp);
+        ps.launches = 2;
+        return dwino_run(d, p, x, static_cast<const float*>(L.packed_w), scratch, s);
+    }
     Launch Ln;
     int rc = resolve_launch(d, &p, &Ln);
     if (rc) return rc;
@@ -633,7 +678,7 @@ int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems) {
         case R_MFMA: {
             const int64_t taps = d->op == S3R_OP_DECONV ? 64 : ipow(d->k, g.nd);
             if (d->dtype == S3R_BF16) *elems = (taps * d->cin * cout_pad_h(d->cout) + 1) / 2;   // bf16, in float units
-            else *elems = taps * d->cin * cout_pad(d->cout) + (wino_layer(d) ? wino_w_elems(d) : 0);
+            else *elems = taps * d->cin * cout_pad(d->cout) + (wino_layer(d) ? wino_w_elems(d) : 0) + (dwino_layer(d) ? dwino_w_elems(d) : 0);
             break;
         }
     }
@@ -664,6 +709,8 @@ int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, void* packedv,
                 if (e == hipSuccess && wino_layer(d))
                     e = s3r::launch_pack_wino(w, packed + ipow(d->k, g.nd) * d->cin * cout_pad(d->cout), d->cin, d->cout,
                                               cout_pad(d->cout), g.nd == 3 ? 3 : 1, 3, s);
+                if (e == hipSuccess && dwino_layer(d))
+                    e = s3r::launch_pack_wino_deconv(w, packed + 64 * (int64_t)d->cin * cout_pad(d->cout), d->cin, d->cout, cout_pad(d->cout), s);
             }
             break;
     }
@@ -689,7 +736,7 @@ int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d) {
     if ((rc = resolve_launch(d, &p, &L))) return rc;
     const int64_t direct = s3r::conv_scratch_elems(p, L.cfg);
     if (d->in_layout == S3R_LAYOUT_WINO_H) return 0;
-    const int64_t wino = wino_ok(d) ? wino_need(d) : 0;         // (a caller that offers less gets the direct kernel)
+    const int64_t wino = wino_ok(d) ? wino_need(d) : (dwino_ok(d) ? dwino_d_elems(d) : 0);   // (a caller that offers less gets the direct kernel)
     return wino > direct ? wino : direct;
 }
 
@@ -798,6 +845,11 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
             p.x = x; p.w = packed_w; p.scale = scale; p.shift = shift; p.y = y;
             // Winograd F(2,3) along H.  The transformed input must stay inside 32-bit byte offsets: larger batches go through in
             // sub-batches (a sample's result does not depend on the batch it is computed in, so neither does it on this split)
+            if (dwino_ok(d) && scratch && scratch_elems >= dwino_d_elems(d)) {
+                ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
+                ps.launches = 2;
+                return dwino_run(d, p, x, packed_w, scratch, s);
+            }
             if (d->in_layout == S3R_LAYOUT_WINO_H) {      // the producer wrote the transformed planes: the class kernel alone
                 if (!wino_layer(d) || d->act == S3R_ACT_SIGMOID || d->out_layout != S3R_LAYOUT_PLAIN || d->tile >= 0 || d->ksplit > 1 ||
                     wino_bmax(d) < d->batch)
@@ -943,7 +995,7 @@ int chain_forward_impl(const s3r_layer* layers, int n_layers, const void* x, con
                 rc = conv_head_fused_h(&pl.d[i], pl.g[i], &pl.d[i + 1], pl.g[i + 1], cur, L, H, static_cast<float*>(out), s);
             else
                 rc = conv_head_fused(&pl.d[i], pl.g[i], &pl.d[i + 1], pl.g[i + 1], static_cast<const float*>(cur), L, H,
-                                     static_cast<float*>(out), s);
+                                     static_cast<float*>(out), pl.scratch_elems ? ws + pl.scratch_off : nullptr, pl.scratch_elems, s);
             if (rc) return rc;
             cur = out;
             ++i;

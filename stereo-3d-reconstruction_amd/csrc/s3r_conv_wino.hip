@@ -284,4 +284,291 @@ hipError_t launch_conv_wino(ConvParams p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+
+// ================================================================================================
+// ConvTranspose3d(k = 4, s = 2, p = 1) with fewer multiplications: Winograd F(2, 2) along H inside every output-parity
+// class.  A class (rd, rh, rw) is a 2 x 2 x 2-tap convolution over the input grid (s3r_conv_glds.hip); two of its outputs
+// that are neighbours along H — input rows ph = 2q and 2q + 1, i.e. output rows 4q + rh and 4q + 2 + rh — read the
+// padded input rows x0, x1, x2 = R, R + 1, R + 2 (R = 2q + rh) through the two H taps g0, g1:
+//     y(2q)     = x0 g0 + x1 g1 = m1 + m2        m1 = (x0 - x1) g0
+//     y(2q + 1) = x1 g0 + x2 g1 = m2 - m3        m2 = x1 (g0 + g1)        m3 = (x1 - x2) g1
+// — three products instead of four: 3/4 of the matrix work.  The transformed input is the padded input itself plus ONE
+// tensor of row differences D[r] = x[r] - x[r + 1] (wino_rowdiff_kernel: the input of a transposed convolution is small),
+// the transformed weights are g0, g0 + g1, g1 per (class, depth tap, column tap).  The kernel is conv_wino_kernel's shape:
+// positions (b, pd, q, pw) over the input grid, 64 couts x 128 positions per workgroup, three F-classes x 2 MFMA tiles of
+// accumulators per wave, the eight parity classes of a tile back to back on one XCD; HEAD = the fused 1 x 1 x 1 head (d3 -> d4).
+__global__ __launch_bounds__(256) void wino_rowdiff_kernel(const float* __restrict__ x, float* __restrict__ D, long long rows,
+                                                           int Hp, int Wp) {
+    const long long total = rows * Wp;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long row = i / Wp;
+        const int r = (int)(row % Hp);
+        D[i] = (r + 1 < Hp) ? x[i] - x[i + Wp] : 0.f;
+    }
+}
+
+hipError_t launch_wino_rowdiff(const float* x, float* D, long long planes, int Hp, int Wp, hipStream_t s) {
+    const long long total = planes * Hp * Wp;
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(wino_rowdiff_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, x, D, planes * Hp, Hp, Wp);
+    return hipGetLastError();
+}
+
+// w[Cin][Cout][4][4][4] -> Up[pc = 8][f = 3][(chunk*4 + (td*2 + tw))*16 + c][CoutPad]
+__global__ void pack_wino_deconv_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int CoutPad) {
+    const size_t per_f = (size_t)4 * Cin * CoutPad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < 24 * per_f; i += (size_t)gridDim.x * blockDim.x) {
+        const int pf = (int)(i / per_f);
+        const int pc = pf / 3, f = pf - pc * 3;
+        size_t r = i % per_f;
+        const int co = (int)(r % CoutPad);
+        r /= CoutPad;
+        const int c = (int)(r & 15);
+        r >>= 4;
+        const int tap = (int)(r & 3);
+        const int cc = (int)(r >> 2);
+        const int cin = cc * 16 + c;
+        float v = 0.f;
+        if (co < Cout) {
+            const int rd = (pc >> 2) & 1, rh = (pc >> 1) & 1, rw = pc & 1;
+            const int td = tap >> 1, tw = tap & 1;
+            const int kd = 3 - rd - 2 * td, kw = 3 - rw - 2 * tw;
+            const float* g = w + ((size_t)cin * Cout + co) * 64 + kd * 16 + kw;
+            const float g0 = g[(3 - rh) * 4], g1 = g[(1 - rh) * 4];          // H taps th = 0, 1: kernel rows 3 - rh, 1 - rh
+            v = f == 0 ? g0 : f == 1 ? g0 + g1 : g1;
+        }
+        wp[i] = v;
+    }
+}
+
+hipError_t launch_pack_wino_deconv(const float* w, float* wp, int Cin, int Cout, int CoutPad, hipStream_t s) {
+    hipLaunchKernelGGL(pack_wino_deconv_kernel, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CoutPad);
+    return hipGetLastError();
+}
+
+// p: the layer's transposed-convolution parameters (make_params) with Nh = row pairs (n / 2), p.x = the padded input,
+// p.part = its row differences (same shape and strides), p.w = the 24 (class, F) slabs.
+template <int VEC, bool HEAD>
+__global__ __launch_bounds__(256, 2) void deconv_wino_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wsmem[];
+    float* As = wsmem;
+    float* Bs = wsmem + WNB * WBK * WBM;
+    constexpr int PB = 64 * VEC;
+    constexpr int NPIECE_B = WBK * WBN / PB;
+    constexpr int NPB = NPIECE_B / 4;
+    constexpr bool B_WIDE = WBN >= PB;
+    constexpr int PPR = B_WIDE ? WBN / PB : 1;
+    constexpr int RPP = B_WIDE ? 1 : PB / WBN;
+    constexpr int LPR_B = WBN / VEC;
+    constexpr int NPD = 1 + NPB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    int bid, pc;
+    {   // an XCD walks its run of tiles with the 8 parity classes of a tile back to back (they read the same input tile)
+        const int nwg = gridDim.x >> 3;
+        const int item = ((int)blockIdx.x & 7) * nwg + ((int)blockIdx.x >> 3);
+        bid = item >> 3;
+        pc = item & 7;
+    }
+    const int rd = (pc >> 2) & 1, rh = (pc >> 1) & 1, rw = pc & 1;
+    const int m_tile = bid % p.m_tiles, n_tile = bid / p.m_tiles;
+    const int m0 = m_tile * WBM, n0 = n_tile * WBN;
+    const int S = p.Nd * p.Nh * p.Nw;
+    const int chunks = p.Cin / WBK;
+    const int nkt = 4 * chunks;                          // K tiles per F-class: (depth tap, column tap) x chunks
+    const int total = 3 * nkt;
+
+    int bvoff;
+    {
+        int col, lrow;
+        if (B_WIDE) { col = (wave % PPR) * PB + lane * VEC; lrow = 0; }
+        else        { col = (lane % LPR_B) * VEC;           lrow = lane / LPR_B; }
+        int n = n0 + col;
+        if (n >= p.Ntotal) n = p.Ntotal - VEC;
+        const int b = p.dS.div(n);
+        int rem = n - b * S;
+        const int pd = p.dHW.div(rem);
+        rem -= pd * p.Nh * p.Nw;
+        const int q = p.dW.div(rem);
+        const int pw = rem - q * p.Nw;
+        // padded indices: depth pd + rd + td, row 2q + rh (+ 1), column pw + rw + tw
+        bvoff = (b * p.Cin * p.x_cs + (pd + rd) * p.x_ds + (2 * q + rh) * p.x_hs + pw + rw + lrow * p.x_cs) * 4;
+    }
+    const int avoff = ((lane >> 4) * p.CoutPad + (lane & 15) * 4) * 4;
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.part), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w), 0, (int)(24u * 4u * (unsigned)p.Cin * (unsigned)p.CoutPad * 4u), 0x00020000);
+    const int b_row0 = B_WIDE ? wave / PPR : wave * RPP;
+    constexpr int B_ROW_STEP = B_WIDE ? 4 / PPR : 4 * RPP;
+    const int b_lds0 = B_WIDE ? b_row0 * WBN + (wave % PPR) * PB : wave * PB;
+    constexpr int B_LDS_STEP = B_WIDE ? B_ROW_STEP * WBN : 4 * PB;
+    const int cs4 = p.x_cs * 4;
+
+    int c_f = 0, c_cc = 0, c_tap = 0, c_kt = pc * total;               // cursor of the NEXT K tile to fetch (scalar)
+    auto issue = [&](int buf) {
+        wdma<16>(wrsrc, As + buf * WBK * WBM + wave * 256, avoff, (c_kt * WBK * p.CoutPad + m0) * 4 + wave * 4 * p.CoutPad * 4);
+        float* sb = Bs + buf * WBK * WBN + b_lds0;
+        // F-class 0: D at row R, 1: X at row R + 1, 2: D at row R + 1
+        const int b_base = ((c_cc * WBK + b_row0) * p.x_cs + (c_tap >> 1) * p.x_ds + (c_f ? p.x_hs : 0) + (c_tap & 1)) * 4;
+        if (c_f == 1) {
+#pragma unroll
+            for (int q = 0; q < NPB; ++q) wdma<4 * VEC>(xrsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NPB; ++q) wdma<4 * VEC>(drsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
+        }
+        ++c_kt;
+        if (++c_tap == 4) {
+            c_tap = 0;
+            if (++c_cc == chunks) { c_cc = 0; ++c_f; }
+        }
+    };
+
+    wf32x16 acc[3][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
+
+#pragma unroll
+    for (int i = 0; i < WNB - 1; ++i)
+        if (i < total) issue(i);
+    if (total >= WNB - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((WNB - 2) * NPD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    const int a_off = h * WBM + j * 2;
+    const int b_off = h * WBN + wave * 32 + j;
+    int cur = 0, g = 0;
+    auto run_class = [&](wf32x16 (&ac)[2]) {
+        for (int kt = 0; kt < nkt; ++kt, ++g) {
+            const bool more = g + WNB - 1 < total;
+            if (more) issue(cur == 0 ? WNB - 1 : cur - 1);
+            const float* a = As + cur * WBK * WBM + a_off;
+            const float* b = Bs + cur * WBK * WBN + b_off;
+#pragma unroll
+            for (int ks = 0; ks < WBK / 2; ++ks) {
+                const wv2f av = *reinterpret_cast<const wv2f*>(a + ks * 2 * WBM);
+                const float bv = b[ks * 2 * WBN];
+                ac[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv, ac[0], 0, 0, 0);
+                ac[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv, ac[1], 0, 0, 0);
+            }
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((WNB - 2) * NPD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cur = cur + 1 == WNB ? 0 : cur + 1;
+        }
+    };
+    run_class(acc[0]);
+    run_class(acc[1]);
+    run_class(acc[2]);
+
+    float* ep_sc = wsmem;
+    float* ep_sf = wsmem + WBM;
+    float* ep_hw = wsmem + 2 * WBM;
+    if (tid < WBM) {
+        const int m = m0 + tid;
+        ep_sc[tid] = (p.scale && m < p.Cout) ? p.scale[m] : 1.f;
+        ep_sf[tid] = (p.shift && m < p.Cout) ? p.shift[m] : 0.f;
+        ep_hw[tid] = (HEAD && p.head_w && m < p.Cout) ? p.head_w[m] : 0.f;
+    }
+    __syncthreads();
+    const int n = n0 + wave * 32 + j;
+    const bool ok = n < p.Ntotal;
+    int e0;
+    {
+        const int nn = ok ? n : 0;
+        const int b = p.dS.div(nn);
+        int rem = nn - b * S;
+        const int pd = p.dHW.div(rem);
+        rem -= pd * p.Nh * p.Nw;
+        const int q = p.dW.div(rem);
+        const int pw = rem - q * p.Nw;
+        // output (2 pd + rd, 2 ph + rh, 2 pw + rw), ph = 2q (row 0) and 2q + 1 (row 1: 2 y_hs further)
+        e0 = b * p.y_bs + p.y_org + (pd * p.y_ds + 2 * q * p.y_hs + pw) * 2 + rd * p.y_ds + rh * p.y_hs + rw;
+    }
+    const int mbase = 8 * h;
+    const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+    if constexpr (HEAD) {
+        // the workgroup's 64 couts are the whole channel axis: 32 of them in this lane, the other 32 in lane j + 32
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dm = ((r & 3) + 8 * (r >> 2)) * 2 + tm;
+                const float sc = ep_sc[mbase + dm], sf = ep_sf[mbase + dm], hw = ep_hw[mbase + dm];
+                const float y0 = acc[0][tm][r] + acc[1][tm][r];
+                const float y1 = acc[1][tm][r] - acc[2][tm][r];
+                t0 = fmaf(fmaxf(fmaf(y0, sc, sf), lo), hw, t0);
+                t1 = fmaf(fmaxf(fmaf(y1, sc, sf), lo), hw, t1);
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        t0 += __shfl_xor(t0, 32, 64);
+        t1 += __shfl_xor(t1, 32, 64);
+        const float hsc = p.head_scale ? p.head_scale[0] : 1.f, hsf = p.head_shift ? p.head_shift[0] : 0.f;
+        t0 = fmaf(t0, hsc, hsf);
+        t1 = fmaf(t1, hsc, hsf);
+        if (p.head_act == ACT_RELU) { t0 = fmaxf(t0, 0.f); t1 = fmaxf(t1, 0.f); }
+        else if (p.head_act == ACT_SIGMOID) { t0 = __builtin_amdgcn_rcpf(1.f + __expf(-t0)); t1 = __builtin_amdgcn_rcpf(1.f + __expf(-t1)); }
+        if (h == 0 && ok) {
+            p.y[e0] = t0;
+            p.y[e0 + 2 * p.y_hs] = t1;
+        }
+        return;
+    } else {
+        const int mlimit = p.Cout - (m0 + mbase);
+        const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
+        const int yvo0 = (e0 + (m0 + mbase) * p.y_cs) * 4;
+        const int yvo1 = yvo0 + 2 * p.y_hs * 4;
+        const int row_bytes = p.y_cs * 4;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dm = ((r & 3) + 8 * (r >> 2)) * 2 + tm;
+                if (dm >= mlimit) continue;
+                const float sc = ep_sc[mbase + dm], sf = ep_sf[mbase + dm];
+                const float y0 = acc[0][tm][r] + acc[1][tm][r];
+                const float y1 = acc[1][tm][r] - acc[2][tm][r];
+                const float v0 = fmaxf(fmaf(y0, sc, sf), lo), v1 = fmaxf(fmaf(y1, sc, sf), lo);
+                const int so = dm * row_bytes;
+                if (ok) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), yrsrc, yvo0, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), yrsrc, yvo1, so, 0);
+                }
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+}
+
+hipError_t launch_deconv_wino(ConvParams p, hipStream_t stream) {
+    if (p.Cin % WBK != 0 || !p.transposed || p.ksplit != 1 || !p.part || p.act == ACT_SIGMOID || (p.head_w && p.Cout > WBM))
+        return hipErrorInvalidValue;
+    p.m_tiles = (p.Cout + WBM - 1) / WBM;
+    p.n_tiles = (p.Ntotal + WBN - 1) / WBN;
+    const size_t lds = (size_t)WNB * WBK * (WBM + WBN) * sizeof(float);
+    const dim3 grid(p.m_tiles * p.n_tiles * 8);
+    const bool v4 = p.Nw % 4 == 0;
+    if (p.head_w) {
+        if (v4) hipLaunchKernelGGL((deconv_wino_kernel<4, true>), grid, dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL((deconv_wino_kernel<1, true>), grid, dim3(256), lds, stream, p);
+    } else {
+        if (v4) hipLaunchKernelGGL((deconv_wino_kernel<4, false>), grid, dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL((deconv_wino_kernel<1, false>), grid, dim3(256), lds, stream, p);
+    }
+    return hipGetLastError();
+}
+
 }  // namespace s3r

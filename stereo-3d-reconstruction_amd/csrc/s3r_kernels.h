@@ -165,6 +165,10 @@ hipError_t launch_pack_conv(const float* w, float* wp, int Cin, int Cout, int Co
 hipError_t launch_wino_input(const float* x, float* V, long long planes, int Hp, int Wp, int H2, hipStream_t s);
 hipError_t launch_pack_wino(const float* w, float* wp, int Cin, int Cout, int CoutPad, int kd, int kw, hipStream_t s);
 hipError_t launch_conv_wino(ConvParams p, hipStream_t stream);
+// Winograd F(2,2) along H inside the parity classes of ConvTranspose3d(k4 s2 p1)
+hipError_t launch_wino_rowdiff(const float* x, float* D, long long planes, int Hp, int Wp, hipStream_t s);
+hipError_t launch_pack_wino_deconv(const float* w, float* wp, int Cin, int Cout, int CoutPad, hipStream_t s);
+hipError_t launch_deconv_wino(ConvParams p, hipStream_t stream);
 // y (N,32,Ho+2h,Wo+2h) <- stem conv of x (N,3,Hi,Wi); y_hs / y_cs / y_org describe the padded output.
 // Images [0, nsplit) are read from x, images [nsplit, N) from x2 (the left / right renders of a stereo batch live in
 // two tensors: no concatenation copy); nsplit = N, x2 = null: one tensor.  u8 != 0: x / x2 are 8-bit renders (N,3,Hi,Wi)

@@ -32,6 +32,8 @@ for layers, n0 in ((spec.ENCODER, spec.IMG_HW), (spec.DECODER, spec.MAX_DISP)):
     for l, n_in, _ in spec.trace(layers, n0):
         if l.op in ("conv2d", "conv3d") and l.k == 3 and l.s == 1 and l.p == 1 and l.cin %% 16 == 0:
             cases.append((l, n_in))
+        if l.op == "deconv3d":                                   # F(2,2) along H inside the parity classes
+            cases.append((l, n_in))
 for l, n_in in cases:
     ch = s3r.modules._HipChain([l], n_in, precision="fp32")
     s3r.seed_module(ch, 7)
@@ -48,6 +50,21 @@ for l, n_in in cases:
     out["layers"][l.name] = {"rel": rel_l2(got.cpu(), want), "deterministic": bool(torch.equal(got, again)),
                              "batch_invariant": bool(torch.equal(one[0], got[1])),
                              "launches": None}
+# ---- d3 with the occupancy head fused into its epilogue (the chain's own plan)
+dl = {l.name: (l, n_in) for l, n_in, _ in spec.trace(spec.DECODER, spec.MAX_DISP)}
+ch = s3r.modules._HipChain([dl["d3"][0], dl["d4"][0]], dl["d3"][1], precision="fp32")
+s3r.seed_module(ch, 9)
+blocks = [oracle._Block(dl[k][0]).eval() for k in ("d3", "d4")]
+for k, blk in zip(("d3", "d4"), blocks):
+    blk.load_state_dict(getattr(ch, k).state_dict())
+ch.to(dev)
+x = torch.randn((3, 128, 16, 16, 16), generator=torch.Generator().manual_seed(4))
+with torch.no_grad():
+    want = blocks[1](blocks[0](x))
+got = ch._run(x.to(dev))
+out["head_rel"] = rel_l2(got.cpu(), want)
+out["head_max"] = float((got.cpu() - want).abs().max())
+out["head_batch_invariant"] = bool(torch.equal(ch._run(x[2:3].to(dev))[0], got[2]))
 # ---- the whole forward against the oracle, and batch invariance of the whole forward
 m = s3r.Stereo2Voxel(); s3r.seed_module(m, 0); m.to(dev)
 ref = oracle.OracleStereo2Voxel(); ref.load_state_dict(m.state_dict()); ref.eval()
@@ -75,7 +92,8 @@ def _run_child(tmp_path, flag):
 
 def test_winograd_path_vs_oracle_and_invariants(tmp_path):
     res, out2 = _run_child(tmp_path, "2")                       # every eligible layer on the Winograd kernel
-    assert set(res["layers"]) == {"e2", "e4", "e6", "e7", "v1", "v3", "v5"}
+    assert set(res["layers"]) == {"e2", "e4", "e6", "e7", "v1", "v3", "v5", "d1", "d2", "d3"}
+    assert res["head_rel"] < 1e-5 and res["head_max"] < 1e-5 and res["head_batch_invariant"]
     for name, r in res["layers"].items():
         assert r["rel"] < 1e-5, (name, r)                       # north_star: 1e-4 relative
         assert r["deterministic"] and r["batch_invariant"], (name, r)
