@@ -226,7 +226,7 @@ int wino_mode() {
 // structural: the layer has a Winograd form (decides the packed layout; independent of any switch)
 bool wino_layer(const s3r_conv_desc* d) {
     return d->dtype != S3R_BF16 && d->op == S3R_OP_CONV && (d->ndim == 2 || d->ndim == 3) && d->k == 3 && d->stride == 1 &&
-           d->pad == 1 && d->cin % 16 == 0 && d->cout > 1 && d->in_size >= 4;
+           d->pad == 1 && d->cin % s3r::wino_bk() == 0 && d->cout > 1 && d->in_size >= 4;
 }
 // this call takes it (scratch is checked by the caller)
 bool wino_ok(const s3r_conv_desc* d) {
@@ -260,7 +260,7 @@ int64_t wino_need(const s3r_conv_desc* d) {
 // tensor of the input's size).
 bool dwino_layer(const s3r_conv_desc* d) {
     return d->dtype != S3R_BF16 && d->op == S3R_OP_DECONV && d->ndim == 3 && d->k == 4 && d->stride == 2 && d->pad == 1 &&
-           d->cin % 16 == 0 && d->in_size >= 2 && (d->in_size & 1) == 0;
+           d->cin % s3r::wino_bk() == 0 && d->in_size >= 2 && (d->in_size & 1) == 0;
 }
 bool dwino_ok(const s3r_conv_desc* d) {
     const int mode = wino_mode();

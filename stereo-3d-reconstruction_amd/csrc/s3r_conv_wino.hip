@@ -14,12 +14,13 @@
 // W axis stays contiguous (16-byte gathers where W % 4 == 0, whole-row stores), and the kernel below is the implicit
 // GEMM of s3r_conv_glds.hip with a class loop around its K loop.  fp32 F(2, 3) is as accurate as the direct fp32 sum
 // here (3-5e-7 relative to fp64 over 64-256 input channels; north_star allows 1e-4), but it is a DIFFERENT summation:
-// results are not bit-identical to the direct kernels', so the path is taken only on request (S3R_WINO=1) this round.
+// results are not bit-identical to the direct kernels' (the library's policy and the S3R_WINO switch: s3r_api.hip).
 //
 //   wino_input_kernel   x (padded NC(D)HW, halo 1) -> V[4][B][C][Dp][H/2][Wp]      (HBM-bound: reads x once, writes 2 x)
-//   pack_wino_kernel    w[Cout][Cin][kd][3][kw]    -> Up[4][(chunk*T' + tap')*16 + c][CoutPad],  T' = kd*kw
+//   pack_wino_kernel    w[Cout][Cin][kd][3][kw]    -> Up[4][(chunk*T' + tap')*32 + c][CoutPad],  T' = kd*kw, 32-channel chunks
 //   conv_wino_kernel    64 couts x 128 positions per workgroup (positions = (b, d, row pair q, w)), 4 waves of 64 x 32,
-//                       4 classes x 2 MFMA tiles of accumulators per wave, 3-stage LDS ring behind counted vmcnt
+//                       4 classes x 2 MFMA tiles of accumulators per wave, K tiles of one tap x 32 channels in a 2-stage LDS
+//                       ring (the next tile's DMAs in flight under the current tile's 32 MFMAs per wave)
 #include "s3r_kernels.h"
 #include <cstdlib>
 
@@ -31,9 +32,15 @@ typedef float wv2f __attribute__((ext_vector_type(2)));
 #define S3R_LDS_PTR_W(p) ((__attribute__((address_space(3))) void*)(p))
 
 #ifndef S3R_WNB
-#define S3R_WNB 3
+#define S3R_WNB 2      // LDS stages.  With 16-channel K tiles: 2 stages -0.3 %, 3 = 4.  32-channel tiles halve the barriers per MFMA
+#endif                  // (32 MFMAs per wave between two, like the direct path's 64 x 256 tile) and, at two stages (48 KiB, three
+                        // workgroups per CU), are 1.3 % of the step faster than 16 x 3: v1 0.807 -> 0.769 ms, d3 0.824 -> 0.803
+#ifndef S3R_WBK
+#define S3R_WBK 32
 #endif
-constexpr int WBM = 64, WBN = 128, WBK = 16, WNB = S3R_WNB;
+constexpr int WBM = 64, WBN = 128, WBK = S3R_WBK, WNB = S3R_WNB;      // K tile: one tap x WBK channels
+constexpr int WNPA = WBK * WBM / 1024;                                // 1 KiB weight pieces per wave and K tile
+int wino_bk() { return WBK; }
 
 template <int BYTES>
 __device__ __forceinline__ void wdma(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, int voffset, int soffset) {
@@ -79,11 +86,11 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict_
         size_t r = i % per_cls;
         const int co = (int)(r % CoutPad);
         r /= CoutPad;
-        const int c = (int)(r & 15);
-        r >>= 4;
+        const int c = (int)(r % WBK);
+        r /= WBK;
         const int tap = (int)(r % T);
         const int cc = (int)(r / T);
-        const int cin = cc * 16 + c;
+        const int cin = cc * WBK + c;
         float v = 0.f;
         if (co < Cout) {
             const int td = tap / kw, tw = tap - td * kw;
@@ -106,8 +113,8 @@ hipError_t launch_pack_wino(const float* w, float* wp, int Cin, int Cout, int Co
 template <int VEC>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float wsmem[];
-    float* As = wsmem;                                   // [WNB][16][64]
-    float* Bs = wsmem + WNB * WBK * WBM;                 // [WNB][16][128]
+    float* As = wsmem;                                   // [WNB][WBK][64]
+    float* Bs = wsmem + WNB * WBK * WBM;                 // [WNB][WBK][128]
     constexpr int PB = 64 * VEC;                         // floats per B piece
     constexpr int NPIECE_B = WBK * WBN / PB;
     constexpr int NPB = NPIECE_B / 4;
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
     constexpr int PPR = B_WIDE ? WBN / PB : 1;
     constexpr int RPP = B_WIDE ? 1 : PB / WBN;
     constexpr int LPR_B = WBN / VEC;
-    constexpr int NPD = 1 + NPB;                         // DMAs per wave per K tile (one 1 KiB weight piece + NPB gathers)
+    constexpr int NPD = WNPA + NPB;                      // DMAs per wave per K tile (WNPA 1 KiB weight pieces + NPB gathers)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -164,7 +171,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
 
     int c_cls = 0, c_cc = 0, c_td = 0, c_tw = 0, c_tap = 0, c_kt = 0;      // cursor of the NEXT K tile to fetch (scalar)
     auto issue = [&](int buf) {
-        wdma<16>(wrsrc, As + buf * WBK * WBM + wave * 256, avoff, (c_kt * WBK * p.CoutPad + m0) * 4 + wave * 4 * p.CoutPad * 4);
+#pragma unroll
+        for (int q = 0; q < WNPA; ++q)
+            wdma<16>(wrsrc, As + buf * WBK * WBM + (wave + 4 * q) * 256, avoff,
+                     (c_kt * WBK * p.CoutPad + m0) * 4 + (wave + 4 * q) * 4 * p.CoutPad * 4);
         float* sb = Bs + buf * WBK * WBN + b_lds0;
         const int b_base = (c_cls * p.x_cls + (c_cc * WBK + b_row0) * p.x_cs + c_td * p.x_ds + c_tw) * 4;
 #pragma unroll
@@ -314,7 +324,7 @@ hipError_t launch_wino_rowdiff(const float* x, float* D, long long planes, int H
     return hipGetLastError();
 }
 
-// w[Cin][Cout][4][4][4] -> Up[pc = 8][f = 3][(chunk*4 + (td*2 + tw))*16 + c][CoutPad]
+// w[Cin][Cout][4][4][4] -> Up[pc = 8][f = 3][(chunk*4 + (td*2 + tw))*32 + c][CoutPad]
 __global__ void pack_wino_deconv_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int CoutPad) {
     const size_t per_f = (size_t)4 * Cin * CoutPad;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < 24 * per_f; i += (size_t)gridDim.x * blockDim.x) {
@@ -323,11 +333,11 @@ __global__ void pack_wino_deconv_kernel(const float* __restrict__ w, float* __re
         size_t r = i % per_f;
         const int co = (int)(r % CoutPad);
         r /= CoutPad;
-        const int c = (int)(r & 15);
-        r >>= 4;
+        const int c = (int)(r % WBK);
+        r /= WBK;
         const int tap = (int)(r & 3);
         const int cc = (int)(r >> 2);
-        const int cin = cc * 16 + c;
+        const int cin = cc * WBK + c;
         float v = 0.f;
         if (co < Cout) {
             const int rd = (pc >> 2) & 1, rh = (pc >> 1) & 1, rw = pc & 1;
@@ -360,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void deconv_wino_kernel(const ConvParams p)
     constexpr int PPR = B_WIDE ? WBN / PB : 1;
     constexpr int RPP = B_WIDE ? 1 : PB / WBN;
     constexpr int LPR_B = WBN / VEC;
-    constexpr int NPD = 1 + NPB;
+    constexpr int NPD = WNPA + NPB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -413,7 +423,10 @@ __global__ __launch_bounds__(256, 2) void deconv_wino_kernel(const ConvParams p)
 
     int c_f = 0, c_cc = 0, c_tap = 0, c_kt = pc * total;               // cursor of the NEXT K tile to fetch (scalar)
     auto issue = [&](int buf) {
-        wdma<16>(wrsrc, As + buf * WBK * WBM + wave * 256, avoff, (c_kt * WBK * p.CoutPad + m0) * 4 + wave * 4 * p.CoutPad * 4);
+#pragma unroll
+        for (int q = 0; q < WNPA; ++q)
+            wdma<16>(wrsrc, As + buf * WBK * WBM + (wave + 4 * q) * 256, avoff,
+                     (c_kt * WBK * p.CoutPad + m0) * 4 + (wave + 4 * q) * 4 * p.CoutPad * 4);
         float* sb = Bs + buf * WBK * WBN + b_lds0;
         // F-class 0: D at row R, 1: X at row R + 1, 2: D at row R + 1
         const int b_base = ((c_cc * WBK + b_row0) * p.x_cs + (c_tap >> 1) * p.x_ds + (c_f ? p.x_hs : 0) + (c_tap & 1)) * 4;

@@ -165,6 +165,7 @@ hipError_t launch_pack_conv(const float* w, float* wp, int Cin, int Cout, int Co
 hipError_t launch_wino_input(const float* x, float* V, long long planes, int Hp, int Wp, int H2, hipStream_t s);
 hipError_t launch_pack_wino(const float* w, float* wp, int Cin, int Cout, int CoutPad, int kd, int kw, hipStream_t s);
 hipError_t launch_conv_wino(ConvParams p, hipStream_t stream);
+int wino_bk();                      // channels per K tile of the Winograd kernels (Cin must be a multiple)
 // Winograd F(2,2) along H inside the parity classes of ConvTranspose3d(k4 s2 p1)
 hipError_t launch_wino_rowdiff(const float* x, float* D, long long planes, int Hp, int Wp, hipStream_t s);
 hipError_t launch_pack_wino_deconv(const float* w, float* wp, int Cin, int Cout, int CoutPad, hipStream_t s);
