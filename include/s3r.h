@@ -135,7 +135,7 @@ int s3r_conv_out_size(const s3r_conv_desc* d);
  * forward runs is decided per call (environment S3R_WINO: unset / 1 = the layers it measured faster on, 0 = never, 2 =
  * every eligible layer; a tile / split-K override, a non-plain layout or too little scratch select the direct kernel).
  * The two kernels agree to fp32 rounding (another summation order), not bit for bit.  The transposed convolutions likewise:
- * 24 F(2,2)-along-H (parity class, F) slabs behind the direct ones, taken for d2 / d3 under the default policy. */
+ * 24 F(2,2)-along-H (parity class, F) slabs behind the direct ones, taken for d1 / d2 / d3 under the default policy. */
 int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems);
 /* repack a torch-layout weight (Conv: [cout][cin][k..]; ConvTranspose: [cin][cout][k..]; Linear:
  * [cout][cin]) into the kernel's K-major layout.  Device to device, on `stream`. */
