@@ -79,9 +79,10 @@ typedef enum s3r_act { S3R_ACT_NONE = 0, S3R_ACT_RELU = 1, S3R_ACT_SIGMOID = 2 }
  *                     (16-byte LDS-DMA where the output width is a multiple of 4) instead of every other dword.  Planned
  *                     by s3r_chain_forward between a convolution and its stride-2 consumer; the K order does not change,
  *                     so results are bit-identical to the plain layout. */
-/*   S3R_LAYOUT_WINO_H  fp32 path, INPUT of a 3 x 3 [x 3] stride-1 pad-1 convolution only, even edge n, in_halo 1: the four
- *                      Winograd F(2,3)-along-H plane sets of the halo-padded tensor, (4, B, C, [n+2,] n/2, n+2) — set i, row q
- *                      = r(2q) - r(2q+2), r(2q+1) + r(2q+2), r(2q+2) - r(2q+1), r(2q+1) - r(2q+3) of the padded rows r.  What
+/*   S3R_LAYOUT_WINO_H  fp32 path, INPUT of a 3 x 3 [x 3] stride-1 pad-1 convolution only, in_halo 1: the Winograd F(R,3)-along-H
+ *                      plane sets of the halo-padded tensor, (R+2, B, C, [n+2,] n/R, n+2) with R = 4 for a 3D layer (edge n a
+ *                      multiple of 4) and R = 2 for a 2D one — set i, row q = the i-th F(R,3) input-transform combination of the
+ *                      padded rows R q .. R q + R + 1 (csrc/s3r_kernels.h, wino_rows_to_classes).  What
  *                      s3r_cost_volume_forward_wino writes: the consumer then skips its input transform.  The batch of such a
  *                      call is bounded: s3r_conv_wino_input_elems returns 0 when the layer / batch cannot take it. */
 typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_S2D = 1, S3R_LAYOUT_WINO_H = 2 } s3r_layout;
@@ -131,7 +132,8 @@ const char* s3r_last_error(void);
 int s3r_conv_out_size(const s3r_conv_desc* d);
 /* size of the packed weight buffer for a layer IN 4-BYTE UNITS (>= the torch weight's numel on the fp32
  * path: couts are padded; about half of it on the bf16 path).  ABI 6: an fp32 3 x 3 [x 3] stride-1 pad-1 convolution packs
- * two forms, the direct slab and the four Winograd F(2,3)-along-H class slabs (csrc/s3r_conv_wino.hip); which kernel a
+ * two forms, the direct slab and the Winograd F(R,3)-along-H class slabs (csrc/s3r_conv_wino.hip: R = 4, six slabs, for 3D
+ * layers - half the multiplications; R = 2, four slabs, for 2D ones); which kernel a
  * forward runs is decided per call (environment S3R_WINO: unset / 1 = the layers it measured faster on, 0 = never, 2 =
  * every eligible layer; a tile / split-K override, a non-plain layout or too little scratch select the direct kernel).
  * The two kernels agree to fp32 rounding (another summation order), not bit for bit.  The transposed convolutions likewise:
@@ -187,8 +189,8 @@ int s3r_cost_volume_forward(const float* feat_left, const float* feat_right, flo
                             int max_disp, int height, int width, int out_halo, void* stream);
 
 /* The volume written directly as the S3R_LAYOUT_WINO_H input of the 3D convolution that consumes it (halo 1):
- * (4, B, 2C, D+2, H/2, W+2) floats, bit-identical to the input transform of the padded volume; the caller zeroed the buffer
- * once (the depth-halo planes are never written).  height even. */
+ * (6, B, 2C, D+2, H/4, W+2) floats (F(4,3) groups), bit-identical to the input transform of the padded volume; the caller
+ * zeroed the buffer once (the depth-halo planes are never written).  height a multiple of 4. */
 int s3r_cost_volume_forward_wino(const float* feat_left, const float* feat_right, float* planes, int batch, int channels,
                                  int max_disp, int height, int width, void* stream);
 /* floats of the S3R_LAYOUT_WINO_H input of layer `d` (in_halo = 1) if a forward of it would run the Winograd kernel under the

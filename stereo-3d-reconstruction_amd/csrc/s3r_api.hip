@@ -33,6 +33,11 @@ int64_t ipow(int64_t b, int e) {
     return r;
 }
 
+// outputs per Winograd group along H of an fp32 3 x 3 [x 3] stride-1 convolution: F(4,3) — half the direct form's multiplications —
+// for 3D layers whose edge is a multiple of 4 (v1: 0.769 -> 0.666 ms against F(2,3)), F(2,3) otherwise (v3, edge 14: four
+// groups of 4 would compute 16 rows for 14 and the six-class kernel holds two workgroups per CU instead of three: 0.483 -> 0.497)
+int wino_r(const s3r_conv_desc* d) { return (d->ndim == 3 && d->in_size % 4 == 0) ? 4 : 2; }
+
 constexpr int64_t kMaxElems = (int64_t)1 << 31;
 constexpr int64_t kMaxBytes = (int64_t)1 << 32;
 
@@ -145,7 +150,8 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
         if (d->dtype != S3R_F32 || d->op != S3R_OP_CONV || d->stride != 1 || d->k != 3 || d->pad != 1 || (g->in & 1) || d->in_halo != 1 ||
             d->cin % 16 != 0 || d->cout <= 1)
             return fail(S3R_ERR_INVALID, "a Winograd-transformed input serves an fp32 Conv k=3 s=1 p=1 over an even edge, in_halo = 1");
-        g->x_elems = 4 * (int64_t)d->batch * d->cin * (g->nd == 3 ? g->in_p : 1) * (g->in / 2) * g->in_p;
+        if (g->in % wino_r(d) != 0) return fail(S3R_ERR_INVALID, "a Winograd-transformed input needs an edge that is a multiple of %d", wino_r(d));
+        g->x_elems = (wino_r(d) + 2) * (int64_t)d->batch * d->cin * (g->nd == 3 ? g->in_p : 1) * (g->in / wino_r(d)) * g->in_p;
     }
     if (d->in_layout == S3R_LAYOUT_S2D) {        // what a stride-2 k3 p1 convolution reads
         if (d->op != S3R_OP_CONV || d->stride != 2 || d->k != 3 || d->pad != 1 || (g->in & 1) || d->in_halo != 1)
@@ -239,12 +245,13 @@ bool wino_ok(const s3r_conv_desc* d) {
 // samples per Winograd call (the transformed input of a call stays below 2 GiB) and the scratch that takes, in floats
 int wino_bmax(const s3r_conv_desc* d);
 int64_t wino_need(const s3r_conv_desc* d);
-int64_t wino_w_elems(const s3r_conv_desc* d) {       // the four class slabs behind the direct slab
-    return 4 * ipow(3, d->ndim - 1) * d->cin * (int64_t)cout_pad(d->cout);
+int64_t wino_w_elems(const s3r_conv_desc* d) {       // the R + 2 class slabs behind the direct slab
+    return (wino_r(d) + 2) * ipow(3, d->ndim - 1) * d->cin * (int64_t)cout_pad(d->cout);
 }
-int64_t wino_v_elems(const s3r_conv_desc* d) {       // the four transformed plane sets: [4][B][Cin][Dp][ceil(H/2)][Wp]
-    const int64_t dp = d->ndim == 3 ? d->in_size + 2 : 1, h2 = (d->in_size + 1) / 2, wp = d->in_size + 2;
-    return 4 * (int64_t)d->batch * d->cin * dp * h2 * wp;
+int64_t wino_v_elems(const s3r_conv_desc* d) {       // the transformed plane sets: [R + 2][B][Cin][Dp][ceil(H / R)][Wp]
+    const int R = wino_r(d);
+    const int64_t dp = d->ndim == 3 ? d->in_size + 2 : 1, hq = (d->in_size + R - 1) / R, wp = d->in_size + 2;
+    return (R + 2) * (int64_t)d->batch * d->cin * dp * hq * wp;
 }
 int wino_bmax(const s3r_conv_desc* d) {
     const int64_t v_sample = wino_v_elems(d) / (d->batch > 0 ? d->batch : 1);
@@ -709,7 +716,7 @@ int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, void* packedv,
                                           d->op == S3R_OP_DECONV ? 8 : (int)ipow(d->k, g.nd), d->op == S3R_OP_DECONV, s);
                 if (e == hipSuccess && wino_layer(d))
                     e = s3r::launch_pack_wino(w, packed + ipow(d->k, g.nd) * d->cin * cout_pad(d->cout), d->cin, d->cout,
-                                              cout_pad(d->cout), g.nd == 3 ? 3 : 1, 3, s);
+                                              cout_pad(d->cout), g.nd == 3 ? 3 : 1, 3, wino_r(d), s);
                 if (e == hipSuccess && dwino_layer(d))
                     e = s3r::launch_pack_wino_deconv(w, packed + 64 * (int64_t)d->cin * cout_pad(d->cout), d->cin, d->cout, cout_pad(d->cout), s);
             }
@@ -856,10 +863,10 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                     wino_bmax(d) < d->batch)
                     return fail(S3R_ERR_INVALID, "a Winograd-transformed input runs the Winograd kernel only: no tile / split-K "
                                 "override, a plain output, at most %d samples per call here (s3r_conv_wino_input_elems)", wino_bmax(d));
-                const int is3 = d->ndim == 3, n = d->in_size, wp = n + 2, h2 = n / 2, dp = is3 ? n + 2 : 1;
+                const int is3 = d->ndim == 3, n = d->in_size, wp = n + 2, h2 = n / wino_r(d), dp = is3 ? n + 2 : 1;
                 ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
                 p.w = packed_w + ipow(3, g.nd) * d->cin * cout_pad(d->cout);
-                p.Nh = h2; p.kh = 1; p.T = p.kd * p.kw;
+                p.Nh = h2; p.kh = wino_r(d); p.T = p.kd * p.kw;      // (kh carries the group size to the launcher)
                 p.x_hs = wp; p.x_ds = is3 ? h2 * wp : 0; p.x_cs = dp * h2 * wp;
                 p.x_cls = d->batch * d->cin * p.x_cs;
                 p.x_org = 0;
@@ -876,14 +883,15 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                 return S3R_OK;
             }
             if (wino_ok(d) && scratch && scratch_elems >= wino_need(d) && wino_need(d) > 0) {
-                const int is3 = d->ndim == 3, n = d->in_size, wp = n + 2, h2 = (n + 1) / 2, dp = is3 ? n + 2 : 1;
+                const int R = wino_r(d);
+                const int is3 = d->ndim == 3, n = d->in_size, wp = n + 2, h2 = (n + R - 1) / R, dp = is3 ? n + 2 : 1;
                 const int64_t v_sample = wino_v_elems(d) / d->batch, x_sample = g.x_elems / d->batch;
                 const int bmax = wino_bmax(d);
                 ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
                 ps.launches = 0;
                 p.w = packed_w + ipow(3, g.nd) * d->cin * cout_pad(d->cout);        // the class slabs sit behind the direct slab
                 p.x = scratch;
-                p.Nh = h2; p.kh = 1; p.T = p.kd * p.kw;
+                p.Nh = h2; p.kh = R; p.T = p.kd * p.kw;              // (kh carries the group size to the launcher)
                 p.x_hs = wp; p.x_ds = is3 ? h2 * wp : 0; p.x_cs = dp * h2 * wp;
                 p.x_org = 0;
                 p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
@@ -893,7 +901,7 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                 p.ksplit = 1;
                 for (int b0 = 0; b0 < d->batch; b0 += bmax) {
                     const int nb = d->batch - b0 < bmax ? d->batch - b0 : bmax;
-                    e = s3r::launch_wino_input(x + (int64_t)b0 * x_sample, scratch, (long long)nb * d->cin * dp, n + 2, wp, h2, s);
+                    e = s3r::launch_wino_input(x + (int64_t)b0 * x_sample, scratch, (long long)nb * d->cin * dp, n + 2, wp, h2, R, s);
                     if (e != hipSuccess) return hip_fail(e, "Winograd input transform launch");
                     p.B = nb;
                     p.x_cls = nb * d->cin * p.x_cs;
@@ -1085,17 +1093,17 @@ int s3r_cost_volume_forward(const float* fl, const float* fr, float* vol, int ba
 int s3r_cost_volume_forward_wino(const float* fl, const float* fr, float* planes, int batch, int channels, int max_disp,
                                  int height, int width, void* stream) {
     if (!fl || !fr || !planes) return fail(S3R_ERR_INVALID, "null tensor pointer");
-    if (batch <= 0 || channels <= 0 || max_disp <= 0 || height < 4 || width <= 0 || (height & 1))
-        return fail(S3R_ERR_INVALID, "bad cost-volume shape for the Winograd layout (even height >= 4)");
+    if (batch <= 0 || channels <= 0 || max_disp <= 0 || height < 4 || width <= 0 || (height & 3))
+        return fail(S3R_ERR_INVALID, "bad cost-volume shape for the Winograd layout (height a multiple of 4: F(4,3) groups)");
     if (max_disp > width) return fail(S3R_ERR_INVALID, "max_disp %d exceeds the feature width %d", max_disp, width);
     if ((size_t)2 * height * width * sizeof(float) > 64 * 1024)
         return fail(S3R_ERR_INVALID, "feature plane %dx%d does not fit the kernel's 64 KiB of LDS", height, width);
-    const int64_t elems = 4 * (int64_t)batch * 2 * channels * (max_disp + 2) * (height / 2) * (width + 2);
+    const int64_t elems = 6 * (int64_t)batch * 2 * channels * (max_disp + 2) * (height / 4) * (width + 2);
     if (elems * 4 >= ((int64_t)1 << 31)) return fail(S3R_ERR_INVALID, "Winograd planes of %lld floats exceed 2 GiB: split the batch", (long long)elems);
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(s, F_COSTVOL, 0, 2.0 * batch * channels * (double)max_disp * height * width,
                  4.0 * batch * channels * (2.0 * height * width) + 4.0 * (double)elems);
-    hipError_t e = s3r::launch_cost_volume_wino(fl, fr, planes, batch, channels, max_disp, height, width, s);
+    hipError_t e = s3r::launch_cost_volume_wino(fl, fr, planes, batch, channels, max_disp, height, width, 4, s);
     if (e != hipSuccess) return hip_fail(e, "cost volume (Winograd layout) launch");
     return S3R_OK;
 }
@@ -1104,7 +1112,7 @@ int64_t s3r_conv_wino_input_elems(const s3r_conv_desc* d) {
     if (!d) return fail(S3R_ERR_INVALID, "null descriptor");
     s3r_conv_desc t = *d;
     t.in_layout = S3R_LAYOUT_PLAIN;
-    if (!wino_ok(&t) || (t.in_size & 1) || wino_bmax(&t) < t.batch) return 0;
+    if (!wino_ok(&t) || t.in_size % wino_r(&t) != 0 || wino_bmax(&t) < t.batch) return 0;
     return wino_v_elems(&t);
 }
 

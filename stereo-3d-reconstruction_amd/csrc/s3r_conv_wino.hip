@@ -49,39 +49,50 @@ __device__ __forceinline__ void wdma(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, S3R_LDS_PTR_W(lds_dst), 4, voffset, soffset, 0, 0);
 }
 
-// ---- input transform: one thread per (plane row of V, column); rows r0..r3 of the padded input plane
+// ---- F(R, 3) along H, R = 2 or 4 outputs per group from R + 2 padded input rows through R + 2 products.
+//   R = 2 (above).   R = 4 (Lavin & Gray's F(4, 3); HALF the direct form's multiplications; in fp32 over 64-128 channels 4.9e-7
+//   relative to an fp64 convolution against the direct sum's 3.6e-7):
+//     v0 = 4 r0 - 5 r2 + r4             u0 = g0 / 4                          y0 = m0 + m1 + m2 + m3 + m4
+//     v1 = -4 r1 - 4 r2 + r3 + r4       u1 = -(g0 + g1 + g2) / 6             y1 = m1 - m2 + 2 m3 - 2 m4
+//     v2 = 4 r1 - 4 r2 - r3 + r4        u2 = -(g0 - g1 + g2) / 6             y2 = m1 + m2 + 4 m3 + 4 m4
+//     v3 = -2 r1 - r2 + 2 r3 + r4       u3 = g0 / 24 + g1 / 12 + g2 / 6      y3 = m1 - m2 + 8 m3 - 8 m4 + m5
+//     v4 = 2 r1 - r2 - 2 r3 + r4        u4 = g0 / 24 - g1 / 12 + g2 / 6
+//     v5 = 4 r1 - 5 r3 + r5             u5 = g2
+// ---- input transform: one thread per (plane row of V, column); rows 0 .. R+1 of the group in the padded input plane
+template <int R>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, long long planes,
-                                                         int Hp, int Wp, int H2, long long cls_stride) {
-    const long long total = planes * H2 * Wp;
+                                                         int Hp, int Wp, int Hq, long long cls_stride) {
+    const long long total = planes * Hq * Wp;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long row = i / Wp;                     // (plane, q)
         const int w = (int)(i - row * Wp);
-        const long long pl = row / H2;
-        const int q = (int)(row - pl * H2);
-        const float* __restrict__ src = x + (pl * Hp + 2 * q) * Wp + w;
-        const float r0 = src[0], r1 = src[Wp], r2 = src[2 * (long long)Wp];
-        const float r3 = (2 * q + 3 < Hp) ? src[3 * (long long)Wp] : 0.f;        // (odd H: the row below the halo is zero)
-        V[i] = r0 - r2;
-        V[i + cls_stride] = r1 + r2;
-        V[i + 2 * cls_stride] = r2 - r1;
-        V[i + 3 * cls_stride] = r1 - r3;
+        const long long pl = row / Hq;
+        const int q = (int)(row - pl * Hq);
+        const float* __restrict__ src = x + (pl * Hp + R * q) * Wp + w;
+        float r[R + 2], v[R + 2];
+#pragma unroll
+        for (int k = 0; k < R + 2; ++k) r[k] = (R * q + k < Hp) ? src[(long long)k * Wp] : 0.f;   // (rows below the halo are zero)
+        wino_rows_to_classes<R>(r, v);
+#pragma unroll
+        for (int k = 0; k < R + 2; ++k) V[i + k * cls_stride] = v[k];
     }
 }
 
-hipError_t launch_wino_input(const float* x, float* V, long long planes, int Hp, int Wp, int H2, hipStream_t s) {
-    const long long total = planes * H2 * Wp;
+hipError_t launch_wino_input(const float* x, float* V, long long planes, int Hp, int Wp, int Hq, int R, hipStream_t s) {
+    const long long total = planes * Hq * Wp;
     const long long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, x, V, planes, Hp, Wp,
-                       H2, total);
+    const dim3 grid((unsigned)(blocks < 65536 ? blocks : 65536));
+    if (R == 4) hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, s, x, V, planes, Hp, Wp, Hq, total);
+    else hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, s, x, V, planes, Hp, Wp, Hq, total);
     return hipGetLastError();
 }
 
-// ---- weights: w[Cout][Cin][kd][3][kw] (torch layout, 2D: kd = 1) -> 4 class slabs in the conv kernel's packed K order
+// ---- weights: w[Cout][Cin][kd][3][kw] (torch layout, 2D: kd = 1) -> R + 2 class slabs in the conv kernel's packed K order
 __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int CoutPad, int kd,
-                                 int kw) {
+                                 int kw, int R) {
     const int T = kd * kw;
     const size_t per_cls = (size_t)T * Cin * CoutPad;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < 4 * per_cls; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)(R + 2) * per_cls; i += (size_t)gridDim.x * blockDim.x) {
         const int cls = (int)(i / per_cls);
         size_t r = i % per_cls;
         const int co = (int)(r % CoutPad);
@@ -96,22 +107,29 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict_
             const int td = tap / kw, tw = tap - td * kw;
             const float* g = w + (((size_t)co * Cin + cin) * kd + td) * 3 * kw + tw;       // g[kh * kw]
             const float g0 = g[0], g1 = g[kw], g2 = g[2 * kw];
-            v = cls == 0 ? g0 : cls == 1 ? ((g0 + g1) + g2) * 0.5f : cls == 2 ? ((g0 - g1) + g2) * 0.5f : g2;
+            if (R == 2) {
+                v = cls == 0 ? g0 : cls == 1 ? ((g0 + g1) + g2) * 0.5f : cls == 2 ? ((g0 - g1) + g2) * 0.5f : g2;
+            } else {
+                const float s02 = g0 + g2, a = g0 * (1.f / 24.f) + g2 * (1.f / 6.f), b12 = g1 * (1.f / 12.f);
+                v = cls == 0 ? g0 * 0.25f : cls == 1 ? (s02 + g1) * (-1.f / 6.f) : cls == 2 ? (s02 - g1) * (-1.f / 6.f)
+                  : cls == 3 ? a + b12 : cls == 4 ? a - b12 : g2;
+            }
         }
         wp[i] = v;
     }
 }
 
-hipError_t launch_pack_wino(const float* w, float* wp, int Cin, int Cout, int CoutPad, int kd, int kw, hipStream_t s) {
-    hipLaunchKernelGGL(pack_wino_kernel, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CoutPad, kd, kw);
+hipError_t launch_pack_wino(const float* w, float* wp, int Cin, int Cout, int CoutPad, int kd, int kw, int R, hipStream_t s) {
+    hipLaunchKernelGGL(pack_wino_kernel, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CoutPad, kd, kw, R);
     return hipGetLastError();
 }
 
 // ---- the four class convolutions and their combination.  p describes the CLASS convolution: p.x = V, x_cs / x_ds / x_hs
 // its strides (x_hs = one V row per row pair), p.x_cls the class stride, Nh = row pairs per plane, kh = 1, T = kd * kw,
 // x_org = 0; p.y the layer's padded output, p.Hout its true height (odd: the last pair's second row is not stored).
-template <int VEC>
+template <int VEC, int R>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
+    constexpr int NCLS = R + 2;
     extern __shared__ __attribute__((aligned(16))) float wsmem[];
     float* As = wsmem;                                   // [WNB][WBK][64]
     float* Bs = wsmem + WNB * WBK * WBM;                 // [WNB][WBK][128]
@@ -141,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
     const int T = p.T;
     const int chunks = p.Cin / WBK;
     const int nkt = T * chunks;                          // K tiles per class
-    const int total = 4 * nkt;
+    const int total = NCLS * nkt;
 
     int bvoff;
     {
@@ -162,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
     const __amdgpu_buffer_rsrc_t xrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.w), 0, (int)(4u * (unsigned)T * (unsigned)p.Cin * (unsigned)p.CoutPad * 4u), 0x00020000);
+        const_cast<float*>(p.w), 0, (int)((unsigned)NCLS * (unsigned)T * (unsigned)p.Cin * (unsigned)p.CoutPad * 4u), 0x00020000);
     const int b_row0 = B_WIDE ? wave / PPR : wave * RPP;
     constexpr int B_ROW_STEP = B_WIDE ? 4 / PPR : 4 * RPP;
     const int b_lds0 = B_WIDE ? b_row0 * WBN + (wave % PPR) * PB : wave * PB;
@@ -187,9 +205,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
         }
     };
 
-    wf32x16 acc[4][2];
+    wf32x16 acc[NCLS][2];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < NCLS; ++c)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -227,10 +245,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
             cur = cur + 1 == WNB ? 0 : cur + 1;
         }
     };
-    run_class(acc[0]);
-    run_class(acc[1]);
-    run_class(acc[2]);
-    run_class(acc[3]);
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) run_class(acc[c]);
 
     // ---- epilogue: per-cout constants through LDS (every wave is past the last barrier: the ring is idle)
     float* ep_sc = wsmem;
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
     __syncthreads();
     const int n = n0 + wave * 32 + j;
     const bool ok = n < p.Ntotal;
-    int e0, row1;
+    int e0, row1;                                        // first output element of the group, rows that exist
     {
         const int nn = ok ? n : 0;
         const int b = p.dS.div(nn);
@@ -252,14 +268,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
         rem -= pd * p.Nh * p.Nw;
         const int q = p.dW.div(rem);
         const int pw = rem - q * p.Nw;
-        e0 = b * p.y_bs + p.y_org + pd * p.y_ds + 2 * q * p.y_hs + pw;
-        row1 = 2 * q + 1 < p.Hout;
+        e0 = b * p.y_bs + p.y_org + pd * p.y_ds + R * q * p.y_hs + pw;
+        row1 = p.Hout - R * q;                           // rows of this group that exist (>= R: all)
     }
     const int mbase = 8 * h;                             // rows of this lane: mbase + ((r & 3) + 8 (r >> 2)) * 2 + tm
     const int mlimit = p.Cout - (m0 + mbase);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
     const int yvo0 = (e0 + (m0 + mbase) * p.y_cs) * 4;
-    const int yvo1 = yvo0 + p.y_hs * 4;
+    const int yrow = p.y_hs * 4;
     const int row_bytes = p.y_cs * 4;
     const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
 #pragma unroll
@@ -269,31 +285,51 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
             const int dm = ((r & 3) + 8 * (r >> 2)) * 2 + tm;
             if (dm >= mlimit) continue;
             const float sc = ep_sc[mbase + dm], sf = ep_sf[mbase + dm];
-            const float y0 = (acc[0][tm][r] + acc[1][tm][r]) + acc[2][tm][r];
-            const float y1 = (acc[1][tm][r] - acc[2][tm][r]) - acc[3][tm][r];
-            const float v0 = fmaxf(fmaf(y0, sc, sf), lo), v1 = fmaxf(fmaf(y1, sc, sf), lo);
+            float y[R];
+            if constexpr (R == 2) {
+                y[0] = (acc[0][tm][r] + acc[1][tm][r]) + acc[2][tm][r];
+                y[1] = (acc[1][tm][r] - acc[2][tm][r]) - acc[3][tm][r];
+            } else {
+                const float s12 = acc[1][tm][r] + acc[2][tm][r], d12 = acc[1][tm][r] - acc[2][tm][r];
+                const float s34 = acc[3][tm][r] + acc[4][tm][r], d34 = acc[3][tm][r] - acc[4][tm][r];
+                y[0] = (acc[0][tm][r] + s12) + s34;
+                y[1] = fmaf(2.f, d34, d12);
+                y[2] = fmaf(4.f, s34, s12);
+                y[3] = fmaf(8.f, d34, d12) + acc[5][tm][r];
+            }
             const int so = dm * row_bytes;
             if (ok) {
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), yrsrc, yvo0, so, 0);
-                if (row1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), yrsrc, yvo1, so, 0);
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+                    if (i < row1) {
+                        const float v = fmaxf(fmaf(y[i], sc, sf), lo);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrsrc, yvo0 + i * yrow, so, 0);
+                    }
             }
             if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
 }
 
-// p: see the kernel.  vec: 4 where Nw % 4 == 0, else 1.
+// p: see the kernel; p.kh = the outputs per group R (2 or 4) on entry (the class convolution's own kh is 1)
 hipError_t launch_conv_wino(ConvParams p, hipStream_t stream) {
-    if (p.Cin % WBK != 0 || p.kh != 1 || p.stride != 1 || p.transposed || p.ksplit != 1 || p.head_w || p.act == ACT_SIGMOID)
+    const int R = p.kh;
+    if (p.Cin % WBK != 0 || (R != 2 && R != 4) || p.stride != 1 || p.transposed || p.ksplit != 1 || p.head_w || p.act == ACT_SIGMOID)
         return hipErrorInvalidValue;
+    p.kh = 1;
     p.m_tiles = (p.Cout + WBM - 1) / WBM;
     p.n_tiles = (p.Ntotal + WBN - 1) / WBN;
     const size_t lds = (size_t)WNB * WBK * (WBM + WBN) * sizeof(float);
     const dim3 grid(p.m_tiles * p.n_tiles);
-    if (p.Nw % 4 == 0) hipLaunchKernelGGL(conv_wino_kernel<4>, grid, dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL(conv_wino_kernel<1>, grid, dim3(256), lds, stream, p);
+    const bool v4 = p.Nw % 4 == 0;
+    if (R == 4) {
+        if (v4) hipLaunchKernelGGL((conv_wino_kernel<4, 4>), grid, dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL((conv_wino_kernel<1, 4>), grid, dim3(256), lds, stream, p);
+    } else {
+        if (v4) hipLaunchKernelGGL((conv_wino_kernel<4, 2>), grid, dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL((conv_wino_kernel<1, 2>), grid, dim3(256), lds, stream, p);
+    }
     return hipGetLastError();
 }
-
 
 // ================================================================================================
 // ConvTranspose3d(k = 4, s = 2, p = 1) with fewer multiplications: Winograd F(2, 2) along H inside every output-parity

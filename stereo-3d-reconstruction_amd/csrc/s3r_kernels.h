@@ -162,8 +162,8 @@ void conv_tile_dims(int tile_cfg, int* bm, int* bn);
 hipError_t launch_pack_conv(const float* w, float* wp, int Cin, int Cout, int CoutPad, int T, int transposed,
                             hipStream_t s);
 // Winograd F(2,3) along H for 3 x 3 [x 3] stride-1 pad-1 convolutions (s3r_conv_wino.hip)
-hipError_t launch_wino_input(const float* x, float* V, long long planes, int Hp, int Wp, int H2, hipStream_t s);
-hipError_t launch_pack_wino(const float* w, float* wp, int Cin, int Cout, int CoutPad, int kd, int kw, hipStream_t s);
+hipError_t launch_wino_input(const float* x, float* V, long long planes, int Hp, int Wp, int Hq, int R, hipStream_t s);
+hipError_t launch_pack_wino(const float* w, float* wp, int Cin, int Cout, int CoutPad, int kd, int kw, int R, hipStream_t s);
 hipError_t launch_conv_wino(ConvParams p, hipStream_t stream);
 int wino_bk();                      // channels per K tile of the Winograd kernels (Cin must be a multiple)
 // Winograd F(2,2) along H inside the parity classes of ConvTranspose3d(k4 s2 p1)
@@ -179,8 +179,8 @@ hipError_t launch_stem(const void* x, const void* x2, int u8, int nsplit, const 
                        hipStream_t s);
 hipError_t launch_cost_volume(const float* fl, const float* fr, float* vol, int B, int C, int D, int H, int W,
                               int halo, hipStream_t s);
-// the same volume written as the Winograd F(2,3)-along-H plane sets of its halo-1 padded form: V[4][B][2C][D+2][H/2][W+2]
-hipError_t launch_cost_volume_wino(const float* fl, const float* fr, float* V, int B, int C, int D, int H, int W, hipStream_t s);
+// the same volume written as the Winograd F(R,3)-along-H plane sets of its halo-1 padded form: V[R+2][B][2C][D+2][H/R][W+2]
+hipError_t launch_cost_volume_wino(const float* fl, const float* fr, float* V, int B, int C, int D, int H, int W, int R, hipStream_t s);
 hipError_t launch_pad_copy(const float* x, float* y, int64_t planes, int D, int H, int W, int hd, int hh, int hw,
                            hipStream_t s);
 hipError_t launch_pack_stem(const float* w, float* wt, hipStream_t s);
@@ -213,5 +213,27 @@ hipError_t launch_disparity_wta(const float* fl, const float* fr, float* dl, flo
                                 hipStream_t s);
 hipError_t launch_disparity_epe(const float* pred, const float* gt, float* epe, int* count, int B, int64_t S,
                                 hipStream_t s);
+
+#if defined(__HIPCC__)
+// Winograd F(R, 3) input transform along one axis (s3r_conv_wino.hip): the R + 2 class values of R + 2 consecutive padded rows.
+// Shared by the transform kernel and the cost-volume kernel that writes the transformed planes directly: same code, same bits.
+template <int R>
+__device__ __forceinline__ void wino_rows_to_classes(const float (&r)[R + 2], float (&v)[R + 2]) {
+    if constexpr (R == 2) {
+        v[0] = r[0] - r[2];
+        v[1] = r[1] + r[2];
+        v[2] = r[2] - r[1];
+        v[3] = r[1] - r[3];
+    } else {
+        v[0] = fmaf(4.f, r[0], fmaf(-5.f, r[2], r[4]));
+        v[1] = fmaf(-4.f, r[1] + r[2], r[3] + r[4]);
+        v[2] = fmaf(4.f, r[1] - r[2], r[4] - r[3]);
+        v[3] = fmaf(2.f, r[3] - r[1], r[4] - r[2]);
+        v[4] = fmaf(2.f, r[1] - r[3], r[4] - r[2]);
+        v[5] = fmaf(4.f, r[1], fmaf(-5.f, r[3], r[5]));
+    }
+}
+
+#endif
 
 }  // namespace s3r

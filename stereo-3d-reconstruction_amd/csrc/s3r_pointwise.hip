@@ -171,10 +171,10 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(const float* __restric
 }
 
 // The cost volume written straight into the layout its consumer's Winograd kernel reads (s3r_conv_wino.hip, S3R_LAYOUT_WINO_H):
-// V_i[b][ch][1 + d][q][wp], i = 0..3, rows r0..r3 = padded rows 2q .. 2q+3 of plane d of the halo-1 volume:
-//   V0 = r0 - r2, V1 = r1 + r2, V2 = r2 - r1, V3 = r1 - r3      (the same operations on the same fp32 values as
-// wino_input_kernel applied to the padded volume: bit-identical) — the volume itself (221 MB at B = 32) is never written
+// V_i[b][ch][1 + d][q][wp], i = 0 .. R+1, from the padded rows R q .. R q + R + 1 of plane d of the halo-1 volume through
+// wino_rows_to_classes (the very function wino_input_kernel applies to the padded volume: bit-identical) — the volume itself (221 MB at B = 32) is never written
 // or re-read.  One workgroup per (b, c) as above; per class and slab the planes d = 0 .. D-1 are one contiguous run.
+template <int R>
 __global__ __launch_bounds__(256) void cost_volume_wino_kernel(const float* __restrict__ fl, const float* __restrict__ fr,
                                                                float* __restrict__ V, int C, int D, int H, int W,
                                                                long long cls_stride, FastDiv dPlane, FastDiv dRow) {
@@ -191,46 +191,46 @@ __global__ __launch_bounds__(256) void cost_volume_wino_kernel(const float* __re
         sr[i] = pr[i];
     }
     __syncthreads();
-    const int Wp = W + 2, H2 = H >> 1, Dp = D + 2;
-    const int ds = H2 * Wp;                              // one plane of a class
+    const int Wp = W + 2, Hq = H / R, Dp = D + 2;
+    const int ds = Hq * Wp;                              // one plane of a class
     const size_t cs = (size_t)Dp * ds;
     const int run = D * ds;
     float* __restrict__ ol = V + ((size_t)b * 2 * C + c) * cs + ds;            // plane dp = 1
     float* __restrict__ orr = V + ((size_t)b * 2 * C + C + c) * cs + ds;
-    auto vol = [&](int d, int hp, int wp, float& a, float& r) {              // the padded volume at (d, hp, wp), both slabs
-        const int h = hp - 1, w = wp - 1;
-        const bool in = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
-        const int hw = h * W + w;
-        a = (in && w >= d) ? sl[hw] - sr[hw - d] : 0.f;
-        r = (in && w + d < W) ? sr[hw] - sl[hw + d] : 0.f;
-    };
     for (int e = threadIdx.x; e < run; e += 256) {
-        const int d = dPlane.div(e);                     // e / (H2*Wp)
+        const int d = dPlane.div(e);                     // e / (Hq*Wp)
         const int rem = e - d * ds;
         const int q = dRow.div(rem);                     // rem / Wp
         const int wp = rem - q * Wp;
-        float a0, a1, a2, a3, r0, r1, r2, r3;
-        vol(d, 2 * q, wp, a0, r0);
-        vol(d, 2 * q + 1, wp, a1, r1);
-        vol(d, 2 * q + 2, wp, a2, r2);
-        vol(d, 2 * q + 3, wp, a3, r3);
-        ol[e] = a0 - a2;
-        ol[e + cls_stride] = a1 + a2;
-        ol[e + 2 * cls_stride] = a2 - a1;
-        ol[e + 3 * cls_stride] = a1 - a3;
-        orr[e] = r0 - r2;
-        orr[e + cls_stride] = r1 + r2;
-        orr[e + 2 * cls_stride] = r2 - r1;
-        orr[e + 3 * cls_stride] = r1 - r3;
+        float a[R + 2], r[R + 2], va[R + 2], vr[R + 2];
+#pragma unroll
+        for (int k = 0; k < R + 2; ++k) {                // the padded volume at (d, R q + k, wp), both slabs
+            const int h = R * q + k - 1, w = wp - 1;
+            const bool in = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+            const int hw = h * W + w;
+            a[k] = (in && w >= d) ? sl[hw] - sr[hw - d] : 0.f;
+            r[k] = (in && w + d < W) ? sr[hw] - sl[hw + d] : 0.f;
+        }
+        wino_rows_to_classes<R>(a, va);
+        wino_rows_to_classes<R>(r, vr);
+#pragma unroll
+        for (int k = 0; k < R + 2; ++k) {
+            ol[e + k * cls_stride] = va[k];
+            orr[e + k * cls_stride] = vr[k];
+        }
     }
 }
 
-hipError_t launch_cost_volume_wino(const float* fl, const float* fr, float* V, int B, int C, int D, int H, int W, hipStream_t s) {
+hipError_t launch_cost_volume_wino(const float* fl, const float* fr, float* V, int B, int C, int D, int H, int W, int R, hipStream_t s) {
     const size_t lds = (size_t)2 * H * W * sizeof(float);
-    const int Wp = W + 2, H2 = H >> 1;
-    const long long cls_stride = (long long)B * 2 * C * (D + 2) * H2 * Wp;
-    hipLaunchKernelGGL(cost_volume_wino_kernel, dim3(B * C), dim3(256), lds, s, fl, fr, V, C, D, H, W, cls_stride,
-                       FastDiv((unsigned)(H2 * Wp)), FastDiv((unsigned)Wp));
+    const int Wp = W + 2, Hq = H / R;
+    const long long cls_stride = (long long)B * 2 * C * (D + 2) * Hq * Wp;
+    if (R == 4)
+        hipLaunchKernelGGL(cost_volume_wino_kernel<4>, dim3(B * C), dim3(256), lds, s, fl, fr, V, C, D, H, W, cls_stride,
+                           FastDiv((unsigned)(Hq * Wp)), FastDiv((unsigned)Wp));
+    else
+        hipLaunchKernelGGL(cost_volume_wino_kernel<2>, dim3(B * C), dim3(256), lds, s, fl, fr, V, C, D, H, W, cls_stride,
+                           FastDiv((unsigned)(Hq * Wp)), FastDiv((unsigned)Wp));
     return hipGetLastError();
 }
 

@@ -272,7 +272,7 @@ class _HipChain(nn.Module):
         x2 (encoder only): a second tensor of as many images — the chain runs over x's images, then x2's."""
         lib = _lib.load()
         device, batch = x.device, x.shape[0] + (x2.shape[0] if x2 is not None else 0)
-        if in_layout == _lib.LAYOUT_WINO_H:                 # (4, B, C, ...): the four transformed plane sets of the padded input
+        if in_layout == _lib.LAYOUT_WINO_H:                 # (6, B, C, ...): the transformed plane sets of the padded input
             batch = x.shape[1]
         if batch == 0:                 # same dtype / layout contract as a non-empty batch
             n0 = len(self._layers) if upto is None else self.names.index(upto) + 1
@@ -461,12 +461,12 @@ class CostVolume(nn.Module):
     @torch.no_grad()
     def forward_wino(self, feat_left: torch.Tensor, feat_right: torch.Tensor) -> torch.Tensor:
         """fp32 internal hand-off to a decoder whose first 3D conv runs the Winograd kernel (`takes_wino_input`): the volume
-        written directly as the four F(2,3)-along-H plane sets of its halo-1 padded form, (4,B,2C,D+2,H/2,W+2) — bit-identical
+        written directly as the six F(4,3)-along-H plane sets of its halo-1 padded form, (6,B,2C,D+2,H/4,W+2) — bit-identical
         to the consumer's own input transform, without the volume's round trip through HBM."""
         fl = _check_input(feat_left, "feat_left", feat_left.shape[1:])
         fr = _check_input(feat_right, "feat_right", feat_left.shape[1:])
         B, Cc, H, W = fl.shape
-        shape = (4, B, 2 * Cc, self.max_disp + 2, H // 2, W + 2)
+        shape = (6, B, 2 * Cc, self.max_disp + 2, H // 4, W + 2)      # F(4,3) along H: six plane sets, one row per four outputs
         if self._planes is None or tuple(self._planes.shape) != shape or self._planes.device != fl.device:
             if getattr(self, "_pinned", False):
                 raise RuntimeError("the padded cost volume of this module is captured in a HIP graph for another shape")
@@ -494,10 +494,10 @@ class CostVolume(nn.Module):
 
 
 def _check_wino_planes(v: torch.Tensor) -> torch.Tensor:
-    want = (2 * spec.FEAT_C, spec.MAX_DISP + 2, spec.FEAT_HW // 2, spec.FEAT_HW + 2)
-    if not isinstance(v, torch.Tensor) or not v.is_cuda or v.dtype != torch.float32 or v.dim() != 6 or v.shape[0] != 4 or \
+    want = (2 * spec.FEAT_C, spec.MAX_DISP + 2, spec.FEAT_HW // 4, spec.FEAT_HW + 2)
+    if not isinstance(v, torch.Tensor) or not v.is_cuda or v.dtype != torch.float32 or v.dim() != 6 or v.shape[0] != 6 or \
             tuple(v.shape[2:]) != want or not v.is_contiguous():
-        raise RuntimeError(f"transformed volume must be a contiguous float32 HIP tensor (4, B, {', '.join(map(str, want))})")
+        raise RuntimeError(f"transformed volume must be a contiguous float32 HIP tensor (6, B, {', '.join(map(str, want))})")
     return v
 
 

@@ -57,7 +57,8 @@ def test_out_size_and_packed_elems(s3r, lib):
             else:
                 pad = (l.cout + 127) // 128 * 128
                 # (ABI 6) a 3 x 3 [x 3] stride-1 pad-1 convolution packs its Winograd F(2,3)-along-H class slabs behind the direct one
-                wino = 4 * 3 ** (nd - 1) * l.cin * pad if (l.op != "deconv3d" and l.k == 3 and l.s == 1 and l.p == 1) else 0
+                # (F(4,3) along H for 3D layers with an edge % 4 == 0: six slabs; F(2,3) otherwise: four)
+                wino = (6 if (nd == 3 and n % 4 == 0) else 4) * 3 ** (nd - 1) * l.cin * pad if (l.op != "deconv3d" and l.k == 3 and l.s == 1 and l.p == 1) else 0
                 if l.op == "deconv3d":            # ... and a transposed convolution its 24 F(2,2) (class, F) slabs of 4 taps
                     wino = 24 * 4 * l.cin * pad
                 assert e.value == l.k ** nd * l.cin * pad + wino

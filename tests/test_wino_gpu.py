@@ -109,8 +109,8 @@ def test_winograd_path_vs_oracle_and_invariants(tmp_path):
 
 
 def test_cost_volume_writes_the_transformed_planes_bitwise(s3r):
-    """CostVolume.forward_wino (S3R_LAYOUT_WINO_H: the volume written as the four F(2,3)-along-H plane sets of its halo-1
-    padded form) equals the transform applied to the padded volume, and the decoder fed with it equals the decoder fed with
+    """CostVolume.forward_wino (S3R_LAYOUT_WINO_H: the volume written as the six F(4,3)-along-H plane sets of its halo-1
+    padded form) equals the transform applied to the padded volume (to fp32 rounding: the kernel uses fused multiply-adds), and the decoder fed with it equals the decoder fed with
     the padded volume (which runs its own input transform in front of the same kernel) — bit for bit; both models take the
     hand-off by themselves; a batch too large for one transformed call keeps the plain hand-off."""
     dev = "cuda:0"
@@ -120,16 +120,19 @@ def test_cost_volume_writes_the_transformed_planes_bitwise(s3r):
     l, r = s3r.synthetic_pairs(3, seed=5)
     feats = m.encoder.forward_pair(l.to(dev), r.to(dev))
     vol = m.cost_volume.forward_padded(feats[:3], feats[3:]).clone()                # (3, 64, 30, 30, 30), zero halo
-    planes = m.cost_volume.forward_wino(feats[:3], feats[3:]).clone()               # (4, 3, 64, 30, 14, 30)
-    r0, r1, r2, r3 = (vol[:, :, :, k:k + 27:2, :] for k in range(4))                # padded rows 2q + k, q = 0 .. 13
-    want = torch.stack([r0 - r2, r1 + r2, r2 - r1, r1 - r3])
-    assert planes.shape == want.shape and torch.equal(planes, want)
+    planes = m.cost_volume.forward_wino(feats[:3], feats[3:]).clone()               # (6, 3, 64, 30, 7, 30)
+    x = [vol[:, :, :, k:k + 25:4, :].double() for k in range(6)]                    # padded rows 4q + k, q = 0 .. 6
+    want = torch.stack([4 * x[0] - 5 * x[2] + x[4], -4 * x[1] - 4 * x[2] + x[3] + x[4], 4 * x[1] - 4 * x[2] - x[3] + x[4],
+                        -2 * x[1] - x[2] + 2 * x[3] + x[4], 2 * x[1] - x[2] - 2 * x[3] + x[4], 4 * x[1] - 5 * x[3] + x[5]])
+    assert planes.shape == want.shape                                               # F(4,3)'s input transform, to fp32 rounding
+    assert (planes.double() - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
+    assert not planes[:, :, :, 0].any() and not planes[:, :, :, -1].any()           # the depth-halo planes stay zero
     assert m.decoder.takes_wino_input(3)
     a = m.decoder.forward_padded(vol)
     b = m.decoder.forward_padded(planes, in_layout=s3r._lib.LAYOUT_WINO_H)
     assert torch.equal(a, b)
     assert torch.equal(m(l.to(dev), r.to(dev)), a)                                   # the model's own forward takes it
-    assert not m.decoder.takes_wino_input(200)                                       # 200 x 12.9 MB of planes: two calls
+    assert not m.decoder.takes_wino_input(300)                                       # 300 x 9.7 MB of planes: two calls
     with pytest.raises(RuntimeError):
         m.decoder.forward_padded(planes[:, :, :, :, :, :29], in_layout=s3r._lib.LAYOUT_WINO_H)
     p = s3r.Stereo2Point()
