@@ -108,11 +108,12 @@ def test_winograd_path_vs_oracle_and_invariants(tmp_path):
         assert float((a.double() - b.double()).norm() / a.double().norm()) < 1e-5
 
 
-def test_cost_volume_writes_the_transformed_planes_bitwise(s3r):
+def test_cost_volume_writes_the_transformed_planes_bitwise(s3r, monkeypatch):
     """CostVolume.forward_wino (S3R_LAYOUT_WINO_H: the volume written as the six F(4,3)-along-H plane sets of its halo-1
     padded form) equals the transform applied to the padded volume (to fp32 rounding: the kernel uses fused multiply-adds), and the decoder fed with it equals the decoder fed with
     the padded volume (which runs its own input transform in front of the same kernel) — bit for bit; both models take the
     hand-off by themselves; a batch too large for one transformed call keeps the plain hand-off."""
+    monkeypatch.delenv("S3R_WINO", raising=False)             # the library's own policy (the switch is read per call)
     dev = "cuda:0"
     m = s3r.Stereo2Voxel()
     s3r.seed_module(m, 0)
