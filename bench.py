@@ -152,7 +152,7 @@ def pmc_summary(variant, dtype, B, plain_run):
 
 def executed_ratio(variant):
     """MFMA multiply-adds the fp32 path EXECUTES over the algorithmic count the roofline is quoted on: the layers the library
-    runs through Winograd along H (S3R_WINO policy: v1 as F(4,3), v3 as F(2,3)) execute 1/2 and 2/3 of theirs, the transposed convolutions it runs
+    runs through Winograd along H (S3R_WINO policy: e2, e4, e6, e7, v1 as F(4,3), v3 as F(2,3)) execute 1/2 and 2/3 of theirs, the transposed convolutions it runs
     through F(2,2) along H (d1, d2, d3) 3/4."""
     import s3r
     spec = s3r.arch_spec
@@ -164,11 +164,11 @@ def executed_ratio(variant):
         if l.name in ("e1", "d4"):
             continue
         m = spec.layer_macs(l, n_in) * (2 if l.name.startswith("e") else 1)
-        wino = mode > 0 and l.op in ("conv2d", "conv3d") and l.k == 3 and l.s == 1 and l.p == 1 and \
-            (mode == 2 or (l.op == "conv3d" and n_in >= 14))
+        wino = mode > 0 and l.op in ("conv2d", "conv3d") and l.k == 3 and l.s == 1 and l.p == 1 and l.cin % 32 == 0 and \
+            (mode == 2 or n_in % 4 == 0 or (l.op == "conv3d" and n_in >= 14))
         dwino = mode > 0 and l.op == "deconv3d" and (mode == 2 or n_in >= 4)          # F(2,2) along H: 3/4
         tot += m
-        f43 = wino and l.op == "conv3d" and n_in % 4 == 0                            # F(4,3) along H: 1/2
+        f43 = wino and n_in % 4 == 0                                                  # F(4,3) along H: 1/2
         exe += m * (0.5 if f43 else 2.0 / 3.0 if wino else 0.75 if dwino else 1.0)
     return round(exe / tot, 4)
 
@@ -221,10 +221,11 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False)
                       "per-tap / row-reuse / plane-reuse gathers)" if bf
             else "conv_glds_kernel / conv_glds_dual_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv, LDS-DMA operand "
                  "staging; dual = a layer's bulk and its re-tiled remainder in one launch) + conv_wino_kernel / wino_input_kernel "
-                 "(v1: Winograd F(4,3) along H, 1/2 of the direct form's multiplications; v3: F(2,3), 2/3) + deconv_wino_kernel / "
+                 "(e2, e4, e6, e7, v1: Winograd F(4,3) along H, 1/2 of the direct form's multiplications; v3: F(2,3), 2/3) + deconv_wino_kernel / "
                  "wino_rowdiff_kernel (d1, d2, d3: F(2,2) along H inside the parity classes, 3/4) — `achieved` counts the DIRECT "
                  "form's algorithmic FLOPs for every layer",
             "executed_over_algorithmic_mfma_flops": executed_ratio(variant) if not bf else 1.0,
+            "frac_executed": round(achieved / peak * (executed_ratio(variant) if not bf else 1.0), 4),
             "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
             "frac_border_excluded": round(achieved / peak * ratio, 4),

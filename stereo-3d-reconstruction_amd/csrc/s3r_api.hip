@@ -34,9 +34,10 @@ int64_t ipow(int64_t b, int e) {
 }
 
 // outputs per Winograd group along H of an fp32 3 x 3 [x 3] stride-1 convolution: F(4,3) — half the direct form's multiplications —
-// for 3D layers whose edge is a multiple of 4 (v1: 0.769 -> 0.666 ms against F(2,3)), F(2,3) otherwise (v3, edge 14: four
-// groups of 4 would compute 16 rows for 14 and the six-class kernel holds two workgroups per CU instead of three: 0.483 -> 0.497)
-int wino_r(const s3r_conv_desc* d) { return (d->ndim == 3 && d->in_size % 4 == 0) ? 4 : 2; }
+// where the edge is a multiple of 4 (v1: 0.769 -> 0.668 ms against F(2,3); the 2D layers e2 / e4 / e6 / e7, which F(2,3) could
+// not pay for its transform pass on, gain 6 / 12 / 22 / 25 %), F(2,3) otherwise (v3, edge 14: four groups of 4 would compute 16
+// rows for 14 and the six-class kernel holds two workgroups per CU instead of three: 0.483 -> 0.497)
+int wino_r(const s3r_conv_desc* d) { return d->in_size % 4 == 0 ? 4 : 2; }
 
 constexpr int64_t kMaxElems = (int64_t)1 << 31;
 constexpr int64_t kMaxBytes = (int64_t)1 << 32;
@@ -219,8 +220,8 @@ int cout_pad(int cout) { return (cout + 127) / 128 * 128; }
 // Winograd F(2,3) along H (s3r_conv_wino.hip) for the fp32 3 x 3 [x 3] stride-1 pad-1 convolutions: 2/3 of the matrix work,
 // another summation order (not bit-identical to the direct kernels, same fp32 accuracy).  Such a layer's packed weights
 // hold BOTH forms — the direct slab, then the four Winograd class slabs — so which kernel runs is decided per call:
-//   S3R_WINO unset / 1: the layers it measured faster on (3D, >= 14 rows: v1, v3 — DESIGN.md §4.1);  0: never;  2: every
-//   eligible layer (experiments).  A call with a tile / split-K override, a non-plain layout, no halo or too little
+//   S3R_WINO unset / 1: the layers it measured faster on (edge % 4 == 0: e2, e4, e6, e7, v1; and v3 — DESIGN.md §4.1);  0: never;
+//   2: every eligible layer (experiments: adds v5).  A call with a tile / split-K override, a non-plain layout, no halo or too little
 //   scratch runs the direct kernel.
 #ifndef S3R_DWINO_MIN_EDGE
 #define S3R_DWINO_MIN_EDGE 4      // library policy: transposed layers with an input edge >= this (d1, d2, d3: with 32-channel K
@@ -239,7 +240,7 @@ bool wino_layer(const s3r_conv_desc* d) {
 bool wino_ok(const s3r_conv_desc* d) {
     const int mode = wino_mode();
     if (mode <= 0 || !wino_layer(d) || d->act == S3R_ACT_SIGMOID) return false;
-    if (mode == 1 && !(d->ndim == 3 && d->in_size >= 14)) return false;
+    if (mode == 1 && !(d->in_size % 4 == 0 || (d->ndim == 3 && d->in_size >= 14))) return false;    // (v5, edge 7: 196 workgroups)
     return d->in_halo == 1 && d->in_layout == S3R_LAYOUT_PLAIN && d->out_layout == S3R_LAYOUT_PLAIN && d->tile < 0 && d->ksplit <= 1;
 }
 // samples per Winograd call (the transformed input of a call stays below 2 GiB) and the scratch that takes, in floats

@@ -57,14 +57,15 @@ def test_out_size_and_packed_elems(s3r, lib):
             else:
                 pad = (l.cout + 127) // 128 * 128
                 # (ABI 6) a 3 x 3 [x 3] stride-1 pad-1 convolution packs its Winograd F(2,3)-along-H class slabs behind the direct one
-                # (F(4,3) along H for 3D layers with an edge % 4 == 0: six slabs; F(2,3) otherwise: four)
-                wino = (6 if (nd == 3 and n % 4 == 0) else 4) * 3 ** (nd - 1) * l.cin * pad if (l.op != "deconv3d" and l.k == 3 and l.s == 1 and l.p == 1) else 0
+                # (F(4,3) along H where the edge % 4 == 0: six slabs; F(2,3) otherwise: four)
+                wino = (6 if n % 4 == 0 else 4) * 3 ** (nd - 1) * l.cin * pad if (l.op != "deconv3d" and l.k == 3 and l.s == 1 and l.p == 1) else 0
                 if l.op == "deconv3d":            # ... and a transposed convolution its 24 F(2,2) (class, F) slabs of 4 taps
                     wino = 24 * 4 * l.cin * pad
                 assert e.value == l.k ** nd * l.cin * pad + wino
 
 
-def test_workspace_query(s3r, lib):
+def test_workspace_query(s3r, lib, monkeypatch):
+    monkeypatch.delenv("S3R_WINO", raising=False)          # the library's own kernel policy (read per call)
     spec = s3r.arch_spec
     rows = spec.stage_table("encoder")
     arr = (s3r._lib.Layer * len(rows))()
@@ -87,10 +88,12 @@ def test_workspace_query(s3r, lib):
     # a chain whose first layer gathers with padding pads an unpadded input itself: one more region
     sub = (s3r._lib.Layer * 2)()
     sub[0].desc, sub[1].desc = _desc(s3r, rows[1][0], 4, rows[1][1]), _desc(s3r, rows[2][0], 4, rows[2][1])
-    need2 = lib.s3r_chain_workspace_elems(sub, 2)            # (e2, e3 do not split K: no scratch)
-    assert need2 == -(-(4 * 32 * 114 * 114) // 256) * 256 + -(-(4 * 64 * 114 * 114) // 256) * 256
+    need2 = lib.s3r_chain_workspace_elems(sub, 2)
+    # (e2, e3 do not split K; e2's Winograd F(4,3) input planes are the chain's scratch: 6 x 4 x 32 x 28 groups x 114 columns)
+    wino = -(-(6 * 4 * 32 * (112 // 4) * 114) // 256) * 256
+    assert need2 == -(-(4 * 32 * 114 * 114) // 256) * 256 + -(-(4 * 64 * 114 * 114) // 256) * 256 + wino
     sub[0].desc.in_halo = 1                       # caller hands a padded input: no pad region
-    assert lib.s3r_chain_workspace_elems(sub, 2) == -(-(4 * 64 * 114 * 114) // 256) * 256
+    assert lib.s3r_chain_workspace_elems(sub, 2) == -(-(4 * 64 * 114 * 114) // 256) * 256 + wino
 
 
 def test_split_k_choice_is_batch_invariant(s3r, lib):
