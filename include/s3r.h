@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define S3R_ABI_VERSION 6
+#define S3R_ABI_VERSION 7
 
 typedef enum s3r_status {
     S3R_OK = 0,
@@ -87,6 +87,26 @@ typedef enum s3r_act { S3R_ACT_NONE = 0, S3R_ACT_RELU = 1, S3R_ACT_SIGMOID = 2 }
  *                      call is bounded: s3r_conv_wino_input_elems returns 0 when the layer / batch cannot take it. */
 typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_S2D = 1, S3R_LAYOUT_WINO_H = 2 } s3r_layout;
 
+/* Which convolution algorithm a layer's forward runs (ABI 7).  The fp32 3 x 3 [x 3] stride-1 pad-1 convolutions and the
+ * transposed convolutions have two kernels — the direct implicit GEMM and a Winograd-along-H form with 1/2 .. 3/4 of the
+ * multiplications (csrc/s3r_conv_wino.hip) — that agree to fp32 rounding, NOT bit for bit.  So the choice is part of the
+ * descriptor and never depends on anything else a caller passes (workspace size, batch):
+ *   S3R_ALGO_AUTO      the library's policy, a function of the layer's PER-SAMPLE geometry only: Winograd where the layer has
+ *                      that form and the library measured it faster (edge a multiple of 4, or a 3D layer with edge >= 14; transposed
+ *                      layers with an input edge >= 4); direct otherwise, and direct whenever the descriptor forces a direct-kernel
+ *                      tile / split-K (tile >= 0 or ksplit >= 1) or a non-plain layout.  The process-level override
+ *                      S3R_WINO (0: AUTO never picks Winograd, 2: AUTO picks it for every layer that has the form) is read ONCE,
+ *                      when the library is loaded;
+ *   S3R_ALGO_DIRECT    the direct kernel;
+ *   S3R_ALGO_WINOGRAD  the Winograd kernel (S3R_ERR_INVALID if the layer has no such form or the descriptor cannot take it:
+ *                      needs in_halo = 1, plain layouts — or S3R_LAYOUT_WINO_H input —, no split-K, no sigmoid).  `tile` >= 0 then
+ *                      forces the launch FORM (tuning / tests; every form gives the same bits): bits 0-1 = 0 serial, 1 class-parallel,
+ *                      2 dual (bulk serial + remainder class-parallel in one launch); bit 2: class-parallel part on 64 x 64 tiles;
+ *                      bit 3: serial part on 64 x 64 tiles.
+ * A call whose scratch is smaller than s3r_conv_scratch_elems says for the RESOLVED algorithm fails with S3R_ERR_WORKSPACE; it
+ * is never answered with the other kernel's bits. */
+typedef enum s3r_algo { S3R_ALGO_AUTO = 0, S3R_ALGO_DIRECT = 1, S3R_ALGO_WINOGRAD = 2 } s3r_algo;
+
 /* One layer's geometry.  Spatial sizes are cubic/square: `in_size` per axis, `ndim` axes.
  *
  * Halos.  The MFMA convolution kernels read their zero padding from memory: an activation may be
@@ -115,6 +135,7 @@ typedef struct s3r_conv_desc {
     int32_t dtype;     /* s3r_dtype: which path (layout + matrix instruction) the layer runs on */
     int32_t in_layout; /* s3r_layout of the input buffer  (S2D: stride-2 k3 p1 convolutions, in_halo must be 1) */
     int32_t out_layout;/* s3r_layout of the output buffer (S2D: MFMA convolutions, out_halo must be 1) */
+    int32_t algo;      /* s3r_algo (ABI 7): AUTO = the library's geometry-only policy */
 } s3r_conv_desc;
 
 /* One layer of a stage: geometry + its packed weights + folded epilogue vectors (device pointers). */
@@ -132,20 +153,20 @@ const char* s3r_last_error(void);
 int s3r_conv_out_size(const s3r_conv_desc* d);
 /* size of the packed weight buffer for a layer IN 4-BYTE UNITS (>= the torch weight's numel on the fp32
  * path: couts are padded; about half of it on the bf16 path).  ABI 6: an fp32 3 x 3 [x 3] stride-1 pad-1 convolution packs
- * two forms, the direct slab and the Winograd F(R,3)-along-H class slabs (csrc/s3r_conv_wino.hip: R = 4, six slabs, for 3D
- * layers - half the multiplications; R = 2, four slabs, for 2D ones); which kernel a
- * forward runs is decided per call (environment S3R_WINO: unset / 1 = the layers it measured faster on, 0 = never, 2 =
- * every eligible layer; a tile / split-K override, a non-plain layout or too little scratch select the direct kernel).
- * The two kernels agree to fp32 rounding (another summation order), not bit for bit.  The transposed convolutions likewise:
- * 24 F(2,2)-along-H (parity class, F) slabs behind the direct ones, taken for d1 / d2 / d3 under the default policy. */
+ * two forms, the direct slab and the Winograd F(R,3)-along-H class slabs (csrc/s3r_conv_wino.hip: R = 4, six slabs, where the
+ * edge is a multiple of 4 - half the multiplications; R = 2, four slabs, otherwise); which kernel a forward runs is the
+ * descriptor's `algo` (s3r_algo above).  The transposed convolutions likewise: 24 F(2,2)-along-H (parity class, F) slabs
+ * behind the direct ones. */
 int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems);
 /* repack a torch-layout weight (Conv: [cout][cin][k..]; ConvTranspose: [cin][cout][k..]; Linear:
  * [cout][cin]) into the kernel's K-major layout.  Device to device, on `stream`. */
 int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, void* packed, void* stream);
-/* floats of split-K scratch s3r_conv_forward wants for this layer (0 when it does not split K) */
+/* floats of scratch s3r_conv_forward needs for this layer under its resolved algorithm: split-K partial slabs (direct
+ * kernel), the transformed input and the class-parallel slabs (Winograd kernel); 0 when it needs none */
 int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d);
-/* y = act(conv(x) * scale + shift); dispatches to the stem / MFMA / head kernel by shape.  `scratch`
- * (may be NULL) holds split-K partial sums; without it a layer the library would split runs unsplit. */
+/* y = act(conv(x) * scale + shift); dispatches to the stem / MFMA / head kernel by shape.  `scratch` must hold
+ * s3r_conv_scratch_elems floats: a smaller one is S3R_ERR_WORKSPACE, never a silent switch to another kernel or another
+ * split (ABI 6 ran such a layer unsplit / on the direct kernel: other bits for the same descriptor). */
 int s3r_conv_forward(const s3r_conv_desc* d, const void* x, const void* packed_w, const float* scale,
                      const float* shift, void* y, float* scratch, int64_t scratch_elems, void* stream);
 
@@ -237,8 +258,12 @@ typedef struct s3r_prof_record {
     int32_t tag;
     float ms;
     int32_t launches;   /* kernel launches bracketed by this record (a conv layer may be 1-3 launches) */
-    double flops;
+    double flops;       /* algorithmic (direct-form) FLOPs of the layer: SURVEY 8d's count */
     double bytes;
+    double exec_flops;  /* FLOPs the kernel that ran EXECUTES on the matrix cores (= flops for the direct kernels; 1/2 .. 3/4 of it
+                           for the Winograd forms) */
+    int32_t algo;       /* what ran: 0 direct, 1 Winograd serial form, 2 class-parallel form, 3 dual form */
+    int32_t reserved;
 } s3r_prof_record;
 int s3r_profile_enable(int max_records);   /* 0 disables and frees the event pool */
 int s3r_profile_reset(void);

@@ -18,13 +18,16 @@ DTYPE = {"fp32": 0, "bf16": 1}
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}
 FAMILY = {0: "conv_mfma", 1: "stem", 2: "head", 3: "cost_volume", 4: "linear", 5: "chamfer", 6: "iou", 7: "pack",
           8: "pad_copy", 9: "disparity"}
-ABI_VERSION = 6
+ABI_VERSION = 7
+ALGO_AUTO, ALGO_DIRECT, ALGO_WINOGRAD = 0, 1, 2
+ALGO = {None: 0, "auto": 0, "direct": 1, "winograd": 2, False: 1, True: 2}
+RAN = {0: "direct", 1: "winograd-serial", 2: "winograd-class-parallel", 3: "winograd-dual"}
 
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("op", "ndim", "batch", "cin", "cout", "in_size", "k", "stride", "pad", "act", "tag", "tile",
-                 "in_halo", "out_halo", "ksplit", "dtype", "in_layout", "out_layout")]
+                 "in_halo", "out_halo", "ksplit", "dtype", "in_layout", "out_layout", "algo")]
 
 
 class Layer(C.Structure):
@@ -33,7 +36,8 @@ class Layer(C.Structure):
 
 class ProfRecord(C.Structure):
     _fields_ = [("family", C.c_int32), ("tag", C.c_int32), ("ms", C.c_float), ("launches", C.c_int32),
-                ("flops", C.c_double), ("bytes", C.c_double)]
+                ("flops", C.c_double), ("bytes", C.c_double), ("exec_flops", C.c_double), ("algo", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class S3RError(RuntimeError):
@@ -120,12 +124,13 @@ def check(rc, what=""):
 LAYOUT_PLAIN, LAYOUT_S2D, LAYOUT_WINO_H = 0, 1, 2
 
 
-def make_desc(layer, batch, in_size, tag=0, tile=-1, in_halo=0, out_halo=0, ksplit=0, dtype=0, in_layout=0, out_layout=0):
-    """arch_spec.Layer -> ConvDesc."""
+def make_desc(layer, batch, in_size, tag=0, tile=-1, in_halo=0, out_halo=0, ksplit=0, dtype=0, in_layout=0, out_layout=0,
+              algo=0):
+    """arch_spec.Layer -> ConvDesc.  algo: ALGO_AUTO (the library's geometry-only policy), ALGO_DIRECT, ALGO_WINOGRAD."""
     op = {"conv2d": OP_CONV, "conv3d": OP_CONV, "deconv3d": OP_DECONV, "linear": OP_LINEAR}[layer.op]
     nd = {"conv2d": 2, "conv3d": 3, "deconv3d": 3, "linear": 0}[layer.op]
     return ConvDesc(op, nd, batch, layer.cin, layer.cout, in_size, layer.k, layer.s, layer.p, ACT[layer.act], tag,
-                    tile, in_halo, out_halo, ksplit, dtype, in_layout, out_layout)
+                    tile, in_halo, out_halo, ksplit, dtype, in_layout, out_layout, algo)
 
 
 def profile_enable(max_records):
@@ -140,4 +145,4 @@ def profile_read(max_records=4096):
     buf = (ProfRecord * max_records)()
     n = check(load().s3r_profile_read(buf, max_records), "profile_read")
     return [dict(family=FAMILY.get(r.family, str(r.family)), tag=r.tag, ms=r.ms, launches=r.launches, flops=r.flops,
-                 bytes=r.bytes) for r in buf[:n]]
+                 bytes=r.bytes, exec_flops=r.exec_flops, ran=RAN.get(r.algo, str(r.algo))) for r in buf[:n]]

@@ -36,8 +36,11 @@ int64_t ipow(int64_t b, int e) {
 // outputs per Winograd group along H of an fp32 3 x 3 [x 3] stride-1 convolution: F(4,3) — half the direct form's multiplications —
 // where the edge is a multiple of 4 (v1: 0.769 -> 0.668 ms against F(2,3); the 2D layers e2 / e4 / e6 / e7, which F(2,3) could
 // not pay for its transform pass on, gain 6 / 12 / 22 / 25 %), F(2,3) otherwise (v3, edge 14: four groups of 4 would compute 16
-// rows for 14 and the six-class kernel holds two workgroups per CU instead of three: 0.483 -> 0.497)
-int wino_r(const s3r_conv_desc* d) { return d->in_size % 4 == 0 ? 4 : 2; }
+// rows for 14).  S3R_WINO_R4=1 (experiments; read once, it decides the PACKED layout too): F(4,3) for every edge >= 4.
+int wino_r(const s3r_conv_desc* d) {
+    static const bool r4_all = getenv("S3R_WINO_R4") && atoi(getenv("S3R_WINO_R4")) != 0;
+    return (d->in_size % 4 == 0 || (r4_all && d->in_size >= 4)) ? 4 : 2;
+}
 
 constexpr int64_t kMaxElems = (int64_t)1 << 31;
 constexpr int64_t kMaxBytes = (int64_t)1 << 32;
@@ -65,6 +68,8 @@ struct ProfScope {
     unsigned gen = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int launches = 1;     // kernel launches inside the scope (a conv may be cut into bulk + remainder, + split-K finish)
+    int algo = 0;         // what ran: 0 direct, 1 / 2 / 3 the Winograd serial / class-parallel / dual form
+    double exec = -1.0;   // MFMA FLOPs executed (< 0: the algorithmic count)
     hipStream_t stream;
     ProfScope(hipStream_t s, int family, int tag, double flops, double bytes) : stream(s) {
         if (!g_prof.on.load(std::memory_order_relaxed)) return;
@@ -75,6 +80,7 @@ struct ProfScope {
         slot = (int)g_prof.rec.size();
         s3r_prof_record r;
         r.family = family; r.tag = tag; r.ms = 0.f; r.flops = flops; r.bytes = bytes; r.launches = 1;
+        r.exec_flops = flops; r.algo = 0; r.reserved = 0;
         g_prof.rec.push_back(r);
         gen = g_prof.gen;
         e0 = g_prof.ev[2 * slot];
@@ -87,7 +93,11 @@ struct ProfScope {
         std::lock_guard<std::mutex> lk(g_prof.mu);
         if (gen != g_prof.gen) return;                       // the pool this scope belongs to is gone
         (void)hipEventRecord(e1, stream);
-        if (slot < (int)g_prof.rec.size()) g_prof.rec[slot].launches = launches;
+        if (slot < (int)g_prof.rec.size()) {
+            g_prof.rec[slot].launches = launches;
+            g_prof.rec[slot].algo = algo;
+            if (exec >= 0.0) g_prof.rec[slot].exec_flops = exec;
+        }
     }
 };
 
@@ -217,35 +227,70 @@ int check_halos(const s3r_conv_desc* d, Route r) {
 
 int cout_pad(int cout) { return (cout + 127) / 128 * 128; }
 
-// Winograd F(2,3) along H (s3r_conv_wino.hip) for the fp32 3 x 3 [x 3] stride-1 pad-1 convolutions: 2/3 of the matrix work,
-// another summation order (not bit-identical to the direct kernels, same fp32 accuracy).  Such a layer's packed weights
-// hold BOTH forms — the direct slab, then the four Winograd class slabs — so which kernel runs is decided per call:
-//   S3R_WINO unset / 1: the layers it measured faster on (edge % 4 == 0: e2, e4, e6, e7, v1; and v3 — DESIGN.md §4.1);  0: never;
-//   2: every eligible layer (experiments: adds v5).  A call with a tile / split-K override, a non-plain layout, no halo or too little
-//   scratch runs the direct kernel.
+// Winograd along H (s3r_conv_wino.hip) for the fp32 3 x 3 [x 3] stride-1 pad-1 convolutions (F(4,3): 1/2 of the matrix work, F(2,3):
+// 2/3) and the transposed convolutions (F(2,2) inside the parity classes: 3/4): another summation order than the direct
+// kernels' — same fp32 accuracy, other bits.  Such a layer's packed weights hold BOTH forms (the direct slab, then the class
+// slabs); which kernel a call runs is the descriptor's `algo` (include/s3r.h): AUTO resolves from the layer's per-sample
+// geometry (and the descriptor's own tile / split-K / layout fields) alone — never from the scratch a caller offers or the
+// batch — under the process-level policy S3R_WINO, read once:
+//   unset / 1: the layers it measured faster on (edge % 4 == 0: e2, e4, e6, e7, v1; 3D layers with edge >= 14: v3; transposed
+//   layers with an input edge >= S3R_DWINO_MIN_EDGE);  0: never;  2: every layer that has the form (adds v5).
 #ifndef S3R_DWINO_MIN_EDGE
 #define S3R_DWINO_MIN_EDGE 4      // library policy: transposed layers with an input edge >= this (d1, d2, d3: with 32-channel K
                                   // tiles d1 gains too, 0.269 -> 0.252 ms)
 #endif
 int wino_mode() {
-    const char* e = getenv("S3R_WINO");                  // (read per call: the A/B tools flip it in-process)
-    return e ? atoi(e) : 1;
+    static const int mode = getenv("S3R_WINO") ? atoi(getenv("S3R_WINO")) : 1;      // process-level: read once
+    return mode;
 }
 // structural: the layer has a Winograd form (decides the packed layout; independent of any switch)
 bool wino_layer(const s3r_conv_desc* d) {
     return d->dtype != S3R_BF16 && d->op == S3R_OP_CONV && (d->ndim == 2 || d->ndim == 3) && d->k == 3 && d->stride == 1 &&
            d->pad == 1 && d->cin % s3r::wino_bk() == 0 && d->cout > 1 && d->in_size >= 4;
 }
-// this call takes it (scratch is checked by the caller)
-bool wino_ok(const s3r_conv_desc* d) {
-    const int mode = wino_mode();
-    if (mode <= 0 || !wino_layer(d) || d->act == S3R_ACT_SIGMOID) return false;
-    if (mode == 1 && !(d->in_size % 4 == 0 || (d->ndim == 3 && d->in_size >= 14))) return false;    // (v5, edge 7: 196 workgroups)
-    return d->in_halo == 1 && d->in_layout == S3R_LAYOUT_PLAIN && d->out_layout == S3R_LAYOUT_PLAIN && d->tile < 0 && d->ksplit <= 1;
+bool dwino_layer(const s3r_conv_desc* d) {
+    return d->dtype != S3R_BF16 && d->op == S3R_OP_DECONV && d->ndim == 3 && d->k == 4 && d->stride == 2 && d->pad == 1 &&
+           d->cin % s3r::wino_bk() == 0 && d->in_size >= 2 && (d->in_size & 1) == 0;
 }
-// samples per Winograd call (the transformed input of a call stays below 2 GiB) and the scratch that takes, in floats
-int wino_bmax(const s3r_conv_desc* d);
-int64_t wino_need(const s3r_conv_desc* d);
+// the descriptor can run its layer's Winograd form
+bool wino_desc_ok(const s3r_conv_desc* d) {
+    if (!(wino_layer(d) || dwino_layer(d)) || d->act == S3R_ACT_SIGMOID || d->in_halo != 1 || d->ksplit > 1) return false;
+    if (d->out_layout != S3R_LAYOUT_PLAIN) return false;
+    return d->in_layout == S3R_LAYOUT_PLAIN || (d->in_layout == S3R_LAYOUT_WINO_H && wino_layer(d));
+}
+// the algorithm a descriptor resolves to: *wino = Winograd (else direct); *form = the forced launch form or -1
+int resolve_algo(const s3r_conv_desc* d, bool* wino, int* form) {
+    *wino = false;
+    *form = -1;
+    if (d->algo != S3R_ALGO_AUTO && d->algo != S3R_ALGO_DIRECT && d->algo != S3R_ALGO_WINOGRAD)
+        return fail(S3R_ERR_INVALID, "unknown algo %d", d->algo);
+    if (d->algo == S3R_ALGO_WINOGRAD) {
+        if (!wino_desc_ok(d))
+            return fail(S3R_ERR_INVALID, "algo = WINOGRAD: this layer / descriptor has no Winograd form (fp32 Conv k3 s1 p1 with cin %% %d "
+                        "== 0 and edge >= 4, or ConvTranspose3d k4 s2 p1 over an even edge; in_halo = 1, plain layouts, no split-K, "
+                        "no sigmoid)", s3r::wino_bk());
+        *wino = true;
+        *form = d->tile;
+        return S3R_OK;
+    }
+    if (d->in_layout == S3R_LAYOUT_WINO_H) {             // only the Winograd kernel reads the transformed planes
+        if (d->algo == S3R_ALGO_DIRECT || !wino_desc_ok(d) || d->tile >= 0)
+            return fail(S3R_ERR_INVALID, "a Winograd-transformed input runs the Winograd kernel only: algo AUTO / WINOGRAD, no direct tile / "
+                        "split-K override, a plain output");
+        *wino = true;
+        return S3R_OK;
+    }
+    if (d->algo == S3R_ALGO_DIRECT || d->tile >= 0 || d->ksplit >= 1 || !wino_desc_ok(d)) return S3R_OK;
+    const int mode = wino_mode();
+    if (mode <= 0) return S3R_OK;
+    if (d->op == S3R_OP_DECONV) *wino = mode >= 2 || d->in_size >= S3R_DWINO_MIN_EDGE;
+    else *wino = mode >= 2 || d->in_size % 4 == 0 || (d->ndim == 3 && d->in_size >= 14);      // (v5, edge 7: S3R_WINO=2 only)
+    return S3R_OK;
+}
+bool resolves_to_wino(const s3r_conv_desc* d) {
+    bool w; int f;
+    return resolve_algo(d, &w, &f) == S3R_OK && w;
+}
 int64_t wino_w_elems(const s3r_conv_desc* d) {       // the R + 2 class slabs behind the direct slab
     return (wino_r(d) + 2) * ipow(3, d->ndim - 1) * d->cin * (int64_t)cout_pad(d->cout);
 }
@@ -254,38 +299,71 @@ int64_t wino_v_elems(const s3r_conv_desc* d) {       // the transformed plane se
     const int64_t dp = d->ndim == 3 ? d->in_size + 2 : 1, hq = (d->in_size + R - 1) / R, wp = d->in_size + 2;
     return (R + 2) * (int64_t)d->batch * d->cin * dp * hq * wp;
 }
+// samples per Winograd call (the transformed input of a call stays below 2 GiB)
 int wino_bmax(const s3r_conv_desc* d) {
     const int64_t v_sample = wino_v_elems(d) / (d->batch > 0 ? d->batch : 1);
     const int64_t m = v_sample > 0 ? (((int64_t)1 << 31) - 1) / (4 * v_sample) : 0;
     return (int)(m < d->batch ? m : d->batch);
 }
-int64_t wino_need(const s3r_conv_desc* d) {
-    return d->batch > 0 ? wino_v_elems(d) / d->batch * wino_bmax(d) : 0;
-}
-
-// The transposed convolutions (k4 s2 p1): Winograd F(2,2) along H inside each output-parity class — 3/4 of the matrix work
-// (s3r_conv_wino.hip).  Same scheme: both weight forms packed (direct: 8 classes x 8 taps; then 24 (class, F) slabs x 4
-// taps), kernel chosen per call; the transformed input is the padded input plus its row differences (scratch: one more
-// tensor of the input's size).
-bool dwino_layer(const s3r_conv_desc* d) {
-    return d->dtype != S3R_BF16 && d->op == S3R_OP_DECONV && d->ndim == 3 && d->k == 4 && d->stride == 2 && d->pad == 1 &&
-           d->cin % s3r::wino_bk() == 0 && d->in_size >= 2 && (d->in_size & 1) == 0;
-}
-bool dwino_ok(const s3r_conv_desc* d) {
-    const int mode = wino_mode();
-    if (mode <= 0 || !dwino_layer(d) || d->act == S3R_ACT_SIGMOID) return false;
-    if (mode == 1 && d->in_size < S3R_DWINO_MIN_EDGE) return false;
-    return d->in_halo == 1 && d->in_layout == S3R_LAYOUT_PLAIN && d->out_layout == S3R_LAYOUT_PLAIN && d->tile < 0 && d->ksplit <= 1;
-}
 int64_t dwino_w_elems(const s3r_conv_desc* d) { return 24 * 4 * (int64_t)d->cin * cout_pad(d->cout); }
 int64_t dwino_d_elems(const s3r_conv_desc* d) { return (int64_t)d->batch * d->cin * ipow(d->in_size + 2, 3); }
+
+// Scratch of a Winograd call: [transformed input V (a convolution fed with plain input) | row differences (transposed) ] then
+// the class-parallel slabs of the launch form the library plans for this batch (every form gives the same bits, so the form
+// — unlike the algorithm — may follow the batch).
+struct WinoNeed { int64_t v, slab, total; };
+int wino_kind(const s3r_conv_desc* d) { return d->op == S3R_OP_DECONV ? 2 : (wino_r(d) == 4 ? 1 : 0); }
+int64_t wino_positions(const s3r_conv_desc* d, int nb) {       // GEMM positions (groups of R output rows) of nb samples
+    const int n = d->in_size;
+    if (d->op == S3R_OP_DECONV) return (int64_t)nb * n * (n / 2) * n;
+    const int R = wino_r(d);
+    return (int64_t)nb * (d->ndim == 3 ? n : 1) * ((n + R - 1) / R) * n;
+}
+WinoNeed wino_need(const s3r_conv_desc* d, int form, bool head) {
+    WinoNeed w = {0, 0, 0};
+    if (d->batch <= 0) return w;
+    const int kind = wino_kind(d);
+    if (d->op == S3R_OP_DECONV) {
+        w.v = dwino_d_elems(d);
+        const int nt = (int)wino_positions(d, d->batch);
+        w.slab = s3r::wino_slab_elems(kind, d->cout, nt, s3r::wino_plan(kind, d->cout, nt, head, form));
+    } else {
+        const int bmax = wino_bmax(d);
+        if (bmax <= 0) return w;
+        if (d->in_layout != S3R_LAYOUT_WINO_H) w.v = wino_v_elems(d) / d->batch * bmax;
+        for (int b0 = 0; b0 < d->batch; b0 += bmax) {          // (at most two different sub-batch sizes)
+            const int nb = d->batch - b0 < bmax ? d->batch - b0 : bmax;
+            if (b0 > 0 && nb == bmax) continue;
+            const int nt = (int)wino_positions(d, nb);
+            const int64_t sl = s3r::wino_slab_elems(kind, d->cout, nt, s3r::wino_plan(kind, d->cout, nt, false, form));
+            if (sl > w.slab) w.slab = sl;
+        }
+    }
+    w.v = (w.v + 255) / 256 * 256;
+    w.total = w.v + w.slab;
+    return w;
+}
+// MFMA FLOPs the Winograd form executes for the whole batch
+double wino_exec_flops(const s3r_conv_desc* d, const Geo& g) {
+    if (d->op == S3R_OP_DECONV) return g.flops * 0.75;
+    const int R = wino_r(d);
+    const double taps = (d->ndim == 3 ? 3.0 : 1.0) * 3.0 * (R + 2);
+    return 2.0 * (double)wino_positions(d, d->batch) * d->cout * d->cin * taps;
+}
+
 // fills the transposed-convolution parameters for the Winograd kernel and runs transform + kernel
-int dwino_run(const s3r_conv_desc* d, s3r::ConvParams p, const float* x, const float* packed_w, float* scratch, hipStream_t s) {
+int dwino_run(const s3r_conv_desc* d, s3r::ConvParams p, const float* x, const float* packed_w, float* scratch, int64_t scratch_elems,
+              int form, hipStream_t s, int* launches, int* ran) {
+    const WinoNeed need = wino_need(d, form, p.head_w != nullptr);
+    if (!scratch || scratch_elems < need.total)
+        return fail(S3R_ERR_WORKSPACE, "the Winograd form of this transposed convolution needs %lld floats of scratch "
+                    "(s3r_conv_scratch_elems), got %lld", (long long)need.total, (long long)(scratch ? scratch_elems : 0));
     const int n = d->in_size;
     hipError_t e = s3r::launch_wino_rowdiff(x, scratch, (long long)d->batch * d->cin * (n + 2), n + 2, n + 2, s);
     if (e != hipSuccess) return hip_fail(e, "Winograd row-difference launch");
     p.x = x;
-    p.part = scratch;
+    p.xd = scratch;
+    p.part = scratch + need.v;
     p.w = packed_w + 64 * (int64_t)d->cin * cout_pad(d->cout);          // behind the direct slab (8 classes x 8 taps)
     p.Nh = n / 2;
     p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
@@ -294,8 +372,12 @@ int dwino_run(const s3r_conv_desc* d, s3r::ConvParams p, const float* x, const f
     p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
     p.dW = s3r::FastDiv((unsigned)p.Nw);
     p.ksplit = 1;
-    e = s3r::launch_deconv_wino(p, s);
+    const s3r::WinoLaunch L = s3r::wino_plan(2, d->cout, p.Ntotal, p.head_w != nullptr, form);
+    int nl = 0;
+    e = s3r::launch_deconv_wino(p, L, s, &nl);
     if (e != hipSuccess) return hip_fail(e, "Winograd transposed-conv launch");
+    *launches = 1 + nl;
+    *ran = 1 + L.mode;
     return S3R_OK;
 }
 int cout_pad_h(int cout) { return (cout + 63) / 64 * 64; }
@@ -564,7 +646,7 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
     for (int i = 0; i + 1 < n; ++i) {
         if (pl->r[i] != R_MFMA || pl->r[i + 1] != R_HEAD || pl->d[i].cout > 64) continue;
         if (pl->d[i + 1].cin != pl->d[i].cout || pl->d[i].out_halo != 0 || pl->d[i].act == S3R_ACT_SIGMOID) continue;
-        if (wino_ok(&pl->d[i])) continue;                   // (the Winograd kernel has no fused-head epilogue)
+        if (pl->d[i].op == S3R_OP_CONV && resolves_to_wino(&pl->d[i])) continue;     // (the Winograd conv kernel has no fused-head epilogue)
         if (pl->d[i].dtype == S3R_BF16) {
             s3r::ConvParamsH ph = make_params_h(&pl->d[i], pl->g[i]);
             LaunchH Lh;
@@ -612,14 +694,18 @@ int conv_head_fused(const s3r_conv_desc* d, const Geo& g, const s3r_conv_desc* h
     p.y_org = hd->out_halo * (p.y_ds + p.y_hs + 1);
     p.y_bytes = (unsigned)(hg.y_elems * 4);
     p.head_w = static_cast<const float*>(H.packed_w); p.head_scale = H.scale; p.head_shift = H.shift; p.head_act = hd->act;
-    if (dwino_ok(d) && d->cout <= 64 && scratch && scratch_elems >= dwino_d_elems(d)) {
+    bool wino; int form;
+    int rc = resolve_algo(d, &wino, &form);
+    if (rc) return rc;
+    if (wino) {
+        if (d->op != S3R_OP_DECONV || d->cout > 64) return fail(S3R_ERR_INVALID, "the fused head rides on the transposed Winograd kernel with <= 64 couts only");
         ProfScope ps(s, F_MFMA, d->tag, g.flops + hg.flops, g.bytes - 4.0 * d->batch * d->cout * (double)g.out_sp +
                      4.0 * d->batch * (double)hg.out_sp);
-        ps.launches = 2;
-        return dwino_run(d, p, x, static_cast<const float*>(L.packed_w), scratch, s);
+        ps.exec = wino_exec_flops(d, g) + hg.flops;
+        return dwino_run(d, p, x, static_cast<const float*>(L.packed_w), scratch, scratch_elems, form, s, &ps.launches, &ps.algo);
     }
     Launch Ln;
-    int rc = resolve_launch(d, &p, &Ln);
+    rc = resolve_launch(d, &p, &Ln);
     if (rc) return rc;
     if (!(Ln.cfg == 1 || Ln.cfg == 2 || Ln.cfg == 7) || (Ln.cfg == 2 && d->cout > 32)) {
         // the heuristic's tile splits the couts over waves: take the widest one-wave-tall tile that fills the chip
@@ -740,13 +826,13 @@ int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d) {
         if ((rc = resolve_launch_h(d, &ph, &Lh))) return rc;
         return s3r::conv_bf16_scratch_elems(ph, Lh.tm);
     }
+    bool wino; int form;
+    if ((rc = resolve_algo(d, &wino, &form))) return rc;
+    if (wino) return wino_need(d, form, false).total;
     s3r::ConvParams p = make_params(d, g);
     Launch L;
     if ((rc = resolve_launch(d, &p, &L))) return rc;
-    const int64_t direct = s3r::conv_scratch_elems(p, L.cfg);
-    if (d->in_layout == S3R_LAYOUT_WINO_H) return 0;
-    const int64_t wino = wino_ok(d) ? wino_need(d) : (dwino_ok(d) ? dwino_d_elems(d) : 0);   // (a caller that offers less gets the direct kernel)
-    return wino > direct ? wino : direct;
+    return s3r::conv_scratch_elems(p, L.cfg);
 }
 
 }  // extern "C"
@@ -812,10 +898,9 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                 if (L.ksplit > 1) {
                     const int64_t need = s3r::conv_bf16_scratch_elems(p, L.tm);
                     if (scratch && scratch_elems >= need) p.part = scratch;
-                    else if (d->ksplit > 0)
-                        return fail(S3R_ERR_WORKSPACE, "ksplit=%d needs %lld floats of scratch, got %lld", L.ksplit,
+                    else
+                        return fail(S3R_ERR_WORKSPACE, "ksplit=%d needs %lld floats of scratch (s3r_conv_scratch_elems), got %lld", L.ksplit,
                                     (long long)need, (long long)(scratch ? scratch_elems : 0));
-                    else p.ksplit = L.ksplit = 1;
                 }
                 ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
                 e = s3r::launch_conv_bf16(p, L.tm, s);
@@ -852,47 +937,35 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
         case R_MFMA: {
             s3r::ConvParams p = make_params(d, g);
             p.x = x; p.w = packed_w; p.scale = scale; p.shift = shift; p.y = y;
-            // Winograd F(2,3) along H.  The transformed input must stay inside 32-bit byte offsets: larger batches go through in
-            // sub-batches (a sample's result does not depend on the batch it is computed in, so neither does it on this split)
-            if (dwino_ok(d) && scratch && scratch_elems >= dwino_d_elems(d)) {
+            bool wino; int form;
+            if ((rc = resolve_algo(d, &wino, &form))) return rc;
+            if (wino && d->op == S3R_OP_DECONV) {
                 ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
-                ps.launches = 2;
-                return dwino_run(d, p, x, packed_w, scratch, s);
+                ps.exec = wino_exec_flops(d, g);
+                return dwino_run(d, p, x, packed_w, scratch, scratch_elems, form, s, &ps.launches, &ps.algo);
             }
-            if (d->in_layout == S3R_LAYOUT_WINO_H) {      // the producer wrote the transformed planes: the class kernel alone
-                if (!wino_layer(d) || d->act == S3R_ACT_SIGMOID || d->out_layout != S3R_LAYOUT_PLAIN || d->tile >= 0 || d->ksplit > 1 ||
-                    wino_bmax(d) < d->batch)
-                    return fail(S3R_ERR_INVALID, "a Winograd-transformed input runs the Winograd kernel only: no tile / split-K "
-                                "override, a plain output, at most %d samples per call here (s3r_conv_wino_input_elems)", wino_bmax(d));
-                const int is3 = d->ndim == 3, n = d->in_size, wp = n + 2, h2 = n / wino_r(d), dp = is3 ? n + 2 : 1;
-                ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
-                p.w = packed_w + ipow(3, g.nd) * d->cin * cout_pad(d->cout);
-                p.Nh = h2; p.kh = wino_r(d); p.T = p.kd * p.kw;      // (kh carries the group size to the launcher)
-                p.x_hs = wp; p.x_ds = is3 ? h2 * wp : 0; p.x_cs = dp * h2 * wp;
-                p.x_cls = d->batch * d->cin * p.x_cs;
-                p.x_org = 0;
-                p.x_bytes = (unsigned)(4 * g.x_elems);
-                p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
-                p.n_begin = 0; p.n_end = p.Ntotal;
-                p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
-                p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
-                p.dW = s3r::FastDiv((unsigned)p.Nw);
-                p.Hout = n;
-                p.ksplit = 1;
-                e = s3r::launch_conv_wino(p, s);
-                if (e != hipSuccess) return hip_fail(e, "Winograd conv launch");
-                return S3R_OK;
-            }
-            if (wino_ok(d) && scratch && scratch_elems >= wino_need(d) && wino_need(d) > 0) {
-                const int R = wino_r(d);
+            if (wino) {
+                // The transformed input must stay inside 32-bit byte offsets: larger batches go through in sub-batches (a sample's
+                // result does not depend on the batch it is computed in, so neither does it on this split)
+                const bool pre = d->in_layout == S3R_LAYOUT_WINO_H;      // the producer wrote the transformed planes
+                const int R = wino_r(d), kind = wino_kind(d);
                 const int is3 = d->ndim == 3, n = d->in_size, wp = n + 2, h2 = (n + R - 1) / R, dp = is3 ? n + 2 : 1;
-                const int64_t v_sample = wino_v_elems(d) / d->batch, x_sample = g.x_elems / d->batch;
                 const int bmax = wino_bmax(d);
+                if (bmax <= 0 || (pre && bmax < d->batch))
+                    return fail(S3R_ERR_INVALID, "a Winograd-transformed input takes at most %d samples per call here "
+                                "(s3r_conv_wino_input_elems)", bmax);
+                const WinoNeed need = wino_need(d, form, false);
+                if (need.total > 0 && (!scratch || scratch_elems < need.total))
+                    return fail(S3R_ERR_WORKSPACE, "the Winograd form of this layer needs %lld floats of scratch (s3r_conv_scratch_elems), "
+                                "got %lld", (long long)need.total, (long long)(scratch ? scratch_elems : 0));
+                const int64_t v_sample = wino_v_elems(d) / d->batch, x_sample = g.x_elems / d->batch;
                 ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
                 ps.launches = 0;
+                ps.exec = wino_exec_flops(d, g);
                 p.w = packed_w + ipow(3, g.nd) * d->cin * cout_pad(d->cout);        // the class slabs sit behind the direct slab
-                p.x = scratch;
-                p.Nh = h2; p.kh = R; p.T = p.kd * p.kw;              // (kh carries the group size to the launcher)
+                p.x = pre ? x : scratch;
+                p.part = scratch ? scratch + need.v : nullptr;
+                p.Nh = h2; p.T = p.kd * p.kw;
                 p.x_hs = wp; p.x_ds = is3 ? h2 * wp : 0; p.x_cs = dp * h2 * wp;
                 p.x_org = 0;
                 p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
@@ -902,18 +975,23 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                 p.ksplit = 1;
                 for (int b0 = 0; b0 < d->batch; b0 += bmax) {
                     const int nb = d->batch - b0 < bmax ? d->batch - b0 : bmax;
-                    e = s3r::launch_wino_input(x + (int64_t)b0 * x_sample, scratch, (long long)nb * d->cin * dp, n + 2, wp, h2, R, s);
-                    if (e != hipSuccess) return hip_fail(e, "Winograd input transform launch");
+                    if (!pre) {
+                        e = s3r::launch_wino_input(x + (int64_t)b0 * x_sample, scratch, (long long)nb * d->cin * dp, n + 2, wp, h2, R, s);
+                        if (e != hipSuccess) return hip_fail(e, "Winograd input transform launch");
+                        ps.launches += 1;
+                    }
                     p.B = nb;
                     p.x_cls = nb * d->cin * p.x_cs;
                     p.x_bytes = (unsigned)(4 * (int64_t)nb * v_sample);
                     p.Ntotal = nb * p.Nd * p.Nh * p.Nw;
-                    p.n_begin = 0; p.n_end = p.Ntotal;
                     p.y = y + (int64_t)b0 * p.y_bs;
                     p.y_bytes = (unsigned)(4 * (int64_t)nb * p.y_bs);
-                    e = s3r::launch_conv_wino(p, s);
+                    const s3r::WinoLaunch WL = s3r::wino_plan(kind, d->cout, p.Ntotal, false, form);
+                    int nl = 0;
+                    e = s3r::launch_conv_wino(p, R, WL, s, &nl);
                     if (e != hipSuccess) return hip_fail(e, "Winograd conv launch");
-                    ps.launches += 2;
+                    ps.launches += nl;
+                    ps.algo = 1 + WL.mode;
                 }
                 return S3R_OK;
             }
@@ -922,10 +1000,9 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
             if (L.ksplit > 1) {
                 const int64_t need = s3r::conv_scratch_elems(p, L.cfg);
                 if (scratch && scratch_elems >= need) p.part = scratch;
-                else if (d->ksplit > 0)
-                    return fail(S3R_ERR_WORKSPACE, "ksplit=%d needs %lld floats of scratch, got %lld", L.ksplit,
+                else      // (never answered unsplit: another summation order is other bits)
+                    return fail(S3R_ERR_WORKSPACE, "ksplit=%d needs %lld floats of scratch (s3r_conv_scratch_elems), got %lld", L.ksplit,
                                 (long long)need, (long long)(scratch ? scratch_elems : 0));
-                else p.ksplit = L.ksplit = 1;     // no scratch offered: run unsplit (same result up to rounding order)
             }
             if (p.y_wsplit && L.ksplit > 1)
                 return fail(S3R_ERR_INVALID, "fp32 path: a parity-split output cannot be combined with split-K (ksplit=%d)", L.ksplit);
@@ -1113,7 +1190,7 @@ int64_t s3r_conv_wino_input_elems(const s3r_conv_desc* d) {
     if (!d) return fail(S3R_ERR_INVALID, "null descriptor");
     s3r_conv_desc t = *d;
     t.in_layout = S3R_LAYOUT_PLAIN;
-    if (!wino_ok(&t) || t.in_size % wino_r(&t) != 0 || wino_bmax(&t) < t.batch) return 0;
+    if (!resolves_to_wino(&t) || t.op != S3R_OP_CONV || t.in_size % wino_r(&t) != 0 || wino_bmax(&t) < t.batch) return 0;
     return wino_v_elems(&t);
 }
 

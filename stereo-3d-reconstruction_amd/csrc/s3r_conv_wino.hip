@@ -28,6 +28,13 @@ namespace s3r {
 
 typedef float wf32x16 __attribute__((ext_vector_type(16)));
 typedef float wv2f __attribute__((ext_vector_type(2)));
+template <int N> struct WVec;
+template <> struct WVec<1> { typedef float type; };
+template <> struct WVec<2> { typedef wv2f type; };
+template <int N>
+__device__ __forceinline__ float wvget(const typename WVec<N>::type& v, int i) {
+    if constexpr (N == 1) return v; else return v[i];
+}
 
 #define S3R_LDS_PTR_W(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -124,213 +131,6 @@ hipError_t launch_pack_wino(const float* w, float* wp, int Cin, int Cout, int Co
     return hipGetLastError();
 }
 
-// ---- the four class convolutions and their combination.  p describes the CLASS convolution: p.x = V, x_cs / x_ds / x_hs
-// its strides (x_hs = one V row per row pair), p.x_cls the class stride, Nh = row pairs per plane, kh = 1, T = kd * kw,
-// x_org = 0; p.y the layer's padded output, p.Hout its true height (odd: the last pair's second row is not stored).
-template <int VEC, int R>
-__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
-    constexpr int NCLS = R + 2;
-    extern __shared__ __attribute__((aligned(16))) float wsmem[];
-    float* As = wsmem;                                   // [WNB][WBK][64]
-    float* Bs = wsmem + WNB * WBK * WBM;                 // [WNB][WBK][128]
-    constexpr int PB = 64 * VEC;                         // floats per B piece
-    constexpr int NPIECE_B = WBK * WBN / PB;
-    constexpr int NPB = NPIECE_B / 4;
-    constexpr bool B_WIDE = WBN >= PB;
-    constexpr int PPR = B_WIDE ? WBN / PB : 1;
-    constexpr int RPP = B_WIDE ? 1 : PB / WBN;
-    constexpr int LPR_B = WBN / VEC;
-    constexpr int NPD = WNPA + NPB;                      // DMAs per wave per K tile (WNPA 1 KiB weight pieces + NPB gathers)
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, h = lane >> 5;
-
-    int bid = blockIdx.x;
-    {   // XCD-aware tile order (as conv_glds_kernel)
-        const int nwg = gridDim.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    const int m_tile = bid % p.m_tiles, n_tile = bid / p.m_tiles;
-    const int m0 = m_tile * WBM, n0 = n_tile * WBN;
-    const int S = p.Nd * p.Nh * p.Nw;
-    const int T = p.T;
-    const int chunks = p.Cin / WBK;
-    const int nkt = T * chunks;                          // K tiles per class
-    const int total = NCLS * nkt;
-
-    int bvoff;
-    {
-        int col, lrow;
-        if (B_WIDE) { col = (wave % PPR) * PB + lane * VEC; lrow = 0; }
-        else        { col = (lane % LPR_B) * VEC;           lrow = lane / LPR_B; }
-        int n = n0 + col;
-        if (n >= p.Ntotal) n = p.Ntotal - VEC;
-        const int b = p.dS.div(n);
-        int rem = n - b * S;
-        const int pd = p.dHW.div(rem);
-        rem -= pd * p.Nh * p.Nw;
-        const int q = p.dW.div(rem);
-        const int pw = rem - q * p.Nw;
-        bvoff = (b * p.Cin * p.x_cs + p.x_org + pd * p.x_ds + q * p.x_hs + pw + lrow * p.x_cs) * 4;
-    }
-    const int avoff = ((lane >> 4) * p.CoutPad + (lane & 15) * 4) * 4;
-    const __amdgpu_buffer_rsrc_t xrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.w), 0, (int)((unsigned)NCLS * (unsigned)T * (unsigned)p.Cin * (unsigned)p.CoutPad * 4u), 0x00020000);
-    const int b_row0 = B_WIDE ? wave / PPR : wave * RPP;
-    constexpr int B_ROW_STEP = B_WIDE ? 4 / PPR : 4 * RPP;
-    const int b_lds0 = B_WIDE ? b_row0 * WBN + (wave % PPR) * PB : wave * PB;
-    constexpr int B_LDS_STEP = B_WIDE ? B_ROW_STEP * WBN : 4 * PB;
-    const int cs4 = p.x_cs * 4;
-
-    int c_cls = 0, c_cc = 0, c_td = 0, c_tw = 0, c_tap = 0, c_kt = 0;      // cursor of the NEXT K tile to fetch (scalar)
-    auto issue = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < WNPA; ++q)
-            wdma<16>(wrsrc, As + buf * WBK * WBM + (wave + 4 * q) * 256, avoff,
-                     (c_kt * WBK * p.CoutPad + m0) * 4 + (wave + 4 * q) * 4 * p.CoutPad * 4);
-        float* sb = Bs + buf * WBK * WBN + b_lds0;
-        const int b_base = (c_cls * p.x_cls + (c_cc * WBK + b_row0) * p.x_cs + c_td * p.x_ds + c_tw) * 4;
-#pragma unroll
-        for (int q = 0; q < NPB; ++q) wdma<4 * VEC>(xrsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
-        ++c_kt;
-        if (++c_tw == p.kw) { c_tw = 0; ++c_td; }
-        if (++c_tap == T) {
-            c_tap = 0; c_td = 0; c_tw = 0;
-            if (++c_cc == chunks) { c_cc = 0; ++c_cls; }
-        }
-    };
-
-    wf32x16 acc[NCLS][2];
-#pragma unroll
-    for (int c = 0; c < NCLS; ++c)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
-
-    // tiles 0 .. WNB-2 go out; tile 0 has landed once at most WNB-2 tiles' DMAs are outstanding
-#pragma unroll
-    for (int i = 0; i < WNB - 1; ++i)
-        if (i < total) issue(i);
-    if (total >= WNB - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((WNB - 2) * NPD) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    const int a_off = h * WBM + j * 2;
-    const int b_off = h * WBN + wave * 32 + j;
-    int cur = 0, g = 0;
-    auto run_class = [&](wf32x16 (&ac)[2]) {
-        for (int kt = 0; kt < nkt; ++kt, ++g) {
-            const bool more = g + WNB - 1 < total;
-            if (more) issue(cur == 0 ? WNB - 1 : cur - 1);        // into the stage tile g - 1 was read from
-            const float* a = As + cur * WBK * WBM + a_off;
-            const float* b = Bs + cur * WBK * WBN + b_off;
-#pragma unroll
-            for (int ks = 0; ks < WBK / 2; ++ks) {
-                const wv2f av = *reinterpret_cast<const wv2f*>(a + ks * 2 * WBM);
-                const float bv = b[ks * 2 * WBN];
-                ac[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv, ac[0], 0, 0, 0);
-                ac[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv, ac[1], 0, 0, 0);
-            }
-            if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((WNB - 2) * NPD) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            cur = cur + 1 == WNB ? 0 : cur + 1;
-        }
-    };
-#pragma unroll
-    for (int c = 0; c < NCLS; ++c) run_class(acc[c]);
-
-    // ---- epilogue: per-cout constants through LDS (every wave is past the last barrier: the ring is idle)
-    float* ep_sc = wsmem;
-    float* ep_sf = wsmem + WBM;
-    if (tid < WBM) {
-        const int m = m0 + tid;
-        ep_sc[tid] = (p.scale && m < p.Cout) ? p.scale[m] : 1.f;
-        ep_sf[tid] = (p.shift && m < p.Cout) ? p.shift[m] : 0.f;
-    }
-    __syncthreads();
-    const int n = n0 + wave * 32 + j;
-    const bool ok = n < p.Ntotal;
-    int e0, row1;                                        // first output element of the group, rows that exist
-    {
-        const int nn = ok ? n : 0;
-        const int b = p.dS.div(nn);
-        int rem = nn - b * S;
-        const int pd = p.dHW.div(rem);
-        rem -= pd * p.Nh * p.Nw;
-        const int q = p.dW.div(rem);
-        const int pw = rem - q * p.Nw;
-        e0 = b * p.y_bs + p.y_org + pd * p.y_ds + R * q * p.y_hs + pw;
-        row1 = p.Hout - R * q;                           // rows of this group that exist (>= R: all)
-    }
-    const int mbase = 8 * h;                             // rows of this lane: mbase + ((r & 3) + 8 (r >> 2)) * 2 + tm
-    const int mlimit = p.Cout - (m0 + mbase);
-    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
-    const int yvo0 = (e0 + (m0 + mbase) * p.y_cs) * 4;
-    const int yrow = p.y_hs * 4;
-    const int row_bytes = p.y_cs * 4;
-    const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int dm = ((r & 3) + 8 * (r >> 2)) * 2 + tm;
-            if (dm >= mlimit) continue;
-            const float sc = ep_sc[mbase + dm], sf = ep_sf[mbase + dm];
-            float y[R];
-            if constexpr (R == 2) {
-                y[0] = (acc[0][tm][r] + acc[1][tm][r]) + acc[2][tm][r];
-                y[1] = (acc[1][tm][r] - acc[2][tm][r]) - acc[3][tm][r];
-            } else {
-                const float s12 = acc[1][tm][r] + acc[2][tm][r], d12 = acc[1][tm][r] - acc[2][tm][r];
-                const float s34 = acc[3][tm][r] + acc[4][tm][r], d34 = acc[3][tm][r] - acc[4][tm][r];
-                y[0] = (acc[0][tm][r] + s12) + s34;
-                y[1] = fmaf(2.f, d34, d12);
-                y[2] = fmaf(4.f, s34, s12);
-                y[3] = fmaf(8.f, d34, d12) + acc[5][tm][r];
-            }
-            const int so = dm * row_bytes;
-            if (ok) {
-#pragma unroll
-                for (int i = 0; i < R; ++i)
-                    if (i < row1) {
-                        const float v = fmaxf(fmaf(y[i], sc, sf), lo);
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrsrc, yvo0 + i * yrow, so, 0);
-                    }
-            }
-            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-}
-
-// p: see the kernel; p.kh = the outputs per group R (2 or 4) on entry (the class convolution's own kh is 1)
-hipError_t launch_conv_wino(ConvParams p, hipStream_t stream) {
-    const int R = p.kh;
-    if (p.Cin % WBK != 0 || (R != 2 && R != 4) || p.stride != 1 || p.transposed || p.ksplit != 1 || p.head_w || p.act == ACT_SIGMOID)
-        return hipErrorInvalidValue;
-    p.kh = 1;
-    p.m_tiles = (p.Cout + WBM - 1) / WBM;
-    p.n_tiles = (p.Ntotal + WBN - 1) / WBN;
-    const size_t lds = (size_t)WNB * WBK * (WBM + WBN) * sizeof(float);
-    const dim3 grid(p.m_tiles * p.n_tiles);
-    const bool v4 = p.Nw % 4 == 0;
-    if (R == 4) {
-        if (v4) hipLaunchKernelGGL((conv_wino_kernel<4, 4>), grid, dim3(256), lds, stream, p);
-        else hipLaunchKernelGGL((conv_wino_kernel<1, 4>), grid, dim3(256), lds, stream, p);
-    } else {
-        if (v4) hipLaunchKernelGGL((conv_wino_kernel<4, 2>), grid, dim3(256), lds, stream, p);
-        else hipLaunchKernelGGL((conv_wino_kernel<1, 2>), grid, dim3(256), lds, stream, p);
-    }
-    return hipGetLastError();
-}
-
 // ================================================================================================
 // ConvTranspose3d(k = 4, s = 2, p = 1) with fewer multiplications: Winograd F(2, 2) along H inside every output-parity
 // class.  A class (rd, rh, rw) is a 2 x 2 x 2-tap convolution over the input grid (s3r_conv_glds.hip); two of its outputs
@@ -392,41 +192,121 @@ hipError_t launch_pack_wino_deconv(const float* w, float* wp, int Cin, int Cout,
     return hipGetLastError();
 }
 
-// p: the layer's transposed-convolution parameters (make_params) with Nh = row pairs (n / 2), p.x = the padded input,
-// p.part = its row differences (same shape and strides), p.w = the 24 (class, F) slabs.
-template <int VEC, bool HEAD>
-__global__ __launch_bounds__(256, 2) void deconv_wino_kernel(const ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) float wsmem[];
-    float* As = wsmem;
-    float* Bs = wsmem + WNB * WBK * WBM;
-    constexpr int PB = 64 * VEC;
-    constexpr int NPIECE_B = WBK * WBN / PB;
+// ================================================================================================
+// The class kernels.  ONE body serves the three Winograd forms of this file,
+//     KIND 0: convolution, F(2,3) along H (4 classes, 2 output rows per group)
+//     KIND 1: convolution, F(4,3) along H (6 classes, 4 output rows per group)
+//     KIND 2: ConvTranspose3d(k4 s2 p1), F(2,2) along H inside every output-parity class (3 classes, 2 output rows)
+// in two launch forms:
+//     serial (CP = false): a workgroup owns a tile of 64 couts x BN positions (position = one group of R output rows of one
+//         column) and walks ALL classes back to back, one accumulator set per class; the output transform, the folded BN +
+//         ReLU (and d3's fused 1 x 1 x 1 head) run on the registers.  4 waves as WM x WN = 1 x 4 (64 couts x 32 positions per
+//         wave, BN = 128: two MFMA tiles per class) or 2 x 2 (32 x 32 per wave, BN = 64: one MFMA tile per class, half the
+//         accumulator registers);
+//     class-parallel (CP = true): a workgroup owns ONE class of a tile, runs that class's K loop — the same MFMA sequence in the
+//         same order as the serial form, so the same bits — and writes the raw class sums to a slab part[class][cout][n];
+//         wino_finish_kernel then applies the output transform and the epilogue through the SAME device functions
+//         (wino_out / wino_act below) in the same operation order: bit-identical to the serial form.  It multiplies the
+//         workgroup count by the class count (x 6 / x 4 / x 3) and divides a workgroup's serial K walk by it: the form for
+//         grids that leave the chip short of workgroups (small batches; v5; d1) and for the REMAINDER of a launch whose
+//         workgroup count is a little over a multiple of the chip's slots (wino_dual_kernel: bulk serial + remainder
+//         class-parallel in one launch — the direct path's plan_tail_cut idea with the class axis as the finer unit).
+// Because the two forms agree bit for bit, which one runs may depend on the batch size (a sample's bits never do).
+template <int KIND> struct WinoKind;
+template <> struct WinoKind<0> { static constexpr int NCLS = 4, R = 2; };
+template <> struct WinoKind<1> { static constexpr int NCLS = 6, R = 4; };
+template <> struct WinoKind<2> { static constexpr int NCLS = 3, R = 2; };
+
+// output transform of one (cout, position): m = the class sums, y = the R output rows.  Adds and explicit fmaf only (nothing
+// the compiler could contract differently in the two kernels that share it).
+template <int KIND>
+__device__ __forceinline__ void wino_out(const float (&m)[WinoKind<KIND>::NCLS], float (&y)[WinoKind<KIND>::R]) {
+    if constexpr (KIND == 0) {
+        y[0] = (m[0] + m[1]) + m[2];
+        y[1] = (m[1] - m[2]) - m[3];
+    } else if constexpr (KIND == 1) {
+        const float s12 = m[1] + m[2], d12 = m[1] - m[2];
+        const float s34 = m[3] + m[4], d34 = m[3] - m[4];
+        y[0] = (m[0] + s12) + s34;
+        y[1] = fmaf(2.f, d34, d12);
+        y[2] = fmaf(4.f, s34, s12);
+        y[3] = fmaf(8.f, d34, d12) + m[5];
+    } else {
+        y[0] = m[0] + m[1];
+        y[1] = m[1] - m[2];
+    }
+}
+__device__ __forceinline__ float wino_act(float y, float sc, float sf, float lo) { return fmaxf(fmaf(y, sc, sf), lo); }
+__device__ __forceinline__ float wino_head_act(float t, int act) {
+    if (act == ACT_RELU) return fmaxf(t, 0.f);
+    if (act == ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.f + __expf(-t));
+    return t;
+}
+
+// p (convolution): the CLASS convolution — p.x = V, x_cs / x_ds / x_hs its strides (x_hs = one V row per group), p.x_cls the class
+//   stride, Nh = groups per plane, T = kd * kw, x_org = 0; p.y the layer's padded output, p.Hout its true height (the last group's
+//   missing rows are not stored).
+// p (transposed): the layer's own parameters (make_params) with Nh = row pairs (n / 2), p.x = the padded input, p.xd = its row
+//   differences (same shape and strides), p.w = the 24 (parity class, F) slabs.
+// p.part: class-parallel slabs [class][Cout][npad], npad = the position range's tile count x BN.
+template <int VEC, int KIND, int WN, bool CP, bool HEAD>
+__device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in, const int nwg_in, const int n_begin,
+                                          const int n_end, float* __restrict__ wsmem) {
+    constexpr bool DECONV = KIND == 2;
+    constexpr int NCLS = WinoKind<KIND>::NCLS, R = WinoKind<KIND>::R;
+    constexpr int WM = 4 / WN, TM = 2 / WM, BN = 32 * WN;
+    constexpr int NACC = CP ? 1 : NCLS;
+    static_assert(WN == 4 || WN == 2, "4 waves as 1 x 4 or 2 x 2");
+    static_assert(!HEAD || (DECONV && !CP && WM == 1), "the fused head: serial transposed form, one wave holds all couts");
+    float* As = wsmem;                                   // [WNB][WBK][64]
+    float* Bs = wsmem + WNB * WBK * WBM;                 // [WNB][WBK][BN]
+    constexpr int PB = 64 * VEC;                         // floats per B piece
+    constexpr int NPIECE_B = WBK * BN / PB;
+    static_assert(NPIECE_B % 4 == 0, "B pieces divide over the 4 waves");
     constexpr int NPB = NPIECE_B / 4;
-    constexpr bool B_WIDE = WBN >= PB;
-    constexpr int PPR = B_WIDE ? WBN / PB : 1;
-    constexpr int RPP = B_WIDE ? 1 : PB / WBN;
-    constexpr int LPR_B = WBN / VEC;
-    constexpr int NPD = WNPA + NPB;
+    constexpr bool B_WIDE = BN >= PB;
+    constexpr int PPR = B_WIDE ? BN / PB : 1;
+    constexpr int RPP = B_WIDE ? 1 : PB / BN;
+    constexpr int LPR_B = BN / VEC;
+    constexpr int NPD = WNPA + NPB;                      // DMAs per wave per K tile (WNPA 1 KiB weight pieces + NPB gathers)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
     const int j = lane & 31, h = lane >> 5;
 
-    int bid, pc;
-    {   // an XCD walks its run of tiles with the 8 parity classes of a tile back to back (they read the same input tile)
-        const int nwg = gridDim.x >> 3;
-        const int item = ((int)blockIdx.x & 7) * nwg + ((int)blockIdx.x >> 3);
+    const int n_tiles = (n_end - n_begin + BN - 1) / BN;
+    int bid = bid_in, cls0 = 0, pc = 0;                  // cls0: the one class of a class-parallel workgroup; pc: output parity class
+    if constexpr (CP) {
+        // an XCD walks a contiguous run of items, class-major: neighbouring workgroups share a class's weight slab (and the
+        // transformed rows their tiles have in common) in that XCD's L2
+        const int nwg = nwg_in;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+        const int item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        const int ntile = p.m_tiles * n_tiles;
+        const int c = item / ntile;
+        bid = item - c * ntile;
+        if constexpr (DECONV) { pc = c / 3; cls0 = c - pc * 3; } else cls0 = c;
+    } else if constexpr (DECONV) {
+        // an XCD walks its run of tiles with the 8 parity classes of a tile back to back (they read the same input tile)
+        const int nwg = nwg_in >> 3;
+        const int item = (bid & 7) * nwg + (bid >> 3);
         bid = item >> 3;
         pc = item & 7;
+    } else {
+        const int nwg = nwg_in;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
     const int rd = (pc >> 2) & 1, rh = (pc >> 1) & 1, rw = pc & 1;
     const int m_tile = bid % p.m_tiles, n_tile = bid / p.m_tiles;
-    const int m0 = m_tile * WBM, n0 = n_tile * WBN;
+    const int m0 = m_tile * WBM, n0 = n_begin + n_tile * BN;
     const int S = p.Nd * p.Nh * p.Nw;
+    const int T = DECONV ? 4 : p.T;                      // taps per class: (depth tap, column tap)
     const int chunks = p.Cin / WBK;
-    const int nkt = 4 * chunks;                          // K tiles per F-class: (depth tap, column tap) x chunks
-    const int total = 3 * nkt;
+    const int nkt = T * chunks;                          // K tiles per class
+    const int total = NACC * nkt;
 
     int bvoff;
     {
@@ -434,60 +314,78 @@ __global__ __launch_bounds__(256, 2) void deconv_wino_kernel(const ConvParams p)
         if (B_WIDE) { col = (wave % PPR) * PB + lane * VEC; lrow = 0; }
         else        { col = (lane % LPR_B) * VEC;           lrow = lane / LPR_B; }
         int n = n0 + col;
-        if (n >= p.Ntotal) n = p.Ntotal - VEC;
+        if (n >= n_end) n = n_end - VEC;                 // tail tile: fetch a valid group, never stored
         const int b = p.dS.div(n);
         int rem = n - b * S;
         const int pd = p.dHW.div(rem);
         rem -= pd * p.Nh * p.Nw;
         const int q = p.dW.div(rem);
         const int pw = rem - q * p.Nw;
-        // padded indices: depth pd + rd + td, row 2q + rh (+ 1), column pw + rw + tw
-        bvoff = (b * p.Cin * p.x_cs + (pd + rd) * p.x_ds + (2 * q + rh) * p.x_hs + pw + rw + lrow * p.x_cs) * 4;
+        if constexpr (DECONV)        // padded indices: depth pd + rd + td, row 2q + rh (+ 1), column pw + rw + tw
+            bvoff = (b * p.Cin * p.x_cs + (pd + rd) * p.x_ds + (2 * q + rh) * p.x_hs + pw + rw + lrow * p.x_cs) * 4;
+        else
+            bvoff = (b * p.Cin * p.x_cs + p.x_org + pd * p.x_ds + q * p.x_hs + pw + lrow * p.x_cs) * 4;
     }
     const int avoff = ((lane >> 4) * p.CoutPad + (lane & 15) * 4) * 4;
     const __amdgpu_buffer_rsrc_t xrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t drsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.part), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drsrc =                 // (transposed form: the row differences)
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DECONV ? p.xd : p.x), 0, (int)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.w), 0, (int)(24u * 4u * (unsigned)p.Cin * (unsigned)p.CoutPad * 4u), 0x00020000);
+        const_cast<float*>(p.w), 0, (int)((unsigned)(DECONV ? 24 : NCLS) * (unsigned)T * (unsigned)p.Cin * (unsigned)p.CoutPad * 4u),
+        0x00020000);
     const int b_row0 = B_WIDE ? wave / PPR : wave * RPP;
     constexpr int B_ROW_STEP = B_WIDE ? 4 / PPR : 4 * RPP;
-    const int b_lds0 = B_WIDE ? b_row0 * WBN + (wave % PPR) * PB : wave * PB;
-    constexpr int B_LDS_STEP = B_WIDE ? B_ROW_STEP * WBN : 4 * PB;
+    const int b_lds0 = B_WIDE ? b_row0 * BN + (wave % PPR) * PB : wave * PB;
+    constexpr int B_LDS_STEP = B_WIDE ? B_ROW_STEP * BN : 4 * PB;
     const int cs4 = p.x_cs * 4;
 
-    int c_f = 0, c_cc = 0, c_tap = 0, c_kt = pc * total;               // cursor of the NEXT K tile to fetch (scalar)
+    // cursor of the NEXT K tile to fetch (scalar): class, chunk, tap; c_kt = its row block in the packed class slabs
+    int c_cls = cls0, c_cc = 0, c_td = 0, c_tw = 0, c_tap = 0;
+    int c_kt = (DECONV ? pc * 3 + cls0 : cls0) * nkt;
     auto issue = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < WNPA; ++q)
             wdma<16>(wrsrc, As + buf * WBK * WBM + (wave + 4 * q) * 256, avoff,
                      (c_kt * WBK * p.CoutPad + m0) * 4 + (wave + 4 * q) * 4 * p.CoutPad * 4);
-        float* sb = Bs + buf * WBK * WBN + b_lds0;
-        // F-class 0: D at row R, 1: X at row R + 1, 2: D at row R + 1
-        const int b_base = ((c_cc * WBK + b_row0) * p.x_cs + (c_tap >> 1) * p.x_ds + (c_f ? p.x_hs : 0) + (c_tap & 1)) * 4;
-        if (c_f == 1) {
+        float* sb = Bs + buf * WBK * BN + b_lds0;
+        if constexpr (DECONV) {
+            // F-class 0: D at row R, 1: X at row R + 1, 2: D at row R + 1
+            const int b_base = ((c_cc * WBK + b_row0) * p.x_cs + (c_tap >> 1) * p.x_ds + (c_cls ? p.x_hs : 0) + (c_tap & 1)) * 4;
+            if (c_cls == 1) {
+#pragma unroll
+                for (int q = 0; q < NPB; ++q) wdma<4 * VEC>(xrsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
+            } else {
+#pragma unroll
+                for (int q = 0; q < NPB; ++q) wdma<4 * VEC>(drsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
+            }
+            ++c_kt;
+            if (++c_tap == 4) {
+                c_tap = 0;
+                if (++c_cc == chunks) { c_cc = 0; ++c_cls; }
+            }
+        } else {
+            const int b_base = (c_cls * p.x_cls + (c_cc * WBK + b_row0) * p.x_cs + c_td * p.x_ds + c_tw) * 4;
 #pragma unroll
             for (int q = 0; q < NPB; ++q) wdma<4 * VEC>(xrsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
-        } else {
-#pragma unroll
-            for (int q = 0; q < NPB; ++q) wdma<4 * VEC>(drsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
-        }
-        ++c_kt;
-        if (++c_tap == 4) {
-            c_tap = 0;
-            if (++c_cc == chunks) { c_cc = 0; ++c_f; }
+            ++c_kt;
+            if (++c_tw == p.kw) { c_tw = 0; ++c_td; }
+            if (++c_tap == T) {
+                c_tap = 0; c_td = 0; c_tw = 0;
+                if (++c_cc == chunks) { c_cc = 0; ++c_cls; }
+            }
         }
     };
 
-    wf32x16 acc[3][2];
+    wf32x16 acc[NACC][TM];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < NACC; ++c)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < TM; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
 
+    // tiles 0 .. WNB-2 go out; tile 0 has landed once at most WNB-2 tiles' DMAs are outstanding
 #pragma unroll
     for (int i = 0; i < WNB - 1; ++i)
         if (i < total) issue(i);
@@ -496,21 +394,22 @@ __global__ __launch_bounds__(256, 2) void deconv_wino_kernel(const ConvParams p)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    const int a_off = h * WBM + j * 2;
-    const int b_off = h * WBN + wave * 32 + j;
+    const int a_off = h * WBM + wm * TM * 32 + j * TM;
+    const int b_off = h * BN + wn * 32 + j;
+    typedef typename WVec<TM>::type AV;
     int cur = 0, g = 0;
-    auto run_class = [&](wf32x16 (&ac)[2]) {
+    auto run_class = [&](wf32x16 (&ac)[TM]) {
         for (int kt = 0; kt < nkt; ++kt, ++g) {
             const bool more = g + WNB - 1 < total;
-            if (more) issue(cur == 0 ? WNB - 1 : cur - 1);
+            if (more) issue(cur == 0 ? WNB - 1 : cur - 1);        // into the stage tile g - 1 was read from
             const float* a = As + cur * WBK * WBM + a_off;
-            const float* b = Bs + cur * WBK * WBN + b_off;
+            const float* b = Bs + cur * WBK * BN + b_off;
 #pragma unroll
             for (int ks = 0; ks < WBK / 2; ++ks) {
-                const wv2f av = *reinterpret_cast<const wv2f*>(a + ks * 2 * WBM);
-                const float bv = b[ks * 2 * WBN];
-                ac[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv, ac[0], 0, 0, 0);
-                ac[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv, ac[1], 0, 0, 0);
+                const AV av = *reinterpret_cast<const AV*>(a + ks * 2 * WBM);
+                const float bv = b[ks * 2 * BN];
+#pragma unroll
+                for (int t = 0; t < TM; ++t) ac[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wvget<TM>(av, t), bv, ac[t], 0, 0, 0);
             }
             if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((WNB - 2) * NPD) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -519,105 +418,349 @@ __global__ __launch_bounds__(256, 2) void deconv_wino_kernel(const ConvParams p)
             cur = cur + 1 == WNB ? 0 : cur + 1;
         }
     };
-    run_class(acc[0]);
-    run_class(acc[1]);
-    run_class(acc[2]);
+#pragma unroll
+    for (int c = 0; c < NACC; ++c) run_class(acc[c]);
 
-    float* ep_sc = wsmem;
-    float* ep_sf = wsmem + WBM;
-    float* ep_hw = wsmem + 2 * WBM;
-    if (tid < WBM) {
-        const int m = m0 + tid;
-        ep_sc[tid] = (p.scale && m < p.Cout) ? p.scale[m] : 1.f;
-        ep_sf[tid] = (p.shift && m < p.Cout) ? p.shift[m] : 0.f;
-        ep_hw[tid] = (HEAD && p.head_w && m < p.Cout) ? p.head_w[m] : 0.f;
+    // rows of this lane: cout m0 + mbase + dm, dm = ((r & 3) + 8 (r >> 2)) * TM + tm
+    const int mbase = wm * TM * 32 + 4 * h * TM;
+    const int mlimit = p.Cout - (m0 + mbase);
+    if constexpr (CP) {
+        // ---- class-parallel: the raw class sums to the slab [class][cout][n - n_begin]; every lane of the tile has a slot
+        const int npad = n_tiles * BN;
+        const int cg = DECONV ? pc * 3 + cls0 : cls0;
+        float* __restrict__ slab = p.part + ((size_t)cg * p.Cout + (m0 + mbase)) * npad + (n0 - n_begin) + wn * 32 + j;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dm = ((r & 3) + 8 * (r >> 2)) * TM + tm;
+                if (dm >= mlimit) continue;
+                slab[(size_t)dm * npad] = acc[0][tm][r];
+            }
+        return;
+    } else {
+        // ---- epilogue: per-cout constants through LDS (every wave is past the last barrier: the ring is idle)
+        float* ep_sc = wsmem;
+        float* ep_sf = wsmem + WBM;
+        float* ep_hw = wsmem + 2 * WBM;
+        if (tid < WBM) {
+            const int m = m0 + tid;
+            ep_sc[tid] = (p.scale && m < p.Cout) ? p.scale[m] : 1.f;
+            ep_sf[tid] = (p.shift && m < p.Cout) ? p.shift[m] : 0.f;
+            if constexpr (HEAD) ep_hw[tid] = (p.head_w && m < p.Cout) ? p.head_w[m] : 0.f;
+        }
+        __syncthreads();
+        const int n = n0 + wn * 32 + j;
+        const bool ok = n < n_end;
+        int e0, row1 = R;                                    // first output element of the group; rows of it that exist
+        {
+            const int nn = ok ? n : 0;
+            const int b = p.dS.div(nn);
+            int rem = nn - b * S;
+            const int pd = p.dHW.div(rem);
+            rem -= pd * p.Nh * p.Nw;
+            const int q = p.dW.div(rem);
+            const int pw = rem - q * p.Nw;
+            if constexpr (DECONV)    // output (2 pd + rd, 2 ph + rh, 2 pw + rw), ph = 2q (row 0) and 2q + 1 (row 1: 2 y_hs further)
+                e0 = b * p.y_bs + p.y_org + (pd * p.y_ds + 2 * q * p.y_hs + pw) * 2 + rd * p.y_ds + rh * p.y_hs + rw;
+            else {
+                e0 = b * p.y_bs + p.y_org + pd * p.y_ds + R * q * p.y_hs + pw;
+                row1 = p.Hout - R * q;
+            }
+        }
+        const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+        constexpr int ROW_STEP = DECONV ? 2 : 1;             // output rows between a group's rows, in y_hs
+        if constexpr (HEAD) {
+            // the workgroup's 64 couts are the whole channel axis: 32 of them in this lane, the other 32 in lane j + 32
+            float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dm = ((r & 3) + 8 * (r >> 2)) * TM + tm;
+                    const float sc = ep_sc[mbase + dm], sf = ep_sf[mbase + dm], hw = ep_hw[mbase + dm];
+                    const float m[3] = {acc[0][tm][r], acc[NACC > 1 ? 1 : 0][tm][r], acc[NACC > 2 ? 2 : 0][tm][r]};
+                    float y[2];
+                    wino_out<2>(m, y);
+                    t0 = fmaf(wino_act(y[0], sc, sf, lo), hw, t0);
+                    t1 = fmaf(wino_act(y[1], sc, sf, lo), hw, t1);
+                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            t0 += __shfl_xor(t0, 32, 64);
+            t1 += __shfl_xor(t1, 32, 64);
+            const float hsc = p.head_scale ? p.head_scale[0] : 1.f, hsf = p.head_shift ? p.head_shift[0] : 0.f;
+            t0 = wino_head_act(fmaf(t0, hsc, hsf), p.head_act);
+            t1 = wino_head_act(fmaf(t1, hsc, hsf), p.head_act);
+            if (h == 0 && ok) {
+                p.y[e0] = t0;
+                p.y[e0 + ROW_STEP * p.y_hs] = t1;
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
+            const int yvo0 = (e0 + (m0 + mbase) * p.y_cs) * 4;
+            const int yrow = ROW_STEP * p.y_hs * 4;
+            const int row_bytes = p.y_cs * 4;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dm = ((r & 3) + 8 * (r >> 2)) * TM + tm;
+                    if (dm >= mlimit) continue;
+                    const float sc = ep_sc[mbase + dm], sf = ep_sf[mbase + dm];
+                    float m[NCLS], y[R];
+#pragma unroll
+                    for (int c = 0; c < NCLS; ++c) m[c] = acc[c][tm][r];
+                    wino_out<KIND>(m, y);
+                    const int so = dm * row_bytes;
+                    if (ok) {
+#pragma unroll
+                        for (int i = 0; i < R; ++i)
+                            if (i < row1) {
+                                const float v = wino_act(y[i], sc, sf, lo);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrsrc, yvo0 + i * yrow, so, 0);
+                            }
+                    }
+                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+        }
     }
-    __syncthreads();
-    const int n = n0 + wave * 32 + j;
-    const bool ok = n < p.Ntotal;
-    int e0;
-    {
-        const int nn = ok ? n : 0;
-        const int b = p.dS.div(nn);
-        int rem = nn - b * S;
+}
+
+// registers: the serial 1 x 4 form holds NCLS x 32 accumulators (F(4,3): 192 -> two workgroups per CU; the others three / four),
+// the 2 x 2 form and the class-parallel forms half / a sixth of that
+template <int KIND, int WN, bool CP> constexpr int wino_min_waves() {
+    return CP ? 4 : (KIND == 1 ? (WN == 4 ? 2 : 3) : (KIND == 0 ? 3 : (WN == 4 ? 3 : 4)));
+}
+
+template <int VEC, int KIND, int WN, bool CP, bool HEAD>
+__global__ __launch_bounds__(256, (HEAD ? 3 : wino_min_waves<KIND, WN, CP>())) void wino_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wsmem[];
+    wino_body<VEC, KIND, WN, CP, HEAD>(p, blockIdx.x, gridDim.x, p.n_begin, p.n_end, wsmem);
+}
+
+// bulk (serial form, 64 x 128 tiles, positions [n_begin, n_cut)) + remainder (class-parallel form, 64 x 32 WNC tiles, positions
+// [n_cut, n_end)) in ONE launch: the remainder's short workgroups fill the slots the bulk's last round leaves
+template <int VEC, int KIND, int WNC>
+__global__ __launch_bounds__(256, (wino_min_waves<KIND, 4, false>())) void wino_dual_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wsmem[];
+    if ((int)blockIdx.x < p.big_wgs)
+        wino_body<VEC, KIND, 4, false, false>(p, blockIdx.x, p.big_wgs, p.n_begin, p.n_cut, wsmem);
+    else
+        wino_body<VEC, KIND, WNC, true, false>(p, (int)blockIdx.x - p.big_wgs, (int)gridDim.x - p.big_wgs, p.n_cut, p.n_end, wsmem);
+}
+
+// ---- class-parallel finish: y = act(transform(class sums) * scale + shift) over positions [n_begin, n_end), through the same
+// wino_out / wino_act as the serial epilogue.  One thread per (parity class,) cout and position; HEAD: one thread per position
+// walks the couts in the serial epilogue's order (the two lane halves' 32-cout chains, then their sum).
+template <int KIND, bool HEAD>
+__global__ __launch_bounds__(256) void wino_finish_kernel(const ConvParams p, const int n_begin, const int n_end, const int npad) {
+    constexpr bool DECONV = KIND == 2;
+    constexpr int NCLS = WinoKind<KIND>::NCLS, R = WinoKind<KIND>::R;
+    constexpr int ROW_STEP = DECONV ? 2 : 1;
+    const int S = p.Nd * p.Nh * p.Nw;
+    const int nn = n_end - n_begin;
+    const int pc = DECONV ? (int)blockIdx.y : 0;
+    const int rd = (pc >> 2) & 1, rh = (pc >> 1) & 1, rw = pc & 1;
+    const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+    const size_t cstride = (size_t)p.Cout * npad;                       // between class slabs
+    const float* __restrict__ base = p.part + (size_t)pc * 3 * cstride;  // (pc = 0 for convolutions)
+    const long long total = HEAD ? nn : (long long)p.Cout * nn;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int mrow = HEAD ? 0 : (int)(i / nn);
+        const int nl = (int)(i - (long long)mrow * nn);
+        const int n = n_begin + nl;
+        const int b = p.dS.div(n);
+        int rem = n - b * S;
         const int pd = p.dHW.div(rem);
         rem -= pd * p.Nh * p.Nw;
         const int q = p.dW.div(rem);
         const int pw = rem - q * p.Nw;
-        // output (2 pd + rd, 2 ph + rh, 2 pw + rw), ph = 2q (row 0) and 2q + 1 (row 1: 2 y_hs further)
-        e0 = b * p.y_bs + p.y_org + (pd * p.y_ds + 2 * q * p.y_hs + pw) * 2 + rd * p.y_ds + rh * p.y_hs + rw;
-    }
-    const int mbase = 8 * h;
-    const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
-    if constexpr (HEAD) {
-        // the workgroup's 64 couts are the whole channel axis: 32 of them in this lane, the other 32 in lane j + 32
-        float t0 = 0.f, t1 = 0.f;
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dm = ((r & 3) + 8 * (r >> 2)) * 2 + tm;
-                const float sc = ep_sc[mbase + dm], sf = ep_sf[mbase + dm], hw = ep_hw[mbase + dm];
-                const float y0 = acc[0][tm][r] + acc[1][tm][r];
-                const float y1 = acc[1][tm][r] - acc[2][tm][r];
-                t0 = fmaf(fmaxf(fmaf(y0, sc, sf), lo), hw, t0);
-                t1 = fmaf(fmaxf(fmaf(y1, sc, sf), lo), hw, t1);
-                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-            }
-        t0 += __shfl_xor(t0, 32, 64);
-        t1 += __shfl_xor(t1, 32, 64);
-        const float hsc = p.head_scale ? p.head_scale[0] : 1.f, hsf = p.head_shift ? p.head_shift[0] : 0.f;
-        t0 = fmaf(t0, hsc, hsf);
-        t1 = fmaf(t1, hsc, hsf);
-        if (p.head_act == ACT_RELU) { t0 = fmaxf(t0, 0.f); t1 = fmaxf(t1, 0.f); }
-        else if (p.head_act == ACT_SIGMOID) { t0 = __builtin_amdgcn_rcpf(1.f + __expf(-t0)); t1 = __builtin_amdgcn_rcpf(1.f + __expf(-t1)); }
-        if (h == 0 && ok) {
-            p.y[e0] = t0;
-            p.y[e0 + 2 * p.y_hs] = t1;
+        int e0, row1 = R;
+        if constexpr (DECONV)
+            e0 = b * p.y_bs + p.y_org + (pd * p.y_ds + 2 * q * p.y_hs + pw) * 2 + rd * p.y_ds + rh * p.y_hs + rw;
+        else {
+            e0 = b * p.y_bs + p.y_org + pd * p.y_ds + R * q * p.y_hs + pw;
+            row1 = p.Hout - R * q;
         }
-        return;
-    } else {
-        const int mlimit = p.Cout - (m0 + mbase);
-        const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
-        const int yvo0 = (e0 + (m0 + mbase) * p.y_cs) * 4;
-        const int yvo1 = yvo0 + 2 * p.y_hs * 4;
-        const int row_bytes = p.y_cs * 4;
+        if constexpr (HEAD) {
+            float th[2][R];
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+            for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dm = ((r & 3) + 8 * (r >> 2)) * 2 + tm;
-                if (dm >= mlimit) continue;
-                const float sc = ep_sc[mbase + dm], sf = ep_sf[mbase + dm];
-                const float y0 = acc[0][tm][r] + acc[1][tm][r];
-                const float y1 = acc[1][tm][r] - acc[2][tm][r];
-                const float v0 = fmaxf(fmaf(y0, sc, sf), lo), v1 = fmaxf(fmaf(y1, sc, sf), lo);
-                const int so = dm * row_bytes;
-                if (ok) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), yrsrc, yvo0, so, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), yrsrc, yvo1, so, 0);
-                }
-                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < R; ++k) th[hh][k] = 0.f;
+                for (int tm = 0; tm < 2; ++tm)
+                    for (int r = 0; r < 16; ++r) {
+                        const int mm = 8 * hh + ((r & 3) + 8 * (r >> 2)) * 2 + tm;
+                        if (mm >= p.Cout) continue;                    // (padded couts carry head weight 0: t + 0 = t)
+                        const float sc = p.scale ? p.scale[mm] : 1.f, sf = p.shift ? p.shift[mm] : 0.f, hw = p.head_w[mm];
+                        float m[NCLS], y[R];
+#pragma unroll
+                        for (int c = 0; c < NCLS; ++c) m[c] = base[(size_t)c * cstride + (size_t)mm * npad + nl];
+                        wino_out<KIND>(m, y);
+#pragma unroll
+                        for (int k = 0; k < R; ++k) th[hh][k] = fmaf(wino_act(y[k], sc, sf, lo), hw, th[hh][k]);
+                    }
             }
+            const float hsc = p.head_scale ? p.head_scale[0] : 1.f, hsf = p.head_shift ? p.head_shift[0] : 0.f;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const float t = th[0][k] + th[1][k];
+                p.y[e0 + k * ROW_STEP * p.y_hs] = wino_head_act(fmaf(t, hsc, hsf), p.head_act);
+            }
+        } else {
+            const float sc = p.scale ? p.scale[mrow] : 1.f, sf = p.shift ? p.shift[mrow] : 0.f;
+            float m[NCLS], y[R];
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) m[c] = base[(size_t)c * cstride + (size_t)mrow * npad + nl];
+            wino_out<KIND>(m, y);
+            float* __restrict__ yo = p.y + (size_t)mrow * p.y_cs + e0;
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                if (k < row1) yo[k * ROW_STEP * p.y_hs] = wino_act(y[k], sc, sf, lo);
+        }
     }
 }
 
-hipError_t launch_deconv_wino(ConvParams p, hipStream_t stream) {
-    if (p.Cin % WBK != 0 || !p.transposed || p.ksplit != 1 || !p.part || p.act == ACT_SIGMOID || (p.head_w && p.Cout > WBM))
-        return hipErrorInvalidValue;
-    p.m_tiles = (p.Cout + WBM - 1) / WBM;
-    p.n_tiles = (p.Ntotal + WBN - 1) / WBN;
-    const size_t lds = (size_t)WNB * WBK * (WBM + WBN) * sizeof(float);
-    const dim3 grid(p.m_tiles * p.n_tiles * 8);
-    const bool v4 = p.Nw % 4 == 0;
-    if (p.head_w) {
-        if (v4) hipLaunchKernelGGL((deconv_wino_kernel<4, true>), grid, dim3(256), lds, stream, p);
-        else hipLaunchKernelGGL((deconv_wino_kernel<1, true>), grid, dim3(256), lds, stream, p);
+template <int KIND>
+static hipError_t launch_wino_finish(const ConvParams& p, int n_begin, int n_end, int npad, hipStream_t stream) {
+    const long long total = p.head_w ? (long long)(n_end - n_begin) : (long long)p.Cout * (n_end - n_begin);
+    const long long blocks = (total + 255) / 256;
+    const dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192), KIND == 2 ? 8 : 1);
+    if constexpr (KIND == 2) {
+        if (p.head_w) hipLaunchKernelGGL((wino_finish_kernel<KIND, true>), grid, dim3(256), 0, stream, p, n_begin, n_end, npad);
+        else hipLaunchKernelGGL((wino_finish_kernel<KIND, false>), grid, dim3(256), 0, stream, p, n_begin, n_end, npad);
     } else {
-        if (v4) hipLaunchKernelGGL((deconv_wino_kernel<4, false>), grid, dim3(256), lds, stream, p);
-        else hipLaunchKernelGGL((deconv_wino_kernel<1, false>), grid, dim3(256), lds, stream, p);
+        hipLaunchKernelGGL((wino_finish_kernel<KIND, false>), grid, dim3(256), 0, stream, p, n_begin, n_end, npad);
     }
     return hipGetLastError();
+}
+
+// ---- launch planning ---------------------------------------------------------------------------
+// serial workgroups a CU hosts at once (register-limited), by kind
+static int wino_slots(int kind) { return kind == 1 ? 2 : (kind == 0 ? 3 : 4); }
+
+int64_t wino_slab_elems(int kind, int cout, int ntotal, const WinoLaunch& L) {
+    if (L.mode == WINO_SERIAL) return 0;
+    const int ncls = kind == 2 ? 24 : (kind == 1 ? 6 : 4);
+    const int bn = 32 * L.wn_cp;
+    const int n0 = L.mode == WINO_DUAL ? L.n_cut : 0;
+    const int64_t npad = (int64_t)((ntotal - n0 + bn - 1) / bn) * bn;
+    return (int64_t)ncls * cout * npad;
+}
+
+// Which form a layer's launch takes.  forced >= 0 (tuning, tests): bits 0-1 mode (0 serial, 1 class-parallel, 2 dual), bit 2: the
+// class-parallel part on 64 x 64 tiles, bit 3: the serial part on 64 x 64 tiles (2 x 2 waves).  Otherwise by workgroup count: the
+// serial form when its grid fills the chip's slots several times over, the class-parallel form when it would leave them short,
+// the dual form when the last round is mostly empty.  All forms produce the same bits.
+WinoLaunch wino_plan(int kind, int cout, int ntotal, bool head, int forced) {
+    WinoLaunch L;
+    L.mode = WINO_SERIAL; L.wn_serial = 4; L.wn_cp = 4; L.n_cut = 0;
+    const int m_tiles = (cout + WBM - 1) / WBM;
+    const int pcs = kind == 2 ? 8 : 1;
+    if (forced >= 0) {
+        L.mode = forced & 3;
+        L.wn_cp = (forced & 4) ? 2 : 4;
+        L.wn_serial = (forced & 8) ? 2 : 4;
+        if (L.mode > WINO_DUAL) L.mode = WINO_SERIAL;
+        if (head && L.wn_serial != 4) L.wn_serial = 4;
+    } else {
+        static const int env_mode = getenv("S3R_WINO_FORM") ? atoi(getenv("S3R_WINO_FORM")) : -1;      // A/B switch, read once
+        if (env_mode >= 0) return wino_plan(kind, cout, ntotal, head, env_mode);
+        const long W = (long)m_tiles * ((ntotal + WBN - 1) / WBN) * pcs;                 // serial workgroups
+        const long slots = 256L * wino_slots(kind);
+        const int ncls = kind == 1 ? 6 : (kind == 0 ? 4 : 3);
+        if (W * 2 <= slots * 3) {                        // <= 1.5 rounds of the slots: every class its own workgroup
+            L.mode = WINO_CP;
+            L.wn_cp = (W * ncls < 2 * 256L * 4) ? 2 : 4;                                  // still sparse: halve the tiles too
+        } else if (kind != 2) {
+            // a little over a whole number of 256-workgroup rounds: cut the tail off and run it class-parallel
+            const long rounds = W / 256, rem = W % 256;
+            const long n_main = (rounds * 256) / m_tiles;                                  // whole N tiles in the bulk
+            if (rounds >= 1 && rounds < 16 && rem > 0 && rem <= 160 && n_main >= 1) {
+                L.mode = WINO_DUAL;
+                L.n_cut = (int)(n_main * WBN);
+                const long items = ((ntotal - L.n_cut + WBN - 1) / WBN) * m_tiles * ncls;
+                L.wn_cp = items < 512 ? 2 : 4;
+            }
+        }
+    }
+    if (L.mode == WINO_DUAL) {
+        if (kind == 2) L.mode = WINO_SERIAL;             // (the transposed form has no dual kernel: its grids are 8 x as long)
+        else {
+            if (L.n_cut <= 0) {                          // forced dual: the whole rounds in the bulk
+                const long W = (long)m_tiles * ((ntotal + WBN - 1) / WBN);
+                const long n_main = ((W / 256) * 256) / m_tiles;
+                L.n_cut = (int)(n_main * WBN);
+            }
+            if (L.n_cut <= 0 || L.n_cut >= ntotal) { L.mode = L.n_cut <= 0 ? WINO_CP : WINO_SERIAL; L.n_cut = 0; }
+        }
+    }
+    return L;
+}
+
+template <int VEC, int KIND>
+static hipError_t launch_wino_forms(ConvParams p, const WinoLaunch& L, hipStream_t stream) {
+    const int ntotal = p.Ntotal;
+    auto lds_of = [](int bn) { return (size_t)WNB * WBK * (WBM + bn) * sizeof(float); };
+    const int pcs = KIND == 2 ? 8 : 1;
+    constexpr int NCLS = WinoKind<KIND>::NCLS;
+    p.n_begin = 0; p.n_end = ntotal;
+    if (L.mode == WINO_SERIAL) {
+        const int bn = 32 * L.wn_serial;
+        const dim3 grid(p.m_tiles * ((ntotal + bn - 1) / bn) * pcs);
+        if constexpr (KIND == 2) {
+            if (p.head_w) {
+                hipLaunchKernelGGL((wino_kernel<VEC, KIND, 4, false, true>), grid, dim3(256), lds_of(128), stream, p);
+                return hipGetLastError();
+            }
+        }
+        if (L.wn_serial == 4) hipLaunchKernelGGL((wino_kernel<VEC, KIND, 4, false, false>), grid, dim3(256), lds_of(128), stream, p);
+        else hipLaunchKernelGGL((wino_kernel<VEC, KIND, 2, false, false>), grid, dim3(256), lds_of(64), stream, p);
+        return hipGetLastError();
+    }
+    if (!p.part) return hipErrorInvalidValue;
+    const int bn = 32 * L.wn_cp;
+    const int n0 = L.mode == WINO_DUAL ? L.n_cut : 0;
+    const int cp_tiles = (ntotal - n0 + bn - 1) / bn;
+    const int cp_wgs = p.m_tiles * cp_tiles * NCLS * pcs;
+    if (L.mode == WINO_DUAL) {
+        if constexpr (KIND == 2) return hipErrorInvalidValue;
+        else {
+            p.n_cut = n0;
+            p.big_wgs = p.m_tiles * (n0 / WBN);
+            const dim3 grid(p.big_wgs + cp_wgs);
+            if (L.wn_cp == 4) hipLaunchKernelGGL((wino_dual_kernel<VEC, KIND, 4>), grid, dim3(256), lds_of(128), stream, p);
+            else hipLaunchKernelGGL((wino_dual_kernel<VEC, KIND, 2>), grid, dim3(256), lds_of(128), stream, p);
+        }
+    } else {
+        const dim3 grid(cp_wgs);
+        if (L.wn_cp == 4) hipLaunchKernelGGL((wino_kernel<VEC, KIND, 4, true, false>), grid, dim3(256), lds_of(128), stream, p);
+        else hipLaunchKernelGGL((wino_kernel<VEC, KIND, 2, true, false>), grid, dim3(256), lds_of(64), stream, p);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_wino_finish<KIND>(p, n0, ntotal, cp_tiles * bn, stream);
+}
+
+// p: see wino_body; R = outputs per group (2 or 4).  Returns the kernel launches made through *launches (may be null).
+hipError_t launch_conv_wino(ConvParams p, int R, const WinoLaunch& L, hipStream_t stream, int* launches) {
+    if (p.Cin % WBK != 0 || (R != 2 && R != 4) || p.stride != 1 || p.transposed || p.ksplit != 1 || p.head_w || p.act == ACT_SIGMOID)
+        return hipErrorInvalidValue;
+    p.kh = 1;
+    p.m_tiles = (p.Cout + WBM - 1) / WBM;
+    if (launches) *launches = L.mode == WINO_SERIAL ? 1 : 2;
+    const bool v4 = p.Nw % 4 == 0;
+    if (R == 4) return v4 ? launch_wino_forms<4, 1>(p, L, stream) : launch_wino_forms<1, 1>(p, L, stream);
+    return v4 ? launch_wino_forms<4, 0>(p, L, stream) : launch_wino_forms<1, 0>(p, L, stream);
+}
+
+hipError_t launch_deconv_wino(ConvParams p, const WinoLaunch& L, hipStream_t stream, int* launches) {
+    if (p.Cin % WBK != 0 || !p.transposed || p.ksplit != 1 || !p.xd || p.act == ACT_SIGMOID || (p.head_w && p.Cout > WBM))
+        return hipErrorInvalidValue;
+    p.m_tiles = (p.Cout + WBM - 1) / WBM;
+    if (launches) *launches = L.mode == WINO_SERIAL ? 1 : 2;
+    const bool v4 = p.Nw % 4 == 0;
+    return v4 ? launch_wino_forms<4, 2>(p, L, stream) : launch_wino_forms<1, 2>(p, L, stream);
 }
 
 }  // namespace s3r

@@ -101,7 +101,16 @@ struct ConvParams {
     // Winograd F(2,3) along H (s3r_conv_wino.hip): x = the four transformed input plane sets, x_cls elements apart; Nh = row
     // pairs per plane; Hout = the output's true height
     int x_cls, Hout;
+    // transposed Winograd form: the row differences of the padded input (same shape and strides as x)
+    const float* xd;
 };
+
+// Launch form of a Winograd layer (s3r_conv_wino.hip): serial (one workgroup walks all classes of its tile), class-parallel (one
+// workgroup per (tile, class), class sums to slabs, a finish kernel transforms them — bit-identical to the serial form), or dual
+// (positions [0, n_cut) serial and [n_cut, N) class-parallel in one launch).  wn_*: waves along the position axis of the serial /
+// class-parallel tiles (4: 64 couts x 128 positions, 2: 64 x 64).
+enum { WINO_SERIAL = 0, WINO_CP = 1, WINO_DUAL = 2 };
+struct WinoLaunch { int mode, wn_serial, wn_cp, n_cut; };
 
 // Tap schedule of a stride-2 k3 p1 convolution over a PARITY-SPLIT input (include/s3r.h, S3R_LAYOUT_S2D), per 32-channel
 // chunk: `ngroups` image loads (one class sub-tensor plane each: 4 in 2D, 12 in 3D), group g reading its g_ntaps[g] taps
@@ -164,12 +173,15 @@ hipError_t launch_pack_conv(const float* w, float* wp, int Cin, int Cout, int Co
 // Winograd F(2,3) along H for 3 x 3 [x 3] stride-1 pad-1 convolutions (s3r_conv_wino.hip)
 hipError_t launch_wino_input(const float* x, float* V, long long planes, int Hp, int Wp, int Hq, int R, hipStream_t s);
 hipError_t launch_pack_wino(const float* w, float* wp, int Cin, int Cout, int CoutPad, int kd, int kw, int R, hipStream_t s);
-hipError_t launch_conv_wino(ConvParams p, hipStream_t stream);
+// kind: 0 conv F(2,3), 1 conv F(4,3), 2 transposed F(2,2); ntotal = positions (groups of R output rows) of the launch
+WinoLaunch wino_plan(int kind, int cout, int ntotal, bool head, int forced);
+int64_t wino_slab_elems(int kind, int cout, int ntotal, const WinoLaunch& L);     // floats of class-parallel slabs (p.part)
+hipError_t launch_conv_wino(ConvParams p, int R, const WinoLaunch& L, hipStream_t stream, int* launches);
 int wino_bk();                      // channels per K tile of the Winograd kernels (Cin must be a multiple)
 // Winograd F(2,2) along H inside the parity classes of ConvTranspose3d(k4 s2 p1)
 hipError_t launch_wino_rowdiff(const float* x, float* D, long long planes, int Hp, int Wp, hipStream_t s);
 hipError_t launch_pack_wino_deconv(const float* w, float* wp, int Cin, int Cout, int CoutPad, hipStream_t s);
-hipError_t launch_deconv_wino(ConvParams p, hipStream_t stream);
+hipError_t launch_deconv_wino(ConvParams p, const WinoLaunch& L, hipStream_t stream, int* launches);
 // y (N,32,Ho+2h,Wo+2h) <- stem conv of x (N,3,Hi,Wi); y_hs / y_cs / y_org describe the padded output.
 // Images [0, nsplit) are read from x, images [nsplit, N) from x2 (the left / right renders of a stereo batch live in
 // two tensors: no concatenation copy); nsplit = N, x2 = null: one tensor.  u8 != 0: x / x2 are 8-bit renders (N,3,Hi,Wi)

@@ -154,11 +154,20 @@ class _HipChain(nn.Module):
 
     _entry = "s3r_chain_forward"
 
-    def __init__(self, layers: Sequence[spec.Layer], in_size: int, tag_base: int = 0, precision: str = "fp32"):
+    def __init__(self, layers: Sequence[spec.Layer], in_size: int, tag_base: int = 0, precision: str = "fp32",
+                 winograd=None):
         super().__init__()
         if precision not in _lib.DTYPE:
             raise ValueError(f"precision must be one of {list(_lib.DTYPE)}")
+        if winograd not in (None, True, False):
+            raise ValueError("winograd must be None (the library's geometry-only policy), True or False")
         self.precision = precision
+        # fp32 convolution algorithm of every layer that has both kernels (include/s3r.h, s3r_algo): None = the library's
+        # policy; False = the direct kernels only (what a latency-bound deployment at batches < 8 may prefer: DESIGN.md);
+        # True = the Winograd kernel wherever the layer has one.  The two agree to fp32 rounding, not bit for bit, so the
+        # choice belongs to the model, never to the batch.
+        self.winograd = winograd
+        self.algo_override: Dict[str, int] = {}      # layer name -> _lib.ALGO_*                    (tuning / tests)
         self._dtype = _lib.DTYPE[precision]
         self._layers = tuple(layers)
         self._in_size = in_size
@@ -231,17 +240,39 @@ class _HipChain(nn.Module):
             pw, scale, shift, _ = packed[i]
             tile = int(os.environ.get(f"S3R_TILE_{l.name}", self.tile_override.get(l.name, -1)))
             ksplit = int(os.environ.get(f"S3R_KSPLIT_{l.name}", self.ksplit_override.get(l.name, 0)))
+            algo = self._algo_of(l)
             # only the chain's own input / output halos are the caller's to state (the output is always
             # a plain contiguous tensor); the library plans the intermediates
             last = i == n_layers - 1
             arr[i].desc = _lib.make_desc(l, batch, n_in, tag=self._tag_base + i, tile=tile,
                                          in_halo=in_halo if i == 0 else 0, out_halo=out_halo if last else 0, ksplit=ksplit,
                                          dtype=self._dtype, in_layout=in_layout if i == 0 else 0,
-                                         out_layout=out_layout if last else 0)
+                                         out_layout=out_layout if last else 0, algo=algo)
             arr[i].packed_w = pw.data_ptr()
             arr[i].scale = scale.data_ptr() if scale is not None else None
             arr[i].shift = shift.data_ptr() if shift is not None else None
         return arr, n_layers
+
+    def _has_winograd_form(self, l: spec.Layer) -> bool:
+        if self.precision != "fp32":
+            return False
+        if l.op == "deconv3d":
+            return l.k == 4 and l.s == 2 and l.p == 1 and l.cin % 32 == 0
+        return l.op in ("conv2d", "conv3d") and l.k == 3 and l.s == 1 and l.p == 1 and l.cin % 32 == 0 and l.cout > 1
+
+    def _algo_of(self, l: spec.Layer) -> int:
+        """s3r_algo of a layer's descriptor: a per-layer override, else the model's `winograd` switch (only layers that
+        have the Winograd form can be asked for it), else AUTO."""
+        if l.name in self.algo_override:
+            return int(self.algo_override[l.name])
+        env = os.environ.get(f"S3R_ALGO_{l.name}")
+        if env is not None:
+            return int(env)
+        if self.winograd is None:
+            return _lib.ALGO_AUTO
+        if self.winograd and self._has_winograd_form(l) and l.act != "sigmoid":
+            return _lib.ALGO_WINOGRAD
+        return _lib.ALGO_DIRECT
 
     def takes_wino_input(self, batch: int) -> bool:
         """Would the chain's first layer run the Winograd kernel on a halo-1 input of this batch (library policy: S3R_WINO)?
@@ -251,7 +282,7 @@ class _HipChain(nn.Module):
         l, (n_in, _) = self._layers[0], self._sizes()[0]
         tile = int(os.environ.get(f"S3R_TILE_{l.name}", self.tile_override.get(l.name, -1)))
         ksplit = int(os.environ.get(f"S3R_KSPLIT_{l.name}", self.ksplit_override.get(l.name, 0)))
-        desc = _lib.make_desc(l, batch, n_in, tile=tile, in_halo=1, ksplit=ksplit, dtype=self._dtype)
+        desc = _lib.make_desc(l, batch, n_in, tile=tile, in_halo=1, ksplit=ksplit, dtype=self._dtype, algo=self._algo_of(l))
         return _lib.load().s3r_conv_wino_input_elems(C.byref(desc)) > 0
 
     def _out_shape(self, batch: int, n_layers: int):
@@ -295,7 +326,7 @@ class _HipChain(nn.Module):
         # the arena's layout is the library's PLAN for this chain: batch, depth, input halo and every layer's
         # requested (tile, split-K) — those decide head fusion and where the split-K scratch starts.  Any change
         # re-zeroes the arena (fresh), so no region is ever read with another plan's bytes in its halo.
-        cfg = tuple((arr[i].desc.tile, arr[i].desc.ksplit) for i in range(n)) + (in_layout, out_layout)
+        cfg = tuple((arr[i].desc.tile, arr[i].desc.ksplit, arr[i].desc.algo) for i in range(n)) + (in_layout, out_layout)
         ws, fresh = self._ws.get(device, need, (batch, n, in_halo, need, cfg))
         u8 = x.dtype == torch.uint8
         if (u8 or x2 is not None) and self._entry != "s3r_encoder_forward":
@@ -380,8 +411,8 @@ class Encoder(_HipChain):
     """
     _entry = "s3r_encoder_forward"
 
-    def __init__(self, precision: str = "fp32"):
-        super().__init__(spec.ENCODER, spec.IMG_HW, tag_base=100, precision=precision)
+    def __init__(self, precision: str = "fp32", winograd=None):
+        super().__init__(spec.ENCODER, spec.IMG_HW, tag_base=100, precision=precision, winograd=winograd)
 
     def forward(self, images: torch.Tensor, upto: Optional[str] = None) -> torch.Tensor:
         """fp32: (N,32,28,28) contiguous.  bf16: (N,32,28,28) bfloat16 in channels_last memory format.
@@ -505,8 +536,8 @@ class Decoder(_HipChain):
     """3D conv hourglass: cost volume (B,64,28,28,28) -> occupancy probabilities (B,32,32,32)."""
     _entry = "s3r_decoder_forward"
 
-    def __init__(self, precision: str = "fp32"):
-        super().__init__(spec.DECODER, spec.MAX_DISP, tag_base=200, precision=precision)
+    def __init__(self, precision: str = "fp32", winograd=None):
+        super().__init__(spec.DECODER, spec.MAX_DISP, tag_base=200, precision=precision, winograd=winograd)
 
     def forward(self, volume: torch.Tensor, upto: Optional[str] = None) -> torch.Tensor:
         tail = (2 * spec.FEAT_C, spec.MAX_DISP, spec.FEAT_HW, spec.FEAT_HW)
@@ -534,8 +565,8 @@ class VolumeEncoder(_HipChain):
     """The down half of the hourglass alone (Stereo2Point): cost volume -> (B,512,4,4,4) latent."""
     _entry = "s3r_decoder_forward"
 
-    def __init__(self, precision: str = "fp32"):
-        super().__init__(spec.DECODER_DOWN, spec.MAX_DISP, tag_base=200, precision=precision)
+    def __init__(self, precision: str = "fp32", winograd=None):
+        super().__init__(spec.DECODER_DOWN, spec.MAX_DISP, tag_base=200, precision=precision, winograd=winograd)
 
     def forward(self, volume: torch.Tensor) -> torch.Tensor:
         tail = (2 * spec.FEAT_C, spec.MAX_DISP, spec.FEAT_HW, spec.FEAT_HW)
@@ -599,12 +630,17 @@ class Stereo2Voxel(_DisparityMixin, nn.Module):
     channels-last bf16 activations with fp32 accumulation (BASELINE configs[2]); parameters stay fp32
     nn.Parameters either way (same state_dict), the bf16 images of the weights are made at pack time."""
 
-    def __init__(self, precision: str = "fp32"):
+    def __init__(self, precision: str = "fp32", winograd=None):
+        """winograd: None = the library's policy (Winograd-along-H kernels on the layers they measured faster on at batch 32:
+        the throughput default — batches below 8 run ~2x..1.1x slower on it than on the direct kernels unless the
+        class-parallel forms cover them); False = the direct kernels only; True = every layer that has the form.
+        Results differ between the settings at fp32 rounding level (never with the batch)."""
         super().__init__()
         self.precision = precision
-        self.encoder = Encoder(precision)
+        self.winograd = winograd
+        self.encoder = Encoder(precision, winograd)
         self.cost_volume = CostVolume(precision=precision)
-        self.decoder = Decoder(precision)
+        self.decoder = Decoder(precision, winograd)
         self.eval()
 
     def train(self, mode: bool = True):
@@ -651,12 +687,13 @@ class Stereo2Point(_DisparityMixin, nn.Module):
     precision="bf16": the convolutional part (encoder, cost volume, v1-v6) on the bf16 MFMA path; the latent is handed
     to the point head as fp32 and the three linear layers stay fp32 (they stream 168 MB of weights: HBM-bound)."""
 
-    def __init__(self, precision: str = "fp32"):
+    def __init__(self, precision: str = "fp32", winograd=None):
         super().__init__()
         self.precision = precision
-        self.encoder = Encoder(precision)
+        self.winograd = winograd
+        self.encoder = Encoder(precision, winograd)
         self.cost_volume = CostVolume(precision=precision)
-        self.decoder = VolumeEncoder(precision)
+        self.decoder = VolumeEncoder(precision, winograd)
         self.point_head = PointHead()
         self.eval()
 

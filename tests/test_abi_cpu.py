@@ -26,13 +26,18 @@ def test_header_symbols_all_exported(s3r, lib):
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.s3r_abi_version() == 6
+    assert lib.s3r_abi_version() == 7
 
 
 def test_struct_layouts_match_header(s3r):
-    assert C.sizeof(s3r._lib.ConvDesc) == 18 * 4
-    assert C.sizeof(s3r._lib.Layer) == 18 * 4 + 3 * 8
-    assert C.sizeof(s3r._lib.ProfRecord) == 32      # 4 x 4 bytes + 2 doubles
+    assert C.sizeof(s3r._lib.ConvDesc) == 19 * 4     # ABI 7: + algo
+    assert C.sizeof(s3r._lib.Layer) == 20 * 4 + 3 * 8       # (the descriptor padded to the pointers' alignment)
+    assert C.sizeof(s3r._lib.ProfRecord) == 48      # 4 x 4 bytes + 3 doubles + algo + reserved
+    header = open(os.path.join(ROOT, "include", "s3r.h")).read()
+    body = header[header.index("typedef struct s3r_conv_desc {"):header.index("} s3r_conv_desc;")]
+    fields = re.findall(r"int32_t\s+([a-z_, ]+);", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    names = [n.strip() for f in fields for n in f.split(",")]
+    assert names == [n for n, _ in s3r._lib.ConvDesc._fields_]
 
 
 def _desc(s3r, layer, batch, n):
@@ -65,7 +70,8 @@ def test_out_size_and_packed_elems(s3r, lib):
 
 
 def test_workspace_query(s3r, lib, monkeypatch):
-    monkeypatch.delenv("S3R_WINO", raising=False)          # the library's own kernel policy (read per call)
+    if os.environ.get("S3R_WINO") not in (None, "1"):
+        pytest.skip("the library's own kernel policy is under test (S3R_WINO is read once, at load)")
     spec = s3r.arch_spec
     rows = spec.stage_table("encoder")
     arr = (s3r._lib.Layer * len(rows))()
@@ -89,8 +95,13 @@ def test_workspace_query(s3r, lib, monkeypatch):
     sub = (s3r._lib.Layer * 2)()
     sub[0].desc, sub[1].desc = _desc(s3r, rows[1][0], 4, rows[1][1]), _desc(s3r, rows[2][0], 4, rows[2][1])
     need2 = lib.s3r_chain_workspace_elems(sub, 2)
-    # (e2, e3 do not split K; e2's Winograd F(4,3) input planes are the chain's scratch: 6 x 4 x 32 x 28 groups x 114 columns)
-    wino = -(-(6 * 4 * 32 * (112 // 4) * 114) // 256) * 256
+    # (e2, e3 do not split K; e2's Winograd scratch is the chain's: its F(4,3) input planes — 6 x 4 x 32 x 28 groups x 114
+    # columns — followed by the class-parallel slabs of the launch form the library plans for 4 images)
+    d2 = _desc(s3r, rows[1][0], 4, rows[1][1])
+    d2.in_halo = 1
+    planes = -(-(6 * 4 * 32 * (112 // 4) * 114) // 256) * 256
+    assert lib.s3r_conv_scratch_elems(C.byref(d2)) >= planes
+    wino = -(-lib.s3r_conv_scratch_elems(C.byref(d2)) // 256) * 256
     assert need2 == -(-(4 * 32 * 114 * 114) // 256) * 256 + -(-(4 * 64 * 114 * 114) // 256) * 256 + wino
     sub[0].desc.in_halo = 1                       # caller hands a padded input: no pad region
     assert lib.s3r_chain_workspace_elems(sub, 2) == -(-(4 * 64 * 114 * 114) // 256) * 256 + wino
@@ -187,3 +198,73 @@ def test_missing_library_fails_loudly(s3r, monkeypatch, tmp_path):
     monkeypatch.setattr(s3r._lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(s3r.S3RError, match="no CPU fallback"):
         s3r._lib.load()
+
+
+def test_algo_field_selects_the_kernel_and_scratch_is_never_a_selector(s3r, lib):
+    """ABI 7: which convolution algorithm runs is the descriptor's `algo` — AUTO resolves from per-sample geometry only — and
+    a scratch buffer smaller than the resolved algorithm needs is S3R_ERR_WORKSPACE, not a silent switch to the other kernel
+    (whose bits differ)."""
+    if os.environ.get("S3R_WINO") not in (None, "1"):
+        pytest.skip("the library's own kernel policy is under test")
+    spec = s3r.arch_spec
+    enc = {l.name: (l, n) for l, n, _ in spec.stage_table("encoder")}
+    dec = {l.name: (l, n) for l, n, _ in spec.stage_table("decoder")}
+    L = s3r._lib
+
+    def scratch(name, algo, batch=4, **kw):
+        l, n = (enc if name in enc else dec)[name]
+        d = L.make_desc(l, batch, n, in_halo=1, algo=algo, **kw)
+        return lib.s3r_conv_scratch_elems(C.byref(d)), d
+
+    planes_e2 = 6 * 4 * 32 * 28 * 114
+    auto, d_auto = scratch("e2", L.ALGO_AUTO)
+    assert auto >= planes_e2                                   # the policy takes e2 (edge 112 = 4 x 28) on the Winograd kernel
+    assert scratch("e2", L.ALGO_WINOGRAD)[0] == auto
+    assert scratch("e2", L.ALGO_DIRECT)[0] == 0                # the direct kernel does not split e2's K
+    assert scratch("e2", L.ALGO_AUTO, tile=3)[0] == 0          # a direct-kernel tile override is a direct-kernel request
+    assert scratch("v5", L.ALGO_AUTO)[0] == scratch("v5", L.ALGO_DIRECT)[0] > 0     # (edge 7: split-K direct kernel)
+    assert scratch("v5", L.ALGO_WINOGRAD)[0] > 0
+    # AUTO never depends on the batch: the same choice at 1 and at 64 samples (the scratch follows the batch, the kernel not)
+    for name in ("e2", "e7", "v1", "v3", "d1", "d3"):
+        assert all(scratch(name, L.ALGO_AUTO, b)[0] > 0 for b in (1, 2, 64)), name
+    assert scratch("e3", L.ALGO_WINOGRAD)[0] == -1             # stride 2: no Winograd form
+    assert b"WINOGRAD" in lib.s3r_last_error()
+    assert scratch("e2", 7)[0] == -1 and b"algo" in lib.s3r_last_error()
+    assert scratch("e2", L.ALGO_WINOGRAD, ksplit=2)[0] == -1
+    # every launch form of the Winograd kernel can be forced (tile = form code), and only the class-parallel ones add slabs
+    serial = scratch("e2", L.ALGO_WINOGRAD, tile=0)[0]
+    assert serial == -(-planes_e2 // 256) * 256
+    assert scratch("e2", L.ALGO_WINOGRAD, tile=1)[0] == serial + 6 * 64 * 12544      # 4 images x 28 groups x 112 columns
+    # too little scratch: an error, before anything is launched (dummy pointers)
+    one = C.c_void_p(1 << 20)
+    assert lib.s3r_conv_forward(C.byref(d_auto), one, one, None, None, one, one, auto - 1, None) == -3
+    assert b"scratch" in lib.s3r_last_error()
+    assert lib.s3r_conv_forward(C.byref(d_auto), one, one, None, None, one, None, 0, None) == -3
+    dv6 = L.make_desc(dec["v6"][0], 4, dec["v6"][1])
+    need = lib.s3r_conv_scratch_elems(C.byref(dv6))
+    assert need > 0                                            # the library splits v6's K
+    assert lib.s3r_conv_forward(C.byref(dv6), one, one, None, None, one, None, 0, None) == -3      # (ABI 6 ran it unsplit)
+    dd = L.make_desc(dec["d2"][0], 4, dec["d2"][1], in_halo=1)
+    assert lib.s3r_conv_forward(C.byref(dd), one, one, None, None, one, one, 16, None) == -3
+
+
+def test_policy_override_is_read_once_at_load(s3r):
+    """S3R_WINO is a PROCESS-level override of what AUTO resolves to, read when the library is loaded."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, ctypes as C\n"
+        "sys.path.insert(0, %r)\n"
+        "import s3r\n"
+        "lib = s3r.load_library(); spec = s3r.arch_spec\n"
+        "l, n, _ = spec.stage_table('encoder')[1]\n"
+        "d = s3r._lib.make_desc(l, 4, n, in_halo=1)\n"
+        "a = lib.s3r_conv_scratch_elems(C.byref(d))\n"
+        "os.environ['S3R_WINO'] = '1'\n"
+        "b = lib.s3r_conv_scratch_elems(C.byref(d))\n"
+        "d.algo = 2\n"
+        "print('RES', a, b, lib.s3r_conv_scratch_elems(C.byref(d)))\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, S3R_WINO="0"), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b, c = [int(v) for v in r.stdout.split("RES")[1].split()]
+    assert a == 0 and b == 0 and c > 0          # AUTO -> direct under S3R_WINO=0, also after the variable changed; WINOGRAD still runs

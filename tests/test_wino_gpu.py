@@ -143,3 +143,157 @@ def test_cost_volume_writes_the_transformed_planes_bitwise(s3r, monkeypatch):
     lat_a = p.decoder.forward_padded(p.cost_volume.forward_padded(fp[:3], fp[3:]))
     lat_b = p.decoder.forward_padded(p.cost_volume.forward_wino(fp[:3], fp[3:]), in_layout=s3r._lib.LAYOUT_WINO_H)
     assert torch.equal(lat_a, lat_b)
+
+
+def _wino_layers(spec):
+    out = []
+    for layers, n0 in ((spec.ENCODER, spec.IMG_HW), (spec.DECODER, spec.MAX_DISP)):
+        for l, n_in, _ in spec.trace(layers, n0):
+            if (l.op in ("conv2d", "conv3d") and l.k == 3 and l.s == 1 and l.p == 1 and l.cin % 32 == 0) or l.op == "deconv3d":
+                out.append((l, n_in))
+    return out
+
+
+def _positions(spec, l, n_in, batch):
+    """GEMM positions of the Winograd launch (groups of R output rows) and its serial workgroup count."""
+    if l.op == "deconv3d":
+        n = batch * n_in * (n_in // 2) * n_in
+        return n, -(-l.cout // 64) * -(-n // 128) * 8
+    R = 4 if n_in % 4 == 0 else 2
+    n = batch * (n_in if l.op == "conv3d" else 1) * -(-n_in // R) * n_in
+    return n, -(-l.cout // 64) * -(-n // 128)
+
+
+def test_every_launch_form_gives_the_serial_forms_bits(s3r):
+    """The class-parallel form (one workgroup per (tile, class), class sums through slabs, `wino_finish_kernel`) and the dual
+    form (bulk serial + remainder class-parallel in one launch) run the same MFMA sequence per class and the same output
+    transform as the serial form: bit for bit, on every layer that has a Winograd kernel, at a batch that makes the dual
+    form's cut fall inside the layer (W > 256 serial workgroups) and at a small one; the 64 x 64 tiles likewise."""
+    dev, spec, L = "cuda:0", s3r.arch_spec, s3r._lib
+    for l, n_in in _wino_layers(spec):
+        batches = [1]
+        b = 1
+        while _positions(spec, l, n_in, b)[1] <= 264 and b < 64:
+            b += 1
+        batches.append(b)
+        for B in batches:
+            ch = s3r.modules._HipChain([l], n_in, precision="fp32")
+            s3r.seed_module(ch, 11)
+            ch.to(dev)
+            ch.algo_override[l.name] = L.ALGO_WINOGRAD
+            x = torch.randn((B, l.cin) + (n_in,) * spec.ndim(l), generator=torch.Generator().manual_seed(B)).to(dev)
+            outs = {}
+            for form in (0, 1, 5, 2, 6, 8):
+                if l.op == "deconv3d" and form in (2, 6):
+                    continue                                       # (no dual kernel for the transposed form)
+                ch.tile_override[l.name] = form
+                s3r.profile_enable(8)
+                outs[form] = ch._run(x).clone()
+                rec = [r for r in s3r.profile_read(8) if r["family"] == "conv_mfma"]
+                s3r.profile_enable(0)
+                assert len(rec) == 1 and rec[0]["ran"].startswith("winograd"), rec
+                if form in (1, 5):
+                    assert rec[0]["ran"] == "winograd-class-parallel", (l.name, form, rec)
+                if form in (2, 6) and _positions(spec, l, n_in, B)[1] > 256:
+                    assert rec[0]["ran"] == "winograd-dual", (l.name, B, form, rec)
+            for form, y in outs.items():
+                assert torch.equal(y, outs[0]), (l.name, B, form, float((y - outs[0]).abs().max()))
+            ch.tile_override.pop(l.name)                           # ... and so does whatever form the library plans itself
+            assert torch.equal(ch._run(x), outs[0]), (l.name, B, "auto form")
+    # d3 with the occupancy head fused: serial epilogue vs the finish kernel's cout walk
+    dl = {l.name: (l, n_in) for l, n_in, _ in spec.trace(spec.DECODER, spec.MAX_DISP)}
+    ch = s3r.modules._HipChain([dl["d3"][0], dl["d4"][0]], dl["d3"][1], precision="fp32")
+    s3r.seed_module(ch, 9)
+    ch.to(dev)
+    ch.algo_override["d3"] = L.ALGO_WINOGRAD
+    for B in (1, 3):
+        x = torch.randn((B, 128, 16, 16, 16), generator=torch.Generator().manual_seed(4)).to(dev)
+        outs = {}
+        for form in (0, 1, 5):
+            ch.tile_override["d3"] = form
+            outs[form] = ch._run(x).clone()
+        assert torch.equal(outs[1], outs[0]) and torch.equal(outs[5], outs[0]), B
+
+
+_FORMS_CHILD = r'''
+import sys, torch
+sys.path.insert(0, %(root)r)
+import s3r
+dev = torch.device("cuda:0")
+m = s3r.Stereo2Voxel(); s3r.seed_module(m, 0); m.to(dev)
+outs = []
+for B in (1, 2, 4, 8, 32):
+    l, r = s3r.synthetic_pairs(B, seed=90 + B)
+    outs.append(m(l.to(dev), r.to(dev)).clone().cpu())
+torch.save(outs, sys.argv[1])
+'''
+
+
+def test_whole_forward_is_form_invariant_at_every_batch(tmp_path):
+    """B = 1, 2, 4, 8, 32: the forward under the library's own launch plan (class-parallel on sparse grids, dual where a
+    layer's last round is mostly empty) equals the forward with every Winograd layer forced to the serial form — bitwise."""
+    res = {}
+    for flag in ("auto", "0"):
+        path = str(tmp_path / f"forms_{flag}.pt")
+        env = dict(os.environ)
+        env.pop("S3R_WINO_FORM", None)
+        if flag != "auto":
+            env["S3R_WINO_FORM"] = flag
+        r = subprocess.run([sys.executable, "-c", _FORMS_CHILD % {"root": ROOT}, path], capture_output=True, text=True,
+                           timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[flag] = torch.load(path)
+    for a, b in zip(res["auto"], res["0"]):
+        assert torch.equal(a, b), a.shape
+
+
+def test_winograd_on_offset_and_heavy_tailed_inputs(s3r):
+    """F(4,3) / F(2,3) / F(2,2) along H in fp32 against an fp64 convolution, beside the direct kernel's error on the same data:
+    a large DC offset (1000 + randn: the input transform's rows sum to zero, so the offset cancels BEFORE the multiplications),
+    heavy tails (|randn| exp(2 randn)) and zero-sum kernels.  Both kernels must stay inside 1e-5 of the problem's own scale
+    (max sum of |w| |x|) and — where the output is not a cancellation — north_star's 1e-4 of the output; the Winograd form within
+    4x of the direct kernel's own error."""
+    import torch.nn.functional as F
+    dev, spec, L = "cuda:0", s3r.arch_spec, s3r._lib
+    g = torch.Generator().manual_seed(123)
+    cases = {l.name: (l, n) for l, n in _wino_layers(spec)}
+    for name in ("e4", "e7", "v3", "d2"):
+        l, n_in = cases[name]
+        shape = (2, l.cin) + (n_in,) * spec.ndim(l)
+        inputs = {"offset": 1000.0 + torch.randn(shape, generator=g),
+                  "heavy": torch.randn(shape, generator=g).abs() * torch.exp(2.0 * torch.randn(shape, generator=g))}
+        for zero_sum in (False, True):
+            ch = s3r.modules._HipChain([l], n_in, precision="fp32")
+            s3r.seed_module(ch, 5)
+            blk = getattr(ch, l.name)
+            with torch.no_grad():
+                if zero_sum:                                       # every kernel sums to zero over its taps
+                    w = blk.conv.weight
+                    w -= w.mean(dim=tuple(range(2, w.dim())), keepdim=True)
+                blk.bn.weight.fill_(1.0); blk.bn.bias.zero_(); blk.bn.running_mean.zero_(); blk.bn.running_var.fill_(1.0 - spec.BN_EPS)
+                blk.conv.bias.zero_()
+            w64 = blk.conv.weight.detach().double()
+            ch.to(dev)
+            for kind, x in inputs.items():
+                if l.op == "deconv3d":
+                    want = F.conv_transpose3d(x.double(), w64, None, 2, 1)
+                else:
+                    want = (F.conv3d if l.op == "conv3d" else F.conv2d)(x.double(), w64, None, 1, 1)
+                want = want.clamp_min(0.0)                          # the layer's ReLU
+                # condition-aware scale: the largest sum of |w| |x| (zero-sum kernels on an offset cancel 1000-sized terms: errors
+                # relative to the OUTPUT are then ill-conditioned for any fp32 summation, the direct one included)
+                if l.op == "deconv3d":
+                    mag = F.conv_transpose3d(x.double().abs(), w64.abs(), None, 2, 1)
+                else:
+                    mag = (F.conv3d if l.op == "conv3d" else F.conv2d)(x.double().abs(), w64.abs(), None, 1, 1)
+                scale = float(mag.max())
+                errs = {}
+                for algo in (L.ALGO_DIRECT, L.ALGO_WINOGRAD):
+                    ch.algo_override[l.name] = algo
+                    got = ch._run(x.to(dev)).cpu().double()
+                    errs[algo] = float((got - want).abs().max())
+                assert errs[L.ALGO_DIRECT] < 1e-5 * scale and errs[L.ALGO_WINOGRAD] < 1e-5 * scale, (name, kind, zero_sum, errs, scale)
+                assert errs[L.ALGO_WINOGRAD] < 4 * errs[L.ALGO_DIRECT] + 1e-7 * scale, (name, kind, zero_sum, errs, scale)
+                if not zero_sum:                                    # north_star's bar, relative to the output itself
+                    out_scale = float(want.abs().max())
+                    assert errs[L.ALGO_DIRECT] < 1e-4 * out_scale and errs[L.ALGO_WINOGRAD] < 1e-4 * out_scale, (name, kind, errs)

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--shapes", default="", help="bf16: MFMA shapes to A/B, e.g. 32,16 (S3R_BF16_MFMA; weights are re-packed per shape)")
     ap.add_argument("--wsplit", action="store_true", help="fp32 stride-2 k3 p1 layers: feed the halo-padded input with "
                     "W-parity-split rows (S3R_LAYOUT_S2D), as the chain hands it over")
+    ap.add_argument("--algo", type=int, default=0, help="fp32: s3r_algo of the layer (0 auto, 1 direct, 2 Winograd: --tiles are then "
+                    "launch-FORM codes: 0 serial, 1 class-parallel, 2 dual, +4 class-parallel part on 64 x 64 tiles, +8 serial part on 64 x 64)")
     ap.add_argument("--zeros", action="store_true", help="all-zero inputs and weights (how much of the rate is power: the\n"
                     "chip holds a higher clock on zeros, MI355X_MICROARCH.md DVFS notes)")
     args = ap.parse_args()
@@ -75,6 +77,7 @@ def main():
             run_kw = dict(in_halo=1, in_layout=1)
         flops = 2.0 * spec.layer_macs(l, n_in) * B
         res = {}
+        ran = {}
         clk = {}
         ref = None
         for rnd in range(args.rounds + 1):
@@ -88,8 +91,12 @@ def main():
                     code = (15 if t < 0 else t) + 16 * v0
                     if args.dtype == "bf16":
                         code = t            # -1 = library heuristic; 1, 2, 4 per-tap; 9, 10 row-reuse
+                    if args.algo == 2:
+                        code = t
                     ch.tile_override[l.name] = code
                     ch.ksplit_override[l.name] = ks
+                    if args.algo:
+                        ch.algo_override[l.name] = args.algo
                     s3r.profile_enable(8)
                     try:
                         y = ch._run(x, None, **run_kw)
@@ -101,12 +108,16 @@ def main():
                     if rnd == 0:
                         if ref is None:
                             ref = y.clone()
+                        elif args.algo == 2 and not torch.equal(y, ref):      # every launch form must give the same bits
+                            print(f"!! {l.name} form {t}: NOT bit-identical to the first form (max {float((y - ref).abs().max()):.3e})")
                         elif not torch.allclose(y.float(), ref.float(), rtol=1e-4 if args.dtype == "fp32" else 2e-2,
                                                 atol=1e-4 if args.dtype == "fp32" else 2e-2):
                             print(f"!! {l.name} tile {t} variant {v}: output differs from first config "
                                   f"(max {float((y - ref).abs().max()):.3e})")
                         continue
-                    res.setdefault((t, v), []).append([r for r in rec if r["family"] == "conv_mfma"][0]["ms"])
+                    mrec = [r for r in rec if r["family"] == "conv_mfma"][0]
+                    res.setdefault((t, v), []).append(mrec["ms"])
+                    ran[(t, v)] = f"{mrec['ran']}/{mrec['launches']}"
                     if dbg_clock is not None:
                         torch.cuda.synchronize()
                         clk[(t, v)] = dbg_clock(256)
@@ -118,7 +129,7 @@ def main():
             tf = flops / med / 1e9
             if best is None or med < best[0]:
                 best = (med, t, v)
-            line += f" | t{t} v{v[0]} k{v[1]}: {med:7.4f} ms {tf:6.1f} TF {tf / PEAK:5.3f}"
+            line += f" | t{t} v{v[0]} k{v[1]}: {med:7.4f} ms {tf:6.1f} TF {tf / PEAK:5.3f} [{ran.get((t, v), '')}]"
             if (t, v) in clk:
                 line += f" @{clk[(t, v)]:.2f}GHz"
             total.setdefault((t, v), [0.0, 0.0])
