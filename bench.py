@@ -150,40 +150,23 @@ def pmc_summary(variant, dtype, B, plain_run):
     return None
 
 
-def executed_ratio(variant):
-    """MFMA multiply-adds the fp32 path EXECUTES over the algorithmic count the roofline is quoted on: the layers the library
-    runs through Winograd along H (S3R_WINO policy: e2, e4, e6, e7, v1 as F(4,3), v3 as F(2,3)) execute 1/2 and 2/3 of theirs, the transposed convolutions it runs
-    through F(2,2) along H (d1, d2, d3) 3/4."""
-    import s3r
-    spec = s3r.arch_spec
-    mode = int(os.environ.get("S3R_WINO", "1"))
-    tot = exe = 0.0
-    layers = list(spec.trace(spec.ENCODER, spec.IMG_HW)) + \
-        list(spec.trace(spec.DECODER if variant == "voxel" else spec.DECODER_DOWN, spec.MAX_DISP))
-    for l, n_in, _ in layers:
-        if l.name in ("e1", "d4"):
-            continue
-        m = spec.layer_macs(l, n_in) * (2 if l.name.startswith("e") else 1)
-        wino = mode > 0 and l.op in ("conv2d", "conv3d") and l.k == 3 and l.s == 1 and l.p == 1 and l.cin % 32 == 0 and \
-            (mode == 2 or n_in % 4 == 0 or (l.op == "conv3d" and n_in >= 14))
-        dwino = mode > 0 and l.op == "deconv3d" and (mode == 2 or n_in >= 4)          # F(2,2) along H: 3/4
-        tot += m
-        f43 = wino and n_in % 4 == 0                                                  # F(4,3) along H: 1/2
-        exe += m * (0.5 if f43 else 2.0 / 3.0 if wino else 0.75 if dwino else 1.0)
-    return round(exe / tot, 4)
-
-
-def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False):
-    """Roofline of the dominant kernel family (the MFMA implicit-GEMM convolution): algorithmic FLOPs of its launches
-    / their HIP-event durations (events recorded by the library on the stream it launches on)."""
+def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False, eager_step_ms=None):
+    """Roofline of the dominant kernel family (the MFMA implicit-GEMM convolution): the FLOPs its launches EXECUTE on the
+    matrix cores / their HIP-event durations (events recorded by the library on the stream it launches on).  The library
+    reports per launch record what ran (direct kernel or a Winograd form) and the FLOPs that form executes; `frac` is that
+    executed rate over the peak (<= 1 by construction: the MFMA pipe's utilisation), `frac_credited` the same time charged
+    with the direct form's algorithmic FLOPs (SURVEY 8d's count: what a layer is WORTH, which a Winograd kernel delivers
+    with 1/2 .. 3/4 of the multiplications)."""
     if not records:
         return None, {}
     fam = family_table(records, steps)
     per_layer = {}
     for r in records:
         if r["family"] == "conv_mfma":
-            e = per_layer.setdefault(r["tag"], {"ms": 0.0, "flops": 0.0, "n": 0})
-            e["ms"] += r["ms"]; e["flops"] += r["flops"]; e["n"] += 1
+            e = per_layer.setdefault(r["tag"], {"ms": 0.0, "flops": 0.0, "exec": 0.0, "n": 0, "ran": r.get("ran", "direct"),
+                                                "launches": 0})
+            e["ms"] += r["ms"]; e["flops"] += r["flops"]; e["exec"] += r.get("exec_flops", r["flops"]); e["n"] += 1
+            e["launches"] += r["launches"]
     names = {100 + i: l.name for i, l in enumerate(spec.ENCODER)}
     names.update({200 + i: l.name for i, l in enumerate(spec.DECODER)})
     bf = dtype == "bf16"
@@ -193,10 +176,12 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False)
         for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
             log(f"  {k:20s} {f['n']:8d} {f['ms'] / steps:9.3f} {f['flops'] / f['ms'] / 1e9 if f['ms'] else 0:9.2f} "
                 f"{f['bytes'] / f['ms'] / 1e6 if f['ms'] else 0:9.1f}")
-        log(f"conv_mfma per layer:   ms/launch   TFLOP/s   frac of {'bf16' if bf else 'fp32'} MFMA peak")
+        log(f"conv_mfma per layer:   ms/layer  launches  executed TFLOP/s  frac of {'bf16' if bf else 'fp32'} MFMA peak   "
+            f"credited TFLOP/s   what ran")
         for tag, e in sorted(per_layer.items()):
-            tf = e["flops"] / e["ms"] / 1e9
-            log(f"  {names.get(tag, tag)!s:6s} {e['ms'] / e['n']:12.4f} {tf:9.2f} {tf / peak:8.3f}")
+            tf, tfe = e["flops"] / e["ms"] / 1e9, e["exec"] / e["ms"] / 1e9
+            log(f"  {names.get(tag, tag)!s:6s} {e['ms'] / e['n']:12.4f} {e['launches'] // e['n']:6d} {tfe:12.2f} {tfe / peak:12.3f} "
+                f"{tf:18.2f}   {e['ran']}")
     kernels = {k: {"ms_per_step": round(f["ms"] / steps, 4),
                    "tflops": round(f["flops"] / f["ms"] / 1e9, 2) if f["ms"] else None,
                    "algorithmic_gbs": round(f["bytes"] / f["ms"] / 1e6, 1) if f["ms"] else None,
@@ -212,31 +197,39 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False)
     if step_sums and not quiet:
         log("conv_mfma kernel ms per eager step, in order: " + " ".join(f"{v:.3f}" for v in step_sums))
     step_sums.sort()
-    achieved = c["flops"] / c["ms"] / 1e9            # TFLOP/s
+    executed = sum(e["exec"] for e in per_layer.values())
+    credited = c["flops"] / c["ms"] / 1e9            # TFLOP/s on the direct form's count
+    achieved = executed / c["ms"] / 1e9              # TFLOP/s the matrix cores execute
     # §8d's formulas count the taps that multiply padding zeros; without them (arch_spec.layer_macs_interior)
     ratio = spec.mfma_flops_per_pair(variant, interior=True) / spec.mfma_flops_per_pair(variant)
     pmc = pmc_summary(variant, dtype, B, plain_run)
+    all_ms = sum(f["ms"] for f in fam.values())
     roof = {"bound": "mfma",
             "kernel": "conv_bf16{,r,p}_kernel (bf16 MFMA implicit-GEMM conv, channels-last, LDS-DMA; "
                       "per-tap / row-reuse / plane-reuse gathers)" if bf
-            else "conv_glds_kernel / conv_glds_dual_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv, LDS-DMA operand "
-                 "staging; dual = a layer's bulk and its re-tiled remainder in one launch) + conv_wino_kernel / wino_input_kernel "
-                 "(e2, e4, e6, e7, v1: Winograd F(4,3) along H, 1/2 of the direct form's multiplications; v3: F(2,3), 2/3) + deconv_wino_kernel / "
-                 "wino_rowdiff_kernel (d1, d2, d3: F(2,2) along H inside the parity classes, 3/4) — `achieved` counts the DIRECT "
-                 "form's algorithmic FLOPs for every layer",
-            "executed_over_algorithmic_mfma_flops": executed_ratio(variant) if not bf else 1.0,
-            "frac_executed": round(achieved / peak * (executed_ratio(variant) if not bf else 1.0), 4),
+            else "the fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM convolution family, LDS-DMA operand staging: conv_glds_kernel / "
+                 "conv_glds_dual_kernel (direct form) + wino_kernel / wino_dual_kernel / wino_finish_kernel with their transform passes "
+                 "wino_input_kernel / wino_rowdiff_kernel (Winograd along H: F(4,3) convolutions execute 1/2, F(2,2) transposed "
+                 "convolutions 3/4 of the direct form's multiplications; serial, class-parallel and dual launch forms, bit-identical)",
             "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
-            "frac_border_excluded": round(achieved / peak * ratio, 4),
+            "achieved_credited": round(credited, 3),
+            "frac_credited": round(credited / peak, 4),
+            "frac_credited_border_excluded": round(credited / peak * ratio, 4),
+            "executed_over_algorithmic_mfma_flops": round(executed / c["flops"], 4),
+            "what_ran": {names.get(t, str(t)): e["ran"] for t, e in sorted(per_layer.items())},
             "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
             "pmc_source": pmc,
             "layers_per_step": c["n"] // steps,
             "launches_per_step": c["launches"] // steps,
+            "executed_gflop_per_launch": round(executed / c["launches"] / 1e9, 3),
             "algorithmic_gflop_per_launch": round(c["flops"] / c["launches"] / 1e9, 3),
             "avg_launch_ms": round(c["ms"] / c["launches"], 5),
+            "executed_gflop_per_step": round(executed / steps / 1e9, 3),
             "algorithmic_gflop_per_step": round(c["flops"] / steps / 1e9, 3),
             "kernel_ms_per_step": round(c["ms"] / steps, 4),
+            "all_kernels_ms_per_step": round(all_ms / steps, 4),
+            "eager_step_ms": round(eager_step_ms, 4) if eager_step_ms else None,
             "kernel_ms_per_step_spread": ({"min": round(step_sums[0], 4), "median": round(step_sums[len(step_sums) // 2], 4),
                                            "max": round(step_sums[-1], 4)} if step_sums else None)}
     return roof, kernels
@@ -247,7 +240,8 @@ def eager_records(s3r, torch, model, left, right, gt_cloud, steps):
     The chip needs a few steps of uninterrupted work to settle after the host-side pause that precedes this pass (the
     first three or four eager steps' kernels ran 2-14 % longer than the rest: clocks ramping back up), so six steps go
     first and the recording starts behind them WITHOUT draining the queue — what is averaged is the steady state the
-    timed region runs in."""
+    timed region runs in.  Returns (records, ms per eager step): the second from one event pair around the K recorded
+    steps on the same stream, so that sum(kernel ms) <= step ms can be read off the line itself."""
     def one():
         yy = model(left, right)
         if gt_cloud is not None:
@@ -256,17 +250,20 @@ def eager_records(s3r, torch, model, left, right, gt_cloud, steps):
     for _ in range(6):
         one()
     s3r.profile_reset()                              # (host-side only: the queue stays full)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     for _ in range(steps):
         one()
+    e1.record()
     torch.cuda.synchronize()
     records = s3r.profile_read(64 * steps + 64)
     s3r.profile_enable(0)
-    return records
+    return records, e0.elapsed_time(e1) / steps
 
 
 # environment switches that change which kernel (or which variant of one) runs without changing the kernel sources: a run
 # under any of them is not the configuration the committed counter passes were taken on
-_KERNEL_ENV = ("S3R_TILE_", "S3R_KSPLIT_", "S3R_BF16_MFMA", "S3R_STEM_MFMA", "S3R_S2D", "S3R_DEEP_RING", "S3R_LINEAR_NT",
+_KERNEL_ENV = ("S3R_TILE_", "S3R_KSPLIT_", "S3R_ALGO_", "S3R_BF16_MFMA", "S3R_STEM_MFMA", "S3R_S2D", "S3R_DEEP_RING", "S3R_LINEAR_NT",
                "S3R_NO_TAIL_CUT", "S3R_NO_FUSE", "S3R_LIB", "S3R_WINO", "S3R_WSPLIT", "S3R_ROWS", "S3R_NO_DUAL", "S3R_DUAL_MODEL",
                "S3R_LINEAR_WGK")
 
@@ -305,8 +302,8 @@ def secondary_config(s3r, torch, dev, variant, dtype, B, steps, warmup, plain_ru
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    records = eager_records(s3r, torch, model, left, right, gt_cloud, steps)
-    roof, kernels = roofline_of(records, steps, dtype, variant, B, spec, plain_run=plain_run)
+    records, eager_ms = eager_records(s3r, torch, model, left, right, gt_cloud, steps)
+    roof, kernels = roofline_of(records, steps, dtype, variant, B, spec, plain_run=plain_run, eager_step_ms=eager_ms)
     fl = spec.flops_per_pair(variant)
     out = {"workload": f"Stereo2{'Voxel' if variant == 'voxel' else 'Point'} forward"
                        f"{' + Chamfer distance vs a (B,2048,3) cloud' if variant == 'point' else ''}, batch={B}, "
@@ -505,8 +502,9 @@ def main():
         ts = sorted(a.elapsed_time(b) for a, b in evs)
         spread = {"min": round(ts[0], 4), "median": round(ts[len(ts) // 2], 4), "max": round(ts[-1], 4)}
 
+    eager_ms = None
     if profiling and graphed is not None:                 # per-kernel HIP events: the same K steps again, eagerly (untimed)
-        records = eager_records(s3r, torch, model, left, right, gt_cloud, args.steps)
+        records, eager_ms = eager_records(s3r, torch, model, left, right, gt_cloud, args.steps)
 
     if rank == 0:
         pairs = world * B * args.steps
@@ -516,7 +514,7 @@ def main():
         overrides = kernel_env_overrides()
         plain_run = not args.autotune and not args.no_graph and not overrides and not args.include_h2d and \
             args.renders == "f32"
-        roof, kernels = roofline_of(records, args.steps, args.dtype, args.variant, B, spec, plain_run)
+        roof, kernels = roofline_of(records, args.steps, args.dtype, args.variant, B, spec, plain_run, eager_step_ms=eager_ms)
         rccl = None
         if dist_on and args.backend == "nccl":
             try:

@@ -79,10 +79,10 @@ typedef enum s3r_act { S3R_ACT_NONE = 0, S3R_ACT_RELU = 1, S3R_ACT_SIGMOID = 2 }
  *                     (16-byte LDS-DMA where the output width is a multiple of 4) instead of every other dword.  Planned
  *                     by s3r_chain_forward between a convolution and its stride-2 consumer; the K order does not change,
  *                     so results are bit-identical to the plain layout. */
-/*   S3R_LAYOUT_WINO_H  fp32 path, INPUT of a 3 x 3 [x 3] stride-1 pad-1 convolution only, in_halo 1: the Winograd F(R,3)-along-H
- *                      plane sets of the halo-padded tensor, (R+2, B, C, [n+2,] n/R, n+2) with R = 4 for a 3D layer (edge n a
- *                      multiple of 4) and R = 2 for a 2D one — set i, row q = the i-th F(R,3) input-transform combination of the
- *                      padded rows R q .. R q + R + 1 (csrc/s3r_kernels.h, wino_rows_to_classes).  What
+/*   S3R_LAYOUT_WINO_H  fp32 path, INPUT of a 3 x 3 [x 3] stride-1 pad-1 convolution only, in_halo 1, edge n a multiple of 4: the six
+ *                      Winograd F(4,3)-along-H plane sets of the halo-padded tensor, (6, B, C, [n+2,] n/4, n+2) — set i, row q =
+ *                      the i-th F(4,3) input-transform combination of the padded rows 4 q .. 4 q + 5 (csrc/s3r_kernels.h,
+ *                      wino_rows_to_classes).  What
  *                      s3r_cost_volume_forward_wino writes: the consumer then skips its input transform.  The batch of such a
  *                      call is bounded: s3r_conv_wino_input_elems returns 0 when the layer / batch cannot take it. */
 typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_S2D = 1, S3R_LAYOUT_WINO_H = 2 } s3r_layout;
@@ -92,11 +92,10 @@ typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_S2D = 1, S3R_LAYOUT_W
  * multiplications (csrc/s3r_conv_wino.hip) — that agree to fp32 rounding, NOT bit for bit.  So the choice is part of the
  * descriptor and never depends on anything else a caller passes (workspace size, batch):
  *   S3R_ALGO_AUTO      the library's policy, a function of the layer's PER-SAMPLE geometry only: Winograd where the layer has
- *                      that form and the library measured it faster (edge a multiple of 4, or a 3D layer with edge >= 14; transposed
- *                      layers with an input edge >= 4); direct otherwise, and direct whenever the descriptor forces a direct-kernel
- *                      tile / split-K (tile >= 0 or ksplit >= 1) or a non-plain layout.  The process-level override
- *                      S3R_WINO (0: AUTO never picks Winograd, 2: AUTO picks it for every layer that has the form) is read ONCE,
- *                      when the library is loaded;
+ *                      that form (fp32 Conv k3 s1 p1 with cin % 32 == 0, cout > 1, edge >= 4; ConvTranspose3d k4 s2 p1 over an
+ *                      even edge, cin % 32 == 0; in_halo = 1, no sigmoid); direct otherwise, and direct whenever the descriptor
+ *                      forces a direct-kernel tile / split-K (tile >= 0 or ksplit >= 1) or a non-plain layout.  The
+ *                      process-level override S3R_WINO=0 (AUTO never picks Winograd) is read ONCE, when the library is loaded;
  *   S3R_ALGO_DIRECT    the direct kernel;
  *   S3R_ALGO_WINOGRAD  the Winograd kernel (S3R_ERR_INVALID if the layer has no such form or the descriptor cannot take it:
  *                      needs in_halo = 1, plain layouts — or S3R_LAYOUT_WINO_H input —, no split-K, no sigmoid).  `tile` >= 0 then
@@ -153,9 +152,8 @@ const char* s3r_last_error(void);
 int s3r_conv_out_size(const s3r_conv_desc* d);
 /* size of the packed weight buffer for a layer IN 4-BYTE UNITS (>= the torch weight's numel on the fp32
  * path: couts are padded; about half of it on the bf16 path).  ABI 6: an fp32 3 x 3 [x 3] stride-1 pad-1 convolution packs
- * two forms, the direct slab and the Winograd F(R,3)-along-H class slabs (csrc/s3r_conv_wino.hip: R = 4, six slabs, where the
- * edge is a multiple of 4 - half the multiplications; R = 2, four slabs, otherwise); which kernel a forward runs is the
- * descriptor's `algo` (s3r_algo above).  The transposed convolutions likewise: 24 F(2,2)-along-H (parity class, F) slabs
+ * two forms, the direct slab and the six Winograd F(4,3)-along-H class slabs (csrc/s3r_conv_wino.hip: half the
+ * multiplications); which kernel a forward runs is the descriptor's `algo` (s3r_algo above).  The transposed convolutions likewise: 24 F(2,2)-along-H (parity class, F) slabs
  * behind the direct ones. */
 int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems);
 /* repack a torch-layout weight (Conv: [cout][cin][k..]; ConvTranspose: [cin][cout][k..]; Linear:

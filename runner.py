@@ -123,9 +123,12 @@ def main():
             model(torch.rand(wb, 3, 224, 224, device=dev), torch.rand(wb, 3, 224, 224, device=dev))
         # ... and so does the metric path's (copy stream, pinned staging, the IoU / Chamfer / read-out kernels' first
         # launches): one tiny untimed pass of the same driver
-        ws = s3r.evaluate.synthetic_eval_set(2, 1, "uint8" if args.renders == "u8" else "float32")
+        # (two samples PER RANK: the eval drivers shard the list over the ranks, and a rank with an empty shard would
+        # meet its first metric launches inside the timed region)
+        nw = 2 * max(1, int(os.environ.get("WORLD_SIZE", "1")))
+        ws = s3r.evaluate.synthetic_eval_set(nw, 1, "uint8" if args.renders == "u8" else "float32")
         if args.variant == "point":
-            s3r.evaluate.test_point_net(model, ws[0], ws[1], torch.rand(2, 2048, 3) - 0.5, batch=2, device=dev)
+            s3r.evaluate.test_point_net(model, ws[0], ws[1], torch.rand(nw, 2048, 3) - 0.5, batch=2, device=dev)
         else:
             s3r.evaluate.test_net(model, ws[0], ws[1], ws[2], batch=2, device=dev)
         zeros = torch.zeros(wb, 3, 224, 224, dtype=ws[0].dtype, device=dev)

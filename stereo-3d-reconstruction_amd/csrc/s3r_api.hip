@@ -33,14 +33,10 @@ int64_t ipow(int64_t b, int e) {
     return r;
 }
 
-// outputs per Winograd group along H of an fp32 3 x 3 [x 3] stride-1 convolution: F(4,3) — half the direct form's multiplications —
-// where the edge is a multiple of 4 (v1: 0.769 -> 0.668 ms against F(2,3); the 2D layers e2 / e4 / e6 / e7, which F(2,3) could
-// not pay for its transform pass on, gain 6 / 12 / 22 / 25 %), F(2,3) otherwise (v3, edge 14: four groups of 4 would compute 16
-// rows for 14).  S3R_WINO_R4=1 (experiments; read once, it decides the PACKED layout too): F(4,3) for every edge >= 4.
-int wino_r(const s3r_conv_desc* d) {
-    static const bool r4_all = getenv("S3R_WINO_R4") && atoi(getenv("S3R_WINO_R4")) != 0;
-    return (d->in_size % 4 == 0 || (r4_all && d->in_size >= 4)) ? 4 : 2;
-}
+// outputs per Winograd group along H of an fp32 3 x 3 [x 3] stride-1 convolution: F(4,3), half the direct form's multiplications.
+// Edges that are not a multiple of 4 compute a partial last group (v3: 16 rows for 14, v5: 8 for 7) and still beat F(2,3), which
+// r03 used for them (v3 0.505 -> 0.431 ms, v5 0.304 -> 0.251 alone at B = 32): one group size, one class kernel.
+int wino_r(const s3r_conv_desc*) { return 4; }
 
 constexpr int64_t kMaxElems = (int64_t)1 << 31;
 constexpr int64_t kMaxBytes = (int64_t)1 << 32;
@@ -233,12 +229,8 @@ int cout_pad(int cout) { return (cout + 127) / 128 * 128; }
 // slabs); which kernel a call runs is the descriptor's `algo` (include/s3r.h): AUTO resolves from the layer's per-sample
 // geometry (and the descriptor's own tile / split-K / layout fields) alone — never from the scratch a caller offers or the
 // batch — under the process-level policy S3R_WINO, read once:
-//   unset / 1: the layers it measured faster on (edge % 4 == 0: e2, e4, e6, e7, v1; 3D layers with edge >= 14: v3; transposed
-//   layers with an input edge >= S3R_DWINO_MIN_EDGE);  0: never;  2: every layer that has the form (adds v5).
-#ifndef S3R_DWINO_MIN_EDGE
-#define S3R_DWINO_MIN_EDGE 4      // library policy: transposed layers with an input edge >= this (d1, d2, d3: with 32-channel K
-                                  // tiles d1 gains too, 0.269 -> 0.252 ms)
-#endif
+//   unset / 1: every layer that has the form (e2, e4, e6, e7, v1, v3, v5, d1, d2, d3 of this network: each measured faster on it at
+//   B = 32, and — with the class-parallel launch form on sparse grids — at every smaller batch);  0: never.
 int wino_mode() {
     static const int mode = getenv("S3R_WINO") ? atoi(getenv("S3R_WINO")) : 1;      // process-level: read once
     return mode;
@@ -281,10 +273,7 @@ int resolve_algo(const s3r_conv_desc* d, bool* wino, int* form) {
         return S3R_OK;
     }
     if (d->algo == S3R_ALGO_DIRECT || d->tile >= 0 || d->ksplit >= 1 || !wino_desc_ok(d)) return S3R_OK;
-    const int mode = wino_mode();
-    if (mode <= 0) return S3R_OK;
-    if (d->op == S3R_OP_DECONV) *wino = mode >= 2 || d->in_size >= S3R_DWINO_MIN_EDGE;
-    else *wino = mode >= 2 || d->in_size % 4 == 0 || (d->ndim == 3 && d->in_size >= 14);      // (v5, edge 7: S3R_WINO=2 only)
+    *wino = wino_mode() > 0;
     return S3R_OK;
 }
 bool resolves_to_wino(const s3r_conv_desc* d) {
@@ -312,7 +301,10 @@ int64_t dwino_d_elems(const s3r_conv_desc* d) { return (int64_t)d->batch * d->ci
 // the class-parallel slabs of the launch form the library plans for this batch (every form gives the same bits, so the form
 // — unlike the algorithm — may follow the batch).
 struct WinoNeed { int64_t v, slab, total; };
-int wino_kind(const s3r_conv_desc* d) { return d->op == S3R_OP_DECONV ? 2 : (wino_r(d) == 4 ? 1 : 0); }
+int wino_kind(const s3r_conv_desc* d) { return d->op == S3R_OP_DECONV ? 2 : 1; }
+int wino_kcls(const s3r_conv_desc* d) {                        // K per class: Cin x (depth taps x column taps)
+    return d->cin * (d->op == S3R_OP_DECONV ? 4 : (d->ndim == 3 ? 9 : 3));
+}
 int64_t wino_positions(const s3r_conv_desc* d, int nb) {       // GEMM positions (groups of R output rows) of nb samples
     const int n = d->in_size;
     if (d->op == S3R_OP_DECONV) return (int64_t)nb * n * (n / 2) * n;
@@ -326,7 +318,7 @@ WinoNeed wino_need(const s3r_conv_desc* d, int form, bool head) {
     if (d->op == S3R_OP_DECONV) {
         w.v = dwino_d_elems(d);
         const int nt = (int)wino_positions(d, d->batch);
-        w.slab = s3r::wino_slab_elems(kind, d->cout, nt, s3r::wino_plan(kind, d->cout, nt, head, form));
+        w.slab = s3r::wino_slab_elems(kind, d->cout, nt, s3r::wino_plan(kind, d->cout, wino_kcls(d), nt, head, form));
     } else {
         const int bmax = wino_bmax(d);
         if (bmax <= 0) return w;
@@ -335,7 +327,7 @@ WinoNeed wino_need(const s3r_conv_desc* d, int form, bool head) {
             const int nb = d->batch - b0 < bmax ? d->batch - b0 : bmax;
             if (b0 > 0 && nb == bmax) continue;
             const int nt = (int)wino_positions(d, nb);
-            const int64_t sl = s3r::wino_slab_elems(kind, d->cout, nt, s3r::wino_plan(kind, d->cout, nt, false, form));
+            const int64_t sl = s3r::wino_slab_elems(kind, d->cout, nt, s3r::wino_plan(kind, d->cout, wino_kcls(d), nt, false, form));
             if (sl > w.slab) w.slab = sl;
         }
     }
@@ -372,7 +364,7 @@ int dwino_run(const s3r_conv_desc* d, s3r::ConvParams p, const float* x, const f
     p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
     p.dW = s3r::FastDiv((unsigned)p.Nw);
     p.ksplit = 1;
-    const s3r::WinoLaunch L = s3r::wino_plan(2, d->cout, p.Ntotal, p.head_w != nullptr, form);
+    const s3r::WinoLaunch L = s3r::wino_plan(2, d->cout, wino_kcls(d), p.Ntotal, p.head_w != nullptr, form);
     int nl = 0;
     e = s3r::launch_deconv_wino(p, L, s, &nl);
     if (e != hipSuccess) return hip_fail(e, "Winograd transposed-conv launch");
@@ -986,9 +978,9 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                     p.Ntotal = nb * p.Nd * p.Nh * p.Nw;
                     p.y = y + (int64_t)b0 * p.y_bs;
                     p.y_bytes = (unsigned)(4 * (int64_t)nb * p.y_bs);
-                    const s3r::WinoLaunch WL = s3r::wino_plan(kind, d->cout, p.Ntotal, false, form);
+                    const s3r::WinoLaunch WL = s3r::wino_plan(kind, d->cout, wino_kcls(d), p.Ntotal, false, form);
                     int nl = 0;
-                    e = s3r::launch_conv_wino(p, R, WL, s, &nl);
+                    e = s3r::launch_conv_wino(p, WL, s, &nl);
                     if (e != hipSuccess) return hip_fail(e, "Winograd conv launch");
                     ps.launches += nl;
                     ps.algo = 1 + WL.mode;
@@ -1112,6 +1104,10 @@ static int encoder_forward(const s3r_layer* layers, int n_layers, const void* im
             return fail(S3R_ERR_INVALID, "encoder layer %d is not a 2D convolution", i);
     if (images_right && (f.batch < 2 || (f.batch & 1)))
         return fail(S3R_ERR_INVALID, "a (left, right) pair of tensors needs an even image count N = 2B (got %d)", f.batch);
+    // the stems fetch render rows by 16-byte LDS-DMA from base + row * width: fp32 tensors from any allocator are aligned, an
+    // 8-bit view at an odd offset is not
+    if (((uintptr_t)images_left & 15) || ((uintptr_t)images_right & 15))
+        return fail(S3R_ERR_INVALID, "render tensors must be 16-byte aligned (got %p, %p)", images_left, images_right);
     return chain_forward_impl(layers, n_layers, images_left, images_right, f.batch / 2, u8, features, ws, ws_elems, ws_fresh,
                               stream);
 }

@@ -1,26 +1,26 @@
-// fp32 3 x 3 [x 3] stride-1 convolutions with FEWER multiplications: Winograd F(2, 3) along the H axis only.
+// fp32 3 x 3 [x 3] stride-1 convolutions and ConvTranspose3d(k4 s2 p1) with FEWER multiplications: Winograd along the H axis only.
 //
-// Two output rows (2q, 2q + 1) of a column need input rows r0..r3 = 2q .. 2q + 3 of the padded input and the three
-// kernel rows g0, g1, g2:
-//     v0 = r0 - r2      u0 = g0                 m_i = sum over (cin, kd, kw) of u_i * v_i        (4 products, not 6)
-//     v1 = r1 + r2      u1 = (g0 + g1 + g2) / 2
-//     v2 = r2 - r1      u2 = (g0 - g1 + g2) / 2      y(2q)     = (m0 + m1) + m2
-//     v3 = r1 - r3      u3 = g2                      y(2q + 1) = (m1 - m2) - m3
-// so the layer becomes FOUR convolutions with a (kd x 1 x kw) kernel — 9 taps instead of 27 in 3D, 3 instead of 9 in 2D,
-// each over its own transformed input plane set V_i and its own transformed weights U_i — whose results are combined in
-// registers: 2/3 of the matrix work of the direct form for the same outputs.  Why only one axis: every further axis
-// doubles the transform-domain accumulators per output again (4 per 2 outputs here; 64 per 8 for F(2,3)^3 — a whole CU's
-// register file for a 32 x 32 tile) and shortens each GEMM's K to Cin; along H alone K stays Cin x 9 (or x 3), the
-// W axis stays contiguous (16-byte gathers where W % 4 == 0, whole-row stores), and the kernel below is the implicit
-// GEMM of s3r_conv_glds.hip with a class loop around its K loop.  fp32 F(2, 3) is as accurate as the direct fp32 sum
-// here (3-5e-7 relative to fp64 over 64-256 input channels; north_star allows 1e-4), but it is a DIFFERENT summation:
-// results are not bit-identical to the direct kernels' (the library's policy and the S3R_WINO switch: s3r_api.hip).
+// Convolutions, F(4, 3) (Lavin & Gray): four output rows (4q .. 4q + 3) of a column need the padded input rows r0..r5 = 4q .. 4q + 5
+// and the three kernel rows g0, g1, g2:
+//     v0 = 4 r0 - 5 r2 + r4             u0 = g0 / 4                          y0 = m0 + m1 + m2 + m3 + m4
+//     v1 = -4 r1 - 4 r2 + r3 + r4       u1 = -(g0 + g1 + g2) / 6             y1 = m1 - m2 + 2 m3 - 2 m4
+//     v2 = 4 r1 - 4 r2 - r3 + r4        u2 = -(g0 - g1 + g2) / 6             y2 = m1 + m2 + 4 m3 + 4 m4
+//     v3 = -2 r1 - r2 + 2 r3 + r4       u3 = g0 / 24 + g1 / 12 + g2 / 6      y3 = m1 - m2 + 8 m3 - 8 m4 + m5
+//     v4 = 2 r1 - r2 - 2 r3 + r4        u4 = g0 / 24 - g1 / 12 + g2 / 6
+//     v5 = 4 r1 - 5 r3 + r5             u5 = g2                              m_i = sum over (cin, kd, kw) of u_i * v_i
+// so the layer becomes SIX convolutions with a (kd x 1 x kw) kernel — 9 taps instead of 27 in 3D, 3 instead of 9 in 2D, each over
+// its own transformed input plane set V_i and its own transformed weights U_i — whose results are combined in registers: HALF
+// the matrix work of the direct form for the same outputs (edges that are not a multiple of 4 compute a partial last group:
+// 16 rows for 14, 8 for 7).  Why only one axis: every further axis multiplies the transform-domain accumulators per output again
+// and shortens each GEMM's K to Cin; along H alone K stays Cin x 9 (or x 3), the W axis stays contiguous (16-byte gathers where
+// W % 4 == 0, whole-row stores), and the kernel below is the implicit GEMM of s3r_conv_glds.hip with a class loop around its
+// K loop.  In fp32 over 64-256 channels it is as accurate as the direct sum (4.9e-7 relative to an fp64 convolution against
+// 3.6e-7; north_star allows 1e-4) but it is a DIFFERENT summation: results are not bit-identical to the direct kernels', which
+// is why the choice between them is part of the layer descriptor (s3r_algo, include/s3r.h).
 //
-//   wino_input_kernel   x (padded NC(D)HW, halo 1) -> V[4][B][C][Dp][H/2][Wp]      (HBM-bound: reads x once, writes 2 x)
-//   pack_wino_kernel    w[Cout][Cin][kd][3][kw]    -> Up[4][(chunk*T' + tap')*32 + c][CoutPad],  T' = kd*kw, 32-channel chunks
-//   conv_wino_kernel    64 couts x 128 positions per workgroup (positions = (b, d, row pair q, w)), 4 waves of 64 x 32,
-//                       4 classes x 2 MFMA tiles of accumulators per wave, K tiles of one tap x 32 channels in a 2-stage LDS
-//                       ring (the next tile's DMAs in flight under the current tile's 32 MFMAs per wave)
+//   wino_input_kernel   x (padded NC(D)HW, halo 1) -> V[6][B][C][Dp][ceil(H/4)][Wp]   (HBM-bound: reads x once, writes 1.5 x)
+//   pack_wino_kernel    w[Cout][Cin][kd][3][kw]    -> Up[6][(chunk*T' + tap')*32 + c][CoutPad],  T' = kd*kw, 32-channel chunks
+//   wino_kernel / wino_dual_kernel / wino_finish_kernel: the class kernels, below
 #include "s3r_kernels.h"
 #include <cstdlib>
 
@@ -56,15 +56,6 @@ __device__ __forceinline__ void wdma(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, S3R_LDS_PTR_W(lds_dst), 4, voffset, soffset, 0, 0);
 }
 
-// ---- F(R, 3) along H, R = 2 or 4 outputs per group from R + 2 padded input rows through R + 2 products.
-//   R = 2 (above).   R = 4 (Lavin & Gray's F(4, 3); HALF the direct form's multiplications; in fp32 over 64-128 channels 4.9e-7
-//   relative to an fp64 convolution against the direct sum's 3.6e-7):
-//     v0 = 4 r0 - 5 r2 + r4             u0 = g0 / 4                          y0 = m0 + m1 + m2 + m3 + m4
-//     v1 = -4 r1 - 4 r2 + r3 + r4       u1 = -(g0 + g1 + g2) / 6             y1 = m1 - m2 + 2 m3 - 2 m4
-//     v2 = 4 r1 - 4 r2 - r3 + r4        u2 = -(g0 - g1 + g2) / 6             y2 = m1 + m2 + 4 m3 + 4 m4
-//     v3 = -2 r1 - r2 + 2 r3 + r4       u3 = g0 / 24 + g1 / 12 + g2 / 6      y3 = m1 - m2 + 8 m3 - 8 m4 + m5
-//     v4 = 2 r1 - r2 - 2 r3 + r4        u4 = g0 / 24 - g1 / 12 + g2 / 6
-//     v5 = 4 r1 - 5 r3 + r5             u5 = g2
 // ---- input transform: one thread per (plane row of V, column); rows 0 .. R+1 of the group in the padded input plane
 template <int R>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, long long planes,
@@ -89,8 +80,8 @@ hipError_t launch_wino_input(const float* x, float* V, long long planes, int Hp,
     const long long total = planes * Hq * Wp;
     const long long blocks = (total + 255) / 256;
     const dim3 grid((unsigned)(blocks < 65536 ? blocks : 65536));
-    if (R == 4) hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, s, x, V, planes, Hp, Wp, Hq, total);
-    else hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, s, x, V, planes, Hp, Wp, Hq, total);
+    if (R != 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, s, x, V, planes, Hp, Wp, Hq, total);
     return hipGetLastError();
 }
 
@@ -114,13 +105,9 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict_
             const int td = tap / kw, tw = tap - td * kw;
             const float* g = w + (((size_t)co * Cin + cin) * kd + td) * 3 * kw + tw;       // g[kh * kw]
             const float g0 = g[0], g1 = g[kw], g2 = g[2 * kw];
-            if (R == 2) {
-                v = cls == 0 ? g0 : cls == 1 ? ((g0 + g1) + g2) * 0.5f : cls == 2 ? ((g0 - g1) + g2) * 0.5f : g2;
-            } else {
-                const float s02 = g0 + g2, a = g0 * (1.f / 24.f) + g2 * (1.f / 6.f), b12 = g1 * (1.f / 12.f);
-                v = cls == 0 ? g0 * 0.25f : cls == 1 ? (s02 + g1) * (-1.f / 6.f) : cls == 2 ? (s02 - g1) * (-1.f / 6.f)
-                  : cls == 3 ? a + b12 : cls == 4 ? a - b12 : g2;
-            }
+            const float s02 = g0 + g2, a = g0 * (1.f / 24.f) + g2 * (1.f / 6.f), b12 = g1 * (1.f / 12.f);
+            v = cls == 0 ? g0 * 0.25f : cls == 1 ? (s02 + g1) * (-1.f / 6.f) : cls == 2 ? (s02 - g1) * (-1.f / 6.f)
+              : cls == 3 ? a + b12 : cls == 4 ? a - b12 : g2;
         }
         wp[i] = v;
     }
@@ -193,27 +180,26 @@ hipError_t launch_pack_wino_deconv(const float* w, float* wp, int Cin, int Cout,
 }
 
 // ================================================================================================
-// The class kernels.  ONE body serves the three Winograd forms of this file,
-//     KIND 0: convolution, F(2,3) along H (4 classes, 2 output rows per group)
+// The class kernels.  ONE body serves the Winograd forms of this file,
 //     KIND 1: convolution, F(4,3) along H (6 classes, 4 output rows per group)
 //     KIND 2: ConvTranspose3d(k4 s2 p1), F(2,2) along H inside every output-parity class (3 classes, 2 output rows)
 // in two launch forms:
 //     serial (CP = false): a workgroup owns a tile of 64 couts x BN positions (position = one group of R output rows of one
 //         column) and walks ALL classes back to back, one accumulator set per class; the output transform, the folded BN +
-//         ReLU (and d3's fused 1 x 1 x 1 head) run on the registers.  4 waves as WM x WN = 1 x 4 (64 couts x 32 positions per
-//         wave, BN = 128: two MFMA tiles per class) or 2 x 2 (32 x 32 per wave, BN = 64: one MFMA tile per class, half the
-//         accumulator registers);
+//         ReLU (and d3's fused 1 x 1 x 1 head) run on the registers.  4 waves as WM x WN = 2 x 2 (32 couts x 32 positions per
+//         wave, BN = 64: one MFMA tile per class — 109 registers for six classes, four workgroups per CU; r03's 64 x 128 tiles
+//         held two and measured 3-13 % slower on every layer) or, for the fused head only, 1 x 4 (64 couts x 32 positions per
+//         wave, BN = 128: one wave holds all couts of its positions);
 //     class-parallel (CP = true): a workgroup owns ONE class of a tile, runs that class's K loop — the same MFMA sequence in the
 //         same order as the serial form, so the same bits — and writes the raw class sums to a slab part[class][cout][n];
 //         wino_finish_kernel then applies the output transform and the epilogue through the SAME device functions
 //         (wino_out / wino_act below) in the same operation order: bit-identical to the serial form.  It multiplies the
-//         workgroup count by the class count (x 6 / x 4 / x 3) and divides a workgroup's serial K walk by it: the form for
+//         workgroup count by the class count (x 6 / x 3) and divides a workgroup's serial K walk by it: the form for
 //         grids that leave the chip short of workgroups (small batches; v5; d1) and for the REMAINDER of a launch whose
 //         workgroup count is a little over a multiple of the chip's slots (wino_dual_kernel: bulk serial + remainder
 //         class-parallel in one launch — the direct path's plan_tail_cut idea with the class axis as the finer unit).
 // Because the two forms agree bit for bit, which one runs may depend on the batch size (a sample's bits never do).
 template <int KIND> struct WinoKind;
-template <> struct WinoKind<0> { static constexpr int NCLS = 4, R = 2; };
 template <> struct WinoKind<1> { static constexpr int NCLS = 6, R = 4; };
 template <> struct WinoKind<2> { static constexpr int NCLS = 3, R = 2; };
 
@@ -221,10 +207,7 @@ template <> struct WinoKind<2> { static constexpr int NCLS = 3, R = 2; };
 // the compiler could contract differently in the two kernels that share it).
 template <int KIND>
 __device__ __forceinline__ void wino_out(const float (&m)[WinoKind<KIND>::NCLS], float (&y)[WinoKind<KIND>::R]) {
-    if constexpr (KIND == 0) {
-        y[0] = (m[0] + m[1]) + m[2];
-        y[1] = (m[1] - m[2]) - m[3];
-    } else if constexpr (KIND == 1) {
+    if constexpr (KIND == 1) {
         const float s12 = m[1] + m[2], d12 = m[1] - m[2];
         const float s34 = m[3] + m[4], d34 = m[3] - m[4];
         y[0] = (m[0] + s12) + s34;
@@ -256,6 +239,7 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
     constexpr int NCLS = WinoKind<KIND>::NCLS, R = WinoKind<KIND>::R;
     constexpr int WM = 4 / WN, TM = 2 / WM, BN = 32 * WN;
     constexpr int NACC = CP ? 1 : NCLS;
+    static_assert(KIND == 1 || KIND == 2, "F(4,3) convolution or F(2,2) transposed convolution");
     static_assert(WN == 4 || WN == 2, "4 waves as 1 x 4 or 2 x 2");
     static_assert(!HEAD || (DECONV && !CP && WM == 1), "the fused head: serial transposed form, one wave holds all couts");
     float* As = wsmem;                                   // [WNB][WBK][64]
@@ -526,27 +510,22 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
     }
 }
 
-// registers: the serial 1 x 4 form holds NCLS x 32 accumulators (F(4,3): 192 -> two workgroups per CU; the others three / four),
-// the 2 x 2 form and the class-parallel forms half / a sixth of that
-template <int KIND, int WN, bool CP> constexpr int wino_min_waves() {
-    return CP ? 4 : (KIND == 1 ? (WN == 4 ? 2 : 3) : (KIND == 0 ? 3 : (WN == 4 ? 3 : 4)));
-}
-
+// registers: six classes of one 32 x 32 tile = 96 accumulators (109 in all: four workgroups per CU); the class-parallel form 16
 template <int VEC, int KIND, int WN, bool CP, bool HEAD>
-__global__ __launch_bounds__(256, (HEAD ? 3 : wino_min_waves<KIND, WN, CP>())) void wino_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (HEAD ? 3 : 4)) void wino_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float wsmem[];
     wino_body<VEC, KIND, WN, CP, HEAD>(p, blockIdx.x, gridDim.x, p.n_begin, p.n_end, wsmem);
 }
 
-// bulk (serial form, 64 x 128 tiles, positions [n_begin, n_cut)) + remainder (class-parallel form, 64 x 32 WNC tiles, positions
-// [n_cut, n_end)) in ONE launch: the remainder's short workgroups fill the slots the bulk's last round leaves
-template <int VEC, int KIND, int WNC>
-__global__ __launch_bounds__(256, (wino_min_waves<KIND, 4, false>())) void wino_dual_kernel(const ConvParams p) {
+// bulk (serial form, positions [n_begin, n_cut)) + remainder (class-parallel form, positions [n_cut, n_end)) in ONE launch: the
+// remainder's short workgroups fill the slots the bulk's last round leaves
+template <int VEC, int KIND>
+__global__ __launch_bounds__(256, 4) void wino_dual_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float wsmem[];
     if ((int)blockIdx.x < p.big_wgs)
-        wino_body<VEC, KIND, 4, false, false>(p, blockIdx.x, p.big_wgs, p.n_begin, p.n_cut, wsmem);
+        wino_body<VEC, KIND, 2, false, false>(p, blockIdx.x, p.big_wgs, p.n_begin, p.n_cut, wsmem);
     else
-        wino_body<VEC, KIND, WNC, true, false>(p, (int)blockIdx.x - p.big_wgs, (int)gridDim.x - p.big_wgs, p.n_cut, p.n_end, wsmem);
+        wino_body<VEC, KIND, 2, true, false>(p, (int)blockIdx.x - p.big_wgs, (int)gridDim.x - p.big_wgs, p.n_cut, p.n_end, wsmem);
 }
 
 // ---- class-parallel finish: y = act(transform(class sums) * scale + shift) over positions [n_begin, n_end), through the same
@@ -636,64 +615,53 @@ static hipError_t launch_wino_finish(const ConvParams& p, int n_begin, int n_end
 }
 
 // ---- launch planning ---------------------------------------------------------------------------
-// serial workgroups a CU hosts at once (register-limited), by kind
-static int wino_slots(int kind) { return kind == 1 ? 2 : (kind == 0 ? 3 : 4); }
+constexpr int WCN = 64;                                  // positions per tile of the serial / class-parallel forms (head: WBN)
 
 int64_t wino_slab_elems(int kind, int cout, int ntotal, const WinoLaunch& L) {
     if (L.mode == WINO_SERIAL) return 0;
-    const int ncls = kind == 2 ? 24 : (kind == 1 ? 6 : 4);
-    const int bn = 32 * L.wn_cp;
+    const int ncls = kind == 2 ? 24 : 6;
     const int n0 = L.mode == WINO_DUAL ? L.n_cut : 0;
-    const int64_t npad = (int64_t)((ntotal - n0 + bn - 1) / bn) * bn;
+    const int64_t npad = (int64_t)((ntotal - n0 + WCN - 1) / WCN) * WCN;
     return (int64_t)ncls * cout * npad;
 }
 
-// Which form a layer's launch takes.  forced >= 0 (tuning, tests): bits 0-1 mode (0 serial, 1 class-parallel, 2 dual), bit 2: the
-// class-parallel part on 64 x 64 tiles, bit 3: the serial part on 64 x 64 tiles (2 x 2 waves).  Otherwise by workgroup count: the
-// serial form when its grid fills the chip's slots several times over, the class-parallel form when it would leave them short,
-// the dual form when the last round is mostly empty.  All forms produce the same bits.
-WinoLaunch wino_plan(int kind, int cout, int ntotal, bool head, int forced) {
+// Which form a layer's launch takes (all forms produce the same bits, so this may follow the batch).  forced >= 0 (tuning,
+// tests): 0 serial, 1 class-parallel, 2 dual.  Otherwise a cost model in units of one K step of a 64 x 64 tile on one CU
+// (13.4 ns at the fp32 MFMA peak), fitted to tools/layer_bench.py --algo 2 sweeps at B = 1 .. 32:
+//   kcls = K per class (Cin x taps), u = serial workgroups per CU;
+//   serial          ceil(u) workgroups of ncls * kcls steps each, at 0.9 of the pipe (0.75 when a CU holds one workgroup)
+//   class-parallel  ceil(u * ncls) workgroups of kcls steps at 0.9, + 100 steps each for their slab's round trip, + a finish launch
+//   dual            floor(u) serial rounds + the remainder class-parallel
+WinoLaunch wino_plan(int kind, int cout, int kcls, int ntotal, bool head, int forced) {
     WinoLaunch L;
-    L.mode = WINO_SERIAL; L.wn_serial = 4; L.wn_cp = 4; L.n_cut = 0;
+    L.mode = WINO_SERIAL; L.n_cut = 0;
     const int m_tiles = (cout + WBM - 1) / WBM;
     const int pcs = kind == 2 ? 8 : 1;
-    if (forced >= 0) {
-        L.mode = forced & 3;
-        L.wn_cp = (forced & 4) ? 2 : 4;
-        L.wn_serial = (forced & 8) ? 2 : 4;
-        if (L.mode > WINO_DUAL) L.mode = WINO_SERIAL;
-        if (head && L.wn_serial != 4) L.wn_serial = 4;
-    } else {
+    const int ncls = kind == 2 ? 3 : 6;
+    const long W = (long)m_tiles * ((ntotal + WCN - 1) / WCN) * pcs;                 // serial workgroups (64-position tiles)
+    if (forced < 0) {
         static const int env_mode = getenv("S3R_WINO_FORM") ? atoi(getenv("S3R_WINO_FORM")) : -1;      // A/B switch, read once
-        if (env_mode >= 0) return wino_plan(kind, cout, ntotal, head, env_mode);
-        const long W = (long)m_tiles * ((ntotal + WBN - 1) / WBN) * pcs;                 // serial workgroups
-        const long slots = 256L * wino_slots(kind);
-        const int ncls = kind == 1 ? 6 : (kind == 0 ? 4 : 3);
-        if (W * 2 <= slots * 3) {                        // <= 1.5 rounds of the slots: every class its own workgroup
-            L.mode = WINO_CP;
-            L.wn_cp = (W * ncls < 2 * 256L * 4) ? 2 : 4;                                  // still sparse: halve the tiles too
-        } else if (kind != 2) {
-            // a little over a whole number of 256-workgroup rounds: cut the tail off and run it class-parallel
-            const long rounds = W / 256, rem = W % 256;
-            const long n_main = (rounds * 256) / m_tiles;                                  // whole N tiles in the bulk
-            if (rounds >= 1 && rounds < 16 && rem > 0 && rem <= 160 && n_main >= 1) {
-                L.mode = WINO_DUAL;
-                L.n_cut = (int)(n_main * WBN);
-                const long items = ((ntotal - L.n_cut + WBN - 1) / WBN) * m_tiles * ncls;
-                L.wn_cp = items < 512 ? 2 : 4;
-            }
+        forced = env_mode;
+    }
+    if (forced >= 0) {
+        L.mode = forced <= WINO_DUAL ? forced : WINO_SERIAL;
+    } else {
+        constexpr double EFF = 0.9, EFF_ALONE = 0.75, SLAB = 100.0, LAUNCH = 220.0;
+        const double u = head ? (double)m_tiles * ((ntotal + WBN - 1) / WBN) * pcs / 256.0 * 2.0 : (double)W / 256.0;
+        const double ru = __builtin_ceil(u), fu = __builtin_floor(u);
+        const double serial = ru * ncls * kcls / (ru >= 2.0 ? EFF : EFF_ALONE);
+        const double cp = __builtin_ceil(u * ncls) * (kcls / EFF + SLAB) + LAUNCH;
+        double best = serial;
+        if (cp < best) { best = cp; L.mode = WINO_CP; }
+        if (kind != 2 && !head && fu >= 1.0 && u > fu) {
+            const double dual = fu * ncls * kcls / EFF + __builtin_ceil((u - fu) * ncls) * (kcls / EFF + SLAB) + LAUNCH;
+            if (dual < 0.97 * best) { best = dual; L.mode = WINO_DUAL; }
         }
     }
     if (L.mode == WINO_DUAL) {
-        if (kind == 2) L.mode = WINO_SERIAL;             // (the transposed form has no dual kernel: its grids are 8 x as long)
-        else {
-            if (L.n_cut <= 0) {                          // forced dual: the whole rounds in the bulk
-                const long W = (long)m_tiles * ((ntotal + WBN - 1) / WBN);
-                const long n_main = ((W / 256) * 256) / m_tiles;
-                L.n_cut = (int)(n_main * WBN);
-            }
-            if (L.n_cut <= 0 || L.n_cut >= ntotal) { L.mode = L.n_cut <= 0 ? WINO_CP : WINO_SERIAL; L.n_cut = 0; }
-        }
+        const long n_main = kind == 2 ? 0 : ((W / 256) * 256) / m_tiles;             // whole rounds of the chip in the bulk
+        L.n_cut = (int)(n_main * WCN);
+        if (L.n_cut <= 0 || L.n_cut >= ntotal) { L.mode = L.n_cut <= 0 ? WINO_CP : WINO_SERIAL; L.n_cut = 0; }
     }
     return L;
 }
@@ -706,52 +674,44 @@ static hipError_t launch_wino_forms(ConvParams p, const WinoLaunch& L, hipStream
     constexpr int NCLS = WinoKind<KIND>::NCLS;
     p.n_begin = 0; p.n_end = ntotal;
     if (L.mode == WINO_SERIAL) {
-        const int bn = 32 * L.wn_serial;
-        const dim3 grid(p.m_tiles * ((ntotal + bn - 1) / bn) * pcs);
         if constexpr (KIND == 2) {
             if (p.head_w) {
-                hipLaunchKernelGGL((wino_kernel<VEC, KIND, 4, false, true>), grid, dim3(256), lds_of(128), stream, p);
+                const dim3 grid(p.m_tiles * ((ntotal + WBN - 1) / WBN) * pcs);
+                hipLaunchKernelGGL((wino_kernel<VEC, KIND, 4, false, true>), grid, dim3(256), lds_of(WBN), stream, p);
                 return hipGetLastError();
             }
         }
-        if (L.wn_serial == 4) hipLaunchKernelGGL((wino_kernel<VEC, KIND, 4, false, false>), grid, dim3(256), lds_of(128), stream, p);
-        else hipLaunchKernelGGL((wino_kernel<VEC, KIND, 2, false, false>), grid, dim3(256), lds_of(64), stream, p);
+        const dim3 grid(p.m_tiles * ((ntotal + WCN - 1) / WCN) * pcs);
+        hipLaunchKernelGGL((wino_kernel<VEC, KIND, 2, false, false>), grid, dim3(256), lds_of(WCN), stream, p);
         return hipGetLastError();
     }
     if (!p.part) return hipErrorInvalidValue;
-    const int bn = 32 * L.wn_cp;
     const int n0 = L.mode == WINO_DUAL ? L.n_cut : 0;
-    const int cp_tiles = (ntotal - n0 + bn - 1) / bn;
+    const int cp_tiles = (ntotal - n0 + WCN - 1) / WCN;
     const int cp_wgs = p.m_tiles * cp_tiles * NCLS * pcs;
     if (L.mode == WINO_DUAL) {
         if constexpr (KIND == 2) return hipErrorInvalidValue;
         else {
             p.n_cut = n0;
-            p.big_wgs = p.m_tiles * (n0 / WBN);
-            const dim3 grid(p.big_wgs + cp_wgs);
-            if (L.wn_cp == 4) hipLaunchKernelGGL((wino_dual_kernel<VEC, KIND, 4>), grid, dim3(256), lds_of(128), stream, p);
-            else hipLaunchKernelGGL((wino_dual_kernel<VEC, KIND, 2>), grid, dim3(256), lds_of(128), stream, p);
+            p.big_wgs = p.m_tiles * (n0 / WCN);
+            hipLaunchKernelGGL((wino_dual_kernel<VEC, KIND>), dim3(p.big_wgs + cp_wgs), dim3(256), lds_of(WCN), stream, p);
         }
     } else {
-        const dim3 grid(cp_wgs);
-        if (L.wn_cp == 4) hipLaunchKernelGGL((wino_kernel<VEC, KIND, 4, true, false>), grid, dim3(256), lds_of(128), stream, p);
-        else hipLaunchKernelGGL((wino_kernel<VEC, KIND, 2, true, false>), grid, dim3(256), lds_of(64), stream, p);
+        hipLaunchKernelGGL((wino_kernel<VEC, KIND, 2, true, false>), dim3(cp_wgs), dim3(256), lds_of(WCN), stream, p);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_wino_finish<KIND>(p, n0, ntotal, cp_tiles * bn, stream);
+    return launch_wino_finish<KIND>(p, n0, ntotal, cp_tiles * WCN, stream);
 }
 
-// p: see wino_body; R = outputs per group (2 or 4).  Returns the kernel launches made through *launches (may be null).
-hipError_t launch_conv_wino(ConvParams p, int R, const WinoLaunch& L, hipStream_t stream, int* launches) {
-    if (p.Cin % WBK != 0 || (R != 2 && R != 4) || p.stride != 1 || p.transposed || p.ksplit != 1 || p.head_w || p.act == ACT_SIGMOID)
+// p: see wino_body.  Returns the kernel launches made through *launches (may be null).
+hipError_t launch_conv_wino(ConvParams p, const WinoLaunch& L, hipStream_t stream, int* launches) {
+    if (p.Cin % WBK != 0 || p.stride != 1 || p.transposed || p.ksplit != 1 || p.head_w || p.act == ACT_SIGMOID)
         return hipErrorInvalidValue;
     p.kh = 1;
     p.m_tiles = (p.Cout + WBM - 1) / WBM;
     if (launches) *launches = L.mode == WINO_SERIAL ? 1 : 2;
-    const bool v4 = p.Nw % 4 == 0;
-    if (R == 4) return v4 ? launch_wino_forms<4, 1>(p, L, stream) : launch_wino_forms<1, 1>(p, L, stream);
-    return v4 ? launch_wino_forms<4, 0>(p, L, stream) : launch_wino_forms<1, 0>(p, L, stream);
+    return p.Nw % 4 == 0 ? launch_wino_forms<4, 1>(p, L, stream) : launch_wino_forms<1, 1>(p, L, stream);
 }
 
 hipError_t launch_deconv_wino(ConvParams p, const WinoLaunch& L, hipStream_t stream, int* launches) {
@@ -759,8 +719,7 @@ hipError_t launch_deconv_wino(ConvParams p, const WinoLaunch& L, hipStream_t str
         return hipErrorInvalidValue;
     p.m_tiles = (p.Cout + WBM - 1) / WBM;
     if (launches) *launches = L.mode == WINO_SERIAL ? 1 : 2;
-    const bool v4 = p.Nw % 4 == 0;
-    return v4 ? launch_wino_forms<4, 2>(p, L, stream) : launch_wino_forms<1, 2>(p, L, stream);
+    return p.Nw % 4 == 0 ? launch_wino_forms<4, 2>(p, L, stream) : launch_wino_forms<1, 2>(p, L, stream);
 }
 
 }  // namespace s3r

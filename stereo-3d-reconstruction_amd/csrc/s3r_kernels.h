@@ -107,10 +107,9 @@ struct ConvParams {
 
 // Launch form of a Winograd layer (s3r_conv_wino.hip): serial (one workgroup walks all classes of its tile), class-parallel (one
 // workgroup per (tile, class), class sums to slabs, a finish kernel transforms them — bit-identical to the serial form), or dual
-// (positions [0, n_cut) serial and [n_cut, N) class-parallel in one launch).  wn_*: waves along the position axis of the serial /
-// class-parallel tiles (4: 64 couts x 128 positions, 2: 64 x 64).
+// (positions [0, n_cut) serial and [n_cut, N) class-parallel in one launch).
 enum { WINO_SERIAL = 0, WINO_CP = 1, WINO_DUAL = 2 };
-struct WinoLaunch { int mode, wn_serial, wn_cp, n_cut; };
+struct WinoLaunch { int mode, n_cut; };
 
 // Tap schedule of a stride-2 k3 p1 convolution over a PARITY-SPLIT input (include/s3r.h, S3R_LAYOUT_S2D), per 32-channel
 // chunk: `ngroups` image loads (one class sub-tensor plane each: 4 in 2D, 12 in 3D), group g reading its g_ntaps[g] taps
@@ -173,10 +172,11 @@ hipError_t launch_pack_conv(const float* w, float* wp, int Cin, int Cout, int Co
 // Winograd F(2,3) along H for 3 x 3 [x 3] stride-1 pad-1 convolutions (s3r_conv_wino.hip)
 hipError_t launch_wino_input(const float* x, float* V, long long planes, int Hp, int Wp, int Hq, int R, hipStream_t s);
 hipError_t launch_pack_wino(const float* w, float* wp, int Cin, int Cout, int CoutPad, int kd, int kw, int R, hipStream_t s);
-// kind: 0 conv F(2,3), 1 conv F(4,3), 2 transposed F(2,2); ntotal = positions (groups of R output rows) of the launch
-WinoLaunch wino_plan(int kind, int cout, int ntotal, bool head, int forced);
+// kind: 1 conv F(4,3), 2 transposed F(2,2); kcls = K per class (Cin x taps per class); ntotal = positions (groups of R output
+// rows) of the launch
+WinoLaunch wino_plan(int kind, int cout, int kcls, int ntotal, bool head, int forced);
 int64_t wino_slab_elems(int kind, int cout, int ntotal, const WinoLaunch& L);     // floats of class-parallel slabs (p.part)
-hipError_t launch_conv_wino(ConvParams p, int R, const WinoLaunch& L, hipStream_t stream, int* launches);
+hipError_t launch_conv_wino(ConvParams p, const WinoLaunch& L, hipStream_t stream, int* launches);
 int wino_bk();                      // channels per K tile of the Winograd kernels (Cin must be a multiple)
 // Winograd F(2,2) along H inside the parity classes of ConvTranspose3d(k4 s2 p1)
 hipError_t launch_wino_rowdiff(const float* x, float* D, long long planes, int Hp, int Wp, hipStream_t s);
@@ -227,23 +227,17 @@ hipError_t launch_disparity_epe(const float* pred, const float* gt, float* epe, 
                                 hipStream_t s);
 
 #if defined(__HIPCC__)
-// Winograd F(R, 3) input transform along one axis (s3r_conv_wino.hip): the R + 2 class values of R + 2 consecutive padded rows.
+// Winograd F(4, 3) input transform along one axis (s3r_conv_wino.hip): the six class values of six consecutive padded rows.
 // Shared by the transform kernel and the cost-volume kernel that writes the transformed planes directly: same code, same bits.
 template <int R>
 __device__ __forceinline__ void wino_rows_to_classes(const float (&r)[R + 2], float (&v)[R + 2]) {
-    if constexpr (R == 2) {
-        v[0] = r[0] - r[2];
-        v[1] = r[1] + r[2];
-        v[2] = r[2] - r[1];
-        v[3] = r[1] - r[3];
-    } else {
-        v[0] = fmaf(4.f, r[0], fmaf(-5.f, r[2], r[4]));
-        v[1] = fmaf(-4.f, r[1] + r[2], r[3] + r[4]);
-        v[2] = fmaf(4.f, r[1] - r[2], r[4] - r[3]);
-        v[3] = fmaf(2.f, r[3] - r[1], r[4] - r[2]);
-        v[4] = fmaf(2.f, r[1] - r[3], r[4] - r[2]);
-        v[5] = fmaf(4.f, r[1], fmaf(-5.f, r[3], r[5]));
-    }
+    static_assert(R == 4, "F(4,3)");
+    v[0] = fmaf(4.f, r[0], fmaf(-5.f, r[2], r[4]));
+    v[1] = fmaf(-4.f, r[1] + r[2], r[3] + r[4]);
+    v[2] = fmaf(4.f, r[1] - r[2], r[4] - r[3]);
+    v[3] = fmaf(2.f, r[3] - r[1], r[4] - r[2]);
+    v[4] = fmaf(2.f, r[1] - r[3], r[4] - r[2]);
+    v[5] = fmaf(4.f, r[1], fmaf(-5.f, r[3], r[5]));
 }
 
 #endif

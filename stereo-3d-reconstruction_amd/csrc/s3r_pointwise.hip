@@ -225,12 +225,9 @@ hipError_t launch_cost_volume_wino(const float* fl, const float* fr, float* V, i
     const size_t lds = (size_t)2 * H * W * sizeof(float);
     const int Wp = W + 2, Hq = H / R;
     const long long cls_stride = (long long)B * 2 * C * (D + 2) * Hq * Wp;
-    if (R == 4)
-        hipLaunchKernelGGL(cost_volume_wino_kernel<4>, dim3(B * C), dim3(256), lds, s, fl, fr, V, C, D, H, W, cls_stride,
-                           FastDiv((unsigned)(Hq * Wp)), FastDiv((unsigned)Wp));
-    else
-        hipLaunchKernelGGL(cost_volume_wino_kernel<2>, dim3(B * C), dim3(256), lds, s, fl, fr, V, C, D, H, W, cls_stride,
-                           FastDiv((unsigned)(Hq * Wp)), FastDiv((unsigned)Wp));
+    if (R != 4) return hipErrorInvalidValue;              // F(4,3) groups
+    hipLaunchKernelGGL(cost_volume_wino_kernel<4>, dim3(B * C), dim3(256), lds, s, fl, fr, V, C, D, H, W, cls_stride,
+                       FastDiv((unsigned)(Hq * Wp)), FastDiv((unsigned)Wp));
     return hipGetLastError();
 }
 

@@ -47,9 +47,11 @@ def composite_over_white_u8(rgba: np.ndarray) -> np.ndarray:
 
 def renders_to_float(u8) :
     """The host form of the stem's 1/255 scaling: float32(u) / float32(255), one correctly rounded division per sample
-    (numpy array or torch tensor).  `model(renders_to_float(x))` == `model(x)` bit for bit for uint8 x."""
+    (numpy array or torch tensor, host or device).  `model(renders_to_float(x))` == `model(x)` bit for bit for uint8 x.
+    The divisor is a TENSOR on the input's device: dividing a device tensor by a Python scalar makes PyTorch multiply by
+    fp32(1/255) instead, which is not the correctly rounded quotient for 126 of the 256 codes."""
     if isinstance(u8, torch.Tensor):
-        return u8.to(torch.float32) / 255.0
+        return torch.div(u8.to(torch.float32), torch.tensor(255.0, dtype=torch.float32, device=u8.device))
     return u8.astype(np.float32) / np.float32(255.0)
 
 

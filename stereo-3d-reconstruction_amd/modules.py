@@ -72,7 +72,10 @@ def _check_render(x: torch.Tensor, name: str) -> torch.Tensor:
     """A batch of renders, (B,3,224,224): float32 in [0,1], or uint8 as a PNG decode yields them (the stem scales by
     1/255 as it reads, bit-identical to `x.float() / 255` on the host: `s3r_encoder_forward_u8`)."""
     dt = x.dtype if isinstance(x, torch.Tensor) and x.dtype == torch.uint8 else torch.float32
-    return _check_input(x, name, (3, spec.IMG_HW, spec.IMG_HW), dt)
+    x = _check_input(x, name, (3, spec.IMG_HW, spec.IMG_HW), dt)
+    if x.data_ptr() % 16:           # the stems fetch whole rows by 16-byte LDS-DMA: a view at an odd storage offset is copied once
+        x = x.clone()
+    return x
 
 
 @torch.no_grad()

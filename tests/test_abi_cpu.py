@@ -61,9 +61,8 @@ def test_out_size_and_packed_elems(s3r, lib):
                 assert e.value == l.cin * l.cout
             else:
                 pad = (l.cout + 127) // 128 * 128
-                # (ABI 6) a 3 x 3 [x 3] stride-1 pad-1 convolution packs its Winograd F(2,3)-along-H class slabs behind the direct one
-                # (F(4,3) along H where the edge % 4 == 0: six slabs; F(2,3) otherwise: four)
-                wino = (6 if n % 4 == 0 else 4) * 3 ** (nd - 1) * l.cin * pad if (l.op != "deconv3d" and l.k == 3 and l.s == 1 and l.p == 1) else 0
+                # a 3 x 3 [x 3] stride-1 pad-1 convolution packs its six Winograd F(4,3)-along-H class slabs behind the direct one
+                wino = 6 * 3 ** (nd - 1) * l.cin * pad if (l.op != "deconv3d" and l.k == 3 and l.s == 1 and l.p == 1) else 0
                 if l.op == "deconv3d":            # ... and a transposed convolution its 24 F(2,2) (class, F) slabs of 4 taps
                     wino = 24 * 4 * l.cin * pad
                 assert e.value == l.k ** nd * l.cin * pad + wino
@@ -222,10 +221,10 @@ def test_algo_field_selects_the_kernel_and_scratch_is_never_a_selector(s3r, lib)
     assert scratch("e2", L.ALGO_WINOGRAD)[0] == auto
     assert scratch("e2", L.ALGO_DIRECT)[0] == 0                # the direct kernel does not split e2's K
     assert scratch("e2", L.ALGO_AUTO, tile=3)[0] == 0          # a direct-kernel tile override is a direct-kernel request
-    assert scratch("v5", L.ALGO_AUTO)[0] == scratch("v5", L.ALGO_DIRECT)[0] > 0     # (edge 7: split-K direct kernel)
-    assert scratch("v5", L.ALGO_WINOGRAD)[0] > 0
+    assert scratch("v5", L.ALGO_DIRECT)[0] > 0                 # (the direct kernel splits v5's K)
+    assert scratch("v5", L.ALGO_AUTO)[0] == scratch("v5", L.ALGO_WINOGRAD)[0] > 0
     # AUTO never depends on the batch: the same choice at 1 and at 64 samples (the scratch follows the batch, the kernel not)
-    for name in ("e2", "e7", "v1", "v3", "d1", "d3"):
+    for name in ("e2", "e7", "v1", "v3", "v5", "d1", "d3"):
         assert all(scratch(name, L.ALGO_AUTO, b)[0] > 0 for b in (1, 2, 64)), name
     assert scratch("e3", L.ALGO_WINOGRAD)[0] == -1             # stride 2: no Winograd form
     assert b"WINOGRAD" in lib.s3r_last_error()

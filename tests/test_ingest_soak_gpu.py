@@ -50,6 +50,13 @@ def test_u8_entry_equals_fp32_entry_bitwise_and_the_oracle(s3r, oracle, precisio
     feats8 = hip.encoder(left.to(DEV), upto="e1")
     feats32 = hip.encoder(fl.to(DEV), upto="e1")
     assert torch.equal(feats8, feats32)
+    # the conversion made ON THE DEVICE is the same correctly rounded quotient (a scalar divisor would multiply by 1/255 there)
+    assert torch.equal(s3r.data.renders_to_float(left.to(DEV)).cpu(), fl)
+    # an 8-bit view at an odd storage offset: the stems' 16-byte row fetches need an aligned base, so the module copies it once
+    buf = torch.zeros(left.numel() + 1, dtype=torch.uint8, device=DEV)
+    buf[1:].copy_(left.to(DEV).flatten())
+    odd = buf[1:].view(left.shape)
+    assert odd.data_ptr() % 16 and torch.equal(hip.encoder(odd, upto="e1"), feats8)
     # mixed dtypes are refused, not converted behind the caller's back
     with pytest.raises(RuntimeError, match="dtype"):
         hip(left.to(DEV), fr.to(DEV))

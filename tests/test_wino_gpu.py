@@ -1,9 +1,9 @@
-"""Winograd F(2,3)-along-H path of the fp32 3 x 3 [x 3] stride-1 convolutions (csrc/s3r_conv_wino.hip).  S3R_WINO: unset / 1 =
-the library's policy (v1 and v3, where it measured faster), 0 = never, 2 = every eligible layer; each setting runs in its
-own child process.  It computes the same convolution with 2/3 of the multiplications in a different summation order, so
-the bar is the oracle at the path's fp32 tolerance (north_star: 1e-4 relative; measured here ~1e-6), not bit-equality with
-the direct kernels; what must stay bitwise are the properties that do not depend on the algorithm: determinism and batch
-invariance."""
+"""Winograd-along-H path of the fp32 3 x 3 [x 3] stride-1 convolutions (F(4,3)) and the transposed convolutions (F(2,2) inside
+the parity classes): csrc/s3r_conv_wino.hip.  S3R_WINO (read once, at load): unset / 1 = the library's policy (every layer
+that has the form), 0 = never; each setting runs in its own child process.  It computes the same convolution with 1/2 (3/4)
+of the multiplications in a different summation order, so the bar against the direct kernels is the oracle at the path's
+fp32 tolerance (north_star: 1e-4 relative; measured here ~1e-6), not bit-equality; what must stay bitwise are the properties
+that do not depend on the algorithm — determinism, batch invariance — and the equality of the Winograd kernel's launch forms."""
 import os
 import subprocess
 import sys
@@ -91,21 +91,18 @@ def _run_child(tmp_path, flag):
 
 
 def test_winograd_path_vs_oracle_and_invariants(tmp_path):
-    res, out2 = _run_child(tmp_path, "2")                       # every eligible layer on the Winograd kernel
+    res, out1 = _run_child(tmp_path, "1")                       # the library's policy: every eligible layer on the Winograd kernel
     assert set(res["layers"]) == {"e2", "e4", "e6", "e7", "v1", "v3", "v5", "d1", "d2", "d3"}
     assert res["head_rel"] < 1e-5 and res["head_max"] < 1e-5 and res["head_batch_invariant"]
     for name, r in res["layers"].items():
         assert r["rel"] < 1e-5, (name, r)                       # north_star: 1e-4 relative
         assert r["deterministic"] and r["batch_invariant"], (name, r)
     assert res["model_rel"] < 1e-5 and res["model_max"] < 1e-4 and res["model_batch_invariant"]
-    res1, out1 = _run_child(tmp_path, "1")                      # the library's policy (the default)
-    assert res1["model_rel"] < 1e-5 and res1["model_batch_invariant"]
     res0, out0 = _run_child(tmp_path, "0")                      # direct kernels only
-    assert res0["model_rel"] < 1e-5
+    assert res0["model_rel"] < 1e-5 and res0["model_batch_invariant"]
     # the switch does something: same convolution, other summation — other bits within the same bar
-    for a, b in ((out0, out1), (out0, out2), (out1, out2)):
-        assert not torch.equal(a, b)
-        assert float((a.double() - b.double()).norm() / a.double().norm()) < 1e-5
+    assert not torch.equal(out0, out1)
+    assert float((out0.double() - out1.double()).norm() / out0.double().norm()) < 1e-5
 
 
 def test_cost_volume_writes_the_transformed_planes_bitwise(s3r, monkeypatch):
@@ -113,7 +110,8 @@ def test_cost_volume_writes_the_transformed_planes_bitwise(s3r, monkeypatch):
     padded form) equals the transform applied to the padded volume (to fp32 rounding: the kernel uses fused multiply-adds), and the decoder fed with it equals the decoder fed with
     the padded volume (which runs its own input transform in front of the same kernel) — bit for bit; both models take the
     hand-off by themselves; a batch too large for one transformed call keeps the plain hand-off."""
-    monkeypatch.delenv("S3R_WINO", raising=False)             # the library's own policy (the switch is read per call)
+    if os.environ.get("S3R_WINO") not in (None, "1"):
+        pytest.skip("the library's own policy is under test (S3R_WINO is read once, at load)")
     dev = "cuda:0"
     m = s3r.Stereo2Voxel()
     s3r.seed_module(m, 0)
@@ -158,17 +156,16 @@ def _positions(spec, l, n_in, batch):
     """GEMM positions of the Winograd launch (groups of R output rows) and its serial workgroup count."""
     if l.op == "deconv3d":
         n = batch * n_in * (n_in // 2) * n_in
-        return n, -(-l.cout // 64) * -(-n // 128) * 8
-    R = 4 if n_in % 4 == 0 else 2
-    n = batch * (n_in if l.op == "conv3d" else 1) * -(-n_in // R) * n_in
-    return n, -(-l.cout // 64) * -(-n // 128)
+        return n, -(-l.cout // 64) * -(-n // 64) * 8
+    n = batch * (n_in if l.op == "conv3d" else 1) * -(-n_in // 4) * n_in
+    return n, -(-l.cout // 64) * -(-n // 64)
 
 
 def test_every_launch_form_gives_the_serial_forms_bits(s3r):
     """The class-parallel form (one workgroup per (tile, class), class sums through slabs, `wino_finish_kernel`) and the dual
     form (bulk serial + remainder class-parallel in one launch) run the same MFMA sequence per class and the same output
     transform as the serial form: bit for bit, on every layer that has a Winograd kernel, at a batch that makes the dual
-    form's cut fall inside the layer (W > 256 serial workgroups) and at a small one; the 64 x 64 tiles likewise."""
+    form's cut fall inside the layer (W > 256 serial workgroups) and at a small one."""
     dev, spec, L = "cuda:0", s3r.arch_spec, s3r._lib
     for l, n_in in _wino_layers(spec):
         batches = [1]
@@ -183,8 +180,8 @@ def test_every_launch_form_gives_the_serial_forms_bits(s3r):
             ch.algo_override[l.name] = L.ALGO_WINOGRAD
             x = torch.randn((B, l.cin) + (n_in,) * spec.ndim(l), generator=torch.Generator().manual_seed(B)).to(dev)
             outs = {}
-            for form in (0, 1, 5, 2, 6, 8):
-                if l.op == "deconv3d" and form in (2, 6):
+            for form in (0, 1, 2):
+                if l.op == "deconv3d" and form == 2:
                     continue                                       # (no dual kernel for the transposed form)
                 ch.tile_override[l.name] = form
                 s3r.profile_enable(8)
@@ -192,9 +189,9 @@ def test_every_launch_form_gives_the_serial_forms_bits(s3r):
                 rec = [r for r in s3r.profile_read(8) if r["family"] == "conv_mfma"]
                 s3r.profile_enable(0)
                 assert len(rec) == 1 and rec[0]["ran"].startswith("winograd"), rec
-                if form in (1, 5):
+                if form == 1:
                     assert rec[0]["ran"] == "winograd-class-parallel", (l.name, form, rec)
-                if form in (2, 6) and _positions(spec, l, n_in, B)[1] > 256:
+                if form == 2 and _positions(spec, l, n_in, B)[1] > 256:
                     assert rec[0]["ran"] == "winograd-dual", (l.name, B, form, rec)
             for form, y in outs.items():
                 assert torch.equal(y, outs[0]), (l.name, B, form, float((y - outs[0]).abs().max()))
@@ -209,10 +206,10 @@ def test_every_launch_form_gives_the_serial_forms_bits(s3r):
     for B in (1, 3):
         x = torch.randn((B, 128, 16, 16, 16), generator=torch.Generator().manual_seed(4)).to(dev)
         outs = {}
-        for form in (0, 1, 5):
+        for form in (0, 1):
             ch.tile_override["d3"] = form
             outs[form] = ch._run(x).clone()
-        assert torch.equal(outs[1], outs[0]) and torch.equal(outs[5], outs[0]), B
+        assert torch.equal(outs[1], outs[0]), B
 
 
 _FORMS_CHILD = r'''

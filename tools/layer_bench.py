@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--wsplit", action="store_true", help="fp32 stride-2 k3 p1 layers: feed the halo-padded input with "
                     "W-parity-split rows (S3R_LAYOUT_S2D), as the chain hands it over")
     ap.add_argument("--algo", type=int, default=0, help="fp32: s3r_algo of the layer (0 auto, 1 direct, 2 Winograd: --tiles are then "
-                    "launch-FORM codes: 0 serial, 1 class-parallel, 2 dual, +4 class-parallel part on 64 x 64 tiles, +8 serial part on 64 x 64)")
+                    "launch-FORM codes: -1 the library's plan, 0 serial, 1 class-parallel, 2 dual)")
     ap.add_argument("--zeros", action="store_true", help="all-zero inputs and weights (how much of the rate is power: the\n"
                     "chip holds a higher clock on zeros, MI355X_MICROARCH.md DVFS notes)")
     args = ap.parse_args()
@@ -92,7 +92,7 @@ def main():
                     if args.dtype == "bf16":
                         code = t            # -1 = library heuristic; 1, 2, 4 per-tap; 9, 10 row-reuse
                     if args.algo == 2:
-                        code = t
+                        code = t            # -1 = the library's own plan
                     ch.tile_override[l.name] = code
                     ch.ksplit_override[l.name] = ks
                     if args.algo:
