@@ -156,7 +156,7 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False,
     reports per launch record what ran (direct kernel or a Winograd form) and the FLOPs that form executes; `frac` is that
     executed rate over the peak (<= 1 by construction: the MFMA pipe's utilisation), `frac_credited` the same time charged
     with the direct form's algorithmic FLOPs (SURVEY 8d's count: what a layer is WORTH, which a Winograd kernel delivers
-    with 1/2 .. 3/4 of the multiplications)."""
+    with 1/2 .. 9/16 of the multiplications)."""
     if not records:
         return None, {}
     fam = family_table(records, steps)
@@ -209,8 +209,8 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False,
                       "per-tap / row-reuse / plane-reuse gathers)" if bf
             else "the fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM convolution family, LDS-DMA operand staging: conv_glds_kernel / "
                  "conv_glds_dual_kernel (direct form) + wino_kernel / wino_dual_kernel / wino_finish_kernel with their transform passes "
-                 "wino_input_kernel / wino_rowdiff_kernel (Winograd along H: F(4,3) convolutions execute 1/2, F(2,2) transposed "
-                 "convolutions 3/4 of the direct form's multiplications; serial, class-parallel and dual launch forms, bit-identical)",
+                 "wino_input_kernel / wino_diff3_kernel (Winograd: F(4,3)-along-H convolutions execute 1/2, F(2,2)-along-D-and-H transposed "
+                 "convolutions 9/16 of the direct form's multiplications; serial, class-parallel and dual launch forms, bit-identical)",
             "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
             "achieved_credited": round(credited, 3),

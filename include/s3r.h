@@ -88,7 +88,7 @@ typedef enum s3r_act { S3R_ACT_NONE = 0, S3R_ACT_RELU = 1, S3R_ACT_SIGMOID = 2 }
 typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_S2D = 1, S3R_LAYOUT_WINO_H = 2 } s3r_layout;
 
 /* Which convolution algorithm a layer's forward runs (ABI 7).  The fp32 3 x 3 [x 3] stride-1 pad-1 convolutions and the
- * transposed convolutions have two kernels — the direct implicit GEMM and a Winograd-along-H form with 1/2 .. 3/4 of the
+ * transposed convolutions have two kernels — the direct implicit GEMM and a Winograd form with 1/2 .. 9/16 of the
  * multiplications (csrc/s3r_conv_wino.hip) — that agree to fp32 rounding, NOT bit for bit.  So the choice is part of the
  * descriptor and never depends on anything else a caller passes (workspace size, batch):
  *   S3R_ALGO_AUTO      the library's policy, a function of the layer's PER-SAMPLE geometry only: Winograd where the layer has
@@ -153,7 +153,7 @@ int s3r_conv_out_size(const s3r_conv_desc* d);
 /* size of the packed weight buffer for a layer IN 4-BYTE UNITS (>= the torch weight's numel on the fp32
  * path: couts are padded; about half of it on the bf16 path).  ABI 6: an fp32 3 x 3 [x 3] stride-1 pad-1 convolution packs
  * two forms, the direct slab and the six Winograd F(4,3)-along-H class slabs (csrc/s3r_conv_wino.hip: half the
- * multiplications); which kernel a forward runs is the descriptor's `algo` (s3r_algo above).  The transposed convolutions likewise: 24 F(2,2)-along-H (parity class, F) slabs
+ * multiplications); which kernel a forward runs is the descriptor's `algo` (s3r_algo above).  The transposed convolutions likewise: 72 F(2,2) x F(2,2) (parity class, class) slabs
  * behind the direct ones. */
 int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems);
 /* repack a torch-layout weight (Conv: [cout][cin][k..]; ConvTranspose: [cin][cout][k..]; Linear:
@@ -258,7 +258,7 @@ typedef struct s3r_prof_record {
     int32_t launches;   /* kernel launches bracketed by this record (a conv layer may be 1-3 launches) */
     double flops;       /* algorithmic (direct-form) FLOPs of the layer: SURVEY 8d's count */
     double bytes;
-    double exec_flops;  /* FLOPs the kernel that ran EXECUTES on the matrix cores (= flops for the direct kernels; 1/2 .. 3/4 of it
+    double exec_flops;  /* FLOPs the kernel that ran EXECUTES on the matrix cores (= flops for the direct kernels; 1/2 .. 9/16 of it
                            for the Winograd forms) */
     int32_t algo;       /* what ran: 0 direct, 1 Winograd serial form, 2 class-parallel form, 3 dual form */
     int32_t reserved;

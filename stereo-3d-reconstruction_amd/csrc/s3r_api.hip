@@ -224,7 +224,7 @@ int check_halos(const s3r_conv_desc* d, Route r) {
 int cout_pad(int cout) { return (cout + 127) / 128 * 128; }
 
 // Winograd along H (s3r_conv_wino.hip) for the fp32 3 x 3 [x 3] stride-1 pad-1 convolutions (F(4,3): 1/2 of the matrix work, F(2,3):
-// 2/3) and the transposed convolutions (F(2,2) inside the parity classes: 3/4): another summation order than the direct
+// 2/3) and the transposed convolutions (F(2,2) along D and H inside the parity classes: 9/16): another summation order than the direct
 // kernels' — same fp32 accuracy, other bits.  Such a layer's packed weights hold BOTH forms (the direct slab, then the class
 // slabs); which kernel a call runs is the descriptor's `algo` (include/s3r.h): AUTO resolves from the layer's per-sample
 // geometry (and the descriptor's own tile / split-K / layout fields) alone — never from the scratch a caller offers or the
@@ -294,20 +294,20 @@ int wino_bmax(const s3r_conv_desc* d) {
     const int64_t m = v_sample > 0 ? (((int64_t)1 << 31) - 1) / (4 * v_sample) : 0;
     return (int)(m < d->batch ? m : d->batch);
 }
-int64_t dwino_w_elems(const s3r_conv_desc* d) { return 24 * 4 * (int64_t)d->cin * cout_pad(d->cout); }
-int64_t dwino_d_elems(const s3r_conv_desc* d) { return (int64_t)d->batch * d->cin * ipow(d->in_size + 2, 3); }
+int64_t dwino_w_elems(const s3r_conv_desc* d) { return 72 * 2 * (int64_t)d->cin * cout_pad(d->cout); }      // (parity class, class) x 2 taps
+int64_t dwino_d_elems(const s3r_conv_desc* d) { return 3 * (int64_t)d->batch * d->cin * ipow(d->in_size + 2, 3); }  // Dh, Dd, Ddh
 
-// Scratch of a Winograd call: [transformed input V (a convolution fed with plain input) | row differences (transposed) ] then
+// Scratch of a Winograd call: [transformed input V (a convolution fed with plain input) | the three difference tensors (transposed) ] then
 // the class-parallel slabs of the launch form the library plans for this batch (every form gives the same bits, so the form
 // — unlike the algorithm — may follow the batch).
 struct WinoNeed { int64_t v, slab, total; };
 int wino_kind(const s3r_conv_desc* d) { return d->op == S3R_OP_DECONV ? 2 : 1; }
 int wino_kcls(const s3r_conv_desc* d) {                        // K per class: Cin x (depth taps x column taps)
-    return d->cin * (d->op == S3R_OP_DECONV ? 4 : (d->ndim == 3 ? 9 : 3));
+    return d->cin * (d->op == S3R_OP_DECONV ? 2 : (d->ndim == 3 ? 9 : 3));
 }
 int64_t wino_positions(const s3r_conv_desc* d, int nb) {       // GEMM positions (groups of R output rows) of nb samples
     const int n = d->in_size;
-    if (d->op == S3R_OP_DECONV) return (int64_t)nb * n * (n / 2) * n;
+    if (d->op == S3R_OP_DECONV) return (int64_t)nb * (n / 2) * (n / 2) * n;
     const int R = wino_r(d);
     return (int64_t)nb * (d->ndim == 3 ? n : 1) * ((n + R - 1) / R) * n;
 }
@@ -337,7 +337,7 @@ WinoNeed wino_need(const s3r_conv_desc* d, int form, bool head) {
 }
 // MFMA FLOPs the Winograd form executes for the whole batch
 double wino_exec_flops(const s3r_conv_desc* d, const Geo& g) {
-    if (d->op == S3R_OP_DECONV) return g.flops * 0.75;
+    if (d->op == S3R_OP_DECONV) return g.flops * 0.5625;
     const int R = wino_r(d);
     const double taps = (d->ndim == 3 ? 3.0 : 1.0) * 3.0 * (R + 2);
     return 2.0 * (double)wino_positions(d, d->batch) * d->cout * d->cin * taps;
@@ -351,13 +351,13 @@ int dwino_run(const s3r_conv_desc* d, s3r::ConvParams p, const float* x, const f
         return fail(S3R_ERR_WORKSPACE, "the Winograd form of this transposed convolution needs %lld floats of scratch "
                     "(s3r_conv_scratch_elems), got %lld", (long long)need.total, (long long)(scratch ? scratch_elems : 0));
     const int n = d->in_size;
-    hipError_t e = s3r::launch_wino_rowdiff(x, scratch, (long long)d->batch * d->cin * (n + 2), n + 2, n + 2, s);
-    if (e != hipSuccess) return hip_fail(e, "Winograd row-difference launch");
+    hipError_t e = s3r::launch_wino_diff3(x, scratch, (long long)d->batch * d->cin, n + 2, n + 2, n + 2, s);
+    if (e != hipSuccess) return hip_fail(e, "Winograd difference-tensor launch");
     p.x = x;
     p.xd = scratch;
     p.part = scratch + need.v;
     p.w = packed_w + 64 * (int64_t)d->cin * cout_pad(d->cout);          // behind the direct slab (8 classes x 8 taps)
-    p.Nh = n / 2;
+    p.Nd = n / 2; p.Nh = n / 2;
     p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
     p.n_begin = 0; p.n_end = p.Ntotal;
     p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));

@@ -119,56 +119,77 @@ hipError_t launch_pack_wino(const float* w, float* wp, int Cin, int Cout, int Co
 }
 
 // ================================================================================================
-// ConvTranspose3d(k = 4, s = 2, p = 1) with fewer multiplications: Winograd F(2, 2) along H inside every output-parity
-// class.  A class (rd, rh, rw) is a 2 x 2 x 2-tap convolution over the input grid (s3r_conv_glds.hip); two of its outputs
-// that are neighbours along H — input rows ph = 2q and 2q + 1, i.e. output rows 4q + rh and 4q + 2 + rh — read the
-// padded input rows x0, x1, x2 = R, R + 1, R + 2 (R = 2q + rh) through the two H taps g0, g1:
-//     y(2q)     = x0 g0 + x1 g1 = m1 + m2        m1 = (x0 - x1) g0
-//     y(2q + 1) = x1 g0 + x2 g1 = m2 - m3        m2 = x1 (g0 + g1)        m3 = (x1 - x2) g1
-// — three products instead of four: 3/4 of the matrix work.  The transformed input is the padded input itself plus ONE
-// tensor of row differences D[r] = x[r] - x[r + 1] (wino_rowdiff_kernel: the input of a transposed convolution is small),
-// the transformed weights are g0, g0 + g1, g1 per (class, depth tap, column tap).  The kernel is conv_wino_kernel's shape:
-// positions (b, pd, q, pw) over the input grid, 64 couts x 128 positions per workgroup, three F-classes x 2 MFMA tiles of
-// accumulators per wave, the eight parity classes of a tile back to back on one XCD; HEAD = the fused 1 x 1 x 1 head (d3 -> d4).
-__global__ __launch_bounds__(256) void wino_rowdiff_kernel(const float* __restrict__ x, float* __restrict__ D, long long rows,
-                                                           int Hp, int Wp) {
-    const long long total = rows * Wp;
+// ConvTranspose3d(k = 4, s = 2, p = 1) with fewer multiplications: Winograd F(2, 2) along D AND H inside every output-parity
+// class.  A class (rd, rh, rw) is a 2 x 2 x 2-tap convolution over the input grid (s3r_conv_glds.hip).  Along one axis, two of its
+// outputs that are neighbours — input positions 2q and 2q + 1 — read the padded input rows x0, x1, x2 = R, R + 1, R + 2 (R = 2q + r)
+// through the axis' two taps g0, g1:
+//     y(2q)     = x0 g0 + x1 g1 = m0 + m1        m0 = (x0 - x1) g0
+//     y(2q + 1) = x1 g0 + x2 g1 = m1 - m2        m1 = x1 (g0 + g1)        m2 = (x1 - x2) g1
+// — three products instead of four.  r03 did this along H (3/4 of the matrix work); nested along D and H it is NINE products
+// M_ab (a, b in 0..2: the D and the H class) for 2 x 2 outputs instead of sixteen: 9/16 of the direct form's multiplications,
+// each product a 2-tap (column) convolution over Cin.  The transformed inputs are the padded input x itself and three tensors of
+// differences (wino_diff3_kernel: the input of a transposed convolution is small) —
+//     Dh[z][r] = x[z][r] - x[z][r + 1],   Dd[z][r] = x[z][r] - x[z + 1][r],   Ddh[z][r] = Dd[z][r] - Dd[z][r + 1]
+// — class (a, b) reads {a = 1: plain, else depth differences} x {b = 1: plain, else row differences} at depth Z + (a ? 1 : 0), row
+// R + (b ? 1 : 0); the transformed weights are the sums of the 2 x 2 (depth tap, row tap) weights over {a: td = 0 | both | 1} x
+// {b: th = 0 | both | 1}, per (parity class, column tap).  Positions are (b, s, q, pw) = (sample, depth pair, row pair, column) over
+// the input grid; the output transform Y[u][v] = sum A[u][a] A[v][b] M_ab, A = [[1, 1, 0], [0, 1, -1]], runs on the accumulator
+// registers; HEAD = the fused 1 x 1 x 1 head (d3 -> d4).
+__global__ __launch_bounds__(256) void wino_diff3_kernel(const float* __restrict__ x, float* __restrict__ D, long long planes,
+                                                         int Dp, int Hp, int Wp) {
+    const long long per = (long long)Dp * Hp * Wp, total = planes * per;
+    const long long hw = (long long)Hp * Wp;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long row = i / Wp;
-        const int r = (int)(row % Hp);
-        D[i] = (r + 1 < Hp) ? x[i] - x[i + Wp] : 0.f;
+        const long long e = i % per;
+        const int z = (int)(e / hw);
+        const int r = (int)((e - (long long)z * hw) / Wp);
+        const bool rn = r + 1 < Hp, zn = z + 1 < Dp;
+        const float x00 = x[i];
+        const float x01 = rn ? x[i + Wp] : 0.f;
+        const float x10 = zn ? x[i + hw] : 0.f;
+        const float x11 = (rn && zn) ? x[i + hw + Wp] : 0.f;
+        const float dd0 = zn ? x00 - x10 : 0.f;          // Dd at (z, r), (z, r + 1)
+        const float dd1 = zn ? x01 - x11 : 0.f;
+        D[i] = rn ? x00 - x01 : 0.f;                     // Dh
+        D[i + total] = dd0;                              // Dd
+        D[i + 2 * total] = rn ? dd0 - dd1 : 0.f;         // Ddh
     }
 }
 
-hipError_t launch_wino_rowdiff(const float* x, float* D, long long planes, int Hp, int Wp, hipStream_t s) {
-    const long long total = planes * Hp * Wp;
+hipError_t launch_wino_diff3(const float* x, float* D, long long planes, int Dp, int Hp, int Wp, hipStream_t s) {
+    const long long total = planes * Dp * Hp * Wp;
     const long long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(wino_rowdiff_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, x, D, planes * Hp, Hp, Wp);
+    hipLaunchKernelGGL(wino_diff3_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, x, D, planes, Dp, Hp, Wp);
     return hipGetLastError();
 }
 
-// w[Cin][Cout][4][4][4] -> Up[pc = 8][f = 3][(chunk*4 + (td*2 + tw))*32 + c][CoutPad]
+// w[Cin][Cout][4][4][4] -> Up[pc = 8][cls = 9][(chunk*2 + tw)*32 + c][CoutPad]
 __global__ void pack_wino_deconv_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int CoutPad) {
-    const size_t per_f = (size_t)4 * Cin * CoutPad;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < 24 * per_f; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t per_f = (size_t)2 * Cin * CoutPad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < 72 * per_f; i += (size_t)gridDim.x * blockDim.x) {
         const int pf = (int)(i / per_f);
-        const int pc = pf / 3, f = pf - pc * 3;
+        const int pc = pf / 9, f = pf - pc * 9;
+        const int fa = f / 3, fb = f - fa * 3;
         size_t r = i % per_f;
         const int co = (int)(r % CoutPad);
         r /= CoutPad;
         const int c = (int)(r % WBK);
         r /= WBK;
-        const int tap = (int)(r & 3);
-        const int cc = (int)(r >> 2);
+        const int tw = (int)(r & 1);
+        const int cc = (int)(r >> 1);
         const int cin = cc * WBK + c;
         float v = 0.f;
         if (co < Cout) {
             const int rd = (pc >> 2) & 1, rh = (pc >> 1) & 1, rw = pc & 1;
-            const int td = tap >> 1, tw = tap & 1;
-            const int kd = 3 - rd - 2 * td, kw = 3 - rw - 2 * tw;
-            const float* g = w + ((size_t)cin * Cout + co) * 64 + kd * 16 + kw;
-            const float g0 = g[(3 - rh) * 4], g1 = g[(1 - rh) * 4];          // H taps th = 0, 1: kernel rows 3 - rh, 1 - rh
-            v = f == 0 ? g0 : f == 1 ? g0 + g1 : g1;
+            const int kw = 3 - rw - 2 * tw;
+            const float* g = w + ((size_t)cin * Cout + co) * 64 + kw;
+            // taps t = 0, 1 along an axis of parity r: kernel index 3 - r, 1 - r
+            auto hsum = [&](int td) {
+                const float* gd = g + (3 - rd - 2 * td) * 16;
+                const float g0 = gd[(3 - rh) * 4], g1 = gd[(1 - rh) * 4];
+                return fb == 0 ? g0 : fb == 2 ? g1 : g0 + g1;
+            };
+            v = fa == 0 ? hsum(0) : fa == 2 ? hsum(1) : hsum(0) + hsum(1);
         }
         wp[i] = v;
     }
@@ -182,26 +203,25 @@ hipError_t launch_pack_wino_deconv(const float* w, float* wp, int Cin, int Cout,
 // ================================================================================================
 // The class kernels.  ONE body serves the Winograd forms of this file,
 //     KIND 1: convolution, F(4,3) along H (6 classes, 4 output rows per group)
-//     KIND 2: ConvTranspose3d(k4 s2 p1), F(2,2) along H inside every output-parity class (3 classes, 2 output rows)
+//     KIND 2: ConvTranspose3d(k4 s2 p1), F(2,2) along D and H inside every output-parity class (9 classes, 2 x 2 outputs)
 // in two launch forms:
 //     serial (CP = false): a workgroup owns a tile of 64 couts x BN positions (position = one group of R output rows of one
 //         column) and walks ALL classes back to back, one accumulator set per class; the output transform, the folded BN +
 //         ReLU (and d3's fused 1 x 1 x 1 head) run on the registers.  4 waves as WM x WN = 2 x 2 (32 couts x 32 positions per
 //         wave, BN = 64: one MFMA tile per class — 109 registers for six classes, four workgroups per CU; r03's 64 x 128 tiles
-//         held two and measured 3-13 % slower on every layer) or, for the fused head only, 1 x 4 (64 couts x 32 positions per
-//         wave, BN = 128: one wave holds all couts of its positions);
+//         held two and measured 3-13 % slower on every layer).  The fused head adds the two waves' 32-cout sums through LDS;
 //     class-parallel (CP = true): a workgroup owns ONE class of a tile, runs that class's K loop — the same MFMA sequence in the
 //         same order as the serial form, so the same bits — and writes the raw class sums to a slab part[class][cout][n];
 //         wino_finish_kernel then applies the output transform and the epilogue through the SAME device functions
 //         (wino_out / wino_act below) in the same operation order: bit-identical to the serial form.  It multiplies the
-//         workgroup count by the class count (x 6 / x 3) and divides a workgroup's serial K walk by it: the form for
+//         workgroup count by the class count (x 6 / x 9) and divides a workgroup's serial K walk by it: the form for
 //         grids that leave the chip short of workgroups (small batches; v5; d1) and for the REMAINDER of a launch whose
 //         workgroup count is a little over a multiple of the chip's slots (wino_dual_kernel: bulk serial + remainder
 //         class-parallel in one launch — the direct path's plan_tail_cut idea with the class axis as the finer unit).
 // Because the two forms agree bit for bit, which one runs may depend on the batch size (a sample's bits never do).
 template <int KIND> struct WinoKind;
 template <> struct WinoKind<1> { static constexpr int NCLS = 6, R = 4; };
-template <> struct WinoKind<2> { static constexpr int NCLS = 3, R = 2; };
+template <> struct WinoKind<2> { static constexpr int NCLS = 9, R = 4; };     // R: outputs per position (2 depths x 2 rows)
 
 // output transform of one (cout, position): m = the class sums, y = the R output rows.  Adds and explicit fmaf only (nothing
 // the compiler could contract differently in the two kernels that share it).
@@ -214,10 +234,22 @@ __device__ __forceinline__ void wino_out(const float (&m)[WinoKind<KIND>::NCLS],
         y[1] = fmaf(2.f, d34, d12);
         y[2] = fmaf(4.f, s34, s12);
         y[3] = fmaf(8.f, d34, d12) + m[5];
-    } else {
-        y[0] = m[0] + m[1];
-        y[1] = m[1] - m[2];
+    } else {             // m[3 a + b]; rows first, then depths: y[2 u + v]
+        const float t00 = m[0] + m[1], t01 = m[1] - m[2];
+        const float t10 = m[3] + m[4], t11 = m[4] - m[5];
+        const float t20 = m[6] + m[7], t21 = m[7] - m[8];
+        y[0] = t00 + t10;
+        y[1] = t01 + t11;
+        y[2] = t10 - t20;
+        y[3] = t11 - t21;
     }
+}
+// element offset of output i of a position from its first output (conv: rows 4q + i; transposed: depth pair u = i >> 1, row pair
+// v = i & 1, two output planes / rows apart)
+template <int KIND>
+__device__ __forceinline__ int wino_out_off(int i, int y_ds, int y_hs) {
+    if constexpr (KIND == 1) return i * y_hs;
+    else return (i >> 1) * 2 * y_ds + (i & 1) * 2 * y_hs;
 }
 __device__ __forceinline__ float wino_act(float y, float sc, float sf, float lo) { return fmaxf(fmaf(y, sc, sf), lo); }
 __device__ __forceinline__ float wino_head_act(float t, int act) {
@@ -229,8 +261,8 @@ __device__ __forceinline__ float wino_head_act(float t, int act) {
 // p (convolution): the CLASS convolution — p.x = V, x_cs / x_ds / x_hs its strides (x_hs = one V row per group), p.x_cls the class
 //   stride, Nh = groups per plane, T = kd * kw, x_org = 0; p.y the layer's padded output, p.Hout its true height (the last group's
 //   missing rows are not stored).
-// p (transposed): the layer's own parameters (make_params) with Nh = row pairs (n / 2), p.x = the padded input, p.xd = its row
-//   differences (same shape and strides), p.w = the 24 (parity class, F) slabs.
+// p (transposed): the layer's own parameters (make_params) with Nd = depth pairs, Nh = row pairs (n / 2), p.x = the padded input,
+//   p.xd = its three difference tensors Dh, Dd, Ddh (each of x's shape and strides), p.w = the 72 (parity class, class) slabs.
 // p.part: class-parallel slabs [class][Cout][npad], npad = the position range's tile count x BN.
 template <int VEC, int KIND, int WN, bool CP, bool HEAD>
 __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in, const int nwg_in, const int n_begin,
@@ -241,7 +273,7 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
     constexpr int NACC = CP ? 1 : NCLS;
     static_assert(KIND == 1 || KIND == 2, "F(4,3) convolution or F(2,2) transposed convolution");
     static_assert(WN == 4 || WN == 2, "4 waves as 1 x 4 or 2 x 2");
-    static_assert(!HEAD || (DECONV && !CP && WM == 1), "the fused head: serial transposed form, one wave holds all couts");
+    static_assert(!HEAD || (DECONV && !CP && WN == 2), "the fused head: serial transposed form");
     float* As = wsmem;                                   // [WNB][WBK][64]
     float* Bs = wsmem + WNB * WBK * WBM;                 // [WNB][WBK][BN]
     constexpr int PB = 64 * VEC;                         // floats per B piece
@@ -271,7 +303,7 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
         const int ntile = p.m_tiles * n_tiles;
         const int c = item / ntile;
         bid = item - c * ntile;
-        if constexpr (DECONV) { pc = c / 3; cls0 = c - pc * 3; } else cls0 = c;
+        if constexpr (DECONV) { pc = c / NCLS; cls0 = c - pc * NCLS; } else cls0 = c;
     } else if constexpr (DECONV) {
         // an XCD walks its run of tiles with the 8 parity classes of a tile back to back (they read the same input tile)
         const int nwg = nwg_in >> 3;
@@ -287,7 +319,7 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
     const int m_tile = bid % p.m_tiles, n_tile = bid / p.m_tiles;
     const int m0 = m_tile * WBM, n0 = n_begin + n_tile * BN;
     const int S = p.Nd * p.Nh * p.Nw;
-    const int T = DECONV ? 4 : p.T;                      // taps per class: (depth tap, column tap)
+    const int T = DECONV ? 2 : p.T;                      // taps per class: (depth tap,) column tap
     const int chunks = p.Cin / WBK;
     const int nkt = T * chunks;                          // K tiles per class
     const int total = NACC * nkt;
@@ -305,18 +337,19 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
         rem -= pd * p.Nh * p.Nw;
         const int q = p.dW.div(rem);
         const int pw = rem - q * p.Nw;
-        if constexpr (DECONV)        // padded indices: depth pd + rd + td, row 2q + rh (+ 1), column pw + rw + tw
-            bvoff = (b * p.Cin * p.x_cs + (pd + rd) * p.x_ds + (2 * q + rh) * p.x_hs + pw + rw + lrow * p.x_cs) * 4;
+        if constexpr (DECONV)        // padded indices: depth 2 pd + rd (+ 1), row 2q + rh (+ 1), column pw + rw + tw
+            bvoff = (b * p.Cin * p.x_cs + (2 * pd + rd) * p.x_ds + (2 * q + rh) * p.x_hs + pw + rw + lrow * p.x_cs) * 4;
         else
             bvoff = (b * p.Cin * p.x_cs + p.x_org + pd * p.x_ds + q * p.x_hs + pw + lrow * p.x_cs) * 4;
     }
     const int avoff = ((lane >> 4) * p.CoutPad + (lane & 15) * 4) * 4;
     const __amdgpu_buffer_rsrc_t xrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t drsrc =                 // (transposed form: the row differences)
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DECONV ? p.xd : p.x), 0, (int)p.x_bytes, 0x00020000);
+    // (transposed form: the difference tensors Dh, Dd, Ddh behind p.xd get a descriptor of their own per K tile — together they
+    // may pass 2 GiB, and a 4-way choice between ready-made descriptors makes the compiler build a lookup table in scratch)
+    const size_t x_el = (size_t)p.x_bytes / 4;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.w), 0, (int)((unsigned)(DECONV ? 24 : NCLS) * (unsigned)T * (unsigned)p.Cin * (unsigned)p.CoutPad * 4u),
+        const_cast<float*>(p.w), 0, (int)((unsigned)(DECONV ? 72 : NCLS) * (unsigned)T * (unsigned)p.Cin * (unsigned)p.CoutPad * 4u),
         0x00020000);
     const int b_row0 = B_WIDE ? wave / PPR : wave * RPP;
     constexpr int B_ROW_STEP = B_WIDE ? 4 / PPR : 4 * RPP;
@@ -326,27 +359,29 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
 
     // cursor of the NEXT K tile to fetch (scalar): class, chunk, tap; c_kt = its row block in the packed class slabs
     int c_cls = cls0, c_cc = 0, c_td = 0, c_tw = 0, c_tap = 0;
-    int c_kt = (DECONV ? pc * 3 + cls0 : cls0) * nkt;
-    auto issue = [&](int buf) {
+    int c_kt = (DECONV ? pc * NCLS + cls0 : cls0) * nkt;
+    int c_a = cls0 / 3, c_b = cls0 - 3 * (cls0 / 3);     // (transposed form) the class's depth / row part
+    auto issue = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < WNPA; ++q)
             wdma<16>(wrsrc, As + buf * WBK * WBM + (wave + 4 * q) * 256, avoff,
                      (c_kt * WBK * p.CoutPad + m0) * 4 + (wave + 4 * q) * 4 * p.CoutPad * 4);
         float* sb = Bs + buf * WBK * BN + b_lds0;
         if constexpr (DECONV) {
-            // F-class 0: D at row R, 1: X at row R + 1, 2: D at row R + 1
-            const int b_base = ((c_cc * WBK + b_row0) * p.x_cs + (c_tap >> 1) * p.x_ds + (c_cls ? p.x_hs : 0) + (c_tap & 1)) * 4;
-            if (c_cls == 1) {
+            // along an axis, F-class 0: differences at index R, 1: plain at R + 1, 2: differences at R + 1
+            const int b_base = ((c_cc * WBK + b_row0) * p.x_cs + (c_a ? p.x_ds : 0) + (c_b ? p.x_hs : 0) + c_tap) * 4;
+            const int t_idx = (c_a != 1 ? 2 : 0) + (c_b != 1 ? 1 : 0);          // 0: x, 1: Dh, 2: Dd, 3: Ddh
+            const float* tb = t_idx == 0 ? p.x : p.xd + (size_t)(t_idx - 1) * x_el;
+            const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tb), 0, (int)p.x_bytes, 0x00020000);
 #pragma unroll
-                for (int q = 0; q < NPB; ++q) wdma<4 * VEC>(xrsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
-            } else {
-#pragma unroll
-                for (int q = 0; q < NPB; ++q) wdma<4 * VEC>(drsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
-            }
+            for (int q = 0; q < NPB; ++q) wdma<4 * VEC>(trsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
             ++c_kt;
-            if (++c_tap == 4) {
+            if (++c_tap == 2) {
                 c_tap = 0;
-                if (++c_cc == chunks) { c_cc = 0; ++c_cls; }
+                if (++c_cc == chunks) {
+                    c_cc = 0; ++c_cls;
+                    if (++c_b == 3) { c_b = 0; ++c_a; }
+                }
             }
         } else {
             const int b_base = (c_cls * p.x_cls + (c_cc * WBK + b_row0) * p.x_cs + c_td * p.x_ds + c_tw) * 4;
@@ -382,7 +417,7 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
     const int b_off = h * BN + wn * 32 + j;
     typedef typename WVec<TM>::type AV;
     int cur = 0, g = 0;
-    auto run_class = [&](wf32x16 (&ac)[TM]) {
+    auto run_class = [&](wf32x16 (&ac)[TM]) __attribute__((always_inline)) {
         for (int kt = 0; kt < nkt; ++kt, ++g) {
             const bool more = g + WNB - 1 < total;
             if (more) issue(cur == 0 ? WNB - 1 : cur - 1);        // into the stage tile g - 1 was read from
@@ -411,7 +446,7 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
     if constexpr (CP) {
         // ---- class-parallel: the raw class sums to the slab [class][cout][n - n_begin]; every lane of the tile has a slot
         const int npad = n_tiles * BN;
-        const int cg = DECONV ? pc * 3 + cls0 : cls0;
+        const int cg = DECONV ? pc * NCLS + cls0 : cls0;
         float* __restrict__ slab = p.part + ((size_t)cg * p.Cout + (m0 + mbase)) * npad + (n0 - n_begin) + wn * 32 + j;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -445,44 +480,51 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
             rem -= pd * p.Nh * p.Nw;
             const int q = p.dW.div(rem);
             const int pw = rem - q * p.Nw;
-            if constexpr (DECONV)    // output (2 pd + rd, 2 ph + rh, 2 pw + rw), ph = 2q (row 0) and 2q + 1 (row 1: 2 y_hs further)
-                e0 = b * p.y_bs + p.y_org + (pd * p.y_ds + 2 * q * p.y_hs + pw) * 2 + rd * p.y_ds + rh * p.y_hs + rw;
+            if constexpr (DECONV)    // outputs (2 (2 pd + u) + rd, 2 (2 q + v) + rh, 2 pw + rw), u, v = 0, 1
+                e0 = b * p.y_bs + p.y_org + (2 * pd * p.y_ds + 2 * q * p.y_hs + pw) * 2 + rd * p.y_ds + rh * p.y_hs + rw;
             else {
                 e0 = b * p.y_bs + p.y_org + pd * p.y_ds + R * q * p.y_hs + pw;
                 row1 = p.Hout - R * q;
             }
         }
         const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
-        constexpr int ROW_STEP = DECONV ? 2 : 1;             // output rows between a group's rows, in y_hs
         if constexpr (HEAD) {
-            // the workgroup's 64 couts are the whole channel axis: 32 of them in this lane, the other 32 in lane j + 32
-            float t0 = 0.f, t1 = 0.f;
+            // the workgroup's 64 couts are the whole channel axis: this wave holds 32 of them (16 in this lane, 16 in lane j + 32),
+            // the wave beside it (wm ^ 1, same wn) the other 32: in-lane chains, the lane halves' sum, then the two waves' sum
+            // through LDS (wino_finish_kernel<2, true> walks the couts in this order)
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dm = ((r & 3) + 8 * (r >> 2)) * TM + tm;
-                    const float sc = ep_sc[mbase + dm], sf = ep_sf[mbase + dm], hw = ep_hw[mbase + dm];
-                    const float m[3] = {acc[0][tm][r], acc[NACC > 1 ? 1 : 0][tm][r], acc[NACC > 2 ? 2 : 0][tm][r]};
-                    float y[2];
-                    wino_out<2>(m, y);
-                    t0 = fmaf(wino_act(y[0], sc, sf, lo), hw, t0);
-                    t1 = fmaf(wino_act(y[1], sc, sf, lo), hw, t1);
-                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int dm = (r & 3) + 8 * (r >> 2);
+                const float sc = ep_sc[mbase + dm], sf = ep_sf[mbase + dm], hw = ep_hw[mbase + dm];
+                const float m[9] = {acc[0][0][r], acc[NACC > 1 ? 1 : 0][0][r], acc[NACC > 2 ? 2 : 0][0][r],
+                                    acc[NACC > 3 ? 3 : 0][0][r], acc[NACC > 4 ? 4 : 0][0][r], acc[NACC > 5 ? 5 : 0][0][r],
+                                    acc[NACC > 6 ? 6 : 0][0][r], acc[NACC > 7 ? 7 : 0][0][r], acc[NACC > 8 ? 8 : 0][0][r]};
+                float y[4];
+                wino_out<2>(m, y);
+                t0 = fmaf(wino_act(y[0], sc, sf, lo), hw, t0);
+                t1 = fmaf(wino_act(y[1], sc, sf, lo), hw, t1);
+                t2 = fmaf(wino_act(y[2], sc, sf, lo), hw, t2);
+                t3 = fmaf(wino_act(y[3], sc, sf, lo), hw, t3);
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
             t0 += __shfl_xor(t0, 32, 64);
             t1 += __shfl_xor(t1, 32, 64);
-            const float hsc = p.head_scale ? p.head_scale[0] : 1.f, hsf = p.head_shift ? p.head_shift[0] : 0.f;
-            t0 = wino_head_act(fmaf(t0, hsc, hsf), p.head_act);
-            t1 = wino_head_act(fmaf(t1, hsc, hsf), p.head_act);
-            if (h == 0 && ok) {
-                p.y[e0] = t0;
-                p.y[e0 + ROW_STEP * p.y_hs] = t1;
+            t2 += __shfl_xor(t2, 32, 64);
+            t3 += __shfl_xor(t3, 32, 64);
+            float* ex = wsmem + 4 * WBM + (wn * 32 + j) * 4;          // behind the epilogue constants
+            if (wm == 1 && h == 0) { ex[0] = t0; ex[1] = t1; ex[2] = t2; ex[3] = t3; }
+            __syncthreads();
+            if (wm == 0 && h == 0 && ok) {
+                const float hsc = p.head_scale ? p.head_scale[0] : 1.f, hsf = p.head_shift ? p.head_shift[0] : 0.f;
+                p.y[e0] = wino_head_act(fmaf(t0 + ex[0], hsc, hsf), p.head_act);
+                p.y[e0 + wino_out_off<KIND>(1, p.y_ds, p.y_hs)] = wino_head_act(fmaf(t1 + ex[1], hsc, hsf), p.head_act);
+                p.y[e0 + wino_out_off<KIND>(2, p.y_ds, p.y_hs)] = wino_head_act(fmaf(t2 + ex[2], hsc, hsf), p.head_act);
+                p.y[e0 + wino_out_off<KIND>(3, p.y_ds, p.y_hs)] = wino_head_act(fmaf(t3 + ex[3], hsc, hsf), p.head_act);
             }
         } else {
             const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
             const int yvo0 = (e0 + (m0 + mbase) * p.y_cs) * 4;
-            const int yrow = ROW_STEP * p.y_hs * 4;
             const int row_bytes = p.y_cs * 4;
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
@@ -501,7 +543,8 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
                         for (int i = 0; i < R; ++i)
                             if (i < row1) {
                                 const float v = wino_act(y[i], sc, sf, lo);
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrsrc, yvo0 + i * yrow, so, 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrsrc,
+                                                                      yvo0 + 4 * wino_out_off<KIND>(i, p.y_ds, p.y_hs), so, 0);
                             }
                     }
                     if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -510,9 +553,10 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
     }
 }
 
-// registers: six classes of one 32 x 32 tile = 96 accumulators (109 in all: four workgroups per CU); the class-parallel form 16
+// registers: six classes of one 32 x 32 tile = 96 accumulators (109 in all: four workgroups per CU), nine = 144 (three per CU);
+// the class-parallel form 16
 template <int VEC, int KIND, int WN, bool CP, bool HEAD>
-__global__ __launch_bounds__(256, (HEAD ? 3 : 4)) void wino_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (CP || KIND == 1 ? 4 : 3)) void wino_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float wsmem[];
     wino_body<VEC, KIND, WN, CP, HEAD>(p, blockIdx.x, gridDim.x, p.n_begin, p.n_end, wsmem);
 }
@@ -520,7 +564,7 @@ __global__ __launch_bounds__(256, (HEAD ? 3 : 4)) void wino_kernel(const ConvPar
 // bulk (serial form, positions [n_begin, n_cut)) + remainder (class-parallel form, positions [n_cut, n_end)) in ONE launch: the
 // remainder's short workgroups fill the slots the bulk's last round leaves
 template <int VEC, int KIND>
-__global__ __launch_bounds__(256, 4) void wino_dual_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (KIND == 1 ? 4 : 3)) void wino_dual_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float wsmem[];
     if ((int)blockIdx.x < p.big_wgs)
         wino_body<VEC, KIND, 2, false, false>(p, blockIdx.x, p.big_wgs, p.n_begin, p.n_cut, wsmem);
@@ -535,14 +579,13 @@ template <int KIND, bool HEAD>
 __global__ __launch_bounds__(256) void wino_finish_kernel(const ConvParams p, const int n_begin, const int n_end, const int npad) {
     constexpr bool DECONV = KIND == 2;
     constexpr int NCLS = WinoKind<KIND>::NCLS, R = WinoKind<KIND>::R;
-    constexpr int ROW_STEP = DECONV ? 2 : 1;
     const int S = p.Nd * p.Nh * p.Nw;
     const int nn = n_end - n_begin;
     const int pc = DECONV ? (int)blockIdx.y : 0;
     const int rd = (pc >> 2) & 1, rh = (pc >> 1) & 1, rw = pc & 1;
     const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
-    const size_t cstride = (size_t)p.Cout * npad;                       // between class slabs
-    const float* __restrict__ base = p.part + (size_t)pc * 3 * cstride;  // (pc = 0 for convolutions)
+    const size_t cstride = (size_t)p.Cout * npad;                            // between class slabs
+    const float* __restrict__ base = p.part + (size_t)pc * NCLS * cstride;    // (pc = 0 for convolutions)
     const long long total = HEAD ? nn : (long long)p.Cout * nn;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int mrow = HEAD ? 0 : (int)(i / nn);
@@ -556,20 +599,24 @@ __global__ __launch_bounds__(256) void wino_finish_kernel(const ConvParams p, co
         const int pw = rem - q * p.Nw;
         int e0, row1 = R;
         if constexpr (DECONV)
-            e0 = b * p.y_bs + p.y_org + (pd * p.y_ds + 2 * q * p.y_hs + pw) * 2 + rd * p.y_ds + rh * p.y_hs + rw;
+            e0 = b * p.y_bs + p.y_org + (2 * pd * p.y_ds + 2 * q * p.y_hs + pw) * 2 + rd * p.y_ds + rh * p.y_hs + rw;
         else {
             e0 = b * p.y_bs + p.y_org + pd * p.y_ds + R * q * p.y_hs + pw;
             row1 = p.Hout - R * q;
         }
         if constexpr (HEAD) {
-            float th[2][R];
+            // the serial epilogue's order: per wave (couts 32 wm ..), per lane half (4 hh + ..), a chain over the 16 registers;
+            // then the lane halves' sum, then the two waves' sum
+            float tw[2][R];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
+            for (int wm = 0; wm < 2; ++wm) {
+                float th[2][R];
 #pragma unroll
-                for (int k = 0; k < R; ++k) th[hh][k] = 0.f;
-                for (int tm = 0; tm < 2; ++tm)
+                for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                    for (int k = 0; k < R; ++k) th[hh][k] = 0.f;
                     for (int r = 0; r < 16; ++r) {
-                        const int mm = 8 * hh + ((r & 3) + 8 * (r >> 2)) * 2 + tm;
+                        const int mm = 32 * wm + 4 * hh + (r & 3) + 8 * (r >> 2);
                         if (mm >= p.Cout) continue;                    // (padded couts carry head weight 0: t + 0 = t)
                         const float sc = p.scale ? p.scale[mm] : 1.f, sf = p.shift ? p.shift[mm] : 0.f, hw = p.head_w[mm];
                         float m[NCLS], y[R];
@@ -579,13 +626,14 @@ __global__ __launch_bounds__(256) void wino_finish_kernel(const ConvParams p, co
 #pragma unroll
                         for (int k = 0; k < R; ++k) th[hh][k] = fmaf(wino_act(y[k], sc, sf, lo), hw, th[hh][k]);
                     }
+                }
+#pragma unroll
+                for (int k = 0; k < R; ++k) tw[wm][k] = th[0][k] + th[1][k];
             }
             const float hsc = p.head_scale ? p.head_scale[0] : 1.f, hsf = p.head_shift ? p.head_shift[0] : 0.f;
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const float t = th[0][k] + th[1][k];
-                p.y[e0 + k * ROW_STEP * p.y_hs] = wino_head_act(fmaf(t, hsc, hsf), p.head_act);
-            }
+            for (int k = 0; k < R; ++k)
+                p.y[e0 + wino_out_off<KIND>(k, p.y_ds, p.y_hs)] = wino_head_act(fmaf(tw[0][k] + tw[1][k], hsc, hsf), p.head_act);
         } else {
             const float sc = p.scale ? p.scale[mrow] : 1.f, sf = p.shift ? p.shift[mrow] : 0.f;
             float m[NCLS], y[R];
@@ -595,7 +643,7 @@ __global__ __launch_bounds__(256) void wino_finish_kernel(const ConvParams p, co
             float* __restrict__ yo = p.y + (size_t)mrow * p.y_cs + e0;
 #pragma unroll
             for (int k = 0; k < R; ++k)
-                if (k < row1) yo[k * ROW_STEP * p.y_hs] = wino_act(y[k], sc, sf, lo);
+                if (k < row1) yo[wino_out_off<KIND>(k, p.y_ds, p.y_hs)] = wino_act(y[k], sc, sf, lo);
         }
     }
 }
@@ -619,7 +667,7 @@ constexpr int WCN = 64;                                  // positions per tile o
 
 int64_t wino_slab_elems(int kind, int cout, int ntotal, const WinoLaunch& L) {
     if (L.mode == WINO_SERIAL) return 0;
-    const int ncls = kind == 2 ? 24 : 6;
+    const int ncls = kind == 2 ? 72 : 6;
     const int n0 = L.mode == WINO_DUAL ? L.n_cut : 0;
     const int64_t npad = (int64_t)((ntotal - n0 + WCN - 1) / WCN) * WCN;
     return (int64_t)ncls * cout * npad;
@@ -637,7 +685,7 @@ WinoLaunch wino_plan(int kind, int cout, int kcls, int ntotal, bool head, int fo
     L.mode = WINO_SERIAL; L.n_cut = 0;
     const int m_tiles = (cout + WBM - 1) / WBM;
     const int pcs = kind == 2 ? 8 : 1;
-    const int ncls = kind == 2 ? 3 : 6;
+    const int ncls = kind == 2 ? 9 : 6;
     const long W = (long)m_tiles * ((ntotal + WCN - 1) / WCN) * pcs;                 // serial workgroups (64-position tiles)
     if (forced < 0) {
         static const int env_mode = getenv("S3R_WINO_FORM") ? atoi(getenv("S3R_WINO_FORM")) : -1;      // A/B switch, read once
@@ -647,7 +695,8 @@ WinoLaunch wino_plan(int kind, int cout, int kcls, int ntotal, bool head, int fo
         L.mode = forced <= WINO_DUAL ? forced : WINO_SERIAL;
     } else {
         constexpr double EFF = 0.9, EFF_ALONE = 0.75, SLAB = 100.0, LAUNCH = 220.0;
-        const double u = head ? (double)m_tiles * ((ntotal + WBN - 1) / WBN) * pcs / 256.0 * 2.0 : (double)W / 256.0;
+        (void)head;
+        const double u = (double)W / 256.0;
         const double ru = __builtin_ceil(u), fu = __builtin_floor(u);
         const double serial = ru * ncls * kcls / (ru >= 2.0 ? EFF : EFF_ALONE);
         const double cp = __builtin_ceil(u * ncls) * (kcls / EFF + SLAB) + LAUNCH;
@@ -674,14 +723,13 @@ static hipError_t launch_wino_forms(ConvParams p, const WinoLaunch& L, hipStream
     constexpr int NCLS = WinoKind<KIND>::NCLS;
     p.n_begin = 0; p.n_end = ntotal;
     if (L.mode == WINO_SERIAL) {
+        const dim3 grid(p.m_tiles * ((ntotal + WCN - 1) / WCN) * pcs);
         if constexpr (KIND == 2) {
             if (p.head_w) {
-                const dim3 grid(p.m_tiles * ((ntotal + WBN - 1) / WBN) * pcs);
-                hipLaunchKernelGGL((wino_kernel<VEC, KIND, 4, false, true>), grid, dim3(256), lds_of(WBN), stream, p);
+                hipLaunchKernelGGL((wino_kernel<VEC, KIND, 2, false, true>), grid, dim3(256), lds_of(WCN), stream, p);
                 return hipGetLastError();
             }
         }
-        const dim3 grid(p.m_tiles * ((ntotal + WCN - 1) / WCN) * pcs);
         hipLaunchKernelGGL((wino_kernel<VEC, KIND, 2, false, false>), grid, dim3(256), lds_of(WCN), stream, p);
         return hipGetLastError();
     }

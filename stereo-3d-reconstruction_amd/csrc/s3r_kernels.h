@@ -101,7 +101,7 @@ struct ConvParams {
     // Winograd F(2,3) along H (s3r_conv_wino.hip): x = the four transformed input plane sets, x_cls elements apart; Nh = row
     // pairs per plane; Hout = the output's true height
     int x_cls, Hout;
-    // transposed Winograd form: the row differences of the padded input (same shape and strides as x)
+    // transposed Winograd form: the three difference tensors Dh, Dd, Ddh of the padded input (each of x's shape and strides)
     const float* xd;
 };
 
@@ -172,14 +172,14 @@ hipError_t launch_pack_conv(const float* w, float* wp, int Cin, int Cout, int Co
 // Winograd F(2,3) along H for 3 x 3 [x 3] stride-1 pad-1 convolutions (s3r_conv_wino.hip)
 hipError_t launch_wino_input(const float* x, float* V, long long planes, int Hp, int Wp, int Hq, int R, hipStream_t s);
 hipError_t launch_pack_wino(const float* w, float* wp, int Cin, int Cout, int CoutPad, int kd, int kw, int R, hipStream_t s);
-// kind: 1 conv F(4,3), 2 transposed F(2,2); kcls = K per class (Cin x taps per class); ntotal = positions (groups of R output
+// kind: 1 conv F(4,3), 2 transposed F(2,2) x F(2,2); kcls = K per class (Cin x taps per class); ntotal = positions (groups of R output
 // rows) of the launch
 WinoLaunch wino_plan(int kind, int cout, int kcls, int ntotal, bool head, int forced);
 int64_t wino_slab_elems(int kind, int cout, int ntotal, const WinoLaunch& L);     // floats of class-parallel slabs (p.part)
 hipError_t launch_conv_wino(ConvParams p, const WinoLaunch& L, hipStream_t stream, int* launches);
 int wino_bk();                      // channels per K tile of the Winograd kernels (Cin must be a multiple)
-// Winograd F(2,2) along H inside the parity classes of ConvTranspose3d(k4 s2 p1)
-hipError_t launch_wino_rowdiff(const float* x, float* D, long long planes, int Hp, int Wp, hipStream_t s);
+// Winograd F(2,2) along D and H inside the parity classes of ConvTranspose3d(k4 s2 p1); D = [Dh | Dd | Ddh]
+hipError_t launch_wino_diff3(const float* x, float* D, long long planes, int Dp, int Hp, int Wp, hipStream_t s);
 hipError_t launch_pack_wino_deconv(const float* w, float* wp, int Cin, int Cout, int CoutPad, hipStream_t s);
 hipError_t launch_deconv_wino(ConvParams p, const WinoLaunch& L, hipStream_t stream, int* launches);
 // y (N,32,Ho+2h,Wo+2h) <- stem conv of x (N,3,Hi,Wi); y_hs / y_cs / y_org describe the padded output.

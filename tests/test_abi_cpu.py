@@ -63,8 +63,8 @@ def test_out_size_and_packed_elems(s3r, lib):
                 pad = (l.cout + 127) // 128 * 128
                 # a 3 x 3 [x 3] stride-1 pad-1 convolution packs its six Winograd F(4,3)-along-H class slabs behind the direct one
                 wino = 6 * 3 ** (nd - 1) * l.cin * pad if (l.op != "deconv3d" and l.k == 3 and l.s == 1 and l.p == 1) else 0
-                if l.op == "deconv3d":            # ... and a transposed convolution its 24 F(2,2) (class, F) slabs of 4 taps
-                    wino = 24 * 4 * l.cin * pad
+                if l.op == "deconv3d":            # ... and a transposed convolution its 72 F(2,2)^2 (parity class, class) slabs of 2 taps
+                    wino = 72 * 2 * l.cin * pad
                 assert e.value == l.k ** nd * l.cin * pad + wino
 
 

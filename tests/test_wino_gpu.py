@@ -1,6 +1,6 @@
 """Winograd-along-H path of the fp32 3 x 3 [x 3] stride-1 convolutions (F(4,3)) and the transposed convolutions (F(2,2) inside
 the parity classes): csrc/s3r_conv_wino.hip.  S3R_WINO (read once, at load): unset / 1 = the library's policy (every layer
-that has the form), 0 = never; each setting runs in its own child process.  It computes the same convolution with 1/2 (3/4)
+that has the form), 0 = never; each setting runs in its own child process.  It computes the same convolution with 1/2 (9/16)
 of the multiplications in a different summation order, so the bar against the direct kernels is the oracle at the path's
 fp32 tolerance (north_star: 1e-4 relative; measured here ~1e-6), not bit-equality; what must stay bitwise are the properties
 that do not depend on the algorithm — determinism, batch invariance — and the equality of the Winograd kernel's launch forms."""
