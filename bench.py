@@ -209,7 +209,7 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False,
                       "per-tap / row-reuse / plane-reuse gathers)" if bf
             else "the fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM convolution family, LDS-DMA operand staging: conv_glds_kernel / "
                  "conv_glds_dual_kernel (direct form) + wino_kernel / wino_dual_kernel / wino_finish_kernel with their transform passes "
-                 "wino_input_kernel / wino_diff3_kernel (Winograd: F(4,3)-along-H convolutions execute 1/2, F(2,2)-along-D-and-H transposed "
+                 "wino_input_kernel / wino_diff_kernel (Winograd: F(4,3)-along-H convolutions execute 1/2, F(2,2)-along-D-and-H transposed "
                  "convolutions 9/16 of the direct form's multiplications; serial, class-parallel and dual launch forms, bit-identical)",
             "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
@@ -264,7 +264,7 @@ def eager_records(s3r, torch, model, left, right, gt_cloud, steps):
 # environment switches that change which kernel (or which variant of one) runs without changing the kernel sources: a run
 # under any of them is not the configuration the committed counter passes were taken on
 _KERNEL_ENV = ("S3R_TILE_", "S3R_KSPLIT_", "S3R_ALGO_", "S3R_BF16_MFMA", "S3R_STEM_MFMA", "S3R_S2D", "S3R_DEEP_RING", "S3R_LINEAR_NT",
-               "S3R_NO_TAIL_CUT", "S3R_NO_FUSE", "S3R_LIB", "S3R_WINO", "S3R_WSPLIT", "S3R_ROWS", "S3R_NO_DUAL", "S3R_DUAL_MODEL",
+               "S3R_NO_TAIL_CUT", "S3R_NO_FUSE", "S3R_LIB", "S3R_WINO", "S3R_DWINO_MAT", "S3R_WSPLIT", "S3R_ROWS", "S3R_NO_DUAL", "S3R_DUAL_MODEL",
                "S3R_LINEAR_WGK")
 
 

@@ -93,7 +93,7 @@ typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_S2D = 1, S3R_LAYOUT_W
  * descriptor and never depends on anything else a caller passes (workspace size, batch):
  *   S3R_ALGO_AUTO      the library's policy, a function of the layer's PER-SAMPLE geometry only: Winograd where the layer has
  *                      that form (fp32 Conv k3 s1 p1 with cin % 32 == 0, cout > 1, edge >= 4; ConvTranspose3d k4 s2 p1 over an
- *                      even edge, cin % 32 == 0; in_halo = 1, no sigmoid); direct otherwise, and direct whenever the descriptor
+ *                      edge that is a multiple of 4, cin % 32 == 0; in_halo = 1, no sigmoid); direct otherwise, and direct whenever the descriptor
  *                      forces a direct-kernel tile / split-K (tile >= 0 or ksplit >= 1) or a non-plain layout.  The
  *                      process-level override S3R_WINO=0 (AUTO never picks Winograd) is read ONCE, when the library is loaded;
  *   S3R_ALGO_DIRECT    the direct kernel;

@@ -242,7 +242,7 @@ bool wino_layer(const s3r_conv_desc* d) {
 }
 bool dwino_layer(const s3r_conv_desc* d) {
     return d->dtype != S3R_BF16 && d->op == S3R_OP_DECONV && d->ndim == 3 && d->k == 4 && d->stride == 2 && d->pad == 1 &&
-           d->cin % s3r::wino_bk() == 0 && d->in_size >= 2 && (d->in_size & 1) == 0;
+           d->cin % s3r::wino_bk() == 0 && d->in_size >= 4 && (d->in_size & 3) == 0;
 }
 // the descriptor can run its layer's Winograd form
 bool wino_desc_ok(const s3r_conv_desc* d) {
@@ -295,9 +295,19 @@ int wino_bmax(const s3r_conv_desc* d) {
     return (int)(m < d->batch ? m : d->batch);
 }
 int64_t dwino_w_elems(const s3r_conv_desc* d) { return 72 * 2 * (int64_t)d->cin * cout_pad(d->cout); }      // (parity class, class) x 2 taps
-int64_t dwino_d_elems(const s3r_conv_desc* d) { return 3 * (int64_t)d->batch * d->cin * ipow(d->in_size + 2, 3); }  // Dh, Dd, Ddh
+// The depth differences of the transposed Winograd form are materialised (two more tensors behind the row differences) while
+// the four tensors stay in the Infinity Cache, and formed inside the class kernel otherwise: same bits either way, so this
+// may follow the batch (s3r_conv_wino.hip).
+bool dwino_materialise(const s3r_conv_desc* d) {
+    static const int forced = getenv("S3R_DWINO_MAT") ? atoi(getenv("S3R_DWINO_MAT")) : -1;      // A/B switch, read once
+    if (forced >= 0) return forced != 0;
+    return 4 * 4 * (int64_t)d->batch * d->cin * ipow(d->in_size + 2, 3) <= (int64_t)192 << 20;
+}
+int64_t dwino_d_elems(const s3r_conv_desc* d) {
+    return (dwino_materialise(d) ? 3 : 1) * (int64_t)d->batch * d->cin * ipow(d->in_size + 2, 3);
+}
 
-// Scratch of a Winograd call: [transformed input V (a convolution fed with plain input) | the three difference tensors (transposed) ] then
+// Scratch of a Winograd call: [transformed input V (a convolution fed with plain input) | the difference tensors (transposed) ] then
 // the class-parallel slabs of the launch form the library plans for this batch (every form gives the same bits, so the form
 // — unlike the algorithm — may follow the batch).
 struct WinoNeed { int64_t v, slab, total; };
@@ -351,7 +361,8 @@ int dwino_run(const s3r_conv_desc* d, s3r::ConvParams p, const float* x, const f
         return fail(S3R_ERR_WORKSPACE, "the Winograd form of this transposed convolution needs %lld floats of scratch "
                     "(s3r_conv_scratch_elems), got %lld", (long long)need.total, (long long)(scratch ? scratch_elems : 0));
     const int n = d->in_size;
-    hipError_t e = s3r::launch_wino_diff3(x, scratch, (long long)d->batch * d->cin, n + 2, n + 2, n + 2, s);
+    p.xd_mode = dwino_materialise(d) ? 1 : 0;
+    hipError_t e = s3r::launch_wino_diff(x, scratch, (long long)d->batch * d->cin, n + 2, n + 2, n + 2, p.xd_mode, s);
     if (e != hipSuccess) return hip_fail(e, "Winograd difference-tensor launch");
     p.x = x;
     p.xd = scratch;

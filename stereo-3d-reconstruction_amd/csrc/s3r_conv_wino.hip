@@ -127,16 +127,21 @@ hipError_t launch_pack_wino(const float* w, float* wp, int Cin, int Cout, int Co
 //     y(2q + 1) = x1 g0 + x2 g1 = m1 - m2        m1 = x1 (g0 + g1)        m2 = (x1 - x2) g1
 // — three products instead of four.  r03 did this along H (3/4 of the matrix work); nested along D and H it is NINE products
 // M_ab (a, b in 0..2: the D and the H class) for 2 x 2 outputs instead of sixteen: 9/16 of the direct form's multiplications,
-// each product a 2-tap (column) convolution over Cin.  The transformed inputs are the padded input x itself and three tensors of
-// differences (wino_diff3_kernel: the input of a transposed convolution is small) —
-//     Dh[z][r] = x[z][r] - x[z][r + 1],   Dd[z][r] = x[z][r] - x[z + 1][r],   Ddh[z][r] = Dd[z][r] - Dd[z][r + 1]
-// — class (a, b) reads {a = 1: plain, else depth differences} x {b = 1: plain, else row differences} at depth Z + (a ? 1 : 0), row
-// R + (b ? 1 : 0); the transformed weights are the sums of the 2 x 2 (depth tap, row tap) weights over {a: td = 0 | both | 1} x
+// each product a 2-tap (column) convolution over Cin.  Class (a, b) reads {a = 1: plain, else depth differences} x {b = 1: plain,
+// else row differences} of the padded input at depth Z + (a ? 1 : 0), row R + (b ? 1 : 0):
+//     Dh[z][r] = x[z][r] - x[z][r + 1],   Dd[z][r] = x[z][r] - x[z + 1][r],   Ddh[z][r] = Dh[z][r] - Dh[z + 1][r].
+// The row differences Dh are always a tensor of their own (wino_diff_kernel: the input of a transposed convolution is small).  The
+// DEPTH differences come in two forms with the same bits: MATERIALISED (p.xd_mode = 1: the same kernel writes Dd and Ddh too, the
+// class kernel reads one tile per K step) where the four tensors stay in the Infinity Cache (d1, d2 at B = 32), or formed IN the
+// kernel (p.xd_mode = 0: a depth-difference class stages the tiles of depths z and z + 1 side by side in LDS and subtracts the two
+// fragments in front of the MFMA, one v_sub per matrix instruction) where writing and re-reading two more tensors would cross HBM
+// (d3 at B = 32: 0.72 -> 0.69 ms; the 1.67 x operand traffic costs d1 / d2, which are L2-delivery bound, 27 / 4 %).  The transformed weights are the sums of the 2 x 2 (depth tap, row tap) weights over {a: td = 0 | both | 1} x
 // {b: th = 0 | both | 1}, per (parity class, column tap).  Positions are (b, s, q, pw) = (sample, depth pair, row pair, column) over
 // the input grid; the output transform Y[u][v] = sum A[u][a] A[v][b] M_ab, A = [[1, 1, 0], [0, 1, -1]], runs on the accumulator
 // registers; HEAD = the fused 1 x 1 x 1 head (d3 -> d4).
-__global__ __launch_bounds__(256) void wino_diff3_kernel(const float* __restrict__ x, float* __restrict__ D, long long planes,
-                                                         int Dp, int Hp, int Wp) {
+// D = [Dh | Dd | Ddh] (three = true) or [Dh]
+__global__ __launch_bounds__(256) void wino_diff_kernel(const float* __restrict__ x, float* __restrict__ D, long long planes,
+                                                        int Dp, int Hp, int Wp, int three) {
     const long long per = (long long)Dp * Hp * Wp, total = planes * per;
     const long long hw = (long long)Hp * Wp;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -146,20 +151,22 @@ __global__ __launch_bounds__(256) void wino_diff3_kernel(const float* __restrict
         const bool rn = r + 1 < Hp, zn = z + 1 < Dp;
         const float x00 = x[i];
         const float x01 = rn ? x[i + Wp] : 0.f;
-        const float x10 = zn ? x[i + hw] : 0.f;
-        const float x11 = (rn && zn) ? x[i + hw + Wp] : 0.f;
-        const float dd0 = zn ? x00 - x10 : 0.f;          // Dd at (z, r), (z, r + 1)
-        const float dd1 = zn ? x01 - x11 : 0.f;
-        D[i] = rn ? x00 - x01 : 0.f;                     // Dh
-        D[i + total] = dd0;                              // Dd
-        D[i + 2 * total] = rn ? dd0 - dd1 : 0.f;         // Ddh
+        const float dh0 = rn ? x00 - x01 : 0.f;
+        D[i] = dh0;
+        if (three) {
+            const float x10 = zn ? x[i + hw] : 0.f;
+            const float x11 = (rn && zn) ? x[i + hw + Wp] : 0.f;
+            const float dh1 = rn ? x10 - x11 : 0.f;          // Dh at depth z + 1
+            D[i + total] = zn ? x00 - x10 : 0.f;
+            D[i + 2 * total] = zn ? dh0 - dh1 : 0.f;
+        }
     }
 }
 
-hipError_t launch_wino_diff3(const float* x, float* D, long long planes, int Dp, int Hp, int Wp, hipStream_t s) {
+hipError_t launch_wino_diff(const float* x, float* D, long long planes, int Dp, int Hp, int Wp, int three, hipStream_t s) {
     const long long total = planes * Dp * Hp * Wp;
     const long long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(wino_diff3_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, x, D, planes, Dp, Hp, Wp);
+    hipLaunchKernelGGL(wino_diff_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, x, D, planes, Dp, Hp, Wp, three);
     return hipGetLastError();
 }
 
@@ -262,9 +269,10 @@ __device__ __forceinline__ float wino_head_act(float t, int act) {
 //   stride, Nh = groups per plane, T = kd * kw, x_org = 0; p.y the layer's padded output, p.Hout its true height (the last group's
 //   missing rows are not stored).
 // p (transposed): the layer's own parameters (make_params) with Nd = depth pairs, Nh = row pairs (n / 2), p.x = the padded input,
-//   p.xd = its three difference tensors Dh, Dd, Ddh (each of x's shape and strides), p.w = the 72 (parity class, class) slabs.
+//   p.xd = its row differences Dh (x's shape and strides; p.xd_mode = 1: followed by Dd and Ddh), p.w = the 72 (parity class, class) slabs.
 // p.part: class-parallel slabs [class][Cout][npad], npad = the position range's tile count x BN.
-template <int VEC, int KIND, int WN, bool CP, bool HEAD>
+// XM (transposed form): the depth differences are materialised (p.xd = [Dh | Dd | Ddh]) instead of formed here
+template <int VEC, int KIND, int WN, bool CP, bool HEAD, bool XM = false>
 __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in, const int nwg_in, const int n_begin,
                                           const int n_end, float* __restrict__ wsmem) {
     constexpr bool DECONV = KIND == 2;
@@ -275,7 +283,8 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
     static_assert(WN == 4 || WN == 2, "4 waves as 1 x 4 or 2 x 2");
     static_assert(!HEAD || (DECONV && !CP && WN == 2), "the fused head: serial transposed form");
     float* As = wsmem;                                   // [WNB][WBK][64]
-    float* Bs = wsmem + WNB * WBK * WBM;                 // [WNB][WBK][BN]
+    constexpr int BSTG = (DECONV ? 2 : 1) * WBK * BN;    // B floats per stage (transposed: depths z and z + 1 side by side)
+    float* Bs = wsmem + WNB * WBK * WBM;                 // [WNB][BSTG]
     constexpr int PB = 64 * VEC;                         // floats per B piece
     constexpr int NPIECE_B = WBK * BN / PB;
     static_assert(NPIECE_B % 4 == 0, "B pieces divide over the 4 waves");
@@ -345,8 +354,8 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
     const int avoff = ((lane >> 4) * p.CoutPad + (lane & 15) * 4) * 4;
     const __amdgpu_buffer_rsrc_t xrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
-    // (transposed form: the difference tensors Dh, Dd, Ddh behind p.xd get a descriptor of their own per K tile — together they
-    // may pass 2 GiB, and a 4-way choice between ready-made descriptors makes the compiler build a lookup table in scratch)
+    const __amdgpu_buffer_rsrc_t drsrc =                 // (transposed form: the row differences)
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DECONV ? p.xd : p.x), 0, (int)p.x_bytes, 0x00020000);
     const size_t x_el = (size_t)p.x_bytes / 4;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.w), 0, (int)((unsigned)(DECONV ? 72 : NCLS) * (unsigned)T * (unsigned)p.Cin * (unsigned)p.CoutPad * 4u),
@@ -366,15 +375,36 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
         for (int q = 0; q < WNPA; ++q)
             wdma<16>(wrsrc, As + buf * WBK * WBM + (wave + 4 * q) * 256, avoff,
                      (c_kt * WBK * p.CoutPad + m0) * 4 + (wave + 4 * q) * 4 * p.CoutPad * 4);
-        float* sb = Bs + buf * WBK * BN + b_lds0;
+        float* sb = Bs + buf * BSTG + b_lds0;
         if constexpr (DECONV) {
             // along an axis, F-class 0: differences at index R, 1: plain at R + 1, 2: differences at R + 1
             const int b_base = ((c_cc * WBK + b_row0) * p.x_cs + (c_a ? p.x_ds : 0) + (c_b ? p.x_hs : 0) + c_tap) * 4;
-            const int t_idx = (c_a != 1 ? 2 : 0) + (c_b != 1 ? 1 : 0);          // 0: x, 1: Dh, 2: Dd, 3: Ddh
-            const float* tb = t_idx == 0 ? p.x : p.xd + (size_t)(t_idx - 1) * x_el;
-            const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tb), 0, (int)p.x_bytes, 0x00020000);
+            if constexpr (XM) {
+                // materialised differences: one tile of x / Dh / Dd / Ddh (a descriptor per K tile: the tensors together may pass
+                // 2 GiB, and a 4-way choice between ready-made descriptors makes the compiler build a lookup table in scratch)
+                const int t_idx = (c_a != 1 ? 2 : 0) + (c_b != 1 ? 1 : 0);          // 0: x, 1: Dh, 2: Dd, 3: Ddh
+                const float* tb = t_idx == 0 ? p.x : p.xd + (size_t)(t_idx - 1) * x_el;
+                const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tb), 0, (int)p.x_bytes, 0x00020000);
 #pragma unroll
-            for (int q = 0; q < NPB; ++q) wdma<4 * VEC>(trsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
+                for (int q = 0; q < NPB; ++q) wdma<4 * VEC>(trsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
+            } else if (c_b == 1) {
+                // row part b: plain / row differences (two descriptors); depth part a: a difference class fetches depth z + 1 as well
+#pragma unroll
+                for (int q = 0; q < NPB; ++q) wdma<4 * VEC>(xrsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
+                if (c_a != 1) {
+#pragma unroll
+                    for (int q = 0; q < NPB; ++q)
+                        wdma<4 * VEC>(xrsrc, sb + WBK * BN + q * B_LDS_STEP, bvoff, b_base + p.x_ds * 4 + q * B_ROW_STEP * cs4);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NPB; ++q) wdma<4 * VEC>(drsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
+                if (c_a != 1) {
+#pragma unroll
+                    for (int q = 0; q < NPB; ++q)
+                        wdma<4 * VEC>(drsrc, sb + WBK * BN + q * B_LDS_STEP, bvoff, b_base + p.x_ds * 4 + q * B_ROW_STEP * cs4);
+                }
+            }
             ++c_kt;
             if (++c_tap == 2) {
                 c_tap = 0;
@@ -417,18 +447,29 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
     const int b_off = h * BN + wn * 32 + j;
     typedef typename WVec<TM>::type AV;
     int cur = 0, g = 0;
-    auto run_class = [&](wf32x16 (&ac)[TM]) __attribute__((always_inline)) {
+    // diff (transposed form, depth part a != 1): the B fragment is the difference of the two depth tiles of the stage
+    auto run_class = [&](wf32x16 (&ac)[TM], const bool diff) __attribute__((always_inline)) {
         for (int kt = 0; kt < nkt; ++kt, ++g) {
             const bool more = g + WNB - 1 < total;
             if (more) issue(cur == 0 ? WNB - 1 : cur - 1);        // into the stage tile g - 1 was read from
             const float* a = As + cur * WBK * WBM + a_off;
-            const float* b = Bs + cur * WBK * BN + b_off;
+            const float* b = Bs + cur * BSTG + b_off;
+            if (DECONV && diff) {
 #pragma unroll
-            for (int ks = 0; ks < WBK / 2; ++ks) {
-                const AV av = *reinterpret_cast<const AV*>(a + ks * 2 * WBM);
-                const float bv = b[ks * 2 * BN];
+                for (int ks = 0; ks < WBK / 2; ++ks) {
+                    const AV av = *reinterpret_cast<const AV*>(a + ks * 2 * WBM);
+                    const float bv = b[ks * 2 * BN] - b[WBK * BN + ks * 2 * BN];
 #pragma unroll
-                for (int t = 0; t < TM; ++t) ac[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wvget<TM>(av, t), bv, ac[t], 0, 0, 0);
+                    for (int t = 0; t < TM; ++t) ac[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wvget<TM>(av, t), bv, ac[t], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < WBK / 2; ++ks) {
+                    const AV av = *reinterpret_cast<const AV*>(a + ks * 2 * WBM);
+                    const float bv = b[ks * 2 * BN];
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) ac[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wvget<TM>(av, t), bv, ac[t], 0, 0, 0);
+                }
             }
             if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((WNB - 2) * NPD) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -437,8 +478,13 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
             cur = cur + 1 == WNB ? 0 : cur + 1;
         }
     };
+    static_assert(WNB == 2 || !DECONV, "the transposed form issues a class-dependent number of DMAs per K tile: vmcnt(0) only");
+    constexpr bool otf = DECONV && !XM;                  // depth differences formed here
+    if constexpr (CP) run_class(acc[0], otf && cls0 / 3 != 1);
+    else {
 #pragma unroll
-    for (int c = 0; c < NACC; ++c) run_class(acc[c]);
+        for (int c = 0; c < NACC; ++c) run_class(acc[c], otf && c / 3 != 1);
+    }
 
     // rows of this lane: cout m0 + mbase + dm, dm = ((r & 3) + 8 (r >> 2)) * TM + tm
     const int mbase = wm * TM * 32 + 4 * h * TM;
@@ -555,10 +601,10 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
 
 // registers: six classes of one 32 x 32 tile = 96 accumulators (109 in all: four workgroups per CU), nine = 144 (three per CU);
 // the class-parallel form 16
-template <int VEC, int KIND, int WN, bool CP, bool HEAD>
+template <int VEC, int KIND, int WN, bool CP, bool HEAD, bool XM = false>
 __global__ __launch_bounds__(256, (CP || KIND == 1 ? 4 : 3)) void wino_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float wsmem[];
-    wino_body<VEC, KIND, WN, CP, HEAD>(p, blockIdx.x, gridDim.x, p.n_begin, p.n_end, wsmem);
+    wino_body<VEC, KIND, WN, CP, HEAD, XM>(p, blockIdx.x, gridDim.x, p.n_begin, p.n_end, wsmem);
 }
 
 // bulk (serial form, positions [n_begin, n_cut)) + remainder (class-parallel form, positions [n_cut, n_end)) in ONE launch: the
@@ -677,9 +723,9 @@ int64_t wino_slab_elems(int kind, int cout, int ntotal, const WinoLaunch& L) {
 // tests): 0 serial, 1 class-parallel, 2 dual.  Otherwise a cost model in units of one K step of a 64 x 64 tile on one CU
 // (13.4 ns at the fp32 MFMA peak), fitted to tools/layer_bench.py --algo 2 sweeps at B = 1 .. 32:
 //   kcls = K per class (Cin x taps), u = serial workgroups per CU;
-//   serial          ceil(u) workgroups of ncls * kcls steps each, at 0.9 of the pipe (0.75 when a CU holds one workgroup)
+//   serial          ceil(u) workgroups of ncls * kcls steps each, at 0.9 of the pipe (0.7 when a CU holds one workgroup)
 //   class-parallel  ceil(u * ncls) workgroups of kcls steps at 0.9, + 100 steps each for their slab's round trip, + a finish launch
-//   dual            floor(u) serial rounds + the remainder class-parallel
+//   dual            floor(u) serial rounds + 0.6 of the remainder class-parallel
 WinoLaunch wino_plan(int kind, int cout, int kcls, int ntotal, bool head, int forced) {
     WinoLaunch L;
     L.mode = WINO_SERIAL; L.n_cut = 0;
@@ -694,7 +740,7 @@ WinoLaunch wino_plan(int kind, int cout, int kcls, int ntotal, bool head, int fo
     if (forced >= 0) {
         L.mode = forced <= WINO_DUAL ? forced : WINO_SERIAL;
     } else {
-        constexpr double EFF = 0.9, EFF_ALONE = 0.75, SLAB = 100.0, LAUNCH = 220.0;
+        constexpr double EFF = 0.9, EFF_ALONE = 0.7, SLAB = 100.0, LAUNCH = 220.0, TAIL = 0.6;
         (void)head;
         const double u = (double)W / 256.0;
         const double ru = __builtin_ceil(u), fu = __builtin_floor(u);
@@ -703,7 +749,8 @@ WinoLaunch wino_plan(int kind, int cout, int kcls, int ntotal, bool head, int fo
         double best = serial;
         if (cp < best) { best = cp; L.mode = WINO_CP; }
         if (kind != 2 && !head && fu >= 1.0 && u > fu) {
-            const double dual = fu * ncls * kcls / EFF + __builtin_ceil((u - fu) * ncls) * (kcls / EFF + SLAB) + LAUNCH;
+            // (the remainder's short workgroups run beside the bulk's last round: TAIL of their own time shows)
+            const double dual = fu * ncls * kcls / EFF + TAIL * __builtin_ceil((u - fu) * ncls) * (kcls / EFF + SLAB) + LAUNCH;
             if (dual < 0.97 * best) { best = dual; L.mode = WINO_DUAL; }
         }
     }
@@ -718,7 +765,7 @@ WinoLaunch wino_plan(int kind, int cout, int kcls, int ntotal, bool head, int fo
 template <int VEC, int KIND>
 static hipError_t launch_wino_forms(ConvParams p, const WinoLaunch& L, hipStream_t stream) {
     const int ntotal = p.Ntotal;
-    auto lds_of = [](int bn) { return (size_t)WNB * WBK * (WBM + bn) * sizeof(float); };
+    auto lds_of = [](int bn) { return (size_t)WNB * WBK * (WBM + (KIND == 2 ? 2 : 1) * bn) * sizeof(float); };
     const int pcs = KIND == 2 ? 8 : 1;
     constexpr int NCLS = WinoKind<KIND>::NCLS;
     p.n_begin = 0; p.n_end = ntotal;
@@ -726,9 +773,13 @@ static hipError_t launch_wino_forms(ConvParams p, const WinoLaunch& L, hipStream
         const dim3 grid(p.m_tiles * ((ntotal + WCN - 1) / WCN) * pcs);
         if constexpr (KIND == 2) {
             if (p.head_w) {
-                hipLaunchKernelGGL((wino_kernel<VEC, KIND, 2, false, true>), grid, dim3(256), lds_of(WCN), stream, p);
-                return hipGetLastError();
+                if (p.xd_mode) hipLaunchKernelGGL((wino_kernel<VEC, KIND, 2, false, true, true>), grid, dim3(256), lds_of(WCN), stream, p);
+                else hipLaunchKernelGGL((wino_kernel<VEC, KIND, 2, false, true, false>), grid, dim3(256), lds_of(WCN), stream, p);
+            } else {
+                if (p.xd_mode) hipLaunchKernelGGL((wino_kernel<VEC, KIND, 2, false, false, true>), grid, dim3(256), lds_of(WCN), stream, p);
+                else hipLaunchKernelGGL((wino_kernel<VEC, KIND, 2, false, false, false>), grid, dim3(256), lds_of(WCN), stream, p);
             }
+            return hipGetLastError();
         }
         hipLaunchKernelGGL((wino_kernel<VEC, KIND, 2, false, false>), grid, dim3(256), lds_of(WCN), stream, p);
         return hipGetLastError();
@@ -744,6 +795,8 @@ static hipError_t launch_wino_forms(ConvParams p, const WinoLaunch& L, hipStream
             p.big_wgs = p.m_tiles * (n0 / WCN);
             hipLaunchKernelGGL((wino_dual_kernel<VEC, KIND>), dim3(p.big_wgs + cp_wgs), dim3(256), lds_of(WCN), stream, p);
         }
+    } else if (KIND == 2 && p.xd_mode) {
+        hipLaunchKernelGGL((wino_kernel<VEC, KIND, 2, true, false, KIND == 2>), dim3(cp_wgs), dim3(256), lds_of(WCN), stream, p);
     } else {
         hipLaunchKernelGGL((wino_kernel<VEC, KIND, 2, true, false>), dim3(cp_wgs), dim3(256), lds_of(WCN), stream, p);
     }
@@ -767,7 +820,8 @@ hipError_t launch_deconv_wino(ConvParams p, const WinoLaunch& L, hipStream_t str
         return hipErrorInvalidValue;
     p.m_tiles = (p.Cout + WBM - 1) / WBM;
     if (launches) *launches = L.mode == WINO_SERIAL ? 1 : 2;
-    return p.Nw % 4 == 0 ? launch_wino_forms<4, 2>(p, L, stream) : launch_wino_forms<1, 2>(p, L, stream);
+    if (p.Nw % 4 != 0) return hipErrorInvalidValue;       // (16-byte gathers only: the library's policy asks for an edge % 4 == 0)
+    return launch_wino_forms<4, 2>(p, L, stream);
 }
 
 }  // namespace s3r

@@ -101,8 +101,10 @@ struct ConvParams {
     // Winograd F(2,3) along H (s3r_conv_wino.hip): x = the four transformed input plane sets, x_cls elements apart; Nh = row
     // pairs per plane; Hout = the output's true height
     int x_cls, Hout;
-    // transposed Winograd form: the three difference tensors Dh, Dd, Ddh of the padded input (each of x's shape and strides)
+    // transposed Winograd form: the row differences Dh of the padded input (x's shape and strides); xd_mode = 1: followed by the
+    // depth differences Dd and the mixed differences Ddh (materialised), 0: those are formed inside the class kernel
     const float* xd;
+    int xd_mode;
 };
 
 // Launch form of a Winograd layer (s3r_conv_wino.hip): serial (one workgroup walks all classes of its tile), class-parallel (one
@@ -178,8 +180,8 @@ WinoLaunch wino_plan(int kind, int cout, int kcls, int ntotal, bool head, int fo
 int64_t wino_slab_elems(int kind, int cout, int ntotal, const WinoLaunch& L);     // floats of class-parallel slabs (p.part)
 hipError_t launch_conv_wino(ConvParams p, const WinoLaunch& L, hipStream_t stream, int* launches);
 int wino_bk();                      // channels per K tile of the Winograd kernels (Cin must be a multiple)
-// Winograd F(2,2) along D and H inside the parity classes of ConvTranspose3d(k4 s2 p1); D = [Dh | Dd | Ddh]
-hipError_t launch_wino_diff3(const float* x, float* D, long long planes, int Dp, int Hp, int Wp, hipStream_t s);
+// Winograd F(2,2) along D and H inside the parity classes of ConvTranspose3d(k4 s2 p1); D = [Dh] or (three) [Dh | Dd | Ddh]
+hipError_t launch_wino_diff(const float* x, float* D, long long planes, int Dp, int Hp, int Wp, int three, hipStream_t s);
 hipError_t launch_pack_wino_deconv(const float* w, float* wp, int Cin, int Cout, int CoutPad, hipStream_t s);
 hipError_t launch_deconv_wino(ConvParams p, const WinoLaunch& L, hipStream_t stream, int* launches);
 // y (N,32,Ho+2h,Wo+2h) <- stem conv of x (N,3,Hi,Wi); y_hs / y_cs / y_org describe the padded output.

@@ -228,20 +228,24 @@ torch.save(outs, sys.argv[1])
 
 def test_whole_forward_is_form_invariant_at_every_batch(tmp_path):
     """B = 1, 2, 4, 8, 32: the forward under the library's own launch plan (class-parallel on sparse grids, dual where a
-    layer's last round is mostly empty) equals the forward with every Winograd layer forced to the serial form — bitwise."""
+    layer's last round is mostly empty; the transposed layers' depth differences materialised or formed in the kernel by
+    input size) equals the forward with every Winograd layer forced to the serial form, and with the depth differences
+    forced either way — bitwise."""
     res = {}
-    for flag in ("auto", "0"):
+    for flag, env_set in (("auto", {}), ("serial", {"S3R_WINO_FORM": "0"}), ("mat0", {"S3R_DWINO_MAT": "0"}),
+                          ("mat1", {"S3R_DWINO_MAT": "1"})):
         path = str(tmp_path / f"forms_{flag}.pt")
         env = dict(os.environ)
         env.pop("S3R_WINO_FORM", None)
-        if flag != "auto":
-            env["S3R_WINO_FORM"] = flag
+        env.pop("S3R_DWINO_MAT", None)
+        env.update(env_set)
         r = subprocess.run([sys.executable, "-c", _FORMS_CHILD % {"root": ROOT}, path], capture_output=True, text=True,
                            timeout=900, cwd=ROOT, env=env)
         assert r.returncode == 0, r.stderr[-3000:]
         res[flag] = torch.load(path)
-    for a, b in zip(res["auto"], res["0"]):
-        assert torch.equal(a, b), a.shape
+    for flag in ("serial", "mat0", "mat1"):
+        for a, b in zip(res["auto"], res[flag]):
+            assert torch.equal(a, b), (flag, a.shape)
 
 
 def test_winograd_on_offset_and_heavy_tailed_inputs(s3r):

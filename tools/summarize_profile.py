@@ -16,7 +16,7 @@ import sys
 from collections import defaultdict
 
 
-FAMILY = "conv_glds,wino_kernel,wino_dual,wino_finish,wino_input,wino_diff3"   # the fp32 conv family: conv_glds_kernel, conv_glds_dual_kernel and the Winograd pair
+FAMILY = "conv_glds,wino_kernel,wino_dual,wino_finish,wino_input,wino_diff"   # the fp32 conv family: conv_glds_kernel, conv_glds_dual_kernel and the Winograd pair
                                             # (input transform + class kernel); third argument overrides it (bf16: "conv_bf16")
 
 
