@@ -139,34 +139,40 @@ hipError_t launch_pack_wino(const float* w, float* wp, int Cin, int Cout, int Co
 // {b: th = 0 | both | 1}, per (parity class, column tap).  Positions are (b, s, q, pw) = (sample, depth pair, row pair, column) over
 // the input grid; the output transform Y[u][v] = sum A[u][a] A[v][b] M_ab, A = [[1, 1, 0], [0, 1, -1]], runs on the accumulator
 // registers; HEAD = the fused 1 x 1 x 1 head (d3 -> d4).
-// D = [Dh | Dd | Ddh] (three = true) or [Dh]
-__global__ __launch_bounds__(256) void wino_diff_kernel(const float* __restrict__ x, float* __restrict__ D, long long planes,
-                                                        int Dp, int Hp, int Wp, int three) {
-    const long long per = (long long)Dp * Hp * Wp, total = planes * per;
-    const long long hw = (long long)Hp * Wp;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long e = i % per;
-        const int z = (int)(e / hw);
-        const int r = (int)((e - (long long)z * hw) / Wp);
-        const bool rn = r + 1 < Hp, zn = z + 1 < Dp;
+// D = [Dh | Dd | Ddh] (THREE) or [Dh].  One thread per element; the index arithmetic is 32-bit mulhi division by launch
+// invariants (the first version's 64-bit % and / per element ran at 2.7 TB/s).
+template <bool THREE>
+__global__ __launch_bounds__(256) void wino_diff_kernel(const float* __restrict__ x, float* __restrict__ D, unsigned total,
+                                                        int Dp, int Hp, int Wp, FastDiv dPer, FastDiv dHW, FastDiv dW) {
+    const unsigned hw = (unsigned)Hp * Wp, per = (unsigned)Dp * hw;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned pl = (unsigned)dPer.div((int)i);
+        const unsigned e = i - pl * per;
+        const unsigned z = (unsigned)dHW.div((int)e);
+        const unsigned r = (unsigned)dW.div((int)(e - z * hw));
+        const bool rn = r + 1 < (unsigned)Hp, zn = z + 1 < (unsigned)Dp;
         const float x00 = x[i];
         const float x01 = rn ? x[i + Wp] : 0.f;
         const float dh0 = rn ? x00 - x01 : 0.f;
         D[i] = dh0;
-        if (three) {
+        if constexpr (THREE) {
             const float x10 = zn ? x[i + hw] : 0.f;
             const float x11 = (rn && zn) ? x[i + hw + Wp] : 0.f;
             const float dh1 = rn ? x10 - x11 : 0.f;          // Dh at depth z + 1
-            D[i + total] = zn ? x00 - x10 : 0.f;
-            D[i + 2 * total] = zn ? dh0 - dh1 : 0.f;
+            D[i + (size_t)total] = zn ? x00 - x10 : 0.f;
+            D[i + 2 * (size_t)total] = zn ? dh0 - dh1 : 0.f;
         }
     }
 }
 
 hipError_t launch_wino_diff(const float* x, float* D, long long planes, int Dp, int Hp, int Wp, int three, hipStream_t s) {
     const long long total = planes * Dp * Hp * Wp;
+    if (total >= (1ll << 31)) return hipErrorInvalidValue;
     const long long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(wino_diff_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, x, D, planes, Dp, Hp, Wp, three);
+    const dim3 grid((unsigned)(blocks < 16384 ? blocks : 16384));
+    const FastDiv dPer((unsigned)(Dp * Hp * Wp)), dHW((unsigned)(Hp * Wp)), dW((unsigned)Wp);
+    if (three) hipLaunchKernelGGL(wino_diff_kernel<true>, grid, dim3(256), 0, s, x, D, (unsigned)total, Dp, Hp, Wp, dPer, dHW, dW);
+    else hipLaunchKernelGGL(wino_diff_kernel<false>, grid, dim3(256), 0, s, x, D, (unsigned)total, Dp, Hp, Wp, dPer, dHW, dW);
     return hipGetLastError();
 }
 
@@ -609,13 +615,13 @@ __global__ __launch_bounds__(256, (CP || KIND == 1 ? 4 : 3)) void wino_kernel(co
 
 // bulk (serial form, positions [n_begin, n_cut)) + remainder (class-parallel form, positions [n_cut, n_end)) in ONE launch: the
 // remainder's short workgroups fill the slots the bulk's last round leaves
-template <int VEC, int KIND>
+template <int VEC, int KIND, bool HEAD = false, bool XM = false>
 __global__ __launch_bounds__(256, (KIND == 1 ? 4 : 3)) void wino_dual_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float wsmem[];
     if ((int)blockIdx.x < p.big_wgs)
-        wino_body<VEC, KIND, 2, false, false>(p, blockIdx.x, p.big_wgs, p.n_begin, p.n_cut, wsmem);
+        wino_body<VEC, KIND, 2, false, HEAD, XM>(p, blockIdx.x, p.big_wgs, p.n_begin, p.n_cut, wsmem);
     else
-        wino_body<VEC, KIND, 2, true, false>(p, (int)blockIdx.x - p.big_wgs, (int)gridDim.x - p.big_wgs, p.n_cut, p.n_end, wsmem);
+        wino_body<VEC, KIND, 2, true, false, XM>(p, (int)blockIdx.x - p.big_wgs, (int)gridDim.x - p.big_wgs, p.n_cut, p.n_end, wsmem);
 }
 
 // ---- class-parallel finish: y = act(transform(class sums) * scale + shift) over positions [n_begin, n_end), through the same
@@ -723,9 +729,10 @@ int64_t wino_slab_elems(int kind, int cout, int ntotal, const WinoLaunch& L) {
 // tests): 0 serial, 1 class-parallel, 2 dual.  Otherwise a cost model in units of one K step of a 64 x 64 tile on one CU
 // (13.4 ns at the fp32 MFMA peak), fitted to tools/layer_bench.py --algo 2 sweeps at B = 1 .. 32:
 //   kcls = K per class (Cin x taps), u = serial workgroups per CU;
-//   serial          ceil(u) workgroups of ncls * kcls steps each, at 0.9 of the pipe (0.7 when a CU holds one workgroup)
+//   serial          ceil(u) workgroups of ncls * kcls steps each, at 0.9 of the pipe (a workgroup left alone on its CU: 0.7)
 //   class-parallel  ceil(u * ncls) workgroups of kcls steps at 0.9, + 100 steps each for their slab's round trip, + a finish launch
-//   dual            floor(u) serial rounds + 0.6 of the remainder class-parallel
+//   dual            k serial workgroups per CU (k = floor(u), or one fewer when the last would run alone) + 0.6 of the remainder
+//                   class-parallel
 WinoLaunch wino_plan(int kind, int cout, int kcls, int ntotal, bool head, int forced) {
     WinoLaunch L;
     L.mode = WINO_SERIAL; L.n_cut = 0;
@@ -737,25 +744,35 @@ WinoLaunch wino_plan(int kind, int cout, int kcls, int ntotal, bool head, int fo
         static const int env_mode = getenv("S3R_WINO_FORM") ? atoi(getenv("S3R_WINO_FORM")) : -1;      // A/B switch, read once
         forced = env_mode;
     }
+    const int occ = kind == 2 ? 3 : 4;                   // serial workgroups a CU holds at once (registers)
+    const double u = (double)W / 256.0;                  // serial workgroups per CU
+    int kb = (int)u;                                     // bulk rounds of a dual launch: whole workgroups per CU
     if (forced >= 0) {
         L.mode = forced <= WINO_DUAL ? forced : WINO_SERIAL;
+        if ((double)kb >= u) kb -= 1;                    // (a forced dual launch always leaves a remainder)
     } else {
-        constexpr double EFF = 0.9, EFF_ALONE = 0.7, SLAB = 100.0, LAUNCH = 220.0, TAIL = 0.6;
         (void)head;
-        const double u = (double)W / 256.0;
-        const double ru = __builtin_ceil(u), fu = __builtin_floor(u);
-        const double serial = ru * ncls * kcls / (ru >= 2.0 ? EFF : EFF_ALONE);
+        constexpr double EFF = 0.9, EFF_ALONE = 0.7, SLAB = 100.0, LAUNCH = 220.0, TAIL = 0.6;
+        const double unit = (double)ncls * kcls;
+        // w workgroups per CU, `occ` at a time: the last one alone on its CU runs at EFF_ALONE
+        auto serial_cost = [&](int w) {
+            const int rem = w % occ;
+            return (w - (rem == 1 ? 1 : 0)) * unit / EFF + (rem == 1 ? unit / EFF_ALONE : 0.0);
+        };
+        const double serial = serial_cost((int)__builtin_ceil(u));
         const double cp = __builtin_ceil(u * ncls) * (kcls / EFF + SLAB) + LAUNCH;
         double best = serial;
         if (cp < best) { best = cp; L.mode = WINO_CP; }
-        if (kind != 2 && !head && fu >= 1.0 && u > fu) {
-            // (the remainder's short workgroups run beside the bulk's last round: TAIL of their own time shows)
-            const double dual = fu * ncls * kcls / EFF + TAIL * __builtin_ceil((u - fu) * ncls) * (kcls / EFF + SLAB) + LAUNCH;
-            if (dual < 0.97 * best) { best = dual; L.mode = WINO_DUAL; }
+        // (the remainder's short workgroups run beside the bulk's last round: TAIL of their own time shows)
+        // k = floor(u), or one fewer when that would leave a CU's last bulk workgroup alone
+        for (int k : {(int)u, (int)u % occ == 1 ? (int)u - 1 : 0}) {
+            if (k < 1 || (double)k >= u) continue;
+            const double dual = serial_cost(k) + TAIL * __builtin_ceil((u - k) * ncls) * (kcls / EFF + SLAB) + LAUNCH;
+            if (dual < 0.97 * best) { best = dual; L.mode = WINO_DUAL; kb = k; }
         }
     }
     if (L.mode == WINO_DUAL) {
-        const long n_main = kind == 2 ? 0 : ((W / 256) * 256) / m_tiles;             // whole rounds of the chip in the bulk
+        const long n_main = ((long)kb * 256) / (m_tiles * pcs);                        // whole N tiles in the bulk
         L.n_cut = (int)(n_main * WCN);
         if (L.n_cut <= 0 || L.n_cut >= ntotal) { L.mode = L.n_cut <= 0 ? WINO_CP : WINO_SERIAL; L.n_cut = 0; }
     }
@@ -789,11 +806,19 @@ static hipError_t launch_wino_forms(ConvParams p, const WinoLaunch& L, hipStream
     const int cp_tiles = (ntotal - n0 + WCN - 1) / WCN;
     const int cp_wgs = p.m_tiles * cp_tiles * NCLS * pcs;
     if (L.mode == WINO_DUAL) {
-        if constexpr (KIND == 2) return hipErrorInvalidValue;
-        else {
-            p.n_cut = n0;
-            p.big_wgs = p.m_tiles * (n0 / WCN);
-            hipLaunchKernelGGL((wino_dual_kernel<VEC, KIND>), dim3(p.big_wgs + cp_wgs), dim3(256), lds_of(WCN), stream, p);
+        p.n_cut = n0;
+        p.big_wgs = p.m_tiles * (n0 / WCN) * pcs;
+        const dim3 grid(p.big_wgs + cp_wgs);
+        if constexpr (KIND == 2) {
+            if (p.head_w) {
+                if (p.xd_mode) hipLaunchKernelGGL((wino_dual_kernel<VEC, KIND, true, true>), grid, dim3(256), lds_of(WCN), stream, p);
+                else hipLaunchKernelGGL((wino_dual_kernel<VEC, KIND, true, false>), grid, dim3(256), lds_of(WCN), stream, p);
+            } else {
+                if (p.xd_mode) hipLaunchKernelGGL((wino_dual_kernel<VEC, KIND, false, true>), grid, dim3(256), lds_of(WCN), stream, p);
+                else hipLaunchKernelGGL((wino_dual_kernel<VEC, KIND, false, false>), grid, dim3(256), lds_of(WCN), stream, p);
+            }
+        } else {
+            hipLaunchKernelGGL((wino_dual_kernel<VEC, KIND>), grid, dim3(256), lds_of(WCN), stream, p);
         }
     } else if (KIND == 2 && p.xd_mode) {
         hipLaunchKernelGGL((wino_kernel<VEC, KIND, 2, true, false, KIND == 2>), dim3(cp_wgs), dim3(256), lds_of(WCN), stream, p);

@@ -155,7 +155,7 @@ def _wino_layers(spec):
 def _positions(spec, l, n_in, batch):
     """GEMM positions of the Winograd launch (groups of R output rows) and its serial workgroup count."""
     if l.op == "deconv3d":
-        n = batch * n_in * (n_in // 2) * n_in
+        n = batch * (n_in // 2) * (n_in // 2) * n_in               # (depth pair, row pair, column)
         return n, -(-l.cout // 64) * -(-n // 64) * 8
     n = batch * (n_in if l.op == "conv3d" else 1) * -(-n_in // 4) * n_in
     return n, -(-l.cout // 64) * -(-n // 64)
@@ -181,8 +181,6 @@ def test_every_launch_form_gives_the_serial_forms_bits(s3r):
             x = torch.randn((B, l.cin) + (n_in,) * spec.ndim(l), generator=torch.Generator().manual_seed(B)).to(dev)
             outs = {}
             for form in (0, 1, 2):
-                if l.op == "deconv3d" and form == 2:
-                    continue                                       # (no dual kernel for the transposed form)
                 ch.tile_override[l.name] = form
                 s3r.profile_enable(8)
                 outs[form] = ch._run(x).clone()
@@ -203,13 +201,13 @@ def test_every_launch_form_gives_the_serial_forms_bits(s3r):
     s3r.seed_module(ch, 9)
     ch.to(dev)
     ch.algo_override["d3"] = L.ALGO_WINOGRAD
-    for B in (1, 3):
+    for B in (1, 5):                                               # (5 samples: 320 serial workgroups, the dual form cuts inside)
         x = torch.randn((B, 128, 16, 16, 16), generator=torch.Generator().manual_seed(4)).to(dev)
         outs = {}
-        for form in (0, 1):
+        for form in (0, 1, 2):
             ch.tile_override["d3"] = form
             outs[form] = ch._run(x).clone()
-        assert torch.equal(outs[1], outs[0]), B
+        assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0]), B
 
 
 _FORMS_CHILD = r'''
