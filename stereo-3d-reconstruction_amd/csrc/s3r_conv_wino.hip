@@ -45,7 +45,7 @@ __device__ __forceinline__ float wvget(const typename WVec<N>::type& v, int i) {
 #ifndef S3R_WBK
 #define S3R_WBK 32
 #endif
-constexpr int WBM = 64, WBN = 128, WBK = S3R_WBK, WNB = S3R_WNB;      // K tile: one tap x WBK channels
+constexpr int WBM = 64, WBK = S3R_WBK, WNB = S3R_WNB;      // K tile: one tap x WBK channels
 constexpr int WNPA = WBK * WBM / 1024;                                // 1 KiB weight pieces per wave and K tile
 int wino_bk() { return WBK; }
 
