@@ -63,29 +63,16 @@ typedef enum s3r_dtype {
 typedef enum s3r_act { S3R_ACT_NONE = 0, S3R_ACT_RELU = 1, S3R_ACT_SIGMOID = 2 } s3r_act;
 
 /* Memory layout of an activation buffer (beyond NCHW vs channels-last, which the dtype fixes):
- *   S3R_LAYOUT_PLAIN  the (halo-padded) tensor as described under "Halos" below;
- *   S3R_LAYOUT_S2D    bf16 path only, even edge n, halo 1: PARITY-SPLIT ("space to depth") — 2^ndim sub-tensors, one per
- *                     parity class of the position (class = 4*(d&1) + 2*(h&1) + (w&1); d = 0 for 2D), each the
- *                     (n/2 + 2)^ndim x C channels-last tensor of the positions of that parity with a zero halo of 1:
- *                     (B, 2^ndim, [n/2+2,] n/2+2, n/2+2, C).  It is what a stride-2 3x3[x3] convolution wants to read:
- *                     every tap then walks ONE sub-tensor at stride 1, so the kernel that reuses a gathered input plane
- *                     for all taps of a group serves stride-2 layers as well (the input crosses L2 -> LDS once per 9/4
- *                     taps instead of once per tap).  s3r_chain_forward plans it between a convolution and a
- *                     stride-2 consumer by itself; the fields exist so that single layers can be driven and tested.
- *                     fp32 path (NC(D)HW), even edge n, halo 1: W-PARITY-SPLIT ROWS — the same (B, C, [n+2,] n+2, n+2)
- *                     buffer, every padded row of n+2 elements stored as its (n+2)/2 even columns followed by its (n+2)/2
- *                     odd columns.  Tap kw of a stride-2 k3 p1 convolution then reads, for consecutive output columns,
- *                     CONSECUTIVE dwords of one half (columns 2 ow + kw): the gather is as wide as a stride-1 layer's
- *                     (16-byte LDS-DMA where the output width is a multiple of 4) instead of every other dword.  Planned
- *                     by s3r_chain_forward between a convolution and its stride-2 consumer; the K order does not change,
- *                     so results are bit-identical to the plain layout. */
-/*   S3R_LAYOUT_WINO_H  fp32 path, INPUT of a 3 x 3 [x 3] stride-1 pad-1 convolution only, in_halo 1, edge n a multiple of 4: the six
+ *   S3R_LAYOUT_PLAIN   the (halo-padded) tensor as described under "Halos" below;
+ *   S3R_LAYOUT_WINO_H  fp32 path, INPUT of a 3 x 3 [x 3] stride-1 pad-1 convolution only, in_halo 1, edge n a multiple of 4: the six
  *                      Winograd F(4,3)-along-H plane sets of the halo-padded tensor, (6, B, C, [n+2,] n/4, n+2) — set i, row q =
  *                      the i-th F(4,3) input-transform combination of the padded rows 4 q .. 4 q + 5 (csrc/s3r_kernels.h,
- *                      wino_rows_to_classes).  What
- *                      s3r_cost_volume_forward_wino writes: the consumer then skips its input transform.  The batch of such a
- *                      call is bounded: s3r_conv_wino_input_elems returns 0 when the layer / batch cannot take it. */
-typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_S2D = 1, S3R_LAYOUT_WINO_H = 2 } s3r_layout;
+ *                      wino_rows_to_classes).  What s3r_cost_volume_forward_wino writes: the consumer then skips its input
+ *                      transform.  The batch of such a call is bounded: s3r_conv_wino_input_elems returns 0 when the layer /
+ *                      batch cannot take it.
+ * (Value 1 was S3R_LAYOUT_S2D — parity-split intermediates for stride-2 consumers, bf16 and fp32 forms — through ABI 6: built,
+ * bit-identical, measured slower / no gain inside the forward in rounds 2 and 3, never planned by default; removed in ABI 7.) */
+typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_WINO_H = 2 } s3r_layout;
 
 /* Which convolution algorithm a layer's forward runs (ABI 7).  The fp32 3 x 3 [x 3] stride-1 pad-1 convolutions and the
  * transposed convolutions have two kernels — the direct implicit GEMM and a Winograd form with 1/2 .. 9/16 of the
@@ -124,16 +111,16 @@ typedef struct s3r_conv_desc {
     int32_t k, stride, pad;
     int32_t act;       /* s3r_act */
     int32_t tag;       /* caller's label, echoed by the profiler */
-    int32_t tile;      /* -1: library picks; >=0 (tuning): S3R_F32: MFMA tile cfg 0..7 + 16*gather_width;
-                          S3R_BF16: 1,2,4 per-tap gather x128 positions (3: 128x128 couts; +16: 32-channel K tiles),
-                          9,10 row-reuse gather, 5,6 / 21,22 plane-reuse gather (64- / 32-channel K tiles),
-                          23 plane-reuse 256x128 couts; 30, 31 plane-reuse over a parity-split input (x64 / x128 couts) */
+    int32_t tile;      /* -1: library picks; >=0 (tuning): S3R_F32 direct kernel: MFMA tile cfg 0..7 + 16*gather_width (algo =
+                          WINOGRAD: the launch form, see s3r_algo); S3R_BF16: 1,2,4 per-tap gather x128 positions (3: 128x128
+                          couts; +16: 32-channel K tiles), 9,10 row-reuse gather, 5,6 / 21,22 plane-reuse gather (64- / 32-channel
+                          K tiles), 23 plane-reuse 256x128 couts, 40 row-persistent (e2's geometry) */
     int32_t in_halo;   /* zero halo of the input buffer  (elements per spatial axis side) */
     int32_t out_halo;  /* zero halo of the output buffer */
     int32_t ksplit;    /* 0: library picks; >=1: force the split-K factor (must divide cin/16; bf16: cin/32) */
     int32_t dtype;     /* s3r_dtype: which path (layout + matrix instruction) the layer runs on */
-    int32_t in_layout; /* s3r_layout of the input buffer  (S2D: stride-2 k3 p1 convolutions, in_halo must be 1) */
-    int32_t out_layout;/* s3r_layout of the output buffer (S2D: MFMA convolutions, out_halo must be 1) */
+    int32_t in_layout; /* s3r_layout of the input buffer  (WINO_H: fp32 k3 s1 p1 convolutions, in_halo must be 1) */
+    int32_t out_layout;/* s3r_layout of the output buffer (PLAIN) */
     int32_t algo;      /* s3r_algo (ABI 7): AUTO = the library's geometry-only policy */
 } s3r_conv_desc;
 

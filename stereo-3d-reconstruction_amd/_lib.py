@@ -121,7 +121,7 @@ def check(rc, what=""):
     return rc
 
 
-LAYOUT_PLAIN, LAYOUT_S2D, LAYOUT_WINO_H = 0, 1, 2
+LAYOUT_PLAIN, LAYOUT_WINO_H = 0, 2
 
 
 def make_desc(layer, batch, in_size, tag=0, tile=-1, in_halo=0, out_halo=0, ksplit=0, dtype=0, in_layout=0, out_layout=0,

@@ -121,11 +121,10 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
     if (d->in_halo < 0 || d->out_halo < 0 || d->in_halo > 8 || d->out_halo > 8)
         return fail(S3R_ERR_INVALID, "halo must be in [0, 8]");
     if (d->dtype != S3R_F32 && d->dtype != S3R_BF16) return fail(S3R_ERR_INVALID, "unknown dtype %d", d->dtype);
-    if ((d->in_layout != S3R_LAYOUT_PLAIN && d->in_layout != S3R_LAYOUT_S2D && d->in_layout != S3R_LAYOUT_WINO_H) ||
-        (d->out_layout != S3R_LAYOUT_PLAIN && d->out_layout != S3R_LAYOUT_S2D))
+    if ((d->in_layout != S3R_LAYOUT_PLAIN && d->in_layout != S3R_LAYOUT_WINO_H) || d->out_layout != S3R_LAYOUT_PLAIN)
         return fail(S3R_ERR_INVALID, "unknown layout");
     if ((d->in_layout || d->out_layout) && d->op == S3R_OP_LINEAR)
-        return fail(S3R_ERR_INVALID, "the parity-split layout exists on the convolution paths only");
+        return fail(S3R_ERR_INVALID, "the transformed input layout exists on the convolution paths only");
     if (d->op == S3R_OP_LINEAR) {
         if (d->in_halo || d->out_halo) return fail(S3R_ERR_INVALID, "linear layers take no halo");
         g->nd = 0; g->in = g->out = g->in_p = g->out_p = 1; g->in_sp = 1; g->out_sp = 1;
@@ -159,17 +158,6 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
             return fail(S3R_ERR_INVALID, "a Winograd-transformed input serves an fp32 Conv k=3 s=1 p=1 over an even edge, in_halo = 1");
         if (g->in % wino_r(d) != 0) return fail(S3R_ERR_INVALID, "a Winograd-transformed input needs an edge that is a multiple of %d", wino_r(d));
         g->x_elems = (wino_r(d) + 2) * (int64_t)d->batch * d->cin * (g->nd == 3 ? g->in_p : 1) * (g->in / wino_r(d)) * g->in_p;
-    }
-    if (d->in_layout == S3R_LAYOUT_S2D) {        // what a stride-2 k3 p1 convolution reads
-        if (d->op != S3R_OP_CONV || d->stride != 2 || d->k != 3 || d->pad != 1 || (g->in & 1) || d->in_halo != 1)
-            return fail(S3R_ERR_INVALID, "a parity-split input serves Conv k=3 s=2 p=1 over an even edge, in_halo = 1");
-        // bf16: (B, 2^nd, (n/2 + 2)^nd, C); fp32: the plain padded tensor with every row stored even columns first
-        if (d->dtype == S3R_BF16) g->x_elems = (int64_t)d->batch * d->cin * ipow(2, g->nd) * ipow(g->in / 2 + 2, g->nd);
-    }
-    if (d->out_layout == S3R_LAYOUT_S2D) {
-        if ((g->out & 1) || d->out_halo != 1) return fail(S3R_ERR_INVALID, "a parity-split output needs an even edge and out_halo = 1");
-        if (d->dtype == S3R_BF16) g->y_elems = (int64_t)d->batch * d->cout * ipow(2, g->nd) * ipow(g->out / 2 + 2, g->nd);
-        else if (d->op != S3R_OP_CONV) return fail(S3R_ERR_INVALID, "fp32 path: a parity-split output is written by convolutions only");
     }
     g->w_elems = (int64_t)d->cin * d->cout * ipow(d->k, g->nd);
     if (d->op == S3R_OP_DECONV)
@@ -211,7 +199,7 @@ int need_halo(const s3r_conv_desc* d, Route r) {
 
 int check_halos(const s3r_conv_desc* d, Route r) {
     if ((d->in_layout || d->out_layout) && r != R_MFMA)
-        return fail(S3R_ERR_INVALID, "the parity-split layout is read and written by the MFMA convolution kernels only");
+        return fail(S3R_ERR_INVALID, "the transformed input layout is read by the MFMA convolution kernels only");
     if (d->in_halo < need_halo(d, r))
         return fail(S3R_ERR_INVALID, "this layer's kernel reads its zero padding from memory: the input must carry a "
                     "zero halo of >= %d (got in_halo=%d); s3r_chain_forward pads unpadded inputs itself",
@@ -397,14 +385,6 @@ s3r::ConvParamsH make_params_h(const s3r_conv_desc* d, const Geo& g) {
     p.y_ws = d->cout; p.y_hs = g.out_p * d->cout; p.y_ds = is3 ? g.out_p * g.out_p * d->cout : 0;
     p.y_bs = (int)ipow(g.out_p, g.nd) * d->cout;
     p.y_org = d->out_halo * (p.y_ds + p.y_hs + p.y_ws);
-    if (d->out_layout == S3R_LAYOUT_S2D) {       // strides of ONE parity class's (n/2 + 2)^nd sub-tensor; y_cs between classes
-        const int e = g.out / 2 + 2;
-        p.y_s2d = 1;
-        p.y_hs = e * d->cout; p.y_ds = is3 ? e * e * d->cout : 0;
-        p.y_cs = (int)ipow(e, g.nd) * d->cout;
-        p.y_bs = (int)ipow(2, g.nd) * p.y_cs;
-        p.y_org = p.y_ds + p.y_hs + p.y_ws;
-    }
     p.x_bytes = (unsigned)(g.x_elems * 2);
     if (d->op == S3R_OP_DECONV) {
         p.transposed = 1;
@@ -418,38 +398,6 @@ s3r::ConvParamsH make_params_h(const s3r_conv_desc* d, const Geo& g) {
         p.kd = is3 ? d->k : 1; p.kh = d->k; p.kw = d->k; p.T = p.kd * p.kh * p.kw;
         p.stride = d->stride;
         p.x_org = (d->in_halo - d->pad) * (p.x_ds + p.x_hs + p.x_ws);
-    }
-    if (d->in_layout == S3R_LAYOUT_S2D) {
-        // stride-2 k3 p1 over a parity-split input: along an axis, output o reads parity 0 at sub-index o (tap k = 1) and
-        // parity 1 at sub-indices o - 1, o (taps k = 0, 2); with the sub-tensors' halo of 1 the padded sub-index is
-        // o + off + 1.  The kernel walks the OUTPUT grid at stride 1 over one class sub-tensor at a time: group =
-        // (class, depth tap), taps = that class's (kh, kw) pairs, image row of tap = lrow + hoff * pitch + woff.
-        const int e = g.in / 2 + 2;
-        p.s2d = 1;
-        p.stride = 1;
-        p.x_ws = d->cin; p.x_hs = e * d->cin; p.x_ds = is3 ? e * e * d->cin : 0;
-        p.x_cs = (int)ipow(e, g.nd) * d->cin;
-        p.x_bs = (int)ipow(2, g.nd) * p.x_cs;
-        p.x_org = 0;
-        static const int kk[2][2] = {{1, -1}, {0, 2}}, oo[2][2] = {{1, -1}, {0, 1}};     // [parity][i]: tap index, padded offset
-        int ng = 0, nt = 0;
-        for (int cls = 0; cls < (is3 ? 8 : 4); ++cls) {
-            const int pdp = (cls >> 2) & 1, php = (cls >> 1) & 1, pwp = cls & 1;
-            for (int id = 0; id < (is3 && pdp ? 2 : 1); ++id) {
-                const int kd = is3 ? kk[pdp][id] : 0, doff = is3 ? oo[pdp][id] : 0;
-                p.tab.g_xoff[ng] = cls * p.x_cs + doff * p.x_ds;
-                p.tab.g_first[ng] = (unsigned char)nt;
-                for (int ih = 0; ih < (php ? 2 : 1); ++ih)
-                    for (int iw = 0; iw < (pwp ? 2 : 1); ++iw) {
-                        p.tab.tap_off[nt] = (short)(oo[php][ih] * e + oo[pwp][iw]);
-                        p.tab.tap_w[nt] = (unsigned char)((kd * 3 + kk[php][ih]) * 3 + kk[pwp][iw]);
-                        ++nt;
-                    }
-                p.tab.g_ntaps[ng] = (unsigned char)(nt - p.tab.g_first[ng]);
-                ++ng;
-            }
-        }
-        p.tab.ngroups = ng;                       // 4 (2D) / 12 (3D) image loads per 32-channel chunk; nt == T
     }
     p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
     p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
@@ -472,15 +420,11 @@ int resolve_launch_h(const s3r_conv_desc* d, s3r::ConvParamsH* p, LaunchH* L) {
     p->ksplit = L->ksplit;
     if (d->tile >= 0 && d->tile != 1 && d->tile != 2 && d->tile != 3 && d->tile != 19 && d->tile != 4 && d->tile != 5 && d->tile != 6 && d->tile != 9 &&
         d->tile != 10 && d->tile != 17 && d->tile != 18 && d->tile != 20 && d->tile != 21 && d->tile != 22 && d->tile != 23 &&
-        d->tile != 30 && d->tile != 31 && d->tile != 40 && d->tile != 42 && d->tile != 43)
+        d->tile != 40)
         return fail(S3R_ERR_INVALID, "bf16 path: tile must be -1 (auto), 1, 2, 4 (x128 positions, per-tap gather), 3 (128 x 128 couts), 5, 6 "
                     "(x128 positions = 1, 2, plane-reuse gather) or 9, 10 (row-reuse gather); per-tap / plane + 16 = "
-                    "32-channel K tiles; 40 (row-persistent e2), 42, 43 (persistent plane kernel, transposed)");
+                    "32-channel K tiles; 40 (row-persistent e2)");
     L->tm = d->tile >= 0 ? d->tile : s3r::conv_bf16_pick_tm(*p);
-    if (d->in_layout == S3R_LAYOUT_S2D && L->tm != 30 && L->tm != 31)
-        return fail(S3R_ERR_INVALID, "a parity-split input is read by tile codes 30 / 31 only");
-    if (d->in_layout != S3R_LAYOUT_S2D && (L->tm == 30 || L->tm == 31))
-        return fail(S3R_ERR_INVALID, "tile codes 30 / 31 read a parity-split input (in_layout = S3R_LAYOUT_S2D)");
     return S3R_OK;
 }
 
@@ -515,9 +459,6 @@ s3r::ConvParams make_params(const s3r_conv_desc* d, const Geo& g) {
     p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
     p.dW = s3r::FastDiv((unsigned)p.Nw);
     p.ksplit = 1;
-    // W-parity-split rows (fp32 form of S3R_LAYOUT_S2D): same strides, columns rearranged inside every padded row
-    if (d->in_layout == S3R_LAYOUT_S2D) { p.x_wsplit = 1; p.x_wh = g.in_p / 2; }
-    if (d->out_layout == S3R_LAYOUT_S2D) { p.y_wsplit = 1; p.y_wh = g.out_p / 2; }
     return p;
 }
 
@@ -566,63 +507,6 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
         int rc = route(&pl->d[i], &pl->r[i]);
         if (rc) return rc;
     }
-    // Parity-split hand-off (bf16 path): a convolution whose consumer is a stride-2 k3 p1 convolution writes its output
-    // as 2^nd parity-class sub-tensors (S3R_LAYOUT_S2D), and the consumer reads it with the plane-reuse kernel — the
-    // input then crosses L2 -> LDS once per 9/4 (27/12) taps instead of once per tap.  Decided from per-sample geometry
-    // only; a caller who forces another tile on the consumer keeps the plain layout.
-    for (int i = 0; i + 1 < n; ++i) {
-        s3r_conv_desc& pr = pl->d[i];
-        s3r_conv_desc& c = pl->d[i + 1];
-        if (pr.dtype != S3R_BF16 || c.dtype != S3R_BF16 || pl->r[i] != R_MFMA || pl->r[i + 1] != R_MFMA) continue;
-        if (pr.op != S3R_OP_CONV || c.op != S3R_OP_CONV || pr.ndim != c.ndim || pr.cout != c.cin) continue;
-        if (c.stride != 2 || c.k != 3 || c.pad != 1 || (c.in_size & 1) || c.cin % 32 != 0) continue;
-        if (pr.stride <= 0 || pr.k <= 0 || out_size(&pr) != c.in_size) continue;
-        // MEASURED SLOWER (r02, B = 256: e3 0.295 -> 0.41 ms, e5 0.186 -> 0.33, v2 0.387 -> 0.64, v4 0.184 -> 0.33): a class
-        // image serves only 1-4 taps, and the plane kernel's single-buffered image exposes one L2 / HBM round trip per
-        // image.  So the hand-off is planned only on request — the consumer's tile forced to 30 / 31, or S3R_S2D=1 —
-        // and the per-tap family remains the default for stride-2 layers.
-        static const bool s2d_env = getenv("S3R_S2D") && atoi(getenv("S3R_S2D")) != 0;
-        if (!(c.tile == 30 || c.tile == 31 || (s2d_env && c.tile < 0))) continue;
-        s3r_conv_desc t = c;
-        t.batch = 1; t.in_layout = S3R_LAYOUT_S2D; t.in_halo = 1; t.out_halo = 0; t.out_layout = S3R_LAYOUT_PLAIN;
-        Geo tg;
-        if (geometry(&t, &tg) != S3R_OK) continue;
-        const s3r::ConvParamsH tp = make_params_h(&t, tg);
-        if (!s3r::conv_bf16_s2d_ok(tp)) continue;
-        pr.out_layout = S3R_LAYOUT_S2D;
-        c.in_layout = S3R_LAYOUT_S2D;
-    }
-    // W-parity-split hand-off (fp32 path): a convolution whose consumer is a stride-2 k3 p1 convolution writes every padded
-    // row as its even columns followed by its odd ones; the consumer's taps then read consecutive dwords for consecutive
-    // output positions, like a stride-1 layer (16-byte LDS-DMA gathers where Nw % 4 == 0; whole lines instead of every
-    // other dword everywhere).  The K order is unchanged: results are bit-identical to the plain layout.  Decided from
-    // per-sample geometry only.
-    // MEASURED NO GAIN (r03, B = 32, three A/B pairs of bench.py on one device): alone, the consumers are 2-8 % faster
-    // (e3 0.149 -> 0.138 ms, e5 0.145 -> 0.133, v2 0.326 -> 0.310, v4 0.179 -> 0.176: tools/layer_bench.py --wsplit), but
-    // inside the forward they are not (e3 0.1353 -> 0.1358, e5 0.134 -> 0.141, v4 0.179 -> 0.183: their input is then
-    // served from the Infinity Cache and what bounds a 64 x 64-tile, K = 576 layer is its per-workgroup fixed cost, not
-    // the width of its gathers), while the producers' split stores cost e2 +0.012 and v1 +0.008 ms: 5.98 -> 6.01 ms per
-    // step.  So the hand-off is planned only on request (S3R_WSPLIT=1); the plain layout stays the default.
-    static const bool wsplit_off = !(getenv("S3R_WSPLIT") && atoi(getenv("S3R_WSPLIT")) != 0);
-    for (int i = 0; i + 1 < n && !wsplit_off; ++i) {
-        s3r_conv_desc& pr = pl->d[i];
-        s3r_conv_desc& c = pl->d[i + 1];
-        if (pr.dtype != S3R_F32 || c.dtype != S3R_F32 || pl->r[i] != R_MFMA || pl->r[i + 1] != R_MFMA) continue;
-        if (pr.op != S3R_OP_CONV || c.op != S3R_OP_CONV || pr.ndim != c.ndim || pr.cout != c.cin) continue;
-        if (c.stride != 2 || c.k != 3 || c.pad != 1 || (c.in_size & 1)) continue;
-        if (pr.stride <= 0 || pr.k <= 0 || out_size(&pr) != c.in_size) continue;
-        {   // the producer's split-K finish kernel writes the plain layout only
-            s3r_conv_desc t = pr;
-            t.in_halo = need_halo(&pr, R_MFMA); t.out_halo = 1;
-            Geo tg;
-            if (geometry(&t, &tg) != S3R_OK) continue;
-            s3r::ConvParams tp = make_params(&t, tg);
-            Launch tl;
-            if (resolve_launch(&t, &tp, &tl) != S3R_OK || tl.ksplit != 1) continue;
-        }
-        pr.out_layout = S3R_LAYOUT_S2D;
-        c.in_layout = S3R_LAYOUT_S2D;
-    }
     const int need0 = need_halo(&pl->d[0], pl->r[0]);
     pl->pad_input = pl->d[0].in_halo < need0;
     const int user_in_halo = pl->d[0].in_halo;
@@ -663,7 +547,7 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
     }
     int64_t off = 0;
     if (pl->pad_input && pl->d[0].in_layout != S3R_LAYOUT_PLAIN)
-        return fail(S3R_ERR_INVALID, "a parity-split chain input must come with its halo (in_halo = 1)");
+        return fail(S3R_ERR_INVALID, "a transformed chain input must come with its halo (in_halo = 1)");
     if (pl->pad_input) {
         if (user_in_halo != 0) return fail(S3R_ERR_INVALID, "chain input halo %d is smaller than the %d its first layer needs",
                                            user_in_halo, need0);
@@ -1007,8 +891,6 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                     return fail(S3R_ERR_WORKSPACE, "ksplit=%d needs %lld floats of scratch (s3r_conv_scratch_elems), got %lld", L.ksplit,
                                 (long long)need, (long long)(scratch ? scratch_elems : 0));
             }
-            if (p.y_wsplit && L.ksplit > 1)
-                return fail(S3R_ERR_INVALID, "fp32 path: a parity-split output cannot be combined with split-K (ksplit=%d)", L.ksplit);
             ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
             e = s3r::launch_conv_mfma(p, L.cfg + 16 * L.vec, s);
             ps.launches = s3r::conv_last_launch_count();

@@ -116,10 +116,6 @@ constexpr int HBN = 64;    // couts per workgroup
 
 // element offset of output position (b, pd, ph, pw) [of parity class (rd, rh, rw) for a transposed conv] in p.y
 __device__ __forceinline__ int out_offset(const ConvParamsH& p, int b, int pd, int ph, int pw, int rd, int rh, int rw) {
-    if (p.y_s2d) {              // parity-split output (S3R_LAYOUT_S2D): the position's class sub-tensor, at half its index
-        const int cls = ((pd & 1) << 2) | ((ph & 1) << 1) | (pw & 1);
-        return b * p.y_bs + cls * p.y_cs + p.y_org + (pd >> 1) * p.y_ds + (ph >> 1) * p.y_hs + (pw >> 1) * p.y_ws;
-    }
     const int ostep = p.transposed ? 2 : 1;
     int ye = b * p.y_bs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw * p.y_ws) * ostep;
     if (p.transposed) ye += rd * p.y_ds + rh * p.y_hs + rw * p.y_ws;
@@ -750,18 +746,13 @@ constexpr int PL_NB = 3;       // weight ring slots
 // KC = 64: 128-byte image rows (whole lines), two workgroups per CU; KC = 32: 64-byte rows, half the LDS, three
 // workgroups per CU (and the only form for Cin = 32).
 // NH = 64-cout halves per workgroup (2: a 256 x 128 tile, the image serves twice the couts; two workgroups per CU).
-// S2D: the input is PARITY-SPLIT (S3R_LAYOUT_S2D) and the layer a stride-2 k3 p1 convolution: the kernel walks the output
-// grid at stride 1 over one class sub-tensor at a time, following p.tab: a group = (32-channel chunk, class, depth tap),
-// its image = that class's plane, its taps = the class's (kh, kw) pairs (1, 2, 2 or 4 of them) — the input crosses
-// L2 -> LDS once per 9/4 taps (27/12 in 3D) in contiguous runs, where the per-tap kernel gathers it once per tap.
 // HEAD: the fused pointwise-head epilogue is its own instantiation (d3 only).  Compiled into the same kernel behind a
 // run-time test (r01), the two epilogues shared one register allocation at the 168-VGPR cap of three waves per SIMD
 // and every layer's kernel spilled 40 bytes per lane to scratch; now the plain kernel needs 113 VGPRs and none.  The
 // head instantiation still spills its 40 bytes at three waves per SIMD — measured faster (d3 1.32 vs 1.45 ms) than
 // giving it 176 registers at two.
-template <int SH, int TM, int KC, int NH, bool S2D = false, bool HEAD = false>
+template <int SH, int TM, int KC, int NH, bool HEAD = false>
 __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p_kernel(const ConvParamsH p, int r_max) {
-    static_assert(!S2D || KC == 32, "the parity-split schedule is built for 32-channel chunks");
     static_assert(!HEAD || NH == 1, "the fused head needs the whole channel axis in one 64-cout tile");
     typedef Mf<SH> M;
     constexpr int MT = M::MT;
@@ -823,12 +814,12 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
     const int T = p.T, kh = p.kh, kw = p.kw;
     const int taps_g = kh * kw;
     const int chunks = (p.Cin / KC) / p.ksplit;
-    const int gpc = S2D ? p.tab.ngroups : p.kd;              // groups (image loads) per chunk
+    const int gpc = p.kd;                                    // groups (image loads) per chunk
     const int ngroups = S3R_ABLH(p, 2) ? 1 : chunks * gpc;
-    const int total = S2D ? (S3R_ABLH(p, 2) ? p.tab.g_ntaps[0] : chunks * T) : ngroups * taps_g;
+    const int total = ngroups * taps_g;
     const int cls_x = p.transposed ? (rd - 1) * p.x_ds + (rh - 1) * p.x_hs + (rw - 1) * p.x_ws : 0;
     const int in_p = p.x_hs / p.x_ws;                        // padded input row length, in positions
-    const int halo = S2D ? in_p + 1 : (kh - 1) * in_p + kw - 1;
+    const int halo = (kh - 1) * in_p + kw - 1;
     const int umax = (p.Nh - 1) * in_p + p.Nw - 1;
     const int LP = umax + 1 + halo;                          // image rows of a whole plane
 
@@ -869,8 +860,7 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
         (int)((unsigned)T * (unsigned)(p.Cin / HKC) * (unsigned)w_tile), 0x00020000);
     int b_cc = kz * chunks, b_tap = 0, b_slot = 0;            // cursor of the NEXT weight tile to fetch
     auto issue_b = [&]() {
-        const int wt = S2D ? (int)p.tab.tap_w[b_tap] : b_tap;     // (S2D: b_tap counts the chunk's taps in schedule order)
-        const int b_base = ((b_cc * (KC / 32) * T + wt) * p.n_tiles + n_tile) * 4096;
+        const int b_base = ((b_cc * (KC / 32) * T + b_tap) * p.n_tiles + n_tile) * 4096;
 #pragma unroll
         for (int q = 0; q < NPB; ++q) dma16(wrsrc, Bs + b_slot * B_BYTES + ((wave + 4 * q) << 10), bvoff[q], b_base);
         if (++b_tap == T) { b_tap = 0; ++b_cc; }
@@ -932,7 +922,7 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     int a_cc = kz * chunks, a_td = 0;                         // cursor of the NEXT image to fetch
     auto issue_a = [&]() {
-        const int a_base = (a_cc * KC + (S2D ? p.tab.g_xoff[a_td] : a_td * p.x_ds)) * 2;
+        const int a_base = (a_cc * KC + a_td * p.x_ds) * 2;
 #pragma unroll
         for (int q = 0; q < NPA_CAP; ++q)
             if ((wave + 4 * q) * RPP < r_max) dma16(xrsrc, smem + ((wave + 4 * q) << 10), avoff[q], a_base);
@@ -955,14 +945,11 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
                                                               //  behind the loop's first barrier)
 
     __builtin_amdgcn_s_setprio(0);
-    int tt = 0, c_slot = 0, gi = 0;
+    int tt = 0, c_slot = 0;
     for (int g = 0; g < ngroups; ++g) {
         int tapoff = 0, c_tw = 0;
-        const int ntaps = S2D ? (int)p.tab.g_ntaps[gi] : taps_g;
-        const int tfirst = S2D ? (int)p.tab.g_first[gi] : 0;
-        if (++gi == gpc) gi = 0;
+        const int ntaps = taps_g;
         for (int t = 0; t < ntaps; ++t, ++tt) {
-            if constexpr (S2D) tapoff = p.tab.tap_off[tfirst + t];
             // this tap's weights (and, at t == 0, the image) have landed; the next tap's may still be in flight.
             // (s_barrier as inline asm: the compiler drains vmcnt before every barrier it knows about, which
             // would cut the weight prefetch back to one tap)
@@ -1017,10 +1004,8 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
                 __builtin_amdgcn_sched_group_barrier(0x008, NCT * NH * NPT, 0);
             }
             if (++c_slot == PL_NB) c_slot = 0;
-            if constexpr (!S2D) {
-                ++tapoff;
-                if (++c_tw == kw) { c_tw = 0; tapoff += in_p - kw; }
-            }
+            ++tapoff;
+            if (++c_tw == kw) { c_tw = 0; tapoff += in_p - kw; }
         }
         asm volatile("s_barrier" ::: "memory");               // every wave is done with this image
         if (g + 1 < ngroups && !S3R_ABLH(p, 3)) issue_a();
@@ -1048,249 +1033,6 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
         for (int i = 0; i < 6; ++i) t[1 + i] = tl[i];
     }
 #endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// Persistent form of the plane-reuse kernel for the transposed convolutions (d1, d2, d3 with its fused head).  Their tiles
-// are ALIGNED: 256 positions of one output-parity class are a whole number of (sample, depth) planes (d3: one 16 x 16
-// plane; d2: four 8 x 8; d1: sixteen 4 x 4, i.e. four samples), so the three position tables of the plane kernel — LDS row
-// of a tile position, output offset of a tile position, source of an image row — are the same for EVERY tile up to one
-// scalar base each.  In the plane kernel a d3 workgroup lives 38.6 us around 26.9 us of K loop (tables 3.9, first image
-// 1.8, epilogue 5.8: tools/timeline_bf16.py) and the layer launches 32 768 of them.  Here a workgroup
-//   * builds the tables ONCE, then walks its XCD's run of work items (tile, class) — the same class-adjacent order;
-//   * requests the NEXT item's first two weight tiles and its image right behind the last barrier of the current K loop,
-//     i.e. under the current epilogue (the epilogue stages through its own LDS, not through the idle operand buffers);
-//   * moves two scalars per item (image base, output base) and rebuilds the weight descriptor of the item's class.
-// The K order is the plane kernel's (chunk-major, depth tap, then the 4 in-plane taps; two 16-channel k-steps per tap), so
-// the two are bit-identical (tests/test_bf16_gpu.py::test_persistent_deconv_kernel_equals_the_plane_kernel_bitwise).
-// MEASURED SLOWER, ON REQUEST ONLY (tile codes 42 / 43; never the library's own pick).  B = 256, same device, inside the
-// forward: d3 + head 1.153 vs 1.024 ms, d2 0.479 vs 0.465, d1 0.241 vs 0.239 (plane kernel codes 22 / 23); alone (no head):
-// d3 1.41 vs 1.04, d2 0.505 vs 0.491, d1 0.252 vs 0.248; delaying the k-th round of co-resident workgroups by 3 - 15 us
-// changes nothing.  A CU that hosts two or three plane-kernel workgroups already hides one's tables, first image and
-// epilogue behind the others' K loops as far as the matrix pipe allows; what persistence adds is its
-// cost: the invariants live across the epilogue (148 VGPRs against 113; the fused-head form spills 55 registers per item
-// where the plane kernel spills 10), a grid that must be resident at once (sized by the occupancy query below), and the
-// hardware's dynamic balancing of 32 768 short workgroups replaced by a static split.
-template <int SH, int NH, bool HEAD>
-__global__ __launch_bounds__(256, NH == 2 ? 2 : 3) void conv_bf16d_kernel(const ConvParamsH p, int r_max) {
-    static_assert(!HEAD || NH == 1, "the fused head needs the whole channel axis in one 64-cout tile");
-    typedef Mf<SH> M;
-    constexpr int MT = M::MT, TM = 2, KC = 32;
-    constexpr int NPT = 32 * TM / MT, NCT = 64 / MT, NKS = KC / M::KS;
-    constexpr int BM = 128 * TM, BNW = HBN * NH, ROWB = KC * 2;
-    constexpr int B_BYTES = BNW * ROWB, NPB = B_BYTES / 4096;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int a_bytes = r_max * ROWB;
-    char* Bs = smem + a_bytes;                                        // [PL_NB][BNW][ROWB]
-    int* yoff = reinterpret_cast<int*>(Bs + PL_NB * B_BYTES);         // [BM] output offset of a tile position, tile-relative
-    int* lrow = yoff + BM;                                            // [BM] LDS row of a tile position (tap 0,0)
-    float* ep = reinterpret_cast<float*>(lrow + BM);                  // [NH][3][64]
-    int* asrc = reinterpret_cast<int*>(ep + 192 * NH);                // [r_max] source byte offset of each image row, tile-relative
-    int* ctab = asrc + r_max;                                         // [8][2] per class: image base (bytes), output base (elements)
-    char* stage = reinterpret_cast<char*>(ctab + 16);                 // [4][32][ST_ROW] (plain epilogue only)
-
-    const int xcd = blockIdx.x & 7, wgs_x = gridDim.x >> 3;           // (launcher: gridDim.x % 8 == 0, wgs_x <= run)
-    const int run = p.m_tiles;                                        // items (tile, class) per XCD: 8 * m_tiles / 8
-    int idx = blockIdx.x >> 3;                                        // this workgroup's position in its XCD's run
-    if (idx >= run) return;
-
-    __builtin_amdgcn_s_setprio(S3R_PRIO_EDGE);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane % MT, lk = lane / MT;
-    const int n_tile = blockIdx.y * NH, n0 = n_tile * HBN;
-
-    const int P = p.Nh * p.Nw;
-    const int T = p.T, kh = p.kh, kw = p.kw;
-    const int taps_g = kh * kw, chunks = p.Cin / KC, gpc = p.kd;
-    const int ngroups = chunks * gpc, total = ngroups * taps_g;
-    const int in_p = p.x_hs / p.x_ws;
-    const int halo = (kh - 1) * in_p + kw - 1;
-    const int LP = (p.Nh - 1) * in_p + p.Nw + halo;                   // image rows of a whole plane
-    const int ppt = BM / P;                                           // planes per tile
-
-    const EpRegs epr = load_ep(p, tid, n0, BNW);
-    for (int t = tid; t < BM; t += 256) {
-        const int dpl = p.dHW.div(t);
-        const int rem = t - dpl * P;
-        const int ph = p.dW.div(rem), pw = rem - ph * p.Nw;
-        const int db = p.dS.div(t), dpd = dpl - db * p.Nd;            // (ppt divides Nd: db = 0; Nd divides ppt: whole samples)
-        yoff[t] = db * p.y_bs + (dpd * p.y_ds + ph * p.y_hs + pw * p.y_ws) * 2;
-        lrow[t] = dpl * LP + ph * in_p + pw;
-    }
-    for (int j = tid; j < r_max; j += 256) {
-        int sgm = j / LP, off = j - sgm * LP;
-        if (sgm >= ppt) { sgm = 0; off = 0; }                        // past the image: any valid address, never read
-        const int db = sgm / p.Nd, dpd = sgm - db * p.Nd;
-        asrc[j] = (db * p.x_bs + dpd * p.x_ds + off * p.x_ws) * 2;
-    }
-    if (tid < 8) {                                                    // what an item's class adds to its two bases
-        const int rd = (tid >> 2) & 1, rh = (tid >> 1) & 1, rw = tid & 1;
-        ctab[2 * tid] = (p.x_org + (rd - 1) * p.x_ds + (rh - 1) * p.x_hs + (rw - 1) * p.x_ws) * 2;
-        ctab[2 * tid + 1] = p.y_org + rd * p.y_ds + rh * p.y_hs + rw * p.y_ws;
-    }
-    store_ep(epr, ep, tid, BNW);                                      // (__syncthreads inside: also publishes the tables)
-
-    // The per-lane loop invariants (image-piece sources, LDS rows of the lane's positions, weight-fragment offsets) are
-    // re-read from LDS at the top of every item instead of being kept across the epilogue: held live there they push the
-    // kernel past its register budget (168 VGPRs at three workgroups per CU) into scratch.
-    int avoff[NPA_PL32], lr[NPT], b_off[NCT * NH];
-    auto load_invariants = [&]() {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));                                  // (opaque: keeps the ALU halves from being hoisted out of the
-        const int l_i = ln % MT, l_k = ln / MT;                       //  item loop and held in registers across the epilogue)
-#pragma unroll
-        for (int q = 0; q < NPA_PL32; ++q) {
-            const int j = (wave + 4 * q) * 16 + (ln >> 2);
-            avoff[q] = (j < r_max ? asrc[j] : 0) + (((ln & 3) ^ swz<KC>(j)) << 4);
-        }
-#pragma unroll
-        for (int pt = 0; pt < NPT; ++pt) lr[pt] = lrow[wave * 32 * TM + pt * MT + l_i];
-#pragma unroll
-        for (int ct = 0; ct < NCT * NH; ++ct) {
-            const int row = ct * MT + l_i;
-            b_off[ct] = row * ROWB + ((l_k ^ swz<KC>(row)) << 4);
-        }
-    };
-    load_invariants();
-    const int bvoff0 = wave * 1024 + lane * 16;                       // weight pieces are stored pre-swizzled for 64-byte rows
-
-    const int w_tile = p.n_tiles * 4096;
-    const unsigned w_bytes = (unsigned)T * (unsigned)(p.Cin / HKC) * (unsigned)w_tile;
-    const __amdgpu_buffer_rsrc_t xrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
-
-    // ---- per item: class, image base (bytes), output base (elements), weight descriptor of the class.  The strides are
-    // re-read from the kernel arguments' LDS copy (ctab) / recomputed per item rather than held in scalar registers across
-    // the K loop: the kernel is short of those (the compiler otherwise spills them to VGPR lanes and moves loop counters
-    // into vector registers, which turns every LDS-DMA into a waterfall loop).
-    const int lg_nd = 31 - __builtin_clz((unsigned)p.Nd);             // (launcher: Nd is a power of two)
-    int cls = 0, a_item = 0, ybase = 0;
-    __amdgpu_buffer_rsrc_t wrsrc;
-    auto setup = [&](int i) {
-        const int item = xcd * run + i;
-        const int tile = item >> 3;
-        cls = item & 7;
-        const int pl0 = tile * ppt, b0 = pl0 >> lg_nd, pd0 = pl0 & (p.Nd - 1);
-        const int2 ct = *reinterpret_cast<const int2*>(ctab + 2 * cls);
-        a_item = __builtin_amdgcn_readfirstlane((b0 * p.x_bs + pd0 * p.x_ds) * 2 + ct.x);
-        ybase = __builtin_amdgcn_readfirstlane(b0 * p.y_bs + pd0 * p.y_ds * 2 + ct.y);
-        wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(reinterpret_cast<const char*>(p.w) + (size_t)cls * w_bytes), 0, (int)w_bytes, 0x00020000);
-    };
-    int b_cc = 0, b_tap = 0, b_slot = 0;                              // cursor of the NEXT weight tile to fetch
-    auto issue_b = [&]() {
-        const int b_base = __builtin_amdgcn_readfirstlane(((b_cc * T + b_tap) * p.n_tiles + n_tile) * 4096);
-#pragma unroll
-        for (int q = 0; q < NPB; ++q) dma16(wrsrc, Bs + b_slot * B_BYTES + ((wave + 4 * q) << 10), bvoff0, b_base + q * 4096);
-        if (++b_tap == T) { b_tap = 0; ++b_cc; }
-        if (++b_slot == PL_NB) b_slot = 0;
-    };
-    int a_cc = 0, a_td = 0;                                           // cursor of the NEXT image to fetch
-    const int npa = (r_max / 16 - wave + 3) >> 2;                     // this wave's 16-row image pieces (dealt round-robin)
-    auto issue_a = [&]() {
-        const int a_base = __builtin_amdgcn_readfirstlane(a_item + (a_cc * KC + a_td * p.x_ds) * 2);   // (a counter the compiler
-                                                              //  moved to a vector register must not make each DMA a waterfall loop)
-        int n = npa;
-        asm volatile("" : "+s"(n));                                   // (opaque: twelve hoisted lane masks cost 24 scalar registers)
-#pragma unroll
-        for (int q = 0; q < NPA_PL32; ++q)
-            if (q < n) dma16(xrsrc, smem + ((wave + 4 * q) << 10), avoff[q], a_base);
-        if (++a_td == gpc) { a_td = 0; ++a_cc; }
-    };
-    auto begin_item = [&](int i) {
-        setup(i);
-        b_cc = 0; b_tap = 0; b_slot = 0; a_cc = 0; a_td = 0;
-        issue_b();
-        if (total > 1) issue_b();
-        issue_a();
-    };
-    begin_item(idx);
-
-    for (;;) {
-        typename M::acc_t acc[NH][NPT][NCT];
-#pragma unroll
-        for (int nh = 0; nh < NH; ++nh)
-#pragma unroll
-            for (int a = 0; a < NPT; ++a)
-#pragma unroll
-                for (int b = 0; b < NCT; ++b)
-#pragma unroll
-                    for (int r = 0; r < M::NACC; ++r) acc[nh][a][b][r] = 0.f;
-        if (idx != (int)(blockIdx.x >> 3)) load_invariants();        // (first item: just loaded)
-        __builtin_amdgcn_s_setprio(0);
-        int tt = 0, c_slot = 0;
-        for (int g = 0; g < ngroups; ++g) {
-            int tapoff = 0, c_tw = 0;
-            for (int t = 0; t < taps_g; ++t, ++tt) {
-                // this tap's weights (and, at t == 0, the image) have landed; the next tap's may still be in flight.  (At
-                // the first tap of an item the count also covers the previous item's epilogue stores, issued after them.)
-                if (t == 0 || tt + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (NPB == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                asm volatile("s_barrier" ::: "memory");           // ... for every wave; ring slot (tt+2)%3 is free
-                if (tt + 2 < total) issue_b();
-                const char* b = Bs + c_slot * B_BYTES;
-                int a_off[NPT];
-#pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) {
-                    const int row = lr[pt] + tapoff;
-                    a_off[pt] = row * ROWB + ((lk ^ swz<KC>(row)) << 4);
-                }
-                bf16x8 av[2][NPT], bv[2][NCT * NH];
-#pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) av[0][pt] = *reinterpret_cast<const bf16x8*>(smem + a_off[pt]);
-#pragma unroll
-                for (int ct = 0; ct < NCT * NH; ++ct) bv[0][ct] = *reinterpret_cast<const bf16x8*>(b + b_off[ct]);
-#pragma unroll
-                for (int q = 0; q < NKS; ++q) {
-                    if (q < NKS - 1) {
-#pragma unroll
-                        for (int pt = 0; pt < NPT; ++pt)
-                            av[(q + 1) & 1][pt] = *reinterpret_cast<const bf16x8*>(smem + (a_off[pt] ^ ((q + 1) * M::NK * 16)));
-#pragma unroll
-                        for (int ct = 0; ct < NCT * NH; ++ct)
-                            bv[(q + 1) & 1][ct] = *reinterpret_cast<const bf16x8*>(b + (b_off[ct] ^ ((q + 1) * M::NK * 16)));
-                    }
-#pragma unroll
-                    for (int pt = 0; pt < NPT; ++pt)
-#pragma unroll
-                        for (int ct = 0; ct < NCT * NH; ++ct)
-                            acc[ct / NCT][pt][ct % NCT] = mma<SH>(bv[q & 1][ct], av[q & 1][pt], acc[ct / NCT][pt][ct % NCT]);
-                }
-                if constexpr (NKS > 1) {                          // (issue order pinned as in the plane kernel)
-                    __builtin_amdgcn_sched_group_barrier(0x100, NPT + NCT * NH, 0);
-#pragma unroll
-                    for (int q = 0; q < NKS - 1; ++q)
-#pragma unroll
-                        for (int i = 0; i < NCT * NH * NPT; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            if (i < NPT + NCT * NH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        }
-                    __builtin_amdgcn_sched_group_barrier(0x008, NCT * NH * NPT, 0);
-                }
-                if (++c_slot == PL_NB) c_slot = 0;
-                ++tapoff;
-                if (++c_tw == kw) { c_tw = 0; tapoff += in_p - kw; }
-            }
-            asm volatile("s_barrier" ::: "memory");               // every wave is done with this image
-            if (g + 1 < ngroups) issue_a();
-        }
-        // every wave is past the last barrier: the image and the whole weight ring are free.  The next item's first
-        // operands go out now and land under this item's epilogue.
-        __builtin_amdgcn_s_setprio(S3R_PRIO_EDGE);
-        const int ybase_cur = ybase, cls_cur = cls;
-        const int nidx = idx + wgs_x;
-        const bool more = nidx < run;
-        if (more) begin_item(nidx);
-#pragma unroll
-        for (int nh = 0; nh < NH; ++nh)
-            epilogue_h<SH, TM, HEAD>(p, acc[nh], yoff, ep + nh * 192, stage + wave * (32 * ST_ROW), wave, li, lk, 0, n0 + nh * HBN,
-                                     cls_cur, 0, BM, ybase_cur);
-        if (!more) break;
-        idx = nidx;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1473,7 +1215,6 @@ __global__ __launch_bounds__(256) void conv_finish_bf16_kernel(const ConvParamsH
 static int rowreuse_rows(const ConvParamsH& p, int bm);
 static int plane_rows(const ConvParamsH& p, int bm, int kc);
 static int rows_strips(const ConvParamsH& p);
-static bool persist_ok(const ConvParamsH& p, int nh);
 
 // Tile / gather choice (tools/layer_bench.py --dtype bf16, B = 256, MI355X):
 //   * stride-1 layers with 4+ taps per plane and K >= 256 whose 256-position plane image leaves room for THREE
@@ -1489,9 +1230,6 @@ int conv_bf16_pick_tm(const ConvParamsH& p) {
     const long classes = (p.transposed ? 8 : 1) * (long)p.ksplit;
     const long n_tiles = p.CoutPad / HBN;
     auto wgs = [&](int tm) { return ((p.Ntotal + 128 * tm - 1) / (128 * tm)) * n_tiles * classes; };
-    // a parity-split input has ONE reader (and one K order, whatever the batch): the plane kernel's S2D form; its
-    // 128-cout tile where the channel axis allows and the grid stays full
-    if (p.s2d) return (n_tiles % 2 == 0 && wgs(2) / 2 >= 512) ? 31 : 30;
     // The K summation order of a layer must not depend on the batch (a sample's result is batch-invariant): the
     // plane / row-reuse kernels and the 32-channel per-tap kernel accumulate chunk32-major, the 64-channel per-tap
     // kernel chunk64-major.  So the FAMILY is chosen from per-sample geometry, only the tile from the batch.
@@ -1516,16 +1254,7 @@ int conv_bf16_pick_tm(const ConvParamsH& p) {
     return 1;
 }
 
-// can the plane kernel read this (stride-2 k3 p1) layer from a parity-split input?  Decided from per-sample geometry
-// only (the layout of a layer's input must not depend on the batch): the 256-position image fits its LDS budget
-bool conv_bf16_s2d_ok(const ConvParamsH& p) {
-    if (!p.s2d || p.Cin % 32 != 0 || p.ksplit != 1) return false;
-    const int r = plane_rows(p, 256, 32);
-    return r > 0 && r <= 64 * NPA_PL32 && (size_t)r * 64 + PL_NB * HBN * 2 * 64 + 2 * 256 * sizeof(int) + 2 * EP_BYTES <= 160 * 1024;
-}
-
 int conv_bf16_pick_ksplit(const ConvParamsH& p) {
-    if (p.s2d) return 1;
     // per-sample geometry at a nominal batch (batch-invariant, as in the fp32 path); 128 here: this path's
     // named configuration is batch 256, where splitting v5 / v6 / d1 further costs 15-30 % of their time
     const int chunks = p.Cin / HKC;
@@ -1538,7 +1267,7 @@ int conv_bf16_pick_ksplit(const ConvParamsH& p) {
 
 int64_t conv_bf16_scratch_elems(const ConvParamsH& p, int tm) {
     if (p.ksplit <= 1) return 0;
-    const int t0 = (tm == 30 || tm == 31 || tm == 42 || tm == 43) ? 2 : tm == 23 ? 2 : tm >= 21 ? tm - 20 : (tm >= 16 ? tm - 16 : (tm >= 9 ? tm - 8 : (tm >= 5 ? tm - 4 : tm)));
+    const int t0 = tm == 23 ? 2 : tm >= 21 ? tm - 20 : (tm >= 16 ? tm - 16 : (tm >= 9 ? tm - 8 : (tm >= 5 ? tm - 4 : tm)));
     const int bm = 128 * (t0 == 3 ? 1 : t0);
     const int64_t mpad = (int64_t)((p.Ntotal + bm - 1) / bm) * bm;
     return (int64_t)(p.transposed ? 8 : 1) * p.ksplit * mpad * p.CoutPad;
@@ -1581,7 +1310,7 @@ static hipError_t launch_tm_rowreuse(ConvParamsH p, hipStream_t stream) {
 static int plane_rows(const ConvParamsH& p, int bm, int kc) {
     if (p.stride != 1 || p.Cin % kc != 0 || p.x_hs % p.x_ws != 0) return 0;
     const int in_p = p.x_hs / p.x_ws, P = p.Nh * p.Nw;
-    const int halo = p.s2d ? in_p + 1 : (p.kh - 1) * in_p + p.kw - 1;       // (parity-split input: tap offsets 0 .. in_p + 1)
+    const int halo = (p.kh - 1) * in_p + p.kw - 1;
     // tiles start at multiples of bm: when rows / planes divide bm (or bm divides the plane) they are never straddled
     // (e2: 112^2 = 49 x 256; d3: 16^2 = 256; d2: 4 planes of 64, d1: 16 planes of 16 per tile)
     const int rows_touched = (bm % p.Nw == 0) ? bm / p.Nw : (bm + p.Nw - 2) / p.Nw + 1;
@@ -1591,12 +1320,11 @@ static int plane_rows(const ConvParamsH& p, int bm, int kc) {
     return (r + unit - 1) / unit * unit;
 }
 
-template <int SH, int TM, int KC, int NH = 1, bool S2D = false>
+template <int SH, int TM, int KC, int NH = 1>
 static hipError_t launch_tm_plane(ConvParamsH p, hipStream_t stream) {
     constexpr int BM = 128 * TM;
     p.m_tiles = (p.Ntotal + BM - 1) / BM;
     p.n_tiles = p.CoutPad / HBN;
-    if (S2D != (p.s2d != 0)) return hipErrorInvalidValue;
     const int r_max = plane_rows(p, BM, KC);
     if (r_max == 0 || r_max > (KC == 64 ? 32 * NPA_PL : 64 * NPA_PL32) || (p.Cin / KC) % p.ksplit != 0)
         return hipErrorInvalidValue;
@@ -1606,19 +1334,19 @@ static hipError_t launch_tm_plane(ConvParamsH p, hipStream_t stream) {
     static LdsAttr lds_attr;
     dim3 grid(p.m_tiles * (p.n_tiles / NH) * (p.transposed ? 8 : 1), 1, p.ksplit);      // (class inside blockIdx.x: see the kernel)
     hipError_t e;
-    if constexpr (NH == 1 && !S2D) {
+    if constexpr (NH == 1) {
         if (p.head_w && p.ksplit == 1) {
             static LdsAttr lds_attr_h;
-            const hipError_t ah = lds_attr_h.ensure(reinterpret_cast<const void*>(&conv_bf16p_kernel<SH, TM, KC, NH, S2D, true>), 160 * 1024);
+            const hipError_t ah = lds_attr_h.ensure(reinterpret_cast<const void*>(&conv_bf16p_kernel<SH, TM, KC, NH, true>), 160 * 1024);
             if (ah != hipSuccess) return ah;
-            hipLaunchKernelGGL((conv_bf16p_kernel<SH, TM, KC, NH, S2D, true>), grid, dim3(256), lds, stream, p, r_max);
+            hipLaunchKernelGGL((conv_bf16p_kernel<SH, TM, KC, NH, true>), grid, dim3(256), lds, stream, p, r_max);
             return hipGetLastError();
         }
     }
     if (p.head_w) return hipErrorInvalidValue;
-    const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_bf16p_kernel<SH, TM, KC, NH, S2D, false>), 160 * 1024);
+    const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_bf16p_kernel<SH, TM, KC, NH, false>), 160 * 1024);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((conv_bf16p_kernel<SH, TM, KC, NH, S2D, false>), grid, dim3(256), lds, stream, p, r_max);
+    hipLaunchKernelGGL((conv_bf16p_kernel<SH, TM, KC, NH, false>), grid, dim3(256), lds, stream, p, r_max);
     e = hipGetLastError();
     if (e == hipSuccess && p.ksplit > 1) {
         const long long total = (long long)p.Ntotal * (p.CoutPad >> 1);
@@ -1679,7 +1407,7 @@ static int rows_strips(const ConvParamsH& p) {
     static const bool off = getenv("S3R_ROWS") && atoi(getenv("S3R_ROWS")) == 0;                   // A/B switch
     if (off || p.transposed || p.stride != 1 || p.kd != 1 || p.kh != 3 || p.kw != 3 || p.Cin != 32 || p.Nd != 1 ||
         p.Nh != 112 || p.Nw != 112 || p.x_ws != 32 || p.x_hs != 114 * 32 || p.x_org != 0 || p.ksplit != 1 || p.head_w ||
-        p.y_s2d || p.s2d || (p.Cout & 7) != 0 || p.act == ACT_SIGMOID)
+        (p.Cout & 7) != 0 || p.act == ACT_SIGMOID)
         return 0;
     for (int strips = 1; strips <= 4; strips *= 2)
         if ((long)p.B * strips >= 512) return strips;
@@ -1707,65 +1435,6 @@ static hipError_t launch_rows(ConvParamsH p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// can the persistent plane kernel serve this layer?  Transposed, tiles aligned to whole planes (see the kernel), no split-K.
-static bool persist_ok(const ConvParamsH& p, int nh) {
-    const int P = p.Nh * p.Nw;
-    if (!p.transposed || p.stride != 1 || p.ksplit != 1 || p.s2d || p.y_s2d || p.Cin % 32 != 0 || P < 1 || 256 % P != 0 ||
-        p.Ntotal % 256 != 0 || p.x_hs % p.x_ws != 0)
-        return false;
-    const int ppt = 256 / P;
-    if ((p.Nd & (p.Nd - 1)) != 0 || (p.Nd % ppt != 0 && ppt % p.Nd != 0)) return false;
-    if (nh == 2 && ((p.CoutPad / HBN) % 2 != 0 || p.head_w)) return false;
-    const int r_max = plane_rows(p, 256, 32);
-    return r_max > 0 && r_max <= 64 * NPA_PL32;
-}
-
-template <int SH, int NH>
-static hipError_t launch_persist(ConvParamsH p, hipStream_t stream) {
-    if (!persist_ok(p, NH)) return hipErrorInvalidValue;
-    p.m_tiles = p.Ntotal / 256;
-    p.n_tiles = p.CoutPad / HBN;
-    const int r_max = plane_rows(p, 256, 32);
-    const bool head = p.head_w != nullptr;
-    const size_t lds = (size_t)r_max * 64 + PL_NB * HBN * NH * 64 + 2 * 256 * sizeof(int) + EP_BYTES * NH + (size_t)r_max * 4 + 64 +
-                       (head ? 0 : 4 * 32 * ST_ROW);
-    static int cus[16] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-    if (!cus[dev] && (hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus[dev] < 8))
-        cus[dev] = 256;
-    // A persistent grid must be RESIDENT all at once (a workgroup that starts after another has finished its run doubles
-    // the launch): workgroups per CU from the runtime's occupancy calculation for this instantiation and LDS size.
-    const void* fn = head ? reinterpret_cast<const void*>(&conv_bf16d_kernel<SH, 1, true>)
-                          : reinterpret_cast<const void*>(&conv_bf16d_kernel<SH, NH, false>);
-    static LdsAttr lds_attr[2];
-    const hipError_t attr = lds_attr[head].ensure(fn, 160 * 1024);
-    if (attr != hipSuccess) return attr;
-    static std::atomic<int> occ[2][16];                               // (queried once per device: r_max, hence lds, is the layer's)
-    static std::atomic<unsigned> occ_lds[2][16];
-    int per_cu = occ_lds[head][dev].load() == (unsigned)lds ? occ[head][dev].load() : 0;
-    if (per_cu < 1) {
-        const hipError_t oe = head ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_bf16d_kernel<SH, 1, true>, 256, lds)
-                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_bf16d_kernel<SH, NH, false>, 256, lds);
-        if (oe != hipSuccess || per_cu < 1) return oe != hipSuccess ? oe : hipErrorInvalidValue;
-        occ[head][dev].store(per_cu);
-        occ_lds[head][dev].store((unsigned)lds);
-    }
-    // workgroups per XCD and cout column: the XCD's CUs x their resident workgroups, shared by the columns
-    const int cols = p.n_tiles / NH;
-    int wgs_x = (cus[dev] / 8) * per_cu / cols;
-    if (wgs_x < 1) wgs_x = 1;
-    if (wgs_x > p.m_tiles) wgs_x = p.m_tiles;
-    dim3 grid(8 * wgs_x, cols, 1);
-    if (head) {
-        if constexpr (NH == 1) hipLaunchKernelGGL((conv_bf16d_kernel<SH, 1, true>), grid, dim3(256), lds, stream, p, r_max);
-        else return hipErrorInvalidValue;
-    } else {
-        hipLaunchKernelGGL((conv_bf16d_kernel<SH, NH, false>), grid, dim3(256), lds, stream, p, r_max);
-    }
-    return hipGetLastError();
-}
-
 template <int SH>
 static hipError_t launch_shape(const ConvParamsH& p, int tm, hipStream_t stream) {
     // tm = 1, 2, 4: per-tap gather (conv_bf16_kernel; + 16: 32-channel K tiles even where 64 are possible);
@@ -1780,13 +1449,9 @@ static hipError_t launch_shape(const ConvParamsH& p, int tm, hipStream_t stream)
         case 21: return launch_tm_plane<SH, 1, 32>(p, stream);
         case 22: return launch_tm_plane<SH, 2, 32>(p, stream);
         case 23: return launch_tm_plane<SH, 2, 32, 2>(p, stream);            // 256 positions x 128 couts
-        case 30: return launch_tm_plane<SH, 2, 32, 1, true>(p, stream);      // plane-reuse over a parity-split input
-        case 31: return launch_tm_plane<SH, 2, 32, 2, true>(p, stream);      // ... 256 positions x 128 couts
         case 9: return launch_tm_rowreuse<SH, 1>(p, stream);
         case 10: return launch_tm_rowreuse<SH, 2>(p, stream);
         case 40: return launch_rows<SH>(p, stream);                          // row-persistent (e2 at large batches)
-        case 42: return launch_persist<SH, 1>(p, stream);                    // persistent plane kernel (aligned transposed classes)
-        case 43: return launch_persist<SH, 2>(p, stream);                    // ... 256 positions x 128 couts
         default: return hipErrorInvalidValue;
     }
 }

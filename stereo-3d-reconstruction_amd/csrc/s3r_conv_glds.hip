@@ -181,9 +181,7 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, const int bi
         rem -= pd * p.Nh * p.Nw;
         const int ph = p.dW.div(rem);
         const int pw = rem - ph * p.Nw;
-        // (W-parity-split rows: the column index is not scaled by the stride — see ConvParams::x_wsplit)
-        int e = b * p.Cin * p.x_cs + p.x_org + (pd * p.x_ds + ph * p.x_hs) * p.stride + pw * (p.x_wsplit ? 1 : p.stride) +
-                lrow * p.x_cs;
+        int e = b * p.Cin * p.x_cs + p.x_org + (pd * p.x_ds + ph * p.x_hs + pw) * p.stride + lrow * p.x_cs;
         if (p.transposed) e += (rd - 1) * p.x_ds + (rh - 1) * p.x_hs + (rw - 1);
         bvoff = e * 4;
     }
@@ -217,8 +215,7 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, const int bi
         }
         // ---- gathered input: 16 channels of chunk c_cc at tap (c_td, c_th, c_tw)
         float* sb = Bs + buf * BK * BN + b_lds0;
-        const int tw_off = p.x_wsplit ? (c_tw & 1) * p.x_wh + (c_tw >> 1) : c_tw;
-        const int b_base = ((c_cc * BK + b_row0) * p.x_cs + c_td * p.x_ds + c_th * p.x_hs + tw_off) * 4;
+        const int b_base = ((c_cc * BK + b_row0) * p.x_cs + c_td * p.x_ds + c_th * p.x_hs + c_tw) * 4;
 #pragma unroll
         for (int q = 0; q < NPB; ++q)
             dma_to_lds<4 * VEC>(xrsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
@@ -374,10 +371,6 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, const int bi
         const int pw = rem - ph * p.Nw;
         int e = b * p.y_bs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw) * ostep;
         if (p.transposed) e += rd * p.y_ds + rh * p.y_hs + rw;
-        if (p.y_wsplit) {          // (convolutions only, out_halo = 1) padded column pw + 1 -> its parity half of the row
-            const int pc = pw + 1;
-            e = b * p.y_bs + (pd + 1) * p.y_ds + (ph + 1) * p.y_hs + (pc & 1) * p.y_wh + (pc >> 1);
-        }
         yoff[tn] = e;
     }
     // ---- fused pointwise head (conv -> 1x1x1 conv to ONE channel + activation, e.g. d3 -> d4 + sigmoid): the
@@ -431,17 +424,7 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, const int bi
         return;
     }
 #endif
-    const bool lane_vec = TN > 1 && vec_ok && yok[TN - 1] && !p.y_wsplit;
-    // W-parity-split output: a lane's TN consecutive columns alternate between the two halves of the row; columns two
-    // apart are neighbours in one half (TN = 4: two 8-byte stores; TN = 2: two dword stores, each 128 contiguous bytes
-    // per 32 lanes)
-    const bool lane_pair = TN == 4 && vec_ok && yok[TN - 1] && p.y_wsplit;
-    // TN = 2 (the tiles the network's producers use): lane 2m holds padded columns (odd c, even c + 1), lane 2m + 1 the next
-    // two; after ONE exchange between the two lanes (DPP, no LDS) lane 2m owns the two neighbouring ODD columns and lane
-    // 2m + 1 the two neighbouring EVEN ones: one 8-byte store per lane and row, as in the plain layout (two dword stores
-    // per row made the producers e2 / e4 / v1 slower than the stride-2 consumers gained: 5.97 -> 5.99 ms per step).
-    // Needs whole groups of 4 columns per row and per launch range (wave-uniform).
-    const bool lane_swap = TN == 2 && vec_ok && p.y_wsplit && (p.Nw & 3) == 0 && ((n_end | n_begin) & 3) == 0;
+    const bool lane_vec = TN > 1 && vec_ok && yok[TN - 1];
     const int mbase = wm * TM * 32 + 4 * h * TM;
     const int mlimit = p.Cout - (m0 + mbase);                  // rows dm >= mlimit are padding
     // buffer stores: per-lane 32-bit byte offset in a VGPR (computed once), the row's cout offset in the SGPR
@@ -450,8 +433,6 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, const int bi
     int yvo[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) yvo[tn] = (yoff[tn] + (m0 + mbase) * p.y_cs) * 4;
-    int yvo_swap = 0;
-    if constexpr (TN == 2) { if (lane_swap) yvo_swap = (lane & 1) ? yvo[1] - 4 : yvo[0]; }   // odd lane: its even column's left neighbour
     const int row_bytes = p.y_cs * 4;
     auto rows = [&](auto sig_tag) {
         constexpr bool SIG = decltype(sig_tag)::value;
@@ -470,25 +451,6 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, const int bi
                     v[tn] = SIG ? act_fn<ACT_SIGMOID>(t) : fmaxf(t, lo);
                 }
                 const int so = dm * row_bytes;
-                if constexpr (TN == 2) {
-                    if (lane_swap) {
-                        const float give = (lane & 1) ? v[0] : v[1];
-                        const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
-                        const v2f t = (lane & 1) ? (v2f){got, v[1]} : (v2f){v[0], got};
-                        if (yok[0]) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, t), yrsrc, yvo_swap, so, 0);
-                        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                        continue;
-                    }
-                }
-                if constexpr (TN == 4) {
-                    if (lane_pair) {
-                        const v2f t0 = {v[0], v[2]}, t1 = {v[1], v[3]};
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, t0), yrsrc, yvo[0], so, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, t1), yrsrc, yvo[1], so, 0);
-                        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                        continue;
-                    }
-                }
                 if (lane_vec) {                    // dword-aligned (not 16-B aligned) vector store: legal on gfx950
                     if constexpr (TN == 2) {
                         const v2f t = {v[0], v[1]};
@@ -701,7 +663,7 @@ int conv_pick_tile(const ConvParams& p) {
 // widest gather the layer geometry allows: VEC consecutive positions of a row must be VEC consecutive
 // input dwords (stride 1) and must not straddle rows (Nw % VEC == 0)
 int conv_pick_vec(const ConvParams& p) {
-    if (p.stride != 1 && !p.x_wsplit) return 1;       // (a W-parity-split input reads like a stride-1 layer's)
+    if (p.stride != 1) return 1;
     return (p.Nw % 4 == 0) ? 4 : 1;   // (there is no 8-byte LDS-DMA)
 }
 

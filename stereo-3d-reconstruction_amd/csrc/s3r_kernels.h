@@ -91,13 +91,6 @@ struct ConvParams {
     const float* head_scale;   // [1] or null
     const float* head_shift;   // [1] or null
     int head_act;
-    // W-parity-split rows (include/s3r.h, S3R_LAYOUT_S2D on the fp32 path): every padded row of Wp elements is stored as
-    // its Wp/2 even columns followed by its Wp/2 odd columns.  x_wsplit: the input of a stride-2 k3 p1 layer is stored
-    // that way (tap tw of output column ow then reads element (tw & 1) * x_wh + (tw >> 1) + ow of the row: consecutive
-    // output positions are consecutive dwords, so the gather is as wide as a stride-1 layer's); y_wsplit: the output is
-    // written that way (out_halo = 1).
-    int x_wsplit, x_wh;
-    int y_wsplit, y_wh;
     // Winograd F(2,3) along H (s3r_conv_wino.hip): x = the four transformed input plane sets, x_cls elements apart; Nh = row
     // pairs per plane; Hout = the output's true height
     int x_cls, Hout;
@@ -112,17 +105,6 @@ struct ConvParams {
 // (positions [0, n_cut) serial and [n_cut, N) class-parallel in one launch).
 enum { WINO_SERIAL = 0, WINO_CP = 1, WINO_DUAL = 2 };
 struct WinoLaunch { int mode, n_cut; };
-
-// Tap schedule of a stride-2 k3 p1 convolution over a PARITY-SPLIT input (include/s3r.h, S3R_LAYOUT_S2D), per 32-channel
-// chunk: `ngroups` image loads (one class sub-tensor plane each: 4 in 2D, 12 in 3D), group g reading its g_ntaps[g] taps
-// tap_*[g_first[g] ...] from image rows lrow + tap_off; tap_w = the tap's index in the packed weights (kd*9 + kh*3 + kw).
-struct S2DTab {
-    int ngroups;
-    int g_xoff[12];               // element offset of the group's plane: class * x_cs + depth offset * x_ds
-    unsigned char g_first[12], g_ntaps[12];
-    short tap_off[27];
-    unsigned char tap_w[27];
-};
 
 // bf16 channels-last path: activations (B, [D,] H, W, C) bf16 with a zero halo, fp32 accumulate
 struct ConvParamsH {
@@ -151,11 +133,6 @@ struct ConvParamsH {
     const float* head_scale;
     const float* head_shift;
     int head_act;
-    // parity-split layouts: y_s2d: the output is written as 2^nd class sub-tensors (y_cs apart; y_ds / y_hs / y_org are
-    // those of one sub-tensor); s2d: the input is read that way (x_cs apart) following `tab`
-    int y_s2d, y_cs;
-    int s2d, x_cs;
-    S2DTab tab;
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
@@ -211,7 +188,6 @@ hipError_t launch_conv_bf16(const ConvParamsH& p, int tm, hipStream_t stream);
 int conv_bf16_pick_tm(const ConvParamsH& p);
 int conv_bf16_shape();              // 16 | 32: the bf16 matrix instruction in use (S3R_BF16_MFMA, else the build's default)
 int conv_bf16_pick_ksplit(const ConvParamsH& p);
-bool conv_bf16_s2d_ok(const ConvParamsH& p);   // parity-split input readable by the plane kernel (per-sample geometry only)
 int64_t conv_bf16_scratch_elems(const ConvParamsH& p, int tm);
 hipError_t launch_pack_bf16(const float* w, void* wp, int Cin, int Cout, int CoutPad, int T, int transposed, hipStream_t s);
 hipError_t launch_stem_bf16(const void* x, const void* x2, int u8, int nsplit, const float* wt, const float* scale,

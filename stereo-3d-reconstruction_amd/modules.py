@@ -234,8 +234,7 @@ class _HipChain(nn.Module):
         self._packed = (key, packed)
         return packed
 
-    def _layer_array(self, batch: int, device, upto: Optional[str] = None, in_halo: int = 0, in_layout: int = 0,
-                     out_layout: int = 0, out_halo: int = 0):
+    def _layer_array(self, batch: int, device, upto: Optional[str] = None, in_halo: int = 0, in_layout: int = 0):
         packed = self._ensure_packed(device)
         n_layers = len(self._layers) if upto is None else self.names.index(upto) + 1
         arr = (_lib.Layer * n_layers)()
@@ -246,11 +245,9 @@ class _HipChain(nn.Module):
             algo = self._algo_of(l)
             # only the chain's own input / output halos are the caller's to state (the output is always
             # a plain contiguous tensor); the library plans the intermediates
-            last = i == n_layers - 1
             arr[i].desc = _lib.make_desc(l, batch, n_in, tag=self._tag_base + i, tile=tile,
-                                         in_halo=in_halo if i == 0 else 0, out_halo=out_halo if last else 0, ksplit=ksplit,
-                                         dtype=self._dtype, in_layout=in_layout if i == 0 else 0,
-                                         out_layout=out_layout if last else 0, algo=algo)
+                                         in_halo=in_halo if i == 0 else 0, ksplit=ksplit,
+                                         dtype=self._dtype, in_layout=in_layout if i == 0 else 0, algo=algo)
             arr[i].packed_w = pw.data_ptr()
             arr[i].scale = scale.data_ptr() if scale is not None else None
             arr[i].shift = shift.data_ptr() if shift is not None else None
@@ -300,7 +297,7 @@ class _HipChain(nn.Module):
 
     @torch.no_grad()
     def _run(self, x: torch.Tensor, upto: Optional[str] = None, in_halo: int = 0,
-             x2: Optional[torch.Tensor] = None, in_layout: int = 0, out_layout: int = 0) -> torch.Tensor:
+             x2: Optional[torch.Tensor] = None, in_layout: int = 0) -> torch.Tensor:
         """x: the chain input; with in_halo > 0 it is a halo-padded buffer (B, C, n+2h, ...) whose border
         is zero (internal hand-off from the cost-volume kernel), otherwise a plain contiguous tensor.
         x2 (encoder only): a second tensor of as many images — the chain runs over x's images, then x2's."""
@@ -314,14 +311,9 @@ class _HipChain(nn.Module):
             if self._out_is_bf16(n0):
                 return _to_logical(torch.empty((0,) + shape[2:] + (shape[1],), dtype=torch.bfloat16, device=device))
             return torch.empty(shape, dtype=torch.float32, device=device)
-        arr, n = self._layer_array(batch, device, upto, in_halo, in_layout, out_layout, 1 if out_layout else 0)
+        arr, n = self._layer_array(batch, device, upto, in_halo, in_layout)
         shape = self._out_shape(batch, n)
-        if out_layout and self.precision != "bf16":   # (tests) fp32: the padded (B,C,m+2,..) tensor, rows W-parity-split
-            y = torch.zeros(shape[:2] + tuple(m + 2 for m in shape[2:]), dtype=torch.float32, device=device)
-        elif out_layout:              # (tests) parity-split output: (B, 2^nd, (m/2+2)^nd, C) bf16, zeroed (halo) here
-            nd = len(shape) - 2
-            y = torch.zeros((shape[0], 2 ** nd) + (shape[2] // 2 + 2,) * nd + (shape[1],), dtype=torch.bfloat16, device=device)
-        elif self._out_is_bf16(n):    # physical channels-last (B,...,C) bf16; handed back as a logical (B,C,...) view
+        if self._out_is_bf16(n):    # physical channels-last (B,...,C) bf16; handed back as a logical (B,C,...) view
             y = torch.empty((shape[0],) + shape[2:] + (shape[1],), dtype=torch.bfloat16, device=device)
         else:
             y = torch.empty(shape, dtype=torch.float32, device=device)
@@ -329,7 +321,7 @@ class _HipChain(nn.Module):
         # the arena's layout is the library's PLAN for this chain: batch, depth, input halo and every layer's
         # requested (tile, split-K) — those decide head fusion and where the split-K scratch starts.  Any change
         # re-zeroes the arena (fresh), so no region is ever read with another plan's bytes in its halo.
-        cfg = tuple((arr[i].desc.tile, arr[i].desc.ksplit, arr[i].desc.algo) for i in range(n)) + (in_layout, out_layout)
+        cfg = tuple((arr[i].desc.tile, arr[i].desc.ksplit, arr[i].desc.algo) for i in range(n)) + (in_layout,)
         ws, fresh = self._ws.get(device, need, (batch, n, in_halo, need, cfg))
         u8 = x.dtype == torch.uint8
         if (u8 or x2 is not None) and self._entry != "s3r_encoder_forward":
@@ -347,8 +339,6 @@ class _HipChain(nn.Module):
             entry = getattr(lib, self._entry if upto is None else "s3r_chain_forward")
             _lib.check(entry(arr, n, x.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), fresh, _stream_ptr(device)),
                        type(self).__name__)
-        if out_layout:
-            return y
         return _to_logical(y) if self._out_is_bf16(n) else y
 
 

@@ -344,154 +344,6 @@ def test_bf16_eval_metric_within_1e3_of_fp32_path(s3r):
         assert abs(x - y) < 1e-3
 
 
-# ------------------------------------------------------------------ parity-split (space-to-depth) hand-off
-def _to_s2d(x_phys):
-    """physical channels-last (B,[D,]H,W,C) with even edges -> (B, 2^nd, [D/2+2,] H/2+2, W/2+2, C): class
-    4*(d&1) + 2*(h&1) + (w&1) holds the positions of that parity, with a zero halo of 1 (include/s3r.h S3R_LAYOUT_S2D)."""
-    nd = x_phys.dim() - 2
-    B, C = x_phys.shape[0], x_phys.shape[-1]
-    n = x_phys.shape[1]
-    out = torch.zeros((B, 2 ** nd) + (n // 2 + 2,) * nd + (C,), dtype=x_phys.dtype, device=x_phys.device)
-    for cls in range(2 ** nd):
-        par = [(cls >> (nd - 1 - a)) & 1 for a in range(nd)]          # 3D: (d, h, w) parities; 2D: (h, w)
-        src = x_phys[(slice(None),) + tuple(slice(p, None, 2) for p in par)]
-        out[(slice(None), cls) + (slice(1, -1),) * nd] = src
-    return out
-
-
-@pytest.mark.parametrize("kind", ["conv2d_c64_w16", "conv2d_c128_w28_cout128", "conv3d_c64_w14_cout128", "conv3d_c32_w8",
-                                  "conv2d_c64_w112"])
-def test_stride2_conv_reads_a_parity_split_input(s3r, oracle, kind, mfma_shape):
-    """The plane-reuse kernel over a parity-split input (tile codes 30 / 31) against the oracle's stride-2 convolution."""
-    Layer = s3r.arch_spec.Layer
-    layer, n_in, B, tiles = {
-        "conv2d_c64_w16": (Layer("t", "conv2d", 64, 64, 3, 2, 1), 16, 5, (-1, 30)),
-        "conv2d_c128_w28_cout128": (Layer("t", "conv2d", 128, 128, 3, 2, 1), 28, 3, (-1, 30, 31)),
-        "conv3d_c64_w14_cout128": (Layer("t", "conv3d", 64, 128, 3, 2, 1), 14, 2, (-1, 30, 31)),
-        "conv3d_c32_w8": (Layer("t", "conv3d", 32, 40, 3, 2, 1), 8, 3, (-1, 30)),
-        "conv2d_c64_w112": (Layer("t", "conv2d", 64, 64, 3, 2, 1), 112, 2, (-1,)),         # e3's own shape
-    }[kind]
-    ch = s3r.modules._HipChain([layer], n_in, precision="bf16")
-    s3r.seed_module(ch, 7)
-    blk = oracle._Block(layer).eval()
-    sd = dict(ch.t.state_dict())
-    sd["conv.weight"] = _bf(sd["conv.weight"])
-    blk.load_state_dict(sd)
-    x = _bf(torch.randn((B, layer.cin) + (n_in,) * s3r.arch_spec.ndim(layer), generator=torch.Generator().manual_seed(3)))
-    with torch.no_grad():
-        want = blk(x)
-    xin = x.to(DEV).to(torch.bfloat16)
-    xin = xin.permute(0, *range(2, xin.dim()), 1).contiguous()
-    xs = _to_s2d(xin)
-    ch.to(DEV)
-    plain = ch._run(xin)                                       # the per-tap family on the plain layout
-    assert rel_l2(plain.cpu(), want) < 3e-3
-    for tm in tiles:
-        if tm >= 0:
-            ch.tile_override["t"] = tm
-        else:
-            ch.tile_override.pop("t", None)
-        got = ch._run(xs, None, 1, None, s3r._lib.LAYOUT_S2D)
-        assert got.shape == want.shape and got.dtype == torch.bfloat16
-        assert rel_l2(got.cpu(), want) < 3e-3, (kind, tm, rel_l2(got.cpu(), want))
-        assert torch.equal(ch._run(xs, None, 1, None, s3r._lib.LAYOUT_S2D), got)
-    ch.tile_override["t"] = 1                                 # a per-tap tile cannot read this layout: refused
-    with pytest.raises(s3r.S3RError):
-        ch._run(xs, None, 1, None, s3r._lib.LAYOUT_S2D)
-
-
-@pytest.mark.parametrize("kind", ["conv2d_plane", "conv3d_plane", "conv2d_pertap_s2", "conv3d_ks2"])
-def test_conv_writes_a_parity_split_output(s3r, oracle, kind, mfma_shape):
-    """Any bf16 MFMA convolution can write its output parity-split (every kernel family computes the same
-    out_offset, the split-K finish included): equal to the plain output rearranged, halo zero."""
-    Layer = s3r.arch_spec.Layer
-    layer, n_in, B, ks = {
-        "conv2d_plane": (Layer("t", "conv2d", 32, 64, 3, 1, 1), 28, 3, 0),
-        "conv3d_plane": (Layer("t", "conv3d", 64, 96, 3, 1, 1), 14, 2, 0),
-        "conv2d_pertap_s2": (Layer("t", "conv2d", 64, 48, 3, 2, 1), 24, 3, 0),
-        "conv3d_ks2": (Layer("t", "conv3d", 128, 64, 3, 1, 1), 6, 2, 2),
-    }[kind]
-    ch = s3r.modules._HipChain([layer], n_in, precision="bf16")
-    s3r.seed_module(ch, 5)
-    if ks:
-        ch.ksplit_override["t"] = ks
-    x = _bf(torch.randn((B, layer.cin) + (n_in,) * s3r.arch_spec.ndim(layer), generator=torch.Generator().manual_seed(4)))
-    xin = x.to(DEV).to(torch.bfloat16)
-    xin = xin.permute(0, *range(2, xin.dim()), 1).contiguous()
-    ch.to(DEV)
-    plain = ch._run(xin)                                       # logical (B,C,...) view of the channels-last output
-    plain_phys = plain.permute(0, *range(2, plain.dim()), 1).contiguous()
-    got = ch._run(xin, None, 0, None, 0, s3r._lib.LAYOUT_S2D)
-    assert torch.equal(got, _to_s2d(plain_phys))
-
-
-def test_chain_plans_the_parity_split_handoff(s3r, oracle, mfma_shape):
-    """conv (stride 1) -> conv (stride 2) with the consumer's tile set to 30 / 31: s3r_chain_forward stores the
-    intermediate parity-split and reads it with the plane kernel; the result is that of the two layers run by hand through
-    the same layouts (bitwise) and the oracle's within bf16 tolerance.  Without the request the chain keeps the plain
-    layout and the per-tap family (the hand-off measured slower: s3r_api.hip plan_chain)."""
-    Layer = s3r.arch_spec.Layer
-    a, b = Layer("a", "conv3d", 32, 64, 3, 1, 1), Layer("b", "conv3d", 64, 128, 3, 2, 1)
-    ch = s3r.modules._HipChain([a, b], 12, precision="bf16")
-    s3r.seed_module(ch, 9)
-    ca, cb = s3r.modules._HipChain([a], 12, precision="bf16"), s3r.modules._HipChain([b], 12, precision="bf16")
-    ca.a.load_state_dict(ch.a.state_dict())
-    cb.b.load_state_dict(ch.b.state_dict())
-    ref = torch.nn.Sequential(oracle._Block(a), oracle._Block(b)).eval()
-    for blk, src in ((ref[0], ch.a), (ref[1], ch.b)):
-        sd = dict(src.state_dict())
-        sd["conv.weight"] = _bf(sd["conv.weight"])
-        blk.load_state_dict(sd)
-    x = _bf(torch.randn(3, 32, 12, 12, 12, generator=torch.Generator().manual_seed(8)))
-    with torch.no_grad():
-        want = ref[1](_bf(ref[0](x)))                          # the intermediate is stored in bf16
-    xin = x.to(DEV).to(torch.bfloat16).permute(0, 2, 3, 4, 1).contiguous()
-    ch.to(DEV), ca.to(DEV), cb.to(DEV)
-    ch.tile_override["b"] = 31                                # (the hand-off is planned on request only: it measured slower)
-    got = ch._run(xin)
-    assert rel_l2(got.cpu(), want) < 4e-3
-    mid = ca._run(xin, None, 0, None, 0, s3r._lib.LAYOUT_S2D)
-    cb.tile_override["b"] = 31
-    by_hand = cb._run(mid, None, 1, None, s3r._lib.LAYOUT_S2D)
-    assert torch.equal(got, by_hand)
-    ch.tile_override.pop("b")
-    plain = ch._run(xin)                                      # default: plain layout, per-tap family
-    assert rel_l2(plain.cpu(), want) < 4e-3 and not torch.equal(plain, got)
-
-
-@pytest.mark.parametrize("name", ["d1", "d2", "d3", "d3+head"])
-def test_persistent_deconv_kernel_equals_the_plane_kernel_bitwise(s3r, oracle, mfma_shape, name):
-    """The PERSISTENT plane kernel for the transposed convolutions (tile codes 42 / 43, on request only — measured slower
-    than the plane kernel, DESIGN.md §4.4: position tables built once per workgroup, a workgroup walks its XCD's run of
-    (tile, class) items and requests the next item's operands under the current epilogue).  Same K order as the plane
-    kernel (22 / 23): bit-identical at every batch — few items per workgroup, many, a run that does not divide by the
-    workgroups of an XCD — and with the fused head."""
-    spec = s3r.arch_spec
-    layers = {l.name: (l, n_in) for l, n_in, _ in spec.trace(spec.DECODER, spec.MAX_DISP)}
-    base = name.split("+")[0]
-    L, n_in = layers[base]
-    chain = [L] + ([layers["d4"][0]] if name.endswith("head") else [])
-    ch = s3r.modules._HipChain(chain, n_in, precision="bf16")
-    s3r.seed_module(ch, 11)
-    ch.to(DEV)
-    g = torch.Generator().manual_seed(13)
-    codes = [(22, 42)] + ([(23, 43)] if L.cout % 128 == 0 else [])
-    for B in {"d1": (4, 36, 256), "d2": (1, 7, 64), "d3": (1, 5, 24), "d3+head": (1, 5, 24)}[name]:
-        x = torch.randn((B,) + (n_in,) * 3 + (L.cin,), generator=g).to(torch.bfloat16).to(DEV)      # physical channels-last
-        for plane, persistent in codes:
-            ch.tile_override[base] = plane
-            want = ch._run(x).clone()
-            ch.tile_override[base] = persistent
-            got = ch._run(x)
-            assert got.dtype == want.dtype and torch.equal(got, want), (B, persistent)
-        del ch.tile_override[base]
-        assert torch.equal(ch._run(x), want)                                   # the library's own pick, whichever it is
-    if name == "d1":                                  # tiles are whole planes of whole samples: B * 64 positions % 256
-        ch.tile_override[base] = 43
-        with pytest.raises(s3r.S3RError):
-            ch._run(x[:5])
-
-
 def test_rows_kernel_equals_the_plane_kernel_bitwise(s3r, oracle, mfma_shape):
     """e2 at large image counts runs the row-persistent kernel (tile code 40: seven waves slide down a strip of rows,
     weights resident in LDS, input rows in a ten-slot ring).  Its K order is the plane kernel's, so the two must agree

@@ -58,90 +58,6 @@ def test_mfma_layout_exact_integers(s3r):
     assert torch.equal(got, want)
 
 
-# ------------------------------------------------------------------ W-parity-split rows (fp32 form of S3R_LAYOUT_S2D)
-def _wsplit(xp):
-    """padded (.., Wp) tensor -> every row as its even columns followed by its odd columns"""
-    return torch.cat([xp[..., 0::2], xp[..., 1::2]], -1).contiguous()
-
-
-def _unwsplit(y):
-    wp = y.shape[-1]
-    out = torch.empty_like(y)
-    out[..., 0::2], out[..., 1::2] = y[..., : wp // 2], y[..., wp // 2:]
-    return out
-
-
-@pytest.mark.parametrize("kind", ["2d_w16", "2d_w12", "3d_w8", "3d_w6"])
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 7, 3 + 16, 1 + 64])
-def test_stride2_conv_reads_wsplit_rows_bitwise(s3r, oracle, kind, tile):
-    """A stride-2 k3 p1 convolution over a W-parity-split input (what the chain plans between a convolution and its
-    stride-2 consumer): the same bits as over the plain padded input, for every tile shape and both gather widths (16-byte
-    LDS-DMA where the output width is a multiple of 4: w16 -> 8, w8 -> 4; dword gathers otherwise), and the oracle."""
-    nd, n = (2, int(kind[4:])) if kind.startswith("2d") else (3, int(kind[4:]))
-    L = s3r.arch_spec.Layer("t", "conv2d" if nd == 2 else "conv3d", 32, 64, 3, 2, 1)
-    ch = _single(s3r, L, n)
-    blk = _oracle_block(oracle, L, ch.t.state_dict())
-    g = torch.Generator().manual_seed(3)
-    x = torch.randn((3, 32) + (n,) * nd, generator=g)
-    xp = F.pad(x, (1,) * (2 * nd))
-    ch.to(DEV)
-    want = ch._run(xp.to(DEV), None, in_halo=1)                        # plain padded input, library's own tile
-    ch.tile_override["t"] = tile
-    try:
-        got = ch._run(_wsplit(xp).to(DEV), None, in_halo=1, in_layout=s3r._lib.LAYOUT_S2D)
-    except s3r.S3RError:
-        pytest.skip("tile / gather width not legal for this shape")
-    assert torch.equal(got, want)
-    with torch.no_grad():
-        ref = blk(x)
-    assert rel_l2(got.cpu(), ref) < 1e-5
-
-
-@pytest.mark.parametrize("kind", ["2d", "3d"])
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 5, 7])
-def test_conv_writes_wsplit_rows_bitwise(s3r, kind, tile):
-    """The producer side: out_layout = S2D writes the padded output with W-parity-split rows — un-split, it is the plain
-    padded output bit for bit, halo zero (every tile shape: 1 / 2 / 4 positions per lane take different store paths)."""
-    nd, n = (2, 16) if kind == "2d" else (3, 8)
-    L = s3r.arch_spec.Layer("t", "conv2d" if nd == 2 else "conv3d", 16, 64, 3, 1, 1)
-    ch = _single(s3r, L, n)
-    g = torch.Generator().manual_seed(4)
-    x = torch.randn((3, 16) + (n,) * nd, generator=g).to(DEV)
-    ch.to(DEV)
-    plain = ch._run(x)
-    ch.tile_override["t"] = tile
-    try:
-        y = ch._run(x, out_layout=s3r._lib.LAYOUT_S2D)
-    except s3r.S3RError:
-        pytest.skip("tile not legal for this shape")
-    got = _unwsplit(y)
-    assert torch.equal(got[(slice(None), slice(None)) + (slice(1, -1),) * nd], plain)
-    inner = got.clone()
-    inner[(slice(None), slice(None)) + (slice(1, -1),) * nd] = 0
-    assert not inner.any()                                              # the halo stays zero
-
-
-def test_chain_plans_the_wsplit_handoff_bitwise(s3r, tmp_path):
-    """With S3R_WSPLIT=1 (read once per process: a child) the chains plan e2 -> e3, e4 -> e5, v1 -> v2 and v3 -> v4 through
-    W-parity-split rows; the forward equals the default (plain-layout) one bit for bit — the K order does not change.
-    (The hand-off measured no gain inside the forward, DESIGN.md §4.1, so the plain layout stays the default.)"""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys, torch, s3r\n"
-            "m = s3r.Stereo2Voxel(); s3r.seed_module(m, 0); m.to('cuda:0')\n"
-            "l, r = s3r.synthetic_pairs(3, seed=71)\n"
-            "torch.save(m(l.to('cuda:0'), r.to('cuda:0')).cpu(), sys.argv[1])\n")
-    outs = []
-    for flag in ("1", "0"):
-        path = str(tmp_path / f"wsplit_{flag}.pt")
-        r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=300, cwd=root,
-                           env=dict(os.environ, S3R_WSPLIT=flag, S3R_WINO="0"))     # (a W-split OUTPUT selects the direct kernel:
-                                                                                    #  compare like with like)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(torch.load(path))
-    assert torch.equal(outs[0], outs[1])
-
-
 # ------------------------------------------------------------------ every layer of the arch, alone
 def _layer_cases(spec):
     cases = []

@@ -29,8 +29,6 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--shapes", default="", help="bf16: MFMA shapes to A/B, e.g. 32,16 (S3R_BF16_MFMA; weights are re-packed per shape)")
-    ap.add_argument("--wsplit", action="store_true", help="fp32 stride-2 k3 p1 layers: feed the halo-padded input with "
-                    "W-parity-split rows (S3R_LAYOUT_S2D), as the chain hands it over")
     ap.add_argument("--algo", type=int, default=0, help="fp32: s3r_algo of the layer (0 auto, 1 direct, 2 Winograd: --tiles are then "
                     "launch-FORM codes: -1 the library's plan, 0 serial, 1 class-parallel, 2 dual)")
     ap.add_argument("--zeros", action="store_true", help="all-zero inputs and weights (how much of the rate is power: the\n"
@@ -71,10 +69,6 @@ def main():
         if args.dtype == "bf16":
             x = x.to(torch.bfloat16).permute(0, *range(2, x.dim()), 1).contiguous()
         run_kw = {}
-        if args.wsplit and args.dtype == "fp32" and l.s == 2 and l.k == 3 and l.p == 1:
-            xp = torch.nn.functional.pad(x, (1,) * (2 * spec.ndim(l)))
-            x = torch.cat([xp[..., 0::2], xp[..., 1::2]], -1).contiguous()
-            run_kw = dict(in_halo=1, in_layout=1)
         flops = 2.0 * spec.layer_macs(l, n_in) * B
         res = {}
         ran = {}
