@@ -86,9 +86,11 @@ typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_WINO_H = 2 } s3r_layo
  *   S3R_ALGO_DIRECT    the direct kernel;
  *   S3R_ALGO_WINOGRAD  the Winograd kernel (S3R_ERR_INVALID if the layer has no such form or the descriptor cannot take it:
  *                      needs in_halo = 1, plain layouts — or S3R_LAYOUT_WINO_H input —, no split-K, no sigmoid).  `tile` >= 0 then
- *                      forces the launch FORM (tuning / tests; every form gives the same bits): bits 0-1 = 0 serial, 1 class-parallel,
- *                      2 dual (bulk serial + remainder class-parallel in one launch); bit 2: class-parallel part on 64 x 64 tiles;
- *                      bit 3: serial part on 64 x 64 tiles.
+ *                      forces the launch FORM of the one-axis kernel (tuning / tests; every form gives the same bits, and the
+ *                      library picks among them by batch): 0 serial, 1 class-parallel, 2 dual (bulk serial + remainder
+ *                      class-parallel in one launch); `tile` = 3: the TWO-AXIS class-parallel form (Conv3d k3 s1 p1 as F(4,3) x
+ *                      F(4,3), k4 s1 p0 as F(2,4) x F(2,4), in_halo = pad) — another algorithm, other bits than the one-axis
+ *                      kernel; AUTO takes it for 3D layers with an edge <= 14 (v3, v5, v6 of this network).
  * A call whose scratch is smaller than s3r_conv_scratch_elems says for the RESOLVED algorithm fails with S3R_ERR_WORKSPACE; it
  * is never answered with the other kernel's bits. */
 typedef enum s3r_algo { S3R_ALGO_AUTO = 0, S3R_ALGO_DIRECT = 1, S3R_ALGO_WINOGRAD = 2 } s3r_algo;
@@ -140,7 +142,8 @@ int s3r_conv_out_size(const s3r_conv_desc* d);
 /* size of the packed weight buffer for a layer IN 4-BYTE UNITS (>= the torch weight's numel on the fp32
  * path: couts are padded; about half of it on the bf16 path).  ABI 6: an fp32 3 x 3 [x 3] stride-1 pad-1 convolution packs
  * two forms, the direct slab and the six Winograd F(4,3)-along-H class slabs (csrc/s3r_conv_wino.hip: half the
- * multiplications); which kernel a forward runs is the descriptor's `algo` (s3r_algo above).  The transposed convolutions likewise: 72 F(2,2) x F(2,2) (parity class, class) slabs
+ * multiplications) — a 3D stride-1 layer also the 36 (k3) / 25 (k4, valid) slabs of the two-axis form; which kernel a forward
+ * runs is the descriptor's `algo` (s3r_algo above).  The transposed convolutions likewise: 72 F(2,2) x F(2,2) (parity class, class) slabs
  * behind the direct ones. */
 int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems);
 /* repack a torch-layout weight (Conv: [cout][cin][k..]; ConvTranspose: [cin][cout][k..]; Linear:
@@ -247,7 +250,7 @@ typedef struct s3r_prof_record {
     double bytes;
     double exec_flops;  /* FLOPs the kernel that ran EXECUTES on the matrix cores (= flops for the direct kernels; 1/2 .. 9/16 of it
                            for the Winograd forms) */
-    int32_t algo;       /* what ran: 0 direct, 1 Winograd serial form, 2 class-parallel form, 3 dual form */
+    int32_t algo;       /* what ran: 0 direct, 1 Winograd serial form, 2 class-parallel form, 3 dual form, 4 two-axis form */
     int32_t reserved;
 } s3r_prof_record;
 int s3r_profile_enable(int max_records);   /* 0 disables and frees the event pool */

@@ -238,35 +238,79 @@ bool wino_desc_ok(const s3r_conv_desc* d) {
     if (d->out_layout != S3R_LAYOUT_PLAIN) return false;
     return d->in_layout == S3R_LAYOUT_PLAIN || (d->in_layout == S3R_LAYOUT_WINO_H && wino_layer(d));
 }
-// the algorithm a descriptor resolves to: *wino = Winograd (else direct); *form = the forced launch form or -1
-int resolve_algo(const s3r_conv_desc* d, bool* wino, int* form) {
-    *wino = false;
+// Two-axis class-parallel Winograd (s3r_conv_wino.hip): the 3D stride-1 layers with a small edge — k3 p1 as F(4,3) x F(4,3)
+// (returns 0), k4 p0 as F(2,4) x F(2,4) (returns 1); -1: the layer has no such form
+int wino2_ax(const s3r_conv_desc* d) {
+    if (d->dtype == S3R_BF16 || d->op != S3R_OP_CONV || d->ndim != 3 || d->stride != 1 || d->cin % s3r::wino_bk() != 0 || d->cout <= 1)
+        return -1;
+    if (d->k == 3 && d->pad == 1 && d->in_size >= 4) return 0;
+    if (d->k == 4 && d->pad == 0 && d->in_size >= 5) return 1;
+    return -1;
+}
+bool wino2_desc_ok(const s3r_conv_desc* d) {
+    return wino2_ax(d) >= 0 && d->act != S3R_ACT_SIGMOID && d->in_halo == d->pad && d->ksplit <= 1 &&
+           d->in_layout == S3R_LAYOUT_PLAIN && d->out_layout == S3R_LAYOUT_PLAIN;
+}
+// library policy: the two-axis form where the output is small enough for its class slabs (ncls / m^2 x the output) to be cheap
+// — v3 (edge 14: 0.438 -> 0.329 ms alone at B = 32), v5, v6 (edge 7: 0.252 -> 0.142, 0.329 direct -> 0.149) of this network, not
+// v1 (edge 28: 405 MB of slabs); S3R_WINO2_MAX_EDGE (read once) moves the bound for experiments
+int wino2_max_edge() {
+    static const int e = getenv("S3R_WINO2_MAX_EDGE") ? atoi(getenv("S3R_WINO2_MAX_EDGE")) : 14;
+    return e;
+}
+enum { ALG_DIRECT = 0, ALG_WINO = 1, ALG_WINO2 = 2 };
+// the algorithm a descriptor resolves to; *form = the forced launch form of the one-axis kernel, or -1
+int resolve_algo(const s3r_conv_desc* d, int* alg, int* form) {
+    *alg = ALG_DIRECT;
     *form = -1;
     if (d->algo != S3R_ALGO_AUTO && d->algo != S3R_ALGO_DIRECT && d->algo != S3R_ALGO_WINOGRAD)
         return fail(S3R_ERR_INVALID, "unknown algo %d", d->algo);
     if (d->algo == S3R_ALGO_WINOGRAD) {
-        if (!wino_desc_ok(d))
-            return fail(S3R_ERR_INVALID, "algo = WINOGRAD: this layer / descriptor has no Winograd form (fp32 Conv k3 s1 p1 with cin %% %d "
-                        "== 0 and edge >= 4, or ConvTranspose3d k4 s2 p1 over an even edge; in_halo = 1, plain layouts, no split-K, "
-                        "no sigmoid)", s3r::wino_bk());
-        *wino = true;
-        *form = d->tile;
+        const bool one = wino_desc_ok(d), two = wino2_desc_ok(d);
+        // tile: -1 the library's pick between the forms the layer has; 0, 1, 2 a launch form of the one-axis kernel; 3 the two-axis form
+        if ((d->tile == 3 && !two) || (d->tile >= 0 && d->tile <= 2 && !one) || (!one && !two) || d->tile > 3)
+            return fail(S3R_ERR_INVALID, "algo = WINOGRAD: this layer / descriptor has no such Winograd form (one-axis: fp32 Conv k3 s1 p1 "
+                        "with cin %% %d == 0 and edge >= 4, or ConvTranspose3d k4 s2 p1 over an edge %% 4 == 0, in_halo = 1; two-axis "
+                        "(tile = 3): Conv3d k3 s1 p1 / k4 s1 p0, in_halo = pad; plain layouts, no split-K, no sigmoid)", s3r::wino_bk());
+        if (d->tile == 3 || !one || (d->tile < 0 && two && d->in_layout == S3R_LAYOUT_PLAIN && d->in_size <= wino2_max_edge()))
+            *alg = ALG_WINO2;
+        else { *alg = ALG_WINO; *form = d->tile; }
         return S3R_OK;
     }
-    if (d->in_layout == S3R_LAYOUT_WINO_H) {             // only the Winograd kernel reads the transformed planes
+    if (d->in_layout == S3R_LAYOUT_WINO_H) {             // only the one-axis Winograd kernel reads the transformed planes
         if (d->algo == S3R_ALGO_DIRECT || !wino_desc_ok(d) || d->tile >= 0)
             return fail(S3R_ERR_INVALID, "a Winograd-transformed input runs the Winograd kernel only: algo AUTO / WINOGRAD, no direct tile / "
                         "split-K override, a plain output");
-        *wino = true;
+        *alg = ALG_WINO;
         return S3R_OK;
     }
-    if (d->algo == S3R_ALGO_DIRECT || d->tile >= 0 || d->ksplit >= 1 || !wino_desc_ok(d)) return S3R_OK;
-    *wino = wino_mode() > 0;
+    if (d->algo == S3R_ALGO_DIRECT || d->tile >= 0 || d->ksplit >= 1 || wino_mode() <= 0) return S3R_OK;
+    if (wino2_desc_ok(d) && d->in_size <= wino2_max_edge()) *alg = ALG_WINO2;
+    else if (wino_desc_ok(d)) *alg = ALG_WINO;
     return S3R_OK;
 }
 bool resolves_to_wino(const s3r_conv_desc* d) {
-    bool w; int f;
-    return resolve_algo(d, &w, &f) == S3R_OK && w;
+    int a, f;
+    return resolve_algo(d, &a, &f) == S3R_OK && a != ALG_DIRECT;
+}
+// ---- two-axis form: sizes
+struct Wino2Geo { int ax, m, n, ncls, out, sg, wp, kw, bmax; int64_t w_elems, v_sample, pos_sample; };
+Wino2Geo wino2_geo(const s3r_conv_desc* d) {
+    Wino2Geo w;
+    w.ax = wino2_ax(d);
+    w.m = s3r::wino2_outputs(w.ax);
+    w.ncls = s3r::wino2_classes(w.ax);
+    w.out = out_size(d);
+    w.sg = (w.out + w.m - 1) / w.m;                       // groups per axis
+    w.wp = d->in_size + 2 * d->in_halo;
+    w.kw = d->k;
+    w.w_elems = (int64_t)w.ncls * w.kw * d->cin * cout_pad(d->cout);
+    w.v_sample = (int64_t)w.ncls * d->cin * w.sg * w.sg * w.wp;
+    w.pos_sample = (int64_t)w.sg * w.sg * w.out;
+    const int64_t mx = w.v_sample > 0 ? (((int64_t)1 << 31) - 1) / (4 * w.v_sample) : 0;
+    w.bmax = (int)(mx < d->batch ? mx : d->batch);
+    w.n = 0;
+    return w;
 }
 int64_t wino_w_elems(const s3r_conv_desc* d) {       // the R + 2 class slabs behind the direct slab
     return (wino_r(d) + 2) * ipow(3, d->ndim - 1) * d->cin * (int64_t)cout_pad(d->cout);
@@ -339,6 +383,65 @@ double wino_exec_flops(const s3r_conv_desc* d, const Geo& g) {
     const int R = wino_r(d);
     const double taps = (d->ndim == 3 ? 3.0 : 1.0) * 3.0 * (R + 2);
     return 2.0 * (double)wino_positions(d, d->batch) * d->cout * d->cin * taps;
+}
+
+// scratch of a two-axis call: [V of one sub-batch | class slabs]
+WinoNeed wino2_need(const s3r_conv_desc* d) {
+    WinoNeed w = {0, 0, 0};
+    const Wino2Geo g2 = wino2_geo(d);
+    if (d->batch <= 0 || g2.bmax <= 0) return w;
+    w.v = (g2.v_sample * g2.bmax + 255) / 256 * 256;
+    const int64_t npad = (g2.pos_sample * g2.bmax + 63) / 64 * 64;
+    w.slab = (int64_t)g2.ncls * d->cout * npad;
+    w.total = w.v + w.slab;
+    return w;
+}
+double wino2_exec_flops(const s3r_conv_desc* d) {
+    const Wino2Geo g2 = wino2_geo(d);
+    return 2.0 * (double)g2.pos_sample * d->batch * g2.ncls * d->cout * d->cin * g2.kw;
+}
+// input transform + class kernel + finish, in sub-batches that keep the transformed input inside 32-bit byte offsets
+int wino2_run(const s3r_conv_desc* d, const Geo& g, s3r::ConvParams p, const float* x, const float* packed_w, float* y, float* scratch,
+              int64_t scratch_elems, hipStream_t s, int* launches) {
+    const Wino2Geo g2 = wino2_geo(d);
+    const WinoNeed need = wino2_need(d);
+    if (g2.bmax <= 0) return fail(S3R_ERR_INVALID, "two-axis Winograd form: one sample's transformed input exceeds 2 GiB");
+    if (!scratch || scratch_elems < need.total)
+        return fail(S3R_ERR_WORKSPACE, "the two-axis Winograd form of this layer needs %lld floats of scratch (s3r_conv_scratch_elems), "
+                    "got %lld", (long long)need.total, (long long)(scratch ? scratch_elems : 0));
+    const int64_t direct_w = ipow(d->k, 3) * d->cin * cout_pad(d->cout);
+    p.w = packed_w + direct_w + (wino_layer(d) ? wino_w_elems(d) : 0);      // behind the direct (and the one-axis) slabs
+    p.x = scratch;
+    p.part = scratch + need.v;
+    p.Nd = g2.sg; p.Nh = g2.sg; p.Nw = g2.out;
+    p.kd = 1; p.kh = 1; p.kw = g2.kw; p.T = g2.kw;
+    p.x_hs = g2.wp; p.x_ds = g2.sg * g2.wp; p.x_cs = g2.sg * g2.sg * g2.wp;
+    p.x_org = 0;
+    p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
+    p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
+    p.dW = s3r::FastDiv((unsigned)p.Nw);
+    p.Hout = g2.out; p.Dout = g2.out;
+    p.ncls = g2.ncls;
+    p.ksplit = 1;
+    const int64_t x_sample = g.x_elems / d->batch;
+    *launches = 0;
+    for (int b0 = 0; b0 < d->batch; b0 += g2.bmax) {
+        const int nb = d->batch - b0 < g2.bmax ? d->batch - b0 : g2.bmax;
+        hipError_t e = s3r::launch_wino2_input(x + (int64_t)b0 * x_sample, scratch, g2.ax, (long long)nb * d->cin, g2.wp, g2.wp, g2.wp,
+                                               g2.sg, g2.sg, s);
+        if (e != hipSuccess) return hip_fail(e, "two-axis Winograd input transform launch");
+        p.B = nb;
+        p.x_cls = nb * d->cin * p.x_cs;
+        p.x_bytes = (unsigned)(4 * (int64_t)nb * g2.v_sample);
+        p.Ntotal = nb * p.Nd * p.Nh * p.Nw;
+        p.y = y + (int64_t)b0 * p.y_bs;
+        p.y_bytes = (unsigned)(4 * (int64_t)nb * p.y_bs);
+        int nl = 0;
+        e = s3r::launch_conv_wino2(p, g2.ax, s, &nl);
+        if (e != hipSuccess) return hip_fail(e, "two-axis Winograd conv launch");
+        *launches += 1 + nl;
+    }
+    return S3R_OK;
 }
 
 // fills the transposed-convolution parameters for the Winograd kernel and runs transform + kernel
@@ -581,11 +684,11 @@ int conv_head_fused(const s3r_conv_desc* d, const Geo& g, const s3r_conv_desc* h
     p.y_org = hd->out_halo * (p.y_ds + p.y_hs + 1);
     p.y_bytes = (unsigned)(hg.y_elems * 4);
     p.head_w = static_cast<const float*>(H.packed_w); p.head_scale = H.scale; p.head_shift = H.shift; p.head_act = hd->act;
-    bool wino; int form;
-    int rc = resolve_algo(d, &wino, &form);
+    int alg, form;
+    int rc = resolve_algo(d, &alg, &form);
     if (rc) return rc;
-    if (wino) {
-        if (d->op != S3R_OP_DECONV || d->cout > 64) return fail(S3R_ERR_INVALID, "the fused head rides on the transposed Winograd kernel with <= 64 couts only");
+    if (alg != ALG_DIRECT) {
+        if (alg != ALG_WINO || d->op != S3R_OP_DECONV || d->cout > 64) return fail(S3R_ERR_INVALID, "the fused head rides on the transposed Winograd kernel with <= 64 couts only");
         ProfScope ps(s, F_MFMA, d->tag, g.flops + hg.flops, g.bytes - 4.0 * d->batch * d->cout * (double)g.out_sp +
                      4.0 * d->batch * (double)hg.out_sp);
         ps.exec = wino_exec_flops(d, g) + hg.flops;
@@ -660,7 +763,8 @@ int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems) {
         case R_MFMA: {
             const int64_t taps = d->op == S3R_OP_DECONV ? 64 : ipow(d->k, g.nd);
             if (d->dtype == S3R_BF16) *elems = (taps * d->cin * cout_pad_h(d->cout) + 1) / 2;   // bf16, in float units
-            else *elems = taps * d->cin * cout_pad(d->cout) + (wino_layer(d) ? wino_w_elems(d) : 0) + (dwino_layer(d) ? dwino_w_elems(d) : 0);
+            else *elems = taps * d->cin * cout_pad(d->cout) + (wino_layer(d) ? wino_w_elems(d) : 0) + (dwino_layer(d) ? dwino_w_elems(d) : 0) +
+                          (wino2_ax(d) >= 0 ? wino2_geo(d).w_elems : 0);
             break;
         }
     }
@@ -693,6 +797,9 @@ int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, void* packedv,
                                               cout_pad(d->cout), g.nd == 3 ? 3 : 1, 3, wino_r(d), s);
                 if (e == hipSuccess && dwino_layer(d))
                     e = s3r::launch_pack_wino_deconv(w, packed + 64 * (int64_t)d->cin * cout_pad(d->cout), d->cin, d->cout, cout_pad(d->cout), s);
+                if (e == hipSuccess && wino2_ax(d) >= 0)
+                    e = s3r::launch_pack_wino2(w, packed + ipow(d->k, g.nd) * d->cin * cout_pad(d->cout) + (wino_layer(d) ? wino_w_elems(d) : 0),
+                                               wino2_ax(d), d->cin, d->cout, cout_pad(d->cout), s);
             }
             break;
     }
@@ -713,9 +820,10 @@ int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d) {
         if ((rc = resolve_launch_h(d, &ph, &Lh))) return rc;
         return s3r::conv_bf16_scratch_elems(ph, Lh.tm);
     }
-    bool wino; int form;
-    if ((rc = resolve_algo(d, &wino, &form))) return rc;
-    if (wino) return wino_need(d, form, false).total;
+    int alg, form;
+    if ((rc = resolve_algo(d, &alg, &form))) return rc;
+    if (alg == ALG_WINO) return wino_need(d, form, false).total;
+    if (alg == ALG_WINO2) return wino2_need(d).total;
     s3r::ConvParams p = make_params(d, g);
     Launch L;
     if ((rc = resolve_launch(d, &p, &L))) return rc;
@@ -824,8 +932,15 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
         case R_MFMA: {
             s3r::ConvParams p = make_params(d, g);
             p.x = x; p.w = packed_w; p.scale = scale; p.shift = shift; p.y = y;
-            bool wino; int form;
-            if ((rc = resolve_algo(d, &wino, &form))) return rc;
+            int alg, form;
+            if ((rc = resolve_algo(d, &alg, &form))) return rc;
+            const bool wino = alg == ALG_WINO;
+            if (alg == ALG_WINO2) {
+                ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
+                ps.exec = wino2_exec_flops(d);
+                ps.algo = 4;
+                return wino2_run(d, g, p, x, packed_w, y, scratch, scratch_elems, s, &ps.launches);
+            }
             if (wino && d->op == S3R_OP_DECONV) {
                 ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
                 ps.exec = wino_exec_flops(d, g);
@@ -1079,7 +1194,10 @@ int64_t s3r_conv_wino_input_elems(const s3r_conv_desc* d) {
     if (!d) return fail(S3R_ERR_INVALID, "null descriptor");
     s3r_conv_desc t = *d;
     t.in_layout = S3R_LAYOUT_PLAIN;
-    if (!resolves_to_wino(&t) || t.op != S3R_OP_CONV || t.in_size % wino_r(&t) != 0 || wino_bmax(&t) < t.batch) return 0;
+    int alg, form;
+    if (resolve_algo(&t, &alg, &form) != S3R_OK || alg != ALG_WINO || t.op != S3R_OP_CONV || t.in_size % wino_r(&t) != 0 ||
+        wino_bmax(&t) < t.batch)
+        return 0;
     return wino_v_elems(&t);
 }
 

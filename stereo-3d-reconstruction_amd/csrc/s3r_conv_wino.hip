@@ -364,7 +364,8 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DECONV ? p.xd : p.x), 0, (int)p.x_bytes, 0x00020000);
     const size_t x_el = (size_t)p.x_bytes / 4;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.w), 0, (int)((unsigned)(DECONV ? 72 : NCLS) * (unsigned)T * (unsigned)p.Cin * (unsigned)p.CoutPad * 4u),
+        const_cast<float*>(p.w), 0,
+        (int)((unsigned)(DECONV ? 72 : (p.ncls ? p.ncls : NCLS)) * (unsigned)T * (unsigned)p.Cin * (unsigned)p.CoutPad * 4u),
         0x00020000);
     const int b_row0 = B_WIDE ? wave / PPR : wave * RPP;
     constexpr int B_ROW_STEP = B_WIDE ? 4 / PPR : 4 * RPP;
@@ -847,6 +848,213 @@ hipError_t launch_deconv_wino(ConvParams p, const WinoLaunch& L, hipStream_t str
     if (launches) *launches = L.mode == WINO_SERIAL ? 1 : 2;
     if (p.Nw % 4 != 0) return hipErrorInvalidValue;       // (16-byte gathers only: the library's policy asks for an edge % 4 == 0)
     return launch_wino_forms<4, 2>(p, L, stream);
+}
+
+// ================================================================================================
+// Two-axis Winograd for the small 3D layers, CLASS-PARALLEL ONLY.  A class-parallel workgroup holds ONE class's accumulators,
+// so nothing limits the number of classes: nesting the transform along D and H turns v5 (3 x 3 x 3 over 7^3) into 36 class
+// convolutions with a 1 x 1 x 3 kernel for 4 x 4 outputs — F(4,3) x F(4,3): 108 multiply-adds per 16 outputs where the direct
+// form spends 432 and the one-axis form 216 — and v6 (4 x 4 x 4, valid, 7^3 -> 4^3) into 25 classes with a 1 x 1 x 4 kernel for
+// 2 x 2 outputs: F(2,4) x F(2,4), 100 per 4 outputs instead of 256.  The class GEMM is the one-axis kernel's class-parallel form
+// unchanged (wino_kernel<VEC, 1, 2, true>: a class is a plane set + a weight slab, K = Cin x kw); what is new is the input
+// transform (a window of n x n rows per group), the weight transform (G x G) and the finish kernel (A^T along H, then D).
+// Slabs cost ncls / (m m) x the output's bytes, which is why only layers with small outputs take it (v5: 11 MB -> 32 MB).
+//   F(2,4), points 0, 1, -1, 2, inf (tools/wino_matrices.py derives and checks both sets in exact arithmetic):
+//     B^T rows (2,-1,-2,1,0) (0,-2,-1,1,0) (0,2,-3,1,0) (0,-1,0,1,0) (0,2,-1,-2,1)
+//     G rows (1/2,0,0,0) (-1/2,-1/2,-1/2,-1/2) (-1/6,1/6,-1/6,1/6) (1/6,1/3,2/3,4/3) (0,0,0,1)     A^T rows (1,1,1,1,0) (0,1,-1,2,1)
+template <int AX> struct WAxis;
+template <> struct WAxis<0> { static constexpr int N = 6, M = 4, R = 3; };      // F(4,3)
+template <> struct WAxis<1> { static constexpr int N = 5, M = 2, R = 4; };      // F(2,4)
+int wino2_classes(int ax) { return ax == 0 ? 36 : 25; }
+int wino2_outputs(int ax) { return ax == 0 ? 4 : 2; }
+
+template <int AX>
+__device__ __forceinline__ void wax_bt(const float (&r)[WAxis<AX>::N], float (&v)[WAxis<AX>::N]) {
+    if constexpr (AX == 0) wino_rows_to_classes<4>(r, v);
+    else {
+        v[0] = fmaf(2.f, r[0] - r[2], r[3] - r[1]);
+        v[1] = fmaf(-2.f, r[1], r[3] - r[2]);
+        v[2] = fmaf(2.f, r[1], fmaf(-3.f, r[2], r[3]));
+        v[3] = r[3] - r[1];
+        v[4] = fmaf(2.f, r[1] - r[3], r[4] - r[2]);
+    }
+}
+template <int AX>
+__device__ __forceinline__ void wax_at(const float (&m)[WAxis<AX>::N], float (&y)[WAxis<AX>::M]) {
+    if constexpr (AX == 0) wino_out<1>(m, y);
+    else {
+        y[0] = ((m[0] + m[1]) + m[2]) + m[3];
+        y[1] = fmaf(2.f, m[3], m[1] - m[2]) + m[4];
+    }
+}
+// transformed weight of class c from the axis' R kernel values
+template <int AX>
+__device__ __forceinline__ float wax_g(int c, const float (&g)[WAxis<AX>::R]) {
+    if constexpr (AX == 0) {
+        const float s02 = g[0] + g[2], a = g[0] * (1.f / 24.f) + g[2] * (1.f / 6.f), b12 = g[1] * (1.f / 12.f);
+        return c == 0 ? g[0] * 0.25f : c == 1 ? (s02 + g[1]) * (-1.f / 6.f) : c == 2 ? (s02 - g[1]) * (-1.f / 6.f)
+             : c == 3 ? a + b12 : c == 4 ? a - b12 : g[2];
+    } else {
+        const float e = g[0] + g[2], o = g[1] + g[3];
+        return c == 0 ? g[0] * 0.5f : c == 1 ? (e + o) * -0.5f : c == 2 ? (o - e) * (1.f / 6.f)
+             : c == 3 ? fmaf(g[3], 4.f / 3.f, fmaf(g[2], 2.f / 3.f, fmaf(g[1], 1.f / 3.f, g[0] * (1.f / 6.f)))) : g[3];
+    }
+}
+
+// one thread per (plane, depth group, row group, column): an N x N window of the input, B^T along H then along D
+template <int AX>
+__global__ __launch_bounds__(256) void wino2_input_kernel(const float* __restrict__ x, float* __restrict__ V, unsigned total,
+                                                          int Dp, int Hp, int Wp, int SD, int SH, FastDiv dW, FastDiv dSH, FastDiv dSD) {
+    constexpr int N = WAxis<AX>::N, M = WAxis<AX>::M;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned row = (unsigned)dW.div((int)i);                   // ((plane, sd), sh)
+        const int w = (int)(i - row * (unsigned)Wp);
+        const unsigned pg = (unsigned)dSH.div((int)row);                 // (plane, sd)
+        const int sh = (int)(row - pg * (unsigned)SH);
+        const unsigned pl = (unsigned)dSD.div((int)pg);
+        const int sd = (int)(pg - pl * (unsigned)SD);
+        const float* __restrict__ src = x + ((size_t)pl * Dp + M * sd) * Hp * Wp + (size_t)M * sh * Wp + w;
+        float t[N][N];                                                   // [depth][row class]
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            float r[N], v[N];
+#pragma unroll
+            for (int b = 0; b < N; ++b)
+                r[b] = (M * sd + a < Dp && M * sh + b < Hp) ? src[((size_t)a * Hp + b) * Wp] : 0.f;
+            wax_bt<AX>(r, v);
+#pragma unroll
+            for (int b = 0; b < N; ++b) t[a][b] = v[b];
+        }
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+            float r[N], v[N];
+#pragma unroll
+            for (int a = 0; a < N; ++a) r[a] = t[a][b];
+            wax_bt<AX>(r, v);
+#pragma unroll
+            for (int a = 0; a < N; ++a) V[(size_t)(a * N + b) * total + i] = v[a];
+        }
+    }
+}
+
+hipError_t launch_wino2_input(const float* x, float* V, int ax, long long planes, int Dp, int Hp, int Wp, int SD, int SH, hipStream_t s) {
+    const long long total = planes * SD * SH * Wp;
+    if (total >= (1ll << 31) || (ax != 0 && ax != 1)) return hipErrorInvalidValue;
+    const long long blocks = (total + 255) / 256;
+    const dim3 grid((unsigned)(blocks < 16384 ? blocks : 16384));
+    const FastDiv dW((unsigned)Wp), dSH((unsigned)SH), dSD((unsigned)SD);
+    if (ax == 0) hipLaunchKernelGGL(wino2_input_kernel<0>, grid, dim3(256), 0, s, x, V, (unsigned)total, Dp, Hp, Wp, SD, SH, dW, dSH, dSD);
+    else hipLaunchKernelGGL(wino2_input_kernel<1>, grid, dim3(256), 0, s, x, V, (unsigned)total, Dp, Hp, Wp, SD, SH, dW, dSH, dSD);
+    return hipGetLastError();
+}
+
+// w[Cout][Cin][k][k][k] (k = R) -> Up[cls = a N + b][(chunk*k + tw)*32 + c][CoutPad]: G along H, then along D
+template <int AX>
+__global__ void pack_wino2_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int CoutPad) {
+    constexpr int N = WAxis<AX>::N, R = WAxis<AX>::R;
+    const size_t per_cls = (size_t)R * Cin * CoutPad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)N * N * per_cls; i += (size_t)gridDim.x * blockDim.x) {
+        const int cls = (int)(i / per_cls);
+        const int ca = cls / N, cb = cls - ca * N;
+        size_t r = i % per_cls;
+        const int co = (int)(r % CoutPad);
+        r /= CoutPad;
+        const int c = (int)(r % WBK);
+        r /= WBK;
+        const int tw = (int)(r % R);
+        const int cc = (int)(r / R);
+        const int cin = cc * WBK + c;
+        float v = 0.f;
+        if (co < Cout) {
+            const float* g = w + ((size_t)co * Cin + cin) * R * R * R + tw;       // g[(kd * R + kh) * R]
+            float gd[R];
+#pragma unroll
+            for (int kd = 0; kd < R; ++kd) {
+                float gh[R];
+#pragma unroll
+                for (int kh = 0; kh < R; ++kh) gh[kh] = g[(kd * R + kh) * R];
+                gd[kd] = wax_g<AX>(cb, gh);
+            }
+            v = wax_g<AX>(ca, gd);
+        }
+        wp[i] = v;
+    }
+}
+
+hipError_t launch_pack_wino2(const float* w, float* wp, int ax, int Cin, int Cout, int CoutPad, hipStream_t s) {
+    if (ax == 0) hipLaunchKernelGGL(pack_wino2_kernel<0>, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CoutPad);
+    else if (ax == 1) hipLaunchKernelGGL(pack_wino2_kernel<1>, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CoutPad);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// slabs [cls][Cout][npad] -> y: A^T along H, then along D, folded BN + activation; outputs beyond the true edge are not stored
+template <int AX>
+__global__ __launch_bounds__(256) void wino2_finish_kernel(const ConvParams p, const int npad) {
+    constexpr int N = WAxis<AX>::N, M = WAxis<AX>::M;
+    const int S = p.Nd * p.Nh * p.Nw;
+    const int nn = p.Ntotal;
+    const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+    const size_t cstride = (size_t)p.Cout * npad;
+    const long long total = (long long)p.Cout * nn;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int mrow = (int)(i / nn);
+        const int n = (int)(i - (long long)mrow * nn);
+        const int b = p.dS.div(n);
+        int rem = n - b * S;
+        const int sd = p.dHW.div(rem);
+        rem -= sd * p.Nh * p.Nw;
+        const int sh = p.dW.div(rem);
+        const int pw = rem - sh * p.Nw;
+        const float* __restrict__ src = p.part + (size_t)mrow * npad + n;
+        float t[N][M];                                                   // [depth class][output row]
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            float m[N], y[M];
+#pragma unroll
+            for (int c = 0; c < N; ++c) m[c] = src[(size_t)(a * N + c) * cstride];
+            wax_at<AX>(m, y);
+#pragma unroll
+            for (int v = 0; v < M; ++v) t[a][v] = y[v];
+        }
+        const float sc = p.scale ? p.scale[mrow] : 1.f, sf = p.shift ? p.shift[mrow] : 0.f;
+        float* __restrict__ yo = p.y + (size_t)b * p.y_bs + (size_t)mrow * p.y_cs + p.y_org + (size_t)M * sd * p.y_ds + M * sh * p.y_hs + pw;
+#pragma unroll
+        for (int v = 0; v < M; ++v) {
+            float m[N], y[M];
+#pragma unroll
+            for (int a = 0; a < N; ++a) m[a] = t[a][v];
+            wax_at<AX>(m, y);
+#pragma unroll
+            for (int u = 0; u < M; ++u)
+                if (M * sd + u < p.Dout && M * sh + v < p.Hout) yo[(size_t)u * p.y_ds + v * p.y_hs] = wino_act(y[u], sc, sf, lo);
+        }
+    }
+}
+
+// p: the CLASS convolution (wino_body): x = V, x_cs / x_ds / x_hs / x_cls its strides, Nd / Nh = depth / row groups, kd = kh = 1,
+// T = kw, ncls = the class count; part = slabs; y / Dout / Hout the layer's output
+hipError_t launch_conv_wino2(ConvParams p, int ax, hipStream_t stream, int* launches) {
+    if (p.Cin % WBK != 0 || p.stride != 1 || p.transposed || p.ksplit != 1 || p.head_w || p.act == ACT_SIGMOID || !p.part ||
+        (ax != 0 && ax != 1) || p.ncls != wino2_classes(ax))
+        return hipErrorInvalidValue;
+    p.kh = 1;
+    p.m_tiles = (p.Cout + WBM - 1) / WBM;
+    p.n_begin = 0; p.n_end = p.Ntotal;
+    const int n_tiles = (p.Ntotal + WCN - 1) / WCN;
+    const dim3 grid(p.m_tiles * n_tiles * p.ncls);
+    const size_t lds = (size_t)WNB * WBK * (WBM + WCN) * sizeof(float);
+    if (p.Nw % 4 == 0) hipLaunchKernelGGL((wino_kernel<4, 1, 2, true, false>), grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((wino_kernel<1, 1, 2, true, false>), grid, dim3(256), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const long long total = (long long)p.Cout * p.Ntotal;
+    const long long blocks = (total + 255) / 256;
+    const dim3 fgrid((unsigned)(blocks < 8192 ? blocks : 8192));
+    if (ax == 0) hipLaunchKernelGGL(wino2_finish_kernel<0>, fgrid, dim3(256), 0, stream, p, n_tiles * WCN);
+    else hipLaunchKernelGGL(wino2_finish_kernel<1>, fgrid, dim3(256), 0, stream, p, n_tiles * WCN);
+    if (launches) *launches = 2;
+    return hipGetLastError();
 }
 
 }  // namespace s3r

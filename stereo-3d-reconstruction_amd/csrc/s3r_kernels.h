@@ -91,9 +91,10 @@ struct ConvParams {
     const float* head_scale;   // [1] or null
     const float* head_shift;   // [1] or null
     int head_act;
-    // Winograd F(2,3) along H (s3r_conv_wino.hip): x = the four transformed input plane sets, x_cls elements apart; Nh = row
-    // pairs per plane; Hout = the output's true height
-    int x_cls, Hout;
+    // Winograd along H (s3r_conv_wino.hip): x = the transformed input plane sets, x_cls elements apart; Nh = row groups per
+    // plane; Hout = the output's true height.  Two-axis form (D and H): Nd = depth groups, Dout = the true depth, ncls = the
+    // number of (depth class, row class) plane sets / weight slabs (0: the one-axis form's own count)
+    int x_cls, Hout, Dout, ncls;
     // transposed Winograd form: the row differences Dh of the padded input (x's shape and strides); xd_mode = 1: followed by the
     // depth differences Dd and the mixed differences Ddh (materialised), 0: those are formed inside the class kernel
     const float* xd;
@@ -156,6 +157,14 @@ hipError_t launch_pack_wino(const float* w, float* wp, int Cin, int Cout, int Co
 WinoLaunch wino_plan(int kind, int cout, int kcls, int ntotal, bool head, int forced);
 int64_t wino_slab_elems(int kind, int cout, int ntotal, const WinoLaunch& L);     // floats of class-parallel slabs (p.part)
 hipError_t launch_conv_wino(ConvParams p, const WinoLaunch& L, hipStream_t stream, int* launches);
+// Two-axis (D and H) class-parallel Winograd convolution of 3D layers with a small edge: ax = 0: F(4,3) on both axes (k3 p1, 36
+// classes per 4 x 4 outputs), 1: F(2,4) (k4 p0, 25 classes per 2 x 2 outputs).  x: (B, C, Dp, Hp, Wp) as the layer reads it;
+// V: [ncls][B][C][SD][SH][Wp]; slabs in p.part
+int wino2_classes(int ax);          // 36 / 25
+int wino2_outputs(int ax);          // outputs per group and axis: 4 / 2
+hipError_t launch_wino2_input(const float* x, float* V, int ax, long long planes, int Dp, int Hp, int Wp, int SD, int SH, hipStream_t s);
+hipError_t launch_pack_wino2(const float* w, float* wp, int ax, int Cin, int Cout, int CoutPad, hipStream_t s);
+hipError_t launch_conv_wino2(ConvParams p, int ax, hipStream_t stream, int* launches);
 int wino_bk();                      // channels per K tile of the Winograd kernels (Cin must be a multiple)
 // Winograd F(2,2) along D and H inside the parity classes of ConvTranspose3d(k4 s2 p1); D = [Dh] or (three) [Dh | Dd | Ddh]
 hipError_t launch_wino_diff(const float* x, float* D, long long planes, int Dp, int Hp, int Wp, int three, hipStream_t s);

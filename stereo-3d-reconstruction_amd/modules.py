@@ -258,6 +258,8 @@ class _HipChain(nn.Module):
             return False
         if l.op == "deconv3d":
             return l.k == 4 and l.s == 2 and l.p == 1 and l.cin % 32 == 0
+        if l.op == "conv3d" and l.k == 4 and l.s == 1 and l.p == 0 and l.cin % 32 == 0 and l.cout > 1:
+            return True                                  # (the two-axis F(2,4) x F(2,4) form)
         return l.op in ("conv2d", "conv3d") and l.k == 3 and l.s == 1 and l.p == 1 and l.cin % 32 == 0 and l.cout > 1
 
     def _algo_of(self, l: spec.Layer) -> int:

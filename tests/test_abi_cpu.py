@@ -65,6 +65,10 @@ def test_out_size_and_packed_elems(s3r, lib):
                 wino = 6 * 3 ** (nd - 1) * l.cin * pad if (l.op != "deconv3d" and l.k == 3 and l.s == 1 and l.p == 1) else 0
                 if l.op == "deconv3d":            # ... and a transposed convolution its 72 F(2,2)^2 (parity class, class) slabs of 2 taps
                     wino = 72 * 2 * l.cin * pad
+                if l.op == "conv3d" and l.s == 1 and l.k == 3 and l.p == 1:      # ... a 3D one also the 36 two-axis F(4,3)^2 slabs
+                    wino += 36 * 3 * l.cin * pad
+                if l.op == "conv3d" and l.s == 1 and l.k == 4 and l.p == 0:      # (v6: 25 F(2,4)^2 slabs of 4 taps)
+                    wino += 25 * 4 * l.cin * pad
                 assert e.value == l.k ** nd * l.cin * pad + wino
 
 
@@ -223,8 +227,17 @@ def test_algo_field_selects_the_kernel_and_scratch_is_never_a_selector(s3r, lib)
     assert scratch("e2", L.ALGO_AUTO, tile=3)[0] == 0          # a direct-kernel tile override is a direct-kernel request
     assert scratch("v5", L.ALGO_DIRECT)[0] > 0                 # (the direct kernel splits v5's K)
     assert scratch("v5", L.ALGO_AUTO)[0] == scratch("v5", L.ALGO_WINOGRAD)[0] > 0
+    # v5 (edge 7) resolves to the TWO-AXIS form: 36 plane sets of 2 x 2 groups x 9 columns per channel, then 36 class slabs
+    v5_two = -(-(36 * 4 * 256 * 2 * 2 * 9) // 256) * 256 + 36 * 256 * -(-(4 * 2 * 2 * 7) // 64) * 64
+    assert scratch("v5", L.ALGO_AUTO)[0] == v5_two == scratch("v5", L.ALGO_WINOGRAD, tile=3)[0]
+    assert scratch("v5", L.ALGO_WINOGRAD, tile=0)[0] != v5_two                 # the one-axis kernel stays selectable
+    l6, n6 = dec["v6"]
+    d6 = L.make_desc(l6, 4, n6, in_halo=0, algo=L.ALGO_AUTO)                   # v6: k4 p0 — F(2,4) x F(2,4), 25 classes
+    assert lib.s3r_conv_scratch_elems(C.byref(d6)) == -(-(25 * 4 * 256 * 2 * 2 * 7) // 256) * 256 + 25 * 512 * 64
+    d6.algo = L.ALGO_WINOGRAD; d6.tile = 0
+    assert lib.s3r_conv_scratch_elems(C.byref(d6)) == -1                       # no one-axis form for a 4-tap kernel
     # AUTO never depends on the batch: the same choice at 1 and at 64 samples (the scratch follows the batch, the kernel not)
-    for name in ("e2", "e7", "v1", "v3", "v5", "d1", "d3"):
+    for name in ("e2", "e7", "v1", "v3", "v5", "d1", "d3"):      # (v3, v5: the two-axis form, v1 and the rest the one-axis one)
         assert all(scratch(name, L.ALGO_AUTO, b)[0] > 0 for b in (1, 2, 64)), name
     assert scratch("e3", L.ALGO_WINOGRAD)[0] == -1             # stride 2: no Winograd form
     assert b"WINOGRAD" in lib.s3r_last_error()
@@ -239,9 +252,9 @@ def test_algo_field_selects_the_kernel_and_scratch_is_never_a_selector(s3r, lib)
     assert lib.s3r_conv_forward(C.byref(d_auto), one, one, None, None, one, one, auto - 1, None) == -3
     assert b"scratch" in lib.s3r_last_error()
     assert lib.s3r_conv_forward(C.byref(d_auto), one, one, None, None, one, None, 0, None) == -3
-    dv6 = L.make_desc(dec["v6"][0], 4, dec["v6"][1])
+    dv6 = L.make_desc(dec["v6"][0], 4, dec["v6"][1], algo=L.ALGO_DIRECT)
     need = lib.s3r_conv_scratch_elems(C.byref(dv6))
-    assert need > 0                                            # the library splits v6's K
+    assert need > 0                                            # the direct kernel splits v6's K
     assert lib.s3r_conv_forward(C.byref(dv6), one, one, None, None, one, None, 0, None) == -3      # (ABI 6 ran it unsplit)
     dd = L.make_desc(dec["d2"][0], 4, dec["d2"][1], in_halo=1)
     assert lib.s3r_conv_forward(C.byref(dd), one, one, None, None, one, one, 16, None) == -3
