@@ -210,7 +210,9 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False,
             else "the fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM convolution family, LDS-DMA operand staging: conv_glds_kernel / "
                  "conv_glds_dual_kernel (direct form) + wino_kernel / wino_dual_kernel / wino_finish_kernel with their transform passes "
                  "wino_input_kernel / wino_diff_kernel (Winograd: F(4,3)-along-H convolutions execute 1/2, F(2,2)-along-D-and-H transposed "
-                 "convolutions 9/16 of the direct form's multiplications; serial, class-parallel and dual launch forms, bit-identical)",
+                 "convolutions 9/16 of the direct form's multiplications; serial, class-parallel and dual launch forms, bit-identical) and "
+                 "the two-axis class-parallel form wino2_input_kernel / wino2_finish_kernel (F(4,3)xF(4,3) on v3 / v5: 1/4, F(2,4)xF(2,4) on "
+                 "v6: 25/64)",
             "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
             "achieved_credited": round(credited, 3),
