@@ -72,7 +72,10 @@ typedef enum s3r_act { S3R_ACT_NONE = 0, S3R_ACT_RELU = 1, S3R_ACT_SIGMOID = 2 }
  *                      batch cannot take it.
  * (Value 1 was S3R_LAYOUT_S2D — parity-split intermediates for stride-2 consumers, bf16 and fp32 forms — through ABI 6: built,
  * bit-identical, measured slower / no gain inside the forward in rounds 2 and 3, never planned by default; removed in ABI 7.) */
-typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_WINO_H = 2 } s3r_layout;
+/*   S3R_LAYOUT_WINO_DH the same for the TWO-AXIS kernel (Conv3d k3 s1 p1, edge a multiple of 4): 36 plane sets
+ *                      (36, B, C, n/4, n/4, n+2), set 6 a + b = depth class a, row class b of the 6 x 6 window of padded depths
+ *                      4 s .. 4 s + 5 and padded rows 4 q .. 4 q + 5 (rows first, then depths).  s3r_cost_volume_forward_wino2 writes it. */
+typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_WINO_H = 2, S3R_LAYOUT_WINO_DH = 3 } s3r_layout;
 
 /* Which convolution algorithm a layer's forward runs (ABI 7).  The fp32 3 x 3 [x 3] stride-1 pad-1 convolutions and the
  * transposed convolutions have two kernels — the direct implicit GEMM and a Winograd form with 1/2 .. 9/16 of the
@@ -88,9 +91,10 @@ typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_WINO_H = 2 } s3r_layo
  *                      needs in_halo = 1, plain layouts — or S3R_LAYOUT_WINO_H input —, no split-K, no sigmoid).  `tile` >= 0 then
  *                      forces the launch FORM of the one-axis kernel (tuning / tests; every form gives the same bits, and the
  *                      library picks among them by batch): 0 serial, 1 class-parallel, 2 dual (bulk serial + remainder
- *                      class-parallel in one launch); `tile` = 3: the TWO-AXIS class-parallel form (Conv3d k3 s1 p1 as F(4,3) x
- *                      F(4,3), k4 s1 p0 as F(2,4) x F(2,4), in_halo = pad) — another algorithm, other bits than the one-axis
- *                      kernel; AUTO takes it for 3D layers with an edge <= 14 (v3, v5, v6 of this network).
+ *                      class-parallel in one launch); `tile` = 3: the TWO-AXIS algorithm (Conv3d k3 s1 p1 as F(4,3) x F(4,3), k4 s1
+ *                      p0 as F(2,4) x F(2,4), in_halo = pad; 4 / 5 force its class-parallel / semi-fused launch form: same
+ *                      bits) — another algorithm, other bits than the one-axis kernel; AUTO takes it for every 3D stride-1
+ *                      layer that has it (v1, v3, v5, v6 of this network).
  * A call whose scratch is smaller than s3r_conv_scratch_elems says for the RESOLVED algorithm fails with S3R_ERR_WORKSPACE; it
  * is never answered with the other kernel's bits. */
 typedef enum s3r_algo { S3R_ALGO_AUTO = 0, S3R_ALGO_DIRECT = 1, S3R_ALGO_WINOGRAD = 2 } s3r_algo;
@@ -205,6 +209,13 @@ int s3r_cost_volume_forward_wino(const float* feat_left, const float* feat_right
 /* floats of the S3R_LAYOUT_WINO_H input of layer `d` (in_halo = 1) if a forward of it would run the Winograd kernel under the
  * library's current policy (S3R_WINO) and the batch fits one call; 0 otherwise (hand the layer its plain input then). */
 int64_t s3r_conv_wino_input_elems(const s3r_conv_desc* d);
+/* ... and which layout that is: S3R_LAYOUT_WINO_H (the one-axis kernel), S3R_LAYOUT_WINO_DH (the two-axis kernel), or
+ * S3R_LAYOUT_PLAIN (none: hand the layer its plain halo-padded input) */
+int s3r_conv_wino_input_layout(const s3r_conv_desc* d);
+/* the volume as the S3R_LAYOUT_WINO_DH input of the 3D convolution that consumes it: (36, B, 2C, D/4, H/4, W+2) floats,
+ * bit-identical to the two-axis input transform of the padded volume; max_disp and height multiples of 4 */
+int s3r_cost_volume_forward_wino2(const float* feat_left, const float* feat_right, float* planes, int batch, int channels,
+                                  int max_disp, int height, int width, void* stream);
 
 /* the same on channels-last bf16 features (B,H,W,C) -> volume (B,D+2h,H+2h,W+2h,2C); channels % 8 == 0 */
 int s3r_cost_volume_forward_bf16(const void* feat_left, const void* feat_right, void* volume, int batch, int channels,

@@ -74,6 +74,9 @@ SIGNATURES = {
     "s3r_cost_volume_forward_wino": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                C.c_int, C.c_void_p]),
     "s3r_conv_wino_input_elems": (C.c_int64, [C.POINTER(ConvDesc)]),
+    "s3r_conv_wino_input_layout": (C.c_int, [C.POINTER(ConvDesc)]),
+    "s3r_cost_volume_forward_wino2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.c_int, C.c_void_p]),
     "s3r_linear_scratch_elems": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "s3r_linear_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -121,7 +124,7 @@ def check(rc, what=""):
     return rc
 
 
-LAYOUT_PLAIN, LAYOUT_WINO_H = 0, 2
+LAYOUT_PLAIN, LAYOUT_WINO_H, LAYOUT_WINO_DH = 0, 2, 3
 
 
 def make_desc(layer, batch, in_size, tag=0, tile=-1, in_halo=0, out_halo=0, ksplit=0, dtype=0, in_layout=0, out_layout=0,

@@ -121,7 +121,8 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
     if (d->in_halo < 0 || d->out_halo < 0 || d->in_halo > 8 || d->out_halo > 8)
         return fail(S3R_ERR_INVALID, "halo must be in [0, 8]");
     if (d->dtype != S3R_F32 && d->dtype != S3R_BF16) return fail(S3R_ERR_INVALID, "unknown dtype %d", d->dtype);
-    if ((d->in_layout != S3R_LAYOUT_PLAIN && d->in_layout != S3R_LAYOUT_WINO_H) || d->out_layout != S3R_LAYOUT_PLAIN)
+    if ((d->in_layout != S3R_LAYOUT_PLAIN && d->in_layout != S3R_LAYOUT_WINO_H && d->in_layout != S3R_LAYOUT_WINO_DH) ||
+        d->out_layout != S3R_LAYOUT_PLAIN)
         return fail(S3R_ERR_INVALID, "unknown layout");
     if ((d->in_layout || d->out_layout) && d->op == S3R_OP_LINEAR)
         return fail(S3R_ERR_INVALID, "the transformed input layout exists on the convolution paths only");
@@ -158,6 +159,12 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
             return fail(S3R_ERR_INVALID, "a Winograd-transformed input serves an fp32 Conv k=3 s=1 p=1 over an even edge, in_halo = 1");
         if (g->in % wino_r(d) != 0) return fail(S3R_ERR_INVALID, "a Winograd-transformed input needs an edge that is a multiple of %d", wino_r(d));
         g->x_elems = (wino_r(d) + 2) * (int64_t)d->batch * d->cin * (g->nd == 3 ? g->in_p : 1) * (g->in / wino_r(d)) * g->in_p;
+    }
+    if (d->in_layout == S3R_LAYOUT_WINO_DH) {    // the 36 two-axis plane sets a 3 x 3 x 3 stride-1 pad-1 convolution reads
+        if (d->dtype != S3R_F32 || d->op != S3R_OP_CONV || d->ndim != 3 || d->stride != 1 || d->k != 3 || d->pad != 1 || (g->in & 3) ||
+            d->in_halo != 1 || d->cin % 32 != 0 || d->cout <= 1)
+            return fail(S3R_ERR_INVALID, "a two-axis Winograd-transformed input serves an fp32 Conv3d k=3 s=1 p=1 over an edge %% 4 == 0, in_halo = 1");
+        g->x_elems = 36 * (int64_t)d->batch * d->cin * (g->in / 4) * (g->in / 4) * g->in_p;
     }
     g->w_elems = (int64_t)d->cin * d->cout * ipow(d->k, g->nd);
     if (d->op == S3R_OP_DECONV)
@@ -249,13 +256,14 @@ int wino2_ax(const s3r_conv_desc* d) {
 }
 bool wino2_desc_ok(const s3r_conv_desc* d) {
     return wino2_ax(d) >= 0 && d->act != S3R_ACT_SIGMOID && d->in_halo == d->pad && d->ksplit <= 1 &&
-           d->in_layout == S3R_LAYOUT_PLAIN && d->out_layout == S3R_LAYOUT_PLAIN;
+           (d->in_layout == S3R_LAYOUT_PLAIN || (d->in_layout == S3R_LAYOUT_WINO_DH && wino2_ax(d) == 0 && d->in_size % 4 == 0)) &&
+           d->out_layout == S3R_LAYOUT_PLAIN;
 }
 // library policy: the two-axis form where the output is small enough for its class slabs (ncls / m^2 x the output) to be cheap
-// — v3 (edge 14: 0.438 -> 0.329 ms alone at B = 32), v5, v6 (edge 7: 0.252 -> 0.142, 0.329 direct -> 0.149) of this network, not
-// v1 (edge 28: 405 MB of slabs); S3R_WINO2_MAX_EDGE (read once) moves the bound for experiments
+// or, in its semi-fused launch form (6 / 4 x the output), worth the halved matrix work — v1 (edge 28), v3 (14), v5, v6 (7) of this
+// network: every 3D stride-1 layer; S3R_WINO2_MAX_EDGE (read once) moves the bound for experiments
 int wino2_max_edge() {
-    static const int e = getenv("S3R_WINO2_MAX_EDGE") ? atoi(getenv("S3R_WINO2_MAX_EDGE")) : 14;
+    static const int e = getenv("S3R_WINO2_MAX_EDGE") ? atoi(getenv("S3R_WINO2_MAX_EDGE")) : 28;
     return e;
 }
 enum { ALG_DIRECT = 0, ALG_WINO = 1, ALG_WINO2 = 2 };
@@ -267,14 +275,27 @@ int resolve_algo(const s3r_conv_desc* d, int* alg, int* form) {
         return fail(S3R_ERR_INVALID, "unknown algo %d", d->algo);
     if (d->algo == S3R_ALGO_WINOGRAD) {
         const bool one = wino_desc_ok(d), two = wino2_desc_ok(d);
-        // tile: -1 the library's pick between the forms the layer has; 0, 1, 2 a launch form of the one-axis kernel; 3 the two-axis form
-        if ((d->tile == 3 && !two) || (d->tile >= 0 && d->tile <= 2 && !one) || (!one && !two) || d->tile > 3)
+        // tile: -1 the library's pick between the forms the layer has; 0, 1, 2 a launch form of the one-axis kernel; 3 the two-axis
+        // algorithm (4: its class-parallel form, 5: its semi-fused form)
+        if ((d->tile >= 3 && !two) || (d->tile >= 0 && d->tile <= 2 && !one) || (!one && !two) || d->tile > 5 ||
+            (d->tile == 5 && wino2_ax(d) != 0))
             return fail(S3R_ERR_INVALID, "algo = WINOGRAD: this layer / descriptor has no such Winograd form (one-axis: fp32 Conv k3 s1 p1 "
                         "with cin %% %d == 0 and edge >= 4, or ConvTranspose3d k4 s2 p1 over an edge %% 4 == 0, in_halo = 1; two-axis "
                         "(tile = 3): Conv3d k3 s1 p1 / k4 s1 p0, in_halo = pad; plain layouts, no split-K, no sigmoid)", s3r::wino_bk());
-        if (d->tile == 3 || !one || (d->tile < 0 && two && d->in_layout == S3R_LAYOUT_PLAIN && d->in_size <= wino2_max_edge()))
+        if (d->in_layout == S3R_LAYOUT_WINO_DH && !(two && (d->tile < 0 || d->tile >= 3)))
+            return fail(S3R_ERR_INVALID, "a two-axis transformed input runs the two-axis kernel only");
+        if (d->tile >= 3 || !one || d->in_layout == S3R_LAYOUT_WINO_DH ||
+            (d->tile < 0 && two && d->in_layout == S3R_LAYOUT_PLAIN && d->in_size <= wino2_max_edge())) {
             *alg = ALG_WINO2;
-        else { *alg = ALG_WINO; *form = d->tile; }
+            *form = d->tile >= 4 ? d->tile - 4 : -1;
+        } else { *alg = ALG_WINO; *form = d->tile; }
+        return S3R_OK;
+    }
+    if (d->in_layout == S3R_LAYOUT_WINO_DH) {            // only the two-axis kernel reads the 36 plane sets
+        if (d->algo == S3R_ALGO_DIRECT || !wino2_desc_ok(d) || d->tile >= 0)
+            return fail(S3R_ERR_INVALID, "a two-axis transformed input runs the two-axis kernel only: algo AUTO / WINOGRAD, no direct tile / "
+                        "split-K override, a plain output");
+        *alg = ALG_WINO2;
         return S3R_OK;
     }
     if (d->in_layout == S3R_LAYOUT_WINO_H) {             // only the one-axis Winograd kernel reads the transformed planes
@@ -385,14 +406,19 @@ double wino_exec_flops(const s3r_conv_desc* d, const Geo& g) {
     return 2.0 * (double)wino_positions(d, d->batch) * d->cout * d->cin * taps;
 }
 
-// scratch of a two-axis call: [V of one sub-batch | class slabs]
-WinoNeed wino2_need(const s3r_conv_desc* d) {
+// scratch of a two-axis call: [V of one sub-batch (unless the producer wrote it) | slabs of the launch form planned for the batch]
+WinoNeed wino2_need(const s3r_conv_desc* d, int form) {
     WinoNeed w = {0, 0, 0};
     const Wino2Geo g2 = wino2_geo(d);
     if (d->batch <= 0 || g2.bmax <= 0) return w;
-    w.v = (g2.v_sample * g2.bmax + 255) / 256 * 256;
-    const int64_t npad = (g2.pos_sample * g2.bmax + 63) / 64 * 64;
-    w.slab = (int64_t)g2.ncls * d->cout * npad;
+    if (d->in_layout != S3R_LAYOUT_WINO_DH) w.v = (g2.v_sample * g2.bmax + 255) / 256 * 256;
+    for (int b0 = 0; b0 < d->batch; b0 += g2.bmax) {              // (at most two different sub-batch sizes)
+        const int nb = d->batch - b0 < g2.bmax ? d->batch - b0 : g2.bmax;
+        if (b0 > 0 && nb == g2.bmax) continue;
+        const int nt = (int)(g2.pos_sample * nb);
+        const int64_t sl = s3r::wino2_slab_elems(g2.ax, d->cout, nt, s3r::wino2_form(g2.ax, d->cout, nt, form));
+        if (sl > w.slab) w.slab = sl;
+    }
     w.total = w.v + w.slab;
     return w;
 }
@@ -402,16 +428,19 @@ double wino2_exec_flops(const s3r_conv_desc* d) {
 }
 // input transform + class kernel + finish, in sub-batches that keep the transformed input inside 32-bit byte offsets
 int wino2_run(const s3r_conv_desc* d, const Geo& g, s3r::ConvParams p, const float* x, const float* packed_w, float* y, float* scratch,
-              int64_t scratch_elems, hipStream_t s, int* launches) {
+              int64_t scratch_elems, int form, hipStream_t s, int* launches) {
     const Wino2Geo g2 = wino2_geo(d);
-    const WinoNeed need = wino2_need(d);
-    if (g2.bmax <= 0) return fail(S3R_ERR_INVALID, "two-axis Winograd form: one sample's transformed input exceeds 2 GiB");
+    const WinoNeed need = wino2_need(d, form);
+    const bool pre = d->in_layout == S3R_LAYOUT_WINO_DH;             // the producer wrote the plane sets
+    if (g2.bmax <= 0 || (pre && g2.bmax < d->batch))
+        return fail(S3R_ERR_INVALID, "two-axis Winograd form: the transformed input of this batch exceeds 2 GiB (at most %d samples per "
+                    "call with a producer-written input: s3r_conv_wino_input_elems)", g2.bmax);
     if (!scratch || scratch_elems < need.total)
         return fail(S3R_ERR_WORKSPACE, "the two-axis Winograd form of this layer needs %lld floats of scratch (s3r_conv_scratch_elems), "
                     "got %lld", (long long)need.total, (long long)(scratch ? scratch_elems : 0));
     const int64_t direct_w = ipow(d->k, 3) * d->cin * cout_pad(d->cout);
     p.w = packed_w + direct_w + (wino_layer(d) ? wino_w_elems(d) : 0);      // behind the direct (and the one-axis) slabs
-    p.x = scratch;
+    p.x = pre ? x : scratch;
     p.part = scratch + need.v;
     p.Nd = g2.sg; p.Nh = g2.sg; p.Nw = g2.out;
     p.kd = 1; p.kh = 1; p.kw = g2.kw; p.T = g2.kw;
@@ -427,9 +456,12 @@ int wino2_run(const s3r_conv_desc* d, const Geo& g, s3r::ConvParams p, const flo
     *launches = 0;
     for (int b0 = 0; b0 < d->batch; b0 += g2.bmax) {
         const int nb = d->batch - b0 < g2.bmax ? d->batch - b0 : g2.bmax;
-        hipError_t e = s3r::launch_wino2_input(x + (int64_t)b0 * x_sample, scratch, g2.ax, (long long)nb * d->cin, g2.wp, g2.wp, g2.wp,
-                                               g2.sg, g2.sg, s);
-        if (e != hipSuccess) return hip_fail(e, "two-axis Winograd input transform launch");
+        hipError_t e = hipSuccess;
+        if (!pre) {
+            e = s3r::launch_wino2_input(x + (int64_t)b0 * x_sample, scratch, g2.ax, (long long)nb * d->cin, g2.wp, g2.wp, g2.wp, g2.sg, g2.sg, s);
+            if (e != hipSuccess) return hip_fail(e, "two-axis Winograd input transform launch");
+            *launches += 1;
+        }
         p.B = nb;
         p.x_cls = nb * d->cin * p.x_cs;
         p.x_bytes = (unsigned)(4 * (int64_t)nb * g2.v_sample);
@@ -437,9 +469,9 @@ int wino2_run(const s3r_conv_desc* d, const Geo& g, s3r::ConvParams p, const flo
         p.y = y + (int64_t)b0 * p.y_bs;
         p.y_bytes = (unsigned)(4 * (int64_t)nb * p.y_bs);
         int nl = 0;
-        e = s3r::launch_conv_wino2(p, g2.ax, s, &nl);
+        e = s3r::launch_conv_wino2(p, g2.ax, s3r::wino2_form(g2.ax, d->cout, p.Ntotal, form), s, &nl);
         if (e != hipSuccess) return hip_fail(e, "two-axis Winograd conv launch");
-        *launches += 1 + nl;
+        *launches += nl;
     }
     return S3R_OK;
 }
@@ -823,7 +855,7 @@ int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d) {
     int alg, form;
     if ((rc = resolve_algo(d, &alg, &form))) return rc;
     if (alg == ALG_WINO) return wino_need(d, form, false).total;
-    if (alg == ALG_WINO2) return wino2_need(d).total;
+    if (alg == ALG_WINO2) return wino2_need(d, form).total;
     s3r::ConvParams p = make_params(d, g);
     Launch L;
     if ((rc = resolve_launch(d, &p, &L))) return rc;
@@ -939,7 +971,7 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                 ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
                 ps.exec = wino2_exec_flops(d);
                 ps.algo = 4;
-                return wino2_run(d, g, p, x, packed_w, y, scratch, scratch_elems, s, &ps.launches);
+                return wino2_run(d, g, p, x, packed_w, y, scratch, scratch_elems, form, s, &ps.launches);
             }
             if (wino && d->op == S3R_OP_DECONV) {
                 ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
@@ -1190,15 +1222,57 @@ int s3r_cost_volume_forward_wino(const float* fl, const float* fr, float* planes
     return S3R_OK;
 }
 
-int64_t s3r_conv_wino_input_elems(const s3r_conv_desc* d) {
-    if (!d) return fail(S3R_ERR_INVALID, "null descriptor");
+// which transformed layout (if any) the producer of layer `d`'s input may write instead of the plain halo-padded tensor
+static int wino_input_layout(const s3r_conv_desc* d, int64_t* elems) {
+    *elems = 0;
+    if (!d) return S3R_LAYOUT_PLAIN;
     s3r_conv_desc t = *d;
     t.in_layout = S3R_LAYOUT_PLAIN;
     int alg, form;
-    if (resolve_algo(&t, &alg, &form) != S3R_OK || alg != ALG_WINO || t.op != S3R_OP_CONV || t.in_size % wino_r(&t) != 0 ||
-        wino_bmax(&t) < t.batch)
-        return 0;
-    return wino_v_elems(&t);
+    if (resolve_algo(&t, &alg, &form) != S3R_OK || t.op != S3R_OP_CONV) return S3R_LAYOUT_PLAIN;
+    if (alg == ALG_WINO && t.in_size % wino_r(&t) == 0 && wino_bmax(&t) >= t.batch) {
+        *elems = wino_v_elems(&t);
+        return S3R_LAYOUT_WINO_H;
+    }
+    if (alg == ALG_WINO2 && wino2_ax(&t) == 0 && t.in_size % 4 == 0) {
+        const Wino2Geo g2 = wino2_geo(&t);
+        if (g2.bmax >= t.batch) {
+            *elems = g2.v_sample * t.batch;
+            return S3R_LAYOUT_WINO_DH;
+        }
+    }
+    return S3R_LAYOUT_PLAIN;
+}
+
+int64_t s3r_conv_wino_input_elems(const s3r_conv_desc* d) {
+    if (!d) return fail(S3R_ERR_INVALID, "null descriptor");
+    int64_t elems;
+    (void)wino_input_layout(d, &elems);
+    return elems;
+}
+
+int s3r_conv_wino_input_layout(const s3r_conv_desc* d) {
+    if (!d) return fail(S3R_ERR_INVALID, "null descriptor");
+    int64_t elems;
+    return wino_input_layout(d, &elems);
+}
+
+int s3r_cost_volume_forward_wino2(const float* fl, const float* fr, float* planes, int batch, int channels, int max_disp,
+                                  int height, int width, void* stream) {
+    if (!fl || !fr || !planes) return fail(S3R_ERR_INVALID, "null tensor pointer");
+    if (batch <= 0 || channels <= 0 || max_disp < 4 || height < 4 || width <= 0 || (height & 3) || (max_disp & 3))
+        return fail(S3R_ERR_INVALID, "bad cost-volume shape for the two-axis Winograd layout (height and max_disp multiples of 4: F(4,3) groups)");
+    if (max_disp > width) return fail(S3R_ERR_INVALID, "max_disp %d exceeds the feature width %d", max_disp, width);
+    if ((size_t)2 * height * width * sizeof(float) > 64 * 1024)
+        return fail(S3R_ERR_INVALID, "feature plane %dx%d does not fit the kernel's 64 KiB of LDS", height, width);
+    const int64_t elems = 36 * (int64_t)batch * 2 * channels * (max_disp / 4) * (height / 4) * (width + 2);
+    if (elems * 4 >= ((int64_t)1 << 31)) return fail(S3R_ERR_INVALID, "two-axis Winograd planes of %lld floats exceed 2 GiB: split the batch", (long long)elems);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(s, F_COSTVOL, 0, 2.0 * batch * channels * (double)max_disp * height * width,
+                 4.0 * batch * channels * (2.0 * height * width) + 4.0 * (double)elems);
+    hipError_t e = s3r::launch_cost_volume_wino2(fl, fr, planes, batch, channels, max_disp, height, width, s);
+    if (e != hipSuccess) return hip_fail(e, "cost volume (two-axis Winograd layout) launch");
+    return S3R_OK;
 }
 
 int s3r_cost_volume_forward_bf16(const void* fl, const void* fr, void* vol, int batch, int channels, int max_disp,

@@ -278,7 +278,10 @@ __device__ __forceinline__ float wino_head_act(float t, int act) {
 //   p.xd = its row differences Dh (x's shape and strides; p.xd_mode = 1: followed by Dd and Ddh), p.w = the 72 (parity class, class) slabs.
 // p.part: class-parallel slabs [class][Cout][npad], npad = the position range's tile count x BN.
 // XM (transposed form): the depth differences are materialised (p.xd = [Dh | Dd | Ddh]) instead of formed here
-template <int VEC, int KIND, int WN, bool CP, bool HEAD, bool XM = false>
+// SEMI (two-axis convolution, below): the workgroup owns ONE depth class a of its tile and walks that class's six row classes
+// serially (plane sets / weight slabs 6 a .. 6 a + 5); the row transform runs on the registers and the four row outputs go,
+// raw, to the slab part[a][row][cout][n] for wino2s_finish_kernel to transform along D
+template <int VEC, int KIND, int WN, bool CP, bool HEAD, bool XM = false, bool SEMI = false>
 __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in, const int nwg_in, const int n_begin,
                                           const int n_end, float* __restrict__ wsmem) {
     constexpr bool DECONV = KIND == 2;
@@ -286,6 +289,7 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
     constexpr int WM = 4 / WN, TM = 2 / WM, BN = 32 * WN;
     constexpr int NACC = CP ? 1 : NCLS;
     static_assert(KIND == 1 || KIND == 2, "F(4,3) convolution or F(2,2) transposed convolution");
+    static_assert(!SEMI || (KIND == 1 && !CP && !HEAD), "the semi-fused form: serial F(4,3) row classes of one depth class");
     static_assert(WN == 4 || WN == 2, "4 waves as 1 x 4 or 2 x 2");
     static_assert(!HEAD || (DECONV && !CP && WN == 2), "the fused head: serial transposed form");
     float* As = wsmem;                                   // [WNB][WBK][64]
@@ -309,7 +313,7 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
 
     const int n_tiles = (n_end - n_begin + BN - 1) / BN;
     int bid = bid_in, cls0 = 0, pc = 0;                  // cls0: the one class of a class-parallel workgroup; pc: output parity class
-    if constexpr (CP) {
+    if constexpr (CP || SEMI) {
         // an XCD walks a contiguous run of items, class-major: neighbouring workgroups share a class's weight slab (and the
         // transformed rows their tiles have in common) in that XCD's L2
         const int nwg = nwg_in;
@@ -318,7 +322,7 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
         const int ntile = p.m_tiles * n_tiles;
         const int c = item / ntile;
         bid = item - c * ntile;
-        if constexpr (DECONV) { pc = c / NCLS; cls0 = c - pc * NCLS; } else cls0 = c;
+        if constexpr (DECONV) { pc = c / NCLS; cls0 = c - pc * NCLS; } else cls0 = SEMI ? c * NCLS : c;
     } else if constexpr (DECONV) {
         // an XCD walks its run of tiles with the 8 parity classes of a tile back to back (they read the same input tile)
         const int nwg = nwg_in >> 3;
@@ -510,6 +514,26 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
                 slab[(size_t)dm * npad] = acc[0][tm][r];
             }
         return;
+    } else if constexpr (SEMI) {
+        // ---- semi-fused two-axis form: the four row outputs of this depth class, raw, to part[(a * 4 + row)][cout][n - n_begin]
+        const int npad = n_tiles * BN;
+        const int a = cls0 / NCLS;
+        float* __restrict__ slab = p.part + ((size_t)a * R * p.Cout + (m0 + mbase)) * npad + (n0 - n_begin) + wn * 32 + j;
+        const size_t rstride = (size_t)p.Cout * npad;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dm = ((r & 3) + 8 * (r >> 2)) * TM + tm;
+                if (dm >= mlimit) continue;
+                float m[NCLS], y[R];
+#pragma unroll
+                for (int c = 0; c < NCLS; ++c) m[c] = acc[c][tm][r];
+                wino_out<KIND>(m, y);
+#pragma unroll
+                for (int i = 0; i < R; ++i) slab[(size_t)i * rstride + (size_t)dm * npad] = y[i];
+            }
+        return;
     } else {
         // ---- epilogue: per-cout constants through LDS (every wave is past the last barrier: the ring is idle)
         float* ep_sc = wsmem;
@@ -608,10 +632,10 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
 
 // registers: six classes of one 32 x 32 tile = 96 accumulators (109 in all: four workgroups per CU), nine = 144 (three per CU);
 // the class-parallel form 16
-template <int VEC, int KIND, int WN, bool CP, bool HEAD, bool XM = false>
+template <int VEC, int KIND, int WN, bool CP, bool HEAD, bool XM = false, bool SEMI = false>
 __global__ __launch_bounds__(256, (CP || KIND == 1 ? 4 : 3)) void wino_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float wsmem[];
-    wino_body<VEC, KIND, WN, CP, HEAD, XM>(p, blockIdx.x, gridDim.x, p.n_begin, p.n_end, wsmem);
+    wino_body<VEC, KIND, WN, CP, HEAD, XM, SEMI>(p, blockIdx.x, gridDim.x, p.n_begin, p.n_end, wsmem);
 }
 
 // bulk (serial form, positions [n_begin, n_cut)) + remainder (class-parallel form, positions [n_cut, n_end)) in ONE launch: the
@@ -1032,9 +1056,58 @@ __global__ __launch_bounds__(256) void wino2_finish_kernel(const ConvParams p, c
     }
 }
 
+// semi-fused form: slabs [a][row][Cout][npad] (the row transform already applied) -> y: A^T along D, epilogue
+__global__ __launch_bounds__(256) void wino2s_finish_kernel(const ConvParams p, const int npad) {
+    constexpr int N = 6, M = 4;
+    const int S = p.Nd * p.Nh * p.Nw;
+    const int nn = p.Ntotal;
+    const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+    const size_t rstride = (size_t)p.Cout * npad;
+    const long long total = (long long)p.Cout * nn;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int mrow = (int)(i / nn);
+        const int n = (int)(i - (long long)mrow * nn);
+        const int b = p.dS.div(n);
+        int rem = n - b * S;
+        const int sd = p.dHW.div(rem);
+        rem -= sd * p.Nh * p.Nw;
+        const int sh = p.dW.div(rem);
+        const int pw = rem - sh * p.Nw;
+        const float* __restrict__ src = p.part + (size_t)mrow * npad + n;
+        const float sc = p.scale ? p.scale[mrow] : 1.f, sf = p.shift ? p.shift[mrow] : 0.f;
+        float* __restrict__ yo = p.y + (size_t)b * p.y_bs + (size_t)mrow * p.y_cs + p.y_org + (size_t)M * sd * p.y_ds + M * sh * p.y_hs + pw;
+#pragma unroll
+        for (int v = 0; v < M; ++v) {
+            float m[N], y[M];
+#pragma unroll
+            for (int a = 0; a < N; ++a) m[a] = src[(size_t)(a * M + v) * rstride];
+            wax_at<0>(m, y);
+#pragma unroll
+            for (int u = 0; u < M; ++u)
+                if (M * sd + u < p.Dout && M * sh + v < p.Hout) yo[(size_t)u * p.y_ds + v * p.y_hs] = wino_act(y[u], sc, sf, lo);
+        }
+    }
+}
+
+// which form a two-axis launch takes (same bits): class-parallel (one workgroup per class: 36 / 25 per tile) or — F(4,3) x F(4,3)
+// only — semi-fused (one workgroup per depth class walks its six row classes: a third less slab traffic, six times the work
+// per workgroup: for grids that fill the chip several times over).  forced: -1 the plan, 0 class-parallel, 1 semi-fused
+int wino2_form(int ax, int cout, int ntotal, int forced) {
+    if (ax != 0) return 0;
+    if (forced >= 0) return forced ? 1 : 0;
+    static const int env_form = getenv("S3R_WINO2_FORM") ? atoi(getenv("S3R_WINO2_FORM")) : -1;      // A/B switch, read once
+    if (env_form >= 0) return env_form ? 1 : 0;
+    const long semi_wgs = (long)((cout + WBM - 1) / WBM) * ((ntotal + WCN - 1) / WCN) * 6;
+    return semi_wgs >= 8 * 256 ? 1 : 0;                  // >= two rounds of the chip's four slots per CU
+}
+int64_t wino2_slab_elems(int ax, int cout, int ntotal, int form) {
+    const int64_t npad = (int64_t)((ntotal + WCN - 1) / WCN) * WCN;
+    return (form ? 6 * 4 : wino2_classes(ax)) * (int64_t)cout * npad;
+}
+
 // p: the CLASS convolution (wino_body): x = V, x_cs / x_ds / x_hs / x_cls its strides, Nd / Nh = depth / row groups, kd = kh = 1,
 // T = kw, ncls = the class count; part = slabs; y / Dout / Hout the layer's output
-hipError_t launch_conv_wino2(ConvParams p, int ax, hipStream_t stream, int* launches) {
+hipError_t launch_conv_wino2(ConvParams p, int ax, int form, hipStream_t stream, int* launches) {
     if (p.Cin % WBK != 0 || p.stride != 1 || p.transposed || p.ksplit != 1 || p.head_w || p.act == ACT_SIGMOID || !p.part ||
         (ax != 0 && ax != 1) || p.ncls != wino2_classes(ax))
         return hipErrorInvalidValue;
@@ -1042,15 +1115,26 @@ hipError_t launch_conv_wino2(ConvParams p, int ax, hipStream_t stream, int* laun
     p.m_tiles = (p.Cout + WBM - 1) / WBM;
     p.n_begin = 0; p.n_end = p.Ntotal;
     const int n_tiles = (p.Ntotal + WCN - 1) / WCN;
-    const dim3 grid(p.m_tiles * n_tiles * p.ncls);
     const size_t lds = (size_t)WNB * WBK * (WBM + WCN) * sizeof(float);
+    const long long total = (long long)p.Cout * p.Ntotal;
+    const long long blocks = (total + 255) / 256;
+    const dim3 fgrid((unsigned)(blocks < 8192 ? blocks : 8192));
+    if (form == 1) {
+        if (ax != 0) return hipErrorInvalidValue;
+        const dim3 grid(p.m_tiles * n_tiles * 6);
+        if (p.Nw % 4 == 0) hipLaunchKernelGGL((wino_kernel<4, 1, 2, false, false, false, true>), grid, dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL((wino_kernel<1, 1, 2, false, false, false, true>), grid, dim3(256), lds, stream, p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(wino2s_finish_kernel, fgrid, dim3(256), 0, stream, p, n_tiles * WCN);
+        if (launches) *launches = 2;
+        return hipGetLastError();
+    }
+    const dim3 grid(p.m_tiles * n_tiles * p.ncls);
     if (p.Nw % 4 == 0) hipLaunchKernelGGL((wino_kernel<4, 1, 2, true, false>), grid, dim3(256), lds, stream, p);
     else hipLaunchKernelGGL((wino_kernel<1, 1, 2, true, false>), grid, dim3(256), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const long long total = (long long)p.Cout * p.Ntotal;
-    const long long blocks = (total + 255) / 256;
-    const dim3 fgrid((unsigned)(blocks < 8192 ? blocks : 8192));
     if (ax == 0) hipLaunchKernelGGL(wino2_finish_kernel<0>, fgrid, dim3(256), 0, stream, p, n_tiles * WCN);
     else hipLaunchKernelGGL(wino2_finish_kernel<1>, fgrid, dim3(256), 0, stream, p, n_tiles * WCN);
     if (launches) *launches = 2;

@@ -164,7 +164,11 @@ int wino2_classes(int ax);          // 36 / 25
 int wino2_outputs(int ax);          // outputs per group and axis: 4 / 2
 hipError_t launch_wino2_input(const float* x, float* V, int ax, long long planes, int Dp, int Hp, int Wp, int SD, int SH, hipStream_t s);
 hipError_t launch_pack_wino2(const float* w, float* wp, int ax, int Cin, int Cout, int CoutPad, hipStream_t s);
-hipError_t launch_conv_wino2(ConvParams p, int ax, hipStream_t stream, int* launches);
+int wino2_form(int ax, int cout, int ntotal, int forced);                      // 0 class-parallel, 1 semi-fused (same bits)
+int64_t wino2_slab_elems(int ax, int cout, int ntotal, int form);
+hipError_t launch_conv_wino2(ConvParams p, int ax, int form, hipStream_t stream, int* launches);
+// the cost volume written as the 36 two-axis plane sets of its halo-1 padded form: V[36][B][2C][(D)/4][H/4][W+2]
+hipError_t launch_cost_volume_wino2(const float* fl, const float* fr, float* V, int B, int C, int D, int H, int W, hipStream_t s);
 int wino_bk();                      // channels per K tile of the Winograd kernels (Cin must be a multiple)
 // Winograd F(2,2) along D and H inside the parity classes of ConvTranspose3d(k4 s2 p1); D = [Dh] or (three) [Dh | Dd | Ddh]
 hipError_t launch_wino_diff(const float* x, float* D, long long planes, int Dp, int Hp, int Wp, int three, hipStream_t s);

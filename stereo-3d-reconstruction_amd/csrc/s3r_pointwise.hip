@@ -231,6 +231,75 @@ hipError_t launch_cost_volume_wino(const float* fl, const float* fr, float* V, i
     return hipGetLastError();
 }
 
+// ... and as the 36 TWO-AXIS plane sets (F(4,3) along D and H: s3r_conv_wino.hip, wino2_input_kernel, S3R_LAYOUT_WINO_DH):
+// V[6 a + b][bb][ch][sd][sh][wp] from the 6 x 6 window of padded depths 4 sd .. 4 sd + 5 and padded rows 4 sh .. 4 sh + 5 at column
+// wp of the halo-1 volume — rows first, then depths, through the same wino_rows_to_classes: bit-identical to the transform
+// kernel applied to the padded volume.  One workgroup per (b, c); a thread per (sd, sh, wp) and slab half.
+__global__ __launch_bounds__(256) void cost_volume_wino2_kernel(const float* __restrict__ fl, const float* __restrict__ fr,
+                                                                float* __restrict__ V, int C, int D, int H, int W,
+                                                                long long cls_stride, FastDiv dPlane, FastDiv dRow) {
+    extern __shared__ __attribute__((aligned(16))) float cvw2_smem[];
+    const int HW = H * W;
+    float* sl = cvw2_smem;
+    float* sr = cvw2_smem + HW;
+    const int bc = blockIdx.x;
+    const int b = bc / C, c = bc - b * C;
+    const float* __restrict__ pl = fl + (size_t)bc * HW;
+    const float* __restrict__ pr = fr + (size_t)bc * HW;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        sl[i] = pl[i];
+        sr[i] = pr[i];
+    }
+    __syncthreads();
+    const int Wp = W + 2, SH = H / 4, SD = (D + 3) / 4;
+    const int ds = SH * Wp;                              // one depth group of a class
+    const int run = SD * ds;
+    for (int half = 0; half < 2; ++half) {               // the L - R(shifted) slab, then the R - L(shifted) slab
+        float* __restrict__ o = V + ((size_t)b * 2 * C + half * C + c) * run;
+        for (int e = threadIdx.x; e < run; e += 256) {
+            const int sd = dPlane.div(e);                // e / (SH*Wp)
+            const int rem = e - sd * ds;
+            const int sh = dRow.div(rem);                // rem / Wp
+            const int wp = rem - sh * Wp;
+            const int w = wp - 1;
+            float t[6][6];                               // [depth][row class]
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const int d = 4 * sd + a - 1;            // padded depth 4 sd + a
+                float r[6], v[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int h = 4 * sh + k - 1;
+                    const bool in = (unsigned)d < (unsigned)D && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+                    const int hw = h * W + w;
+                    r[k] = half == 0 ? ((in && w >= d) ? sl[hw] - sr[hw - d] : 0.f) : ((in && w + d < W) ? sr[hw] - sl[hw + d] : 0.f);
+                }
+                wino_rows_to_classes<4>(r, v);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) t[a][k] = v[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                float r[6], v[6];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) r[a] = t[a][k];
+                wino_rows_to_classes<4>(r, v);
+#pragma unroll
+                for (int a = 0; a < 6; ++a) o[e + (size_t)(a * 6 + k) * cls_stride] = v[a];
+            }
+        }
+    }
+}
+
+hipError_t launch_cost_volume_wino2(const float* fl, const float* fr, float* V, int B, int C, int D, int H, int W, hipStream_t s) {
+    const size_t lds = (size_t)2 * H * W * sizeof(float);
+    const int Wp = W + 2, SH = H / 4, SD = (D + 3) / 4;
+    const long long cls_stride = (long long)B * 2 * C * SD * SH * Wp;
+    hipLaunchKernelGGL(cost_volume_wino2_kernel, dim3(B * C), dim3(256), lds, s, fl, fr, V, C, D, H, W, cls_stride,
+                       FastDiv((unsigned)(SH * Wp)), FastDiv((unsigned)Wp));
+    return hipGetLastError();
+}
+
 hipError_t launch_cost_volume(const float* fl, const float* fr, float* vol, int B, int C, int D, int H, int W,
                               int halo, hipStream_t s) {
     const size_t lds = (size_t)2 * H * W * sizeof(float);

@@ -276,16 +276,20 @@ class _HipChain(nn.Module):
             return _lib.ALGO_WINOGRAD
         return _lib.ALGO_DIRECT
 
-    def takes_wino_input(self, batch: int) -> bool:
-        """Would the chain's first layer run the Winograd kernel on a halo-1 input of this batch (library policy: S3R_WINO)?
-        Then its producer may write the transformed planes directly (CostVolume.forward_wino, S3R_LAYOUT_WINO_H)."""
+    def wino_input_layout(self, batch: int) -> int:
+        """The transformed layout the chain's first layer would read from its producer for a halo-1 input of this batch —
+        `_lib.LAYOUT_WINO_H` (one-axis Winograd kernel), `_lib.LAYOUT_WINO_DH` (two-axis kernel) — or `_lib.LAYOUT_PLAIN` when
+        it runs the direct kernel or the batch does not fit one transformed call (CostVolume.forward_wino / forward_wino2)."""
         if self.precision != "fp32" or batch <= 0:
-            return False
+            return _lib.LAYOUT_PLAIN
         l, (n_in, _) = self._layers[0], self._sizes()[0]
         tile = int(os.environ.get(f"S3R_TILE_{l.name}", self.tile_override.get(l.name, -1)))
         ksplit = int(os.environ.get(f"S3R_KSPLIT_{l.name}", self.ksplit_override.get(l.name, 0)))
         desc = _lib.make_desc(l, batch, n_in, tile=tile, in_halo=1, ksplit=ksplit, dtype=self._dtype, algo=self._algo_of(l))
-        return _lib.load().s3r_conv_wino_input_elems(C.byref(desc)) > 0
+        return _lib.check(_lib.load().s3r_conv_wino_input_layout(C.byref(desc)), "wino_input_layout")
+
+    def takes_wino_input(self, batch: int) -> bool:
+        return self.wino_input_layout(batch) != _lib.LAYOUT_PLAIN
 
     def _out_shape(self, batch: int, n_layers: int):
         l = self._layers[n_layers - 1]
@@ -305,7 +309,7 @@ class _HipChain(nn.Module):
         x2 (encoder only): a second tensor of as many images — the chain runs over x's images, then x2's."""
         lib = _lib.load()
         device, batch = x.device, x.shape[0] + (x2.shape[0] if x2 is not None else 0)
-        if in_layout == _lib.LAYOUT_WINO_H:                 # (6, B, C, ...): the transformed plane sets of the padded input
+        if in_layout in (_lib.LAYOUT_WINO_H, _lib.LAYOUT_WINO_DH):      # (6 | 36, B, C, ...): the transformed plane sets of the padded input
             batch = x.shape[1]
         if batch == 0:                 # same dtype / layout contract as a non-empty batch
             n0 = len(self._layers) if upto is None else self.names.index(upto) + 1
@@ -437,7 +441,7 @@ class CostVolume(nn.Module):
         self.max_disp = max_disp
         self.precision = precision
         self._padded: Optional[torch.Tensor] = None      # resident halo-padded volume (internal hand-off)
-        self._planes: Optional[torch.Tensor] = None      # ... or its Winograd-transformed planes (forward_wino)
+        self._planes: Optional[torch.Tensor] = None      # ... or its Winograd-transformed planes (forward_wino / forward_wino2)
 
     def _bf16(self, feat_left, feat_right, halo, resident):
         """bf16 path: logical (B,C,H,W) channels_last features -> physical (B,D+2h,H+2h,W+2h,2C) volume."""
@@ -502,6 +506,31 @@ class CostVolume(nn.Module):
         return self._planes
 
     @torch.no_grad()
+    def forward_wino2(self, feat_left: torch.Tensor, feat_right: torch.Tensor) -> torch.Tensor:
+        """The same hand-off for a decoder whose first 3D conv runs the TWO-AXIS Winograd kernel: the 36 F(4,3) x F(4,3) plane
+        sets of the halo-1 padded volume, (36,B,2C,D/4,H/4,W+2), bit-identical to the consumer's own input transform."""
+        fl = _check_input(feat_left, "feat_left", feat_left.shape[1:])
+        fr = _check_input(feat_right, "feat_right", feat_left.shape[1:])
+        B, Cc, H, W = fl.shape
+        shape = (36, B, 2 * Cc, self.max_disp // 4, H // 4, W + 2)
+        if self._planes is None or tuple(self._planes.shape) != shape or self._planes.device != fl.device:
+            if getattr(self, "_pinned", False):
+                raise RuntimeError("the padded cost volume of this module is captured in a HIP graph for another shape")
+            self._planes = torch.zeros(shape, dtype=torch.float32, device=fl.device)
+        _lib.check(_lib.load().s3r_cost_volume_forward_wino2(fl.data_ptr(), fr.data_ptr(), self._planes.data_ptr(), B, Cc,
+                                                             self.max_disp, H, W, _stream_ptr(fl.device)), "cost_volume (wino2)")
+        return self._planes
+
+    def forward_for(self, consumer, feat_left: torch.Tensor, feat_right: torch.Tensor):
+        """(volume, in_layout) in whatever form `consumer` (a Decoder / VolumeEncoder) reads fastest for this batch."""
+        layout = consumer.wino_input_layout(feat_left.shape[0])
+        if layout == _lib.LAYOUT_WINO_H:
+            return self.forward_wino(feat_left, feat_right), layout
+        if layout == _lib.LAYOUT_WINO_DH:
+            return self.forward_wino2(feat_left, feat_right), layout
+        return self.forward_padded(feat_left, feat_right), _lib.LAYOUT_PLAIN
+
+    @torch.no_grad()
     def forward(self, feat_left: torch.Tensor, feat_right: torch.Tensor) -> torch.Tensor:
         if self.precision == "bf16":      # logical (B,2C,D,H,W) view of the channels-last volume
             return _to_logical(self._bf16(feat_left, feat_right, 0, resident=False))
@@ -519,11 +548,14 @@ class CostVolume(nn.Module):
         return vol
 
 
-def _check_wino_planes(v: torch.Tensor) -> torch.Tensor:
-    want = (2 * spec.FEAT_C, spec.MAX_DISP + 2, spec.FEAT_HW // 4, spec.FEAT_HW + 2)
-    if not isinstance(v, torch.Tensor) or not v.is_cuda or v.dtype != torch.float32 or v.dim() != 6 or v.shape[0] != 6 or \
+def _check_wino_planes(v: torch.Tensor, layout: int = _lib.LAYOUT_WINO_H) -> torch.Tensor:
+    if layout == _lib.LAYOUT_WINO_DH:
+        ncls, want = 36, (2 * spec.FEAT_C, spec.MAX_DISP // 4, spec.FEAT_HW // 4, spec.FEAT_HW + 2)
+    else:
+        ncls, want = 6, (2 * spec.FEAT_C, spec.MAX_DISP + 2, spec.FEAT_HW // 4, spec.FEAT_HW + 2)
+    if not isinstance(v, torch.Tensor) or not v.is_cuda or v.dtype != torch.float32 or v.dim() != 6 or v.shape[0] != ncls or \
             tuple(v.shape[2:]) != want or not v.is_contiguous():
-        raise RuntimeError(f"transformed volume must be a contiguous float32 HIP tensor (6, B, {', '.join(map(str, want))})")
+        raise RuntimeError(f"transformed volume must be a contiguous float32 HIP tensor ({ncls}, B, {', '.join(map(str, want))})")
     return v
 
 
@@ -546,8 +578,8 @@ class Decoder(_HipChain):
     def forward_padded(self, volume_padded: torch.Tensor, halo: int = 1, in_layout: int = 0) -> torch.Tensor:
         """Decoder on the halo-padded volume CostVolume.forward_padded produced (no pad copy), or (in_layout =
         LAYOUT_WINO_H) on the transformed planes CostVolume.forward_wino produced."""
-        if in_layout == _lib.LAYOUT_WINO_H:
-            return self._run(_check_wino_planes(volume_padded), None, in_halo=1, in_layout=in_layout).squeeze(1)
+        if in_layout in (_lib.LAYOUT_WINO_H, _lib.LAYOUT_WINO_DH):
+            return self._run(_check_wino_planes(volume_padded, in_layout), None, in_halo=1, in_layout=in_layout).squeeze(1)
         n = (spec.MAX_DISP + 2 * halo, spec.FEAT_HW + 2 * halo, spec.FEAT_HW + 2 * halo)
         if self.precision == "bf16":
             x = _check_input(volume_padded, "volume_padded", n + (2 * spec.FEAT_C,), torch.bfloat16)
@@ -570,8 +602,8 @@ class VolumeEncoder(_HipChain):
         return self._run(_check_input(volume, "volume", tail))
 
     def forward_padded(self, volume_padded: torch.Tensor, halo: int = 1, in_layout: int = 0) -> torch.Tensor:
-        if in_layout == _lib.LAYOUT_WINO_H:
-            return self._run(_check_wino_planes(volume_padded), None, in_halo=1, in_layout=in_layout)
+        if in_layout in (_lib.LAYOUT_WINO_H, _lib.LAYOUT_WINO_DH):
+            return self._run(_check_wino_planes(volume_padded, in_layout), None, in_halo=1, in_layout=in_layout)
         n = (spec.MAX_DISP + 2 * halo, spec.FEAT_HW + 2 * halo, spec.FEAT_HW + 2 * halo)
         if self.precision == "bf16":            # physical (B,D+2h,H+2h,W+2h,2C) bf16 -> logical (B,512,4,4,4) bf16
             x = _check_input(volume_padded, "volume_padded", n + (2 * spec.FEAT_C,), torch.bfloat16)
@@ -655,12 +687,9 @@ class Stereo2Voxel(_DisparityMixin, nn.Module):
             l, r = left[s:s + MAX_CHUNK], right[s:s + MAX_CHUNK]
             b = l.shape[0]
             feats = self.encoder.forward_pair(l, r)          # (2b,32,28,28): left batch, then right batch
-            if self.decoder.takes_wino_input(b):             # v1 on the Winograd kernel: the volume goes over transformed
-                vol = self.cost_volume.forward_wino(feats[:b], feats[b:])
-                outs.append(self.decoder.forward_padded(vol, in_layout=_lib.LAYOUT_WINO_H))
-                continue
-            vol = self.cost_volume.forward_padded(feats[:b], feats[b:])
-            outs.append(self.decoder.forward_padded(vol))
+            # (v1 on a Winograd kernel: the volume goes over in the transformed layout that kernel reads)
+            vol, layout = self.cost_volume.forward_for(self.decoder, feats[:b], feats[b:])
+            outs.append(self.decoder.forward_padded(vol, in_layout=layout))
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
     @torch.no_grad()
@@ -708,11 +737,8 @@ class Stereo2Point(_DisparityMixin, nn.Module):
             l, r = left[s:s + MAX_CHUNK], right[s:s + MAX_CHUNK]
             b = l.shape[0]
             feats = self.encoder.forward_pair(l, r)
-            if self.decoder.takes_wino_input(b):
-                latent = self.decoder.forward_padded(self.cost_volume.forward_wino(feats[:b], feats[b:]),
-                                                     in_layout=_lib.LAYOUT_WINO_H)
-            else:
-                latent = self.decoder.forward_padded(self.cost_volume.forward_padded(feats[:b], feats[b:]))
+            vol, layout = self.cost_volume.forward_for(self.decoder, feats[:b], feats[b:])
+            latent = self.decoder.forward_padded(vol, in_layout=layout)
             if latent.dtype != torch.float32:                      # bf16 channels-last view -> fp32 (B,512,4,4,4): HIP kernel
                 latent = channels_last_to_f32(latent)
             outs.append(self.point_head(latent))

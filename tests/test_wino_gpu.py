@@ -108,41 +108,59 @@ def test_winograd_path_vs_oracle_and_invariants(tmp_path):
 
 
 def test_cost_volume_writes_the_transformed_planes_bitwise(s3r, monkeypatch):
-    """CostVolume.forward_wino (S3R_LAYOUT_WINO_H: the volume written as the six F(4,3)-along-H plane sets of its halo-1
-    padded form) equals the transform applied to the padded volume (to fp32 rounding: the kernel uses fused multiply-adds), and the decoder fed with it equals the decoder fed with
-    the padded volume (which runs its own input transform in front of the same kernel) — bit for bit; both models take the
+    """The cost volume written directly in the layout its consumer's Winograd kernel reads — the 36 two-axis plane sets
+    (S3R_LAYOUT_WINO_DH: what the default policy's v1 takes) or the six one-axis plane sets (S3R_LAYOUT_WINO_H) — equals the
+    input transform of the padded volume (to fp32 rounding against a float64 evaluation; bitwise through the decoder, which
+    runs its own transform kernel in front of the same class kernel when handed the padded volume); both models take the
     hand-off by themselves; a batch too large for one transformed call keeps the plain hand-off."""
     if os.environ.get("S3R_WINO") not in (None, "1"):
         pytest.skip("the library's own policy is under test (S3R_WINO is read once, at load)")
-    dev = "cuda:0"
+    dev, L = "cuda:0", s3r._lib
     m = s3r.Stereo2Voxel()
     s3r.seed_module(m, 0)
     m.to(dev)
     l, r = s3r.synthetic_pairs(3, seed=5)
     feats = m.encoder.forward_pair(l.to(dev), r.to(dev))
     vol = m.cost_volume.forward_padded(feats[:3], feats[3:]).clone()                # (3, 64, 30, 30, 30), zero halo
-    planes = m.cost_volume.forward_wino(feats[:3], feats[3:]).clone()               # (6, 3, 64, 30, 7, 30)
-    x = [vol[:, :, :, k:k + 25:4, :].double() for k in range(6)]                    # padded rows 4q + k, q = 0 .. 6
-    want = torch.stack([4 * x[0] - 5 * x[2] + x[4], -4 * x[1] - 4 * x[2] + x[3] + x[4], 4 * x[1] - 4 * x[2] - x[3] + x[4],
-                        -2 * x[1] - x[2] + 2 * x[3] + x[4], 2 * x[1] - x[2] - 2 * x[3] + x[4], 4 * x[1] - 5 * x[3] + x[5]])
-    assert planes.shape == want.shape                                               # F(4,3)'s input transform, to fp32 rounding
-    assert (planes.double() - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
-    assert not planes[:, :, :, 0].any() and not planes[:, :, :, -1].any()           # the depth-halo planes stay zero
-    assert m.decoder.takes_wino_input(3)
+    BT = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                       [0, 4, 0, -5, 0, 1]], dtype=torch.float64, device=dev)
+    rows = torch.stack([vol[:, :, :, k:k + 25:4, :].double() for k in range(6)])    # padded rows 4q + k, q = 0 .. 6
+    want1 = torch.einsum("ck,kbxdqw->cbxdqw", BT, rows)                             # F(4,3)'s input transform along H
+    # ---- the default policy: v1 on the two-axis kernel
+    assert m.decoder.wino_input_layout(3) == L.LAYOUT_WINO_DH
+    planes2 = m.cost_volume.forward_wino2(feats[:3], feats[3:]).clone()             # (36, 3, 64, 7, 7, 30)
+    deps = torch.stack([want1[:, :, :, k:k + 25:4] for k in range(6)])              # (depth k, row class, b, c, sd, q, w)
+    want2 = torch.einsum("ak,kcbxsqw->acbxsqw", BT, deps).reshape(36, 3, 64, 7, 7, 30)
+    assert planes2.shape == want2.shape
+    assert (planes2.double() - want2).abs().max().item() < 1e-5 * max(1.0, want2.abs().max().item())
     a = m.decoder.forward_padded(vol)
-    b = m.decoder.forward_padded(planes, in_layout=s3r._lib.LAYOUT_WINO_H)
+    b = m.decoder.forward_padded(planes2, in_layout=L.LAYOUT_WINO_DH)
     assert torch.equal(a, b)
     assert torch.equal(m(l.to(dev), r.to(dev)), a)                                   # the model's own forward takes it
-    assert not m.decoder.takes_wino_input(300)                                       # 300 x 9.7 MB of planes: two calls
+    assert m.decoder.wino_input_layout(300) == L.LAYOUT_PLAIN                        # 300 x 13.5 MB of planes: two calls
     with pytest.raises(RuntimeError):
-        m.decoder.forward_padded(planes[:, :, :, :, :, :29], in_layout=s3r._lib.LAYOUT_WINO_H)
+        m.decoder.forward_padded(planes2[:, :, :, :, :, :29], in_layout=L.LAYOUT_WINO_DH)
+    # ---- the one-axis kernel (forced per layer) and its layout
+    m.decoder.algo_override["v1"], m.decoder.tile_override["v1"] = L.ALGO_WINOGRAD, 0
+    assert m.decoder.wino_input_layout(3) == L.LAYOUT_WINO_H
+    planes = m.cost_volume.forward_wino(feats[:3], feats[3:]).clone()               # (6, 3, 64, 30, 7, 30)
+    assert planes.shape == want1.shape
+    assert (planes.double() - want1).abs().max().item() < 2e-6 * max(1.0, want1.abs().max().item())
+    assert not planes[:, :, :, 0].any() and not planes[:, :, :, -1].any()           # the depth-halo planes stay zero
+    a1 = m.decoder.forward_padded(vol)
+    m.decoder.tile_override.pop("v1")                       # (a transformed input takes no form override)
+    m.decoder.algo_override["v1"] = L.ALGO_AUTO
+    b1 = m.decoder.forward_padded(planes, in_layout=L.LAYOUT_WINO_H)
+    assert torch.equal(a1, b1) and not torch.equal(a1, a)
+    m.decoder.algo_override.pop("v1")
     p = s3r.Stereo2Point()
     s3r.seed_module(p, 1)
     p.to(dev)
     fp = p.encoder.forward_pair(l.to(dev), r.to(dev))
     lat_a = p.decoder.forward_padded(p.cost_volume.forward_padded(fp[:3], fp[3:]))
-    lat_b = p.decoder.forward_padded(p.cost_volume.forward_wino(fp[:3], fp[3:]), in_layout=s3r._lib.LAYOUT_WINO_H)
-    assert torch.equal(lat_a, lat_b)
+    vol_b, layout = p.cost_volume.forward_for(p.decoder, fp[:3], fp[3:])
+    assert layout == L.LAYOUT_WINO_DH
+    assert torch.equal(lat_a, p.decoder.forward_padded(vol_b, in_layout=layout))
 
 
 def _wino_layers(spec):
@@ -234,21 +252,23 @@ torch.save(outs, sys.argv[1])
 def test_whole_forward_is_form_invariant_at_every_batch(tmp_path):
     """B = 1, 2, 4, 8, 32: the forward under the library's own launch plan (class-parallel on sparse grids, dual where a
     layer's last round is mostly empty; the transposed layers' depth differences materialised or formed in the kernel by
-    input size) equals the forward with every Winograd layer forced to the serial form, and with the depth differences
-    forced either way — bitwise."""
+    input size; the two-axis layers class-parallel or semi-fused) equals the forward with every one-axis Winograd layer forced
+    to the serial form, with the depth differences forced either way, and with the two-axis layers forced to either of their
+    forms — bitwise."""
     res = {}
     for flag, env_set in (("auto", {}), ("serial", {"S3R_WINO_FORM": "0"}), ("mat0", {"S3R_DWINO_MAT": "0"}),
-                          ("mat1", {"S3R_DWINO_MAT": "1"})):
+                          ("mat1", {"S3R_DWINO_MAT": "1"}), ("cp2", {"S3R_WINO2_FORM": "0"}), ("semi2", {"S3R_WINO2_FORM": "1"})):
         path = str(tmp_path / f"forms_{flag}.pt")
         env = dict(os.environ)
         env.pop("S3R_WINO_FORM", None)
         env.pop("S3R_DWINO_MAT", None)
+        env.pop("S3R_WINO2_FORM", None)
         env.update(env_set)
         r = subprocess.run([sys.executable, "-c", _FORMS_CHILD % {"root": ROOT}, path], capture_output=True, text=True,
                            timeout=900, cwd=ROOT, env=env)
         assert r.returncode == 0, r.stderr[-3000:]
         res[flag] = torch.load(path)
-    for flag in ("serial", "mat0", "mat1"):
+    for flag in ("serial", "mat0", "mat1", "cp2", "semi2"):
         for a, b in zip(res["auto"], res[flag]):
             assert torch.equal(a, b), (flag, a.shape)
 
@@ -343,6 +363,12 @@ def test_two_axis_form_vs_oracle_and_invariants(s3r, oracle):
         assert rel < 1e-5, (name, rel)
         assert torch.equal(ch._run(x.to(dev)), got)                                   # deterministic
         assert torch.equal(ch._run(x[B - 1:].to(dev))[0], got[B - 1])                 # batch-invariant
+        for form in (4, 5):                                                           # class-parallel / semi-fused launch forms
+            if name == "v6" and form == 5:
+                continue                                                              # (F(2,4): class-parallel only)
+            ch.tile_override[name] = form
+            assert torch.equal(ch._run(x.to(dev)), got), (name, form)
+        ch.tile_override[name] = 3
         if name != "v6":
             ch.tile_override[name] = 0
             one = ch._run(x.to(dev))
