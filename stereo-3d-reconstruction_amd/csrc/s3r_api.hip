@@ -245,11 +245,13 @@ bool wino_desc_ok(const s3r_conv_desc* d) {
     if (d->out_layout != S3R_LAYOUT_PLAIN) return false;
     return d->in_layout == S3R_LAYOUT_PLAIN || (d->in_layout == S3R_LAYOUT_WINO_H && wino_layer(d));
 }
-// Two-axis class-parallel Winograd (s3r_conv_wino.hip): the 3D stride-1 layers with a small edge — k3 p1 as F(4,3) x F(4,3)
-// (returns 0), k4 p0 as F(2,4) x F(2,4) (returns 1); -1: the layer has no such form
+// Two-axis class-parallel Winograd (s3r_conv_wino.hip): the stride-1 layers with a small edge — Conv3d k3 p1 as F(4,3) x F(4,3)
+// over D and H (returns 0), Conv3d k4 p0 as F(2,4) x F(2,4) (returns 1), Conv2d k3 p1 as F(4,3) x F(4,3) over H and W (returns 2);
+// -1: the layer has no such form
 int wino2_ax(const s3r_conv_desc* d) {
-    if (d->dtype == S3R_BF16 || d->op != S3R_OP_CONV || d->ndim != 3 || d->stride != 1 || d->cin % s3r::wino_bk() != 0 || d->cout <= 1)
-        return -1;
+    if (d->dtype == S3R_BF16 || d->op != S3R_OP_CONV || d->stride != 1 || d->cin % s3r::wino_bk() != 0 || d->cout <= 1) return -1;
+    if (d->ndim == 2) return d->k == 3 && d->pad == 1 && d->in_size >= 4 ? 2 : -1;
+    if (d->ndim != 3) return -1;
     if (d->k == 3 && d->pad == 1 && d->in_size >= 4) return 0;
     if (d->k == 4 && d->pad == 0 && d->in_size >= 5) return 1;
     return -1;
@@ -278,7 +280,7 @@ int resolve_algo(const s3r_conv_desc* d, int* alg, int* form) {
         // tile: -1 the library's pick between the forms the layer has; 0, 1, 2 a launch form of the one-axis kernel; 3 the two-axis
         // algorithm (4: its class-parallel form, 5: its semi-fused form)
         if ((d->tile >= 3 && !two) || (d->tile >= 0 && d->tile <= 2 && !one) || (!one && !two) || d->tile > 5 ||
-            (d->tile == 5 && wino2_ax(d) != 0))
+            (d->tile == 5 && wino2_ax(d) == 1))
             return fail(S3R_ERR_INVALID, "algo = WINOGRAD: this layer / descriptor has no such Winograd form (one-axis: fp32 Conv k3 s1 p1 "
                         "with cin %% %d == 0 and edge >= 4, or ConvTranspose3d k4 s2 p1 over an edge %% 4 == 0, in_halo = 1; two-axis "
                         "(tile = 3): Conv3d k3 s1 p1 / k4 s1 p0, in_halo = pad; plain layouts, no split-K, no sigmoid)", s3r::wino_bk());
@@ -324,10 +326,11 @@ Wino2Geo wino2_geo(const s3r_conv_desc* d) {
     w.out = out_size(d);
     w.sg = (w.out + w.m - 1) / w.m;                       // groups per axis
     w.wp = d->in_size + 2 * d->in_halo;
-    w.kw = d->k;
+    w.kw = w.ax == 2 ? 1 : d->k;                          // column taps left to the class kernel
     w.w_elems = (int64_t)w.ncls * w.kw * d->cin * cout_pad(d->cout);
-    w.v_sample = (int64_t)w.ncls * d->cin * w.sg * w.sg * w.wp;
-    w.pos_sample = (int64_t)w.sg * w.sg * w.out;
+    // ax 2: V is [36][Cin][positions of the sub-batch rounded up to a GEMM tile]: v_sample is the bound used to size a sub-batch
+    w.v_sample = w.ax == 2 ? (int64_t)w.ncls * d->cin * (w.sg * w.sg + 64) : (int64_t)w.ncls * d->cin * w.sg * w.sg * w.wp;
+    w.pos_sample = w.ax == 2 ? (int64_t)w.sg * w.sg : (int64_t)w.sg * w.sg * w.out;
     const int64_t mx = w.v_sample > 0 ? (((int64_t)1 << 31) - 1) / (4 * w.v_sample) : 0;
     w.bmax = (int)(mx < d->batch ? mx : d->batch);
     w.n = 0;
@@ -411,7 +414,8 @@ WinoNeed wino2_need(const s3r_conv_desc* d, int form) {
     WinoNeed w = {0, 0, 0};
     const Wino2Geo g2 = wino2_geo(d);
     if (d->batch <= 0 || g2.bmax <= 0) return w;
-    if (d->in_layout != S3R_LAYOUT_WINO_DH) w.v = (g2.v_sample * g2.bmax + 255) / 256 * 256;
+    if (d->in_layout != S3R_LAYOUT_WINO_DH)
+        w.v = ((g2.ax == 2 ? g2.ncls * d->cin * s3r::wino2_npad(g2.pos_sample * g2.bmax) : g2.v_sample * g2.bmax) + 255) / 256 * 256;
     for (int b0 = 0; b0 < d->batch; b0 += g2.bmax) {              // (at most two different sub-batch sizes)
         const int nb = d->batch - b0 < g2.bmax ? d->batch - b0 : g2.bmax;
         if (b0 > 0 && nb == g2.bmax) continue;
@@ -438,7 +442,7 @@ int wino2_run(const s3r_conv_desc* d, const Geo& g, s3r::ConvParams p, const flo
     if (!scratch || scratch_elems < need.total)
         return fail(S3R_ERR_WORKSPACE, "the two-axis Winograd form of this layer needs %lld floats of scratch (s3r_conv_scratch_elems), "
                     "got %lld", (long long)need.total, (long long)(scratch ? scratch_elems : 0));
-    const int64_t direct_w = ipow(d->k, 3) * d->cin * cout_pad(d->cout);
+    const int64_t direct_w = ipow(d->k, g.nd) * d->cin * cout_pad(d->cout);
     p.w = packed_w + direct_w + (wino_layer(d) ? wino_w_elems(d) : 0);      // behind the direct (and the one-axis) slabs
     p.x = pre ? x : scratch;
     p.part = scratch + need.v;
@@ -449,6 +453,11 @@ int wino2_run(const s3r_conv_desc* d, const Geo& g, s3r::ConvParams p, const flo
     p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
     p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
     p.dW = s3r::FastDiv((unsigned)p.Nw);
+    if (g2.ax == 2) {                                     // (the finish kernel's view; launch_conv_wino2 derives the class GEMM's)
+        p.Nd = 1; p.Nw = g2.sg;
+        p.dS = s3r::FastDiv((unsigned)(g2.sg * g2.sg));
+        p.dW = s3r::FastDiv((unsigned)g2.sg);
+    }
     p.Hout = g2.out; p.Dout = g2.out;
     p.ncls = g2.ncls;
     p.ksplit = 1;
@@ -458,7 +467,11 @@ int wino2_run(const s3r_conv_desc* d, const Geo& g, s3r::ConvParams p, const flo
         const int nb = d->batch - b0 < g2.bmax ? d->batch - b0 : g2.bmax;
         hipError_t e = hipSuccess;
         if (!pre) {
-            e = s3r::launch_wino2_input(x + (int64_t)b0 * x_sample, scratch, g2.ax, (long long)nb * d->cin, g2.wp, g2.wp, g2.wp, g2.sg, g2.sg, s);
+            if (g2.ax == 2)
+                e = s3r::launch_wino2p_input(x + (int64_t)b0 * x_sample, scratch, nb, d->cin, g2.wp, g2.wp, g2.sg, g2.sg,
+                                             s3r::wino2_npad(g2.pos_sample * nb), s);
+            else
+                e = s3r::launch_wino2_input(x + (int64_t)b0 * x_sample, scratch, g2.ax, (long long)nb * d->cin, g2.wp, g2.wp, g2.wp, g2.sg, g2.sg, s);
             if (e != hipSuccess) return hip_fail(e, "two-axis Winograd input transform launch");
             *launches += 1;
         }

@@ -31,6 +31,8 @@ typedef float wv2f __attribute__((ext_vector_type(2)));
 template <int N> struct WVec;
 template <> struct WVec<1> { typedef float type; };
 template <> struct WVec<2> { typedef wv2f type; };
+typedef float wv4f __attribute__((ext_vector_type(4)));
+template <> struct WVec<4> { typedef wv4f type; };
 template <int N>
 __device__ __forceinline__ float wvget(const typename WVec<N>::type& v, int i) {
     if constexpr (N == 1) return v; else return v[i];
@@ -889,8 +891,8 @@ hipError_t launch_deconv_wino(ConvParams p, const WinoLaunch& L, hipStream_t str
 template <int AX> struct WAxis;
 template <> struct WAxis<0> { static constexpr int N = 6, M = 4, R = 3; };      // F(4,3)
 template <> struct WAxis<1> { static constexpr int N = 5, M = 2, R = 4; };      // F(2,4)
-int wino2_classes(int ax) { return ax == 0 ? 36 : 25; }
-int wino2_outputs(int ax) { return ax == 0 ? 4 : 2; }
+int wino2_classes(int ax) { return ax == 1 ? 25 : 36; }      // ax 2: the 2D layers' (H, W) nesting, F(4,3) x F(4,3) again
+int wino2_outputs(int ax) { return ax == 1 ? 2 : 4; }
 
 template <int AX>
 __device__ __forceinline__ void wax_bt(const float (&r)[WAxis<AX>::N], float (&v)[WAxis<AX>::N]) {
@@ -1005,16 +1007,108 @@ __global__ void pack_wino2_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
+__global__ void pack_wino2p_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int CoutPad);    // (ax 2, below)
 hipError_t launch_pack_wino2(const float* w, float* wp, int ax, int Cin, int Cout, int CoutPad, hipStream_t s) {
     if (ax == 0) hipLaunchKernelGGL(pack_wino2_kernel<0>, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CoutPad);
     else if (ax == 1) hipLaunchKernelGGL(pack_wino2_kernel<1>, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CoutPad);
+    else if (ax == 2) hipLaunchKernelGGL(pack_wino2p_kernel, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CoutPad);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
+// Finish kernels.  The output tensors carry their consumer's halo, so rows are (W + 2 halo) floats long: a kernel that stores
+// interiors only leaves EVERY 128-byte line partly written, and partial lines cost the memory side a read-modify-write (measured on
+// v1's finish: its stores alone ran at 2.5 TB/s, its loads at 6).  So a workgroup builds whole padded slices in LDS — halo zeros
+// included — and writes them out as contiguous 16-byte stores: the halo is rewritten with the zeros it already holds.
+__device__ __forceinline__ void wino2_copy_out(const float* __restrict__ lds, float* __restrict__ dst, int count, int tid) {
+    if ((count & 3) == 0 && (reinterpret_cast<size_t>(dst) & 15) == 0) {
+        for (int i = tid * 4; i < count; i += 1024) *reinterpret_cast<wv4f*>(dst + i) = *reinterpret_cast<const wv4f*>(lds + i);
+    } else {
+        for (int i = tid; i < count; i += 256) dst[i] = lds[i];
+    }
+}
+__device__ __forceinline__ void wino2_zero_out(float* __restrict__ dst, int count, int tid) {
+    if ((count & 3) == 0 && (reinterpret_cast<size_t>(dst) & 15) == 0) {
+        for (int i = tid * 4; i < count; i += 1024) *reinterpret_cast<wv4f*>(dst + i) = wv4f{0.f, 0.f, 0.f, 0.f};
+    } else {
+        for (int i = tid; i < count; i += 256) dst[i] = 0.f;
+    }
+}
+
+// 3D, semi-fused form: one workgroup per (cout, SUB consecutive (sample, depth group) pairs — as many as give its 256 threads a
+// group each): slabs [a][row][Cout][npad] (the row transform already applied by the class kernel) -> 4 output slices per pair:
+// A^T along D, folded BN + activation.  y: halo-padded, y_hs = W + 2 halo, y_ds = a slice
+__global__ __launch_bounds__(256) void wino2s_finish_kernel(const ConvParams p, const int npad, const int halo, const int SUB,
+                                                            const FastDiv dNd, const FastDiv dMS) {
+    constexpr int N = 6, M = 4;
+    extern __shared__ __attribute__((aligned(16))) float fsm[];          // SUB x M slices of Hp x Wp
+    const int tid = threadIdx.x;
+    const int G = p.Nh * p.Nw, Wp = p.y_hs, slice = p.y_ds, MS = M * slice;
+    const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+    const size_t cstride = (size_t)p.Cout * npad;
+    const int per_c = p.B * p.Nd;
+    const int nrg = (per_c + SUB - 1) / SUB;
+    const bool vec = (slice & 3) == 0 && (reinterpret_cast<size_t>(p.y) & 15) == 0;
+    for (int item = blockIdx.x; item < p.Cout * nrg; item += gridDim.x) {
+        const int mrow = item / nrg;
+        const int r0 = (item - mrow * nrg) * SUB;                        // first (sample, depth group) pair
+        const int nsub = per_c - r0 < SUB ? per_c - r0 : SUB;
+        for (int i = tid; i < nsub * MS; i += 256) fsm[i] = 0.f;
+        __syncthreads();
+        const float sc = p.scale ? p.scale[mrow] : 1.f, sf = p.shift ? p.shift[mrow] : 0.f;
+        for (int t = tid; t < nsub * G; t += 256) {
+            const int sub = p.dHW.div(t);
+            const int g = t - sub * G;
+            const int sh = p.dW.div(g);
+            const int pw = g - sh * p.Nw;
+            const int r = r0 + sub;
+            const int sd = r - dNd.div(r) * p.Nd;
+            const float* __restrict__ src = p.part + (size_t)mrow * npad + (size_t)r0 * G + t;
+            float* __restrict__ o = fsm + sub * MS + (halo + M * sh) * Wp + halo + pw;
+#pragma unroll
+            for (int v = 0; v < M; ++v) {
+                float m[N], y[M];
+#pragma unroll
+                for (int a = 0; a < N; ++a) m[a] = src[(size_t)(a * M + v) * cstride];
+                wax_at<0>(m, y);
+#pragma unroll
+                for (int u = 0; u < M; ++u)
+                    if (M * sd + u < p.Dout && M * sh + v < p.Hout) o[u * slice + v * Wp] = wino_act(y[u], sc, sf, lo);
+            }
+        }
+        __syncthreads();
+        float* __restrict__ yc = p.y + (size_t)mrow * p.y_cs;
+        // every pair's slices are one contiguous run of the output (the depth halo slices of a sample's first / last pair with them)
+        for (int e = vec ? tid * 4 : tid; e < nsub * MS; e += vec ? 1024 : 256) {
+            const int sub = dMS.div(e);
+            const int off = e - sub * MS;
+            const int r = r0 + sub;
+            const int b = dNd.div(r);
+            const int sd = r - b * p.Nd;
+            const int nsl = p.Dout - M * sd < M ? p.Dout - M * sd : M;
+            if (off >= nsl * slice) continue;
+            float* __restrict__ dst = yc + (size_t)b * p.y_bs + (size_t)(halo + M * sd) * slice + off;
+            if (vec) *reinterpret_cast<wv4f*>(dst) = *reinterpret_cast<const wv4f*>(fsm + e);
+            else *dst = fsm[e];
+        }
+        if (halo > 0)
+            for (int sub = 0; sub < nsub; ++sub) {
+                const int r = r0 + sub;
+                const int b = dNd.div(r);
+                const int sd = r - b * p.Nd;
+                if (sd == 0) wino2_zero_out(yc + (size_t)b * p.y_bs, halo * slice, tid);
+                if (sd == p.Nd - 1) wino2_zero_out(yc + (size_t)b * p.y_bs + (size_t)(halo + p.Dout) * slice, halo * slice, tid);
+            }
+        __syncthreads();
+    }
+}
+
+// The class-parallel form of the 3D layers keeps the flat finish kernel — one thread per (cout, position), interiors only: its
+// outputs are small (v3: 45 MB, v5 / v6: 11 / 4 MB) and the staged kernel's zero / barrier / copy chain costs more than the
+// partial lines do (v3 42 -> 44 us, v5 11 -> 18, v6 10 -> 19).
 // slabs [cls][Cout][npad] -> y: A^T along H, then along D, folded BN + activation; outputs beyond the true edge are not stored
 template <int AX>
-__global__ __launch_bounds__(256) void wino2_finish_kernel(const ConvParams p, const int npad) {
+__global__ __launch_bounds__(256) void wino2_finish_flat_kernel(const ConvParams p, const int npad) {
     constexpr int N = WAxis<AX>::N, M = WAxis<AX>::M;
     const int S = p.Nd * p.Nh * p.Nw;
     const int nn = p.Ntotal;
@@ -1056,36 +1150,135 @@ __global__ __launch_bounds__(256) void wino2_finish_kernel(const ConvParams p, c
     }
 }
 
-// semi-fused form: slabs [a][row][Cout][npad] (the row transform already applied) -> y: A^T along D, epilogue
-__global__ __launch_bounds__(256) void wino2s_finish_kernel(const ConvParams p, const int npad) {
+// ---- the same nesting for a 2D layer, over H and W (ax = 2): 36 classes of a 1 x 1 kernel — K = Cin, 36 multiply-adds per 16
+// outputs where the direct form spends 144 and the one-axis form 72.  With no tap left to shift along W the positions of the whole
+// sub-batch are laid out FLAT: V[cls = a 6 + b][Cin][npad], n = (sample, row group, column group), a = the column class, b = the
+// row class — the class GEMM sees one "sample" npad columns wide, so every gather is 16-byte even over a 7 x 7 grid of groups.
+// one thread per (cin, sample, row group, column group), positions innermost — a wave's 36 stores are 256 contiguous bytes each
+// (the windows it reads lie in a few 3.6 KB planes: L1 / L2 hits): a 6 x 6 window, B^T along H then along W
+__global__ __launch_bounds__(256) void wino2p_input_kernel(const float* __restrict__ x, float* __restrict__ V, unsigned total, int Cin,
+                                                           int Hp, int Wp, int SH, int SW, unsigned npad, unsigned nn, FastDiv dSW,
+                                                           FastDiv dSH, FastDiv dN) {
     constexpr int N = 6, M = 4;
-    const int S = p.Nd * p.Nh * p.Nw;
-    const int nn = p.Ntotal;
-    const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
-    const size_t rstride = (size_t)p.Cout * npad;
-    const long long total = (long long)p.Cout * nn;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int mrow = (int)(i / nn);
-        const int n = (int)(i - (long long)mrow * nn);
-        const int b = p.dS.div(n);
-        int rem = n - b * S;
-        const int sd = p.dHW.div(rem);
-        rem -= sd * p.Nh * p.Nw;
-        const int sh = p.dW.div(rem);
-        const int pw = rem - sh * p.Nw;
-        const float* __restrict__ src = p.part + (size_t)mrow * npad + n;
-        const float sc = p.scale ? p.scale[mrow] : 1.f, sf = p.shift ? p.shift[mrow] : 0.f;
-        float* __restrict__ yo = p.y + (size_t)b * p.y_bs + (size_t)mrow * p.y_cs + p.y_org + (size_t)M * sd * p.y_ds + M * sh * p.y_hs + pw;
+    const size_t cstride = (size_t)Cin * npad;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned c = (unsigned)dN.div((int)i);                     // i = c nn + n, n = (sample, sh, sw)
+        const unsigned n = i - c * nn;
+        const unsigned row = (unsigned)dSW.div((int)n);                  // (sample, sh)
+        const int sw = (int)(n - row * (unsigned)SW);
+        const unsigned b = (unsigned)dSH.div((int)row);
+        const int sh = (int)(row - b * (unsigned)SH);
+        const float* __restrict__ src = x + (((size_t)b * Cin + c) * Hp + M * sh) * Wp + M * sw;
+        float t[N][N];                                                   // [row class][column]
 #pragma unroll
-        for (int v = 0; v < M; ++v) {
-            float m[N], y[M];
+        for (int jc = 0; jc < N; ++jc) {
+            float r[N], v[N];
 #pragma unroll
-            for (int a = 0; a < N; ++a) m[a] = src[(size_t)(a * M + v) * rstride];
-            wax_at<0>(m, y);
+            for (int ir = 0; ir < N; ++ir) r[ir] = (M * sh + ir < Hp && M * sw + jc < Wp) ? src[(size_t)ir * Wp + jc] : 0.f;
+            wax_bt<0>(r, v);
 #pragma unroll
-            for (int u = 0; u < M; ++u)
-                if (M * sd + u < p.Dout && M * sh + v < p.Hout) yo[(size_t)u * p.y_ds + v * p.y_hs] = wino_act(y[u], sc, sf, lo);
+            for (int ir = 0; ir < N; ++ir) t[ir][jc] = v[ir];
         }
+        float* __restrict__ dst = V + (size_t)c * npad + n;
+#pragma unroll
+        for (int bb = 0; bb < N; ++bb) {
+            float v[N];
+            wax_bt<0>(t[bb], v);
+#pragma unroll
+            for (int a = 0; a < N; ++a) dst[(size_t)(a * N + bb) * cstride] = v[a];
+        }
+    }
+}
+
+hipError_t launch_wino2p_input(const float* x, float* V, int B, int Cin, int Hp, int Wp, int SH, int SW, long long npad, hipStream_t s) {
+    const long long nn = (long long)B * SH * SW, total = nn * Cin;
+    if (total >= (1ll << 31) || npad >= (1ll << 31)) return hipErrorInvalidValue;
+    const long long blocks = (total + 255) / 256;
+    const dim3 grid((unsigned)(blocks < 16384 ? blocks : 16384));
+    hipLaunchKernelGGL(wino2p_input_kernel, grid, dim3(256), 0, s, x, V, (unsigned)total, Cin, Hp, Wp, SH, SW, (unsigned)npad, (unsigned)nn,
+                       FastDiv((unsigned)SW), FastDiv((unsigned)SH), FastDiv((unsigned)nn));
+    return hipGetLastError();
+}
+
+// w[Cout][Cin][3][3] -> Up[cls = a 6 + b][cin][CoutPad]: G along W (a), then along H (b)
+__global__ void pack_wino2p_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int CoutPad) {
+    const size_t per_cls = (size_t)Cin * CoutPad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < 36 * per_cls; i += (size_t)gridDim.x * blockDim.x) {
+        const int cls = (int)(i / per_cls);
+        const int ca = cls / 6, cb = cls - ca * 6;
+        const size_t r = i % per_cls;
+        const int co = (int)(r % CoutPad);
+        const int cin = (int)(r / CoutPad);
+        float v = 0.f;
+        if (co < Cout) {
+            const float* g = w + ((size_t)co * Cin + cin) * 9;
+            float gh[3];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const float gw[3] = {g[kh * 3], g[kh * 3 + 1], g[kh * 3 + 2]};
+                gh[kh] = wax_g<0>(ca, gw);
+            }
+            v = wax_g<0>(cb, gh);
+        }
+        wp[i] = v;
+    }
+}
+
+// 2D: one workgroup per (cout, PL consecutive samples): slabs -> PL whole padded planes.  SEMI: [a][row][Cout][npad] (A^T along H
+// already applied by the class kernel), otherwise [a 6 + b][Cout][npad]: A^T along H, then along W.  y_hs = W + 2 halo, y_cs = a plane
+template <bool SEMI>
+__global__ __launch_bounds__(256) void wino2p_finish_kernel(const ConvParams p, const int npad, const int halo, const int PL) {
+    constexpr int N = 6, M = 4;
+    extern __shared__ __attribute__((aligned(16))) float fsm[];          // PL planes of Hp x Wp
+    const int tid = threadIdx.x;
+    const int G = p.Nh * p.Nw, Wp = p.y_hs, plane = p.y_cs;
+    const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+    const size_t cstride = (size_t)p.Cout * npad;
+    const int nbg = (p.B + PL - 1) / PL;
+    for (int item = blockIdx.x; item < p.Cout * nbg; item += gridDim.x) {
+        const int mrow = item / nbg;
+        const int b0 = (item - mrow * nbg) * PL;
+        const int npl = p.B - b0 < PL ? p.B - b0 : PL;
+        for (int i = tid; i < npl * plane; i += 256) fsm[i] = 0.f;
+        __syncthreads();
+        const float sc = p.scale ? p.scale[mrow] : 1.f, sf = p.shift ? p.shift[mrow] : 0.f;
+        for (int t = tid; t < npl * G; t += 256) {
+            const int pl = p.dS.div(t);
+            const int s = t - pl * G;
+            const int sh = p.dW.div(s);
+            const int sw = s - sh * p.Nw;
+            const float* __restrict__ src = p.part + (size_t)mrow * npad + (size_t)b0 * G + t;
+            float tt[N][M];                                              // [column class][output row]
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                if constexpr (SEMI) {
+#pragma unroll
+                    for (int v = 0; v < M; ++v) tt[a][v] = src[(size_t)(a * M + v) * cstride];
+                } else {
+                    float m[N], y[M];
+#pragma unroll
+                    for (int c = 0; c < N; ++c) m[c] = src[(size_t)(a * N + c) * cstride];
+                    wax_at<0>(m, y);
+#pragma unroll
+                    for (int v = 0; v < M; ++v) tt[a][v] = y[v];
+                }
+            }
+            float* __restrict__ o = fsm + pl * plane + (halo + M * sh) * Wp + halo + M * sw;
+#pragma unroll
+            for (int v = 0; v < M; ++v) {
+                float m[N], y[M];
+#pragma unroll
+                for (int a = 0; a < N; ++a) m[a] = tt[a][v];
+                wax_at<0>(m, y);
+#pragma unroll
+                for (int u = 0; u < M; ++u)
+                    if (M * sh + v < p.Hout && M * sw + u < p.Hout) o[v * Wp + u] = wino_act(y[u], sc, sf, lo);
+            }
+        }
+        __syncthreads();
+        for (int pl = 0; pl < npl; ++pl)
+            wino2_copy_out(fsm + pl * plane, p.y + (size_t)(b0 + pl) * p.y_bs + (size_t)mrow * p.y_cs, plane, tid);
+        __syncthreads();
     }
 }
 
@@ -1093,13 +1286,16 @@ __global__ __launch_bounds__(256) void wino2s_finish_kernel(const ConvParams p, 
 // only — semi-fused (one workgroup per depth class walks its six row classes: a third less slab traffic, six times the work
 // per workgroup: for grids that fill the chip several times over).  forced: -1 the plan, 0 class-parallel, 1 semi-fused
 int wino2_form(int ax, int cout, int ntotal, int forced) {
-    if (ax != 0) return 0;
+    if (ax == 1) return 0;
     if (forced >= 0) return forced ? 1 : 0;
     static const int env_form = getenv("S3R_WINO2_FORM") ? atoi(getenv("S3R_WINO2_FORM")) : -1;      // A/B switch, read once
     if (env_form >= 0) return env_form ? 1 : 0;
     const long semi_wgs = (long)((cout + WBM - 1) / WBM) * ((ntotal + WCN - 1) / WCN) * 6;
-    return semi_wgs >= 8 * 256 ? 1 : 0;                  // >= two rounds of the chip's four slots per CU
+    // 3D: >= two rounds of the chip's four slots per CU.  2D: a class is Cin / 32 K tiles only, too short a workgroup on its own —
+    // semi-fused from half a round on
+    return semi_wgs >= (ax == 2 ? 2 * 256 : 8 * 256) ? 1 : 0;
 }
+int64_t wino2_npad(int64_t ntotal) { return (ntotal + WCN - 1) / WCN * WCN; }
 int64_t wino2_slab_elems(int ax, int cout, int ntotal, int form) {
     const int64_t npad = (int64_t)((ntotal + WCN - 1) / WCN) * WCN;
     return (form ? 6 * 4 : wino2_classes(ax)) * (int64_t)cout * npad;
@@ -1109,16 +1305,53 @@ int64_t wino2_slab_elems(int ax, int cout, int ntotal, int form) {
 // T = kw, ncls = the class count; part = slabs; y / Dout / Hout the layer's output
 hipError_t launch_conv_wino2(ConvParams p, int ax, int form, hipStream_t stream, int* launches) {
     if (p.Cin % WBK != 0 || p.stride != 1 || p.transposed || p.ksplit != 1 || p.head_w || p.act == ACT_SIGMOID || !p.part ||
-        (ax != 0 && ax != 1) || p.ncls != wino2_classes(ax))
+        ax < 0 || ax > 2 || p.ncls != wino2_classes(ax))
         return hipErrorInvalidValue;
     p.kh = 1;
     p.m_tiles = (p.Cout + WBM - 1) / WBM;
     p.n_begin = 0; p.n_end = p.Ntotal;
     const int n_tiles = (p.Ntotal + WCN - 1) / WCN;
     const size_t lds = (size_t)WNB * WBK * (WBM + WCN) * sizeof(float);
-    const long long total = (long long)p.Cout * p.Ntotal;
-    const long long blocks = (total + 255) / 256;
-    const dim3 fgrid((unsigned)(blocks < 8192 ? blocks : 8192));
+    // finish kernels: whole padded slices / planes through LDS (the output's halo comes back from its strides)
+    const int halo = (p.y_hs - p.Hout) / 2;
+    if (halo < 0 || p.y_hs != p.Hout + 2 * halo) return hipErrorInvalidValue;
+    if (ax == 2) {
+        // p describes the layer for the finish kernel (Nh x Nw groups per sample); the class GEMM runs over the flat positions
+        const int plane = p.y_hs * p.y_hs, G = p.Nh * p.Nw;
+        if (p.y_cs != plane || (size_t)plane * 4 > 64 * 1024) return hipErrorInvalidValue;
+        int PL = 256 / G < 1 ? 1 : 256 / G;
+        if (PL > p.B) PL = p.B;
+        while (PL > 1 && (size_t)PL * plane * 4 > 64 * 1024) --PL;
+        const int npad = n_tiles * WCN;
+        ConvParams q = p;
+        q.B = 1; q.Nd = 1; q.Nh = 1; q.Nw = npad;
+        q.dS = q.dHW = q.dW = FastDiv((unsigned)npad);
+        q.kd = q.kh = q.kw = 1; q.T = 1;
+        q.x_org = 0; q.x_ds = 0; q.x_hs = 0; q.x_cs = npad; q.x_cls = p.Cin * npad;
+        q.x_bytes = (unsigned)(4ull * 36 * p.Cin * npad);
+        q.Ntotal = npad; q.n_end = npad;
+        const dim3 grid(p.m_tiles * n_tiles * (form == 1 ? 6 : 36));
+        if (form == 1) hipLaunchKernelGGL((wino_kernel<4, 1, 2, false, false, false, true>), grid, dim3(256), lds, stream, q);
+        else hipLaunchKernelGGL((wino_kernel<4, 1, 2, true, false>), grid, dim3(256), lds, stream, q);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const long long items = (long long)p.Cout * ((p.B + PL - 1) / PL);
+        const dim3 fgrid((unsigned)(items < 16384 ? items : 16384));
+        const size_t flds = (size_t)PL * plane * 4;
+        if (form == 1) hipLaunchKernelGGL(wino2p_finish_kernel<true>, fgrid, dim3(256), flds, stream, p, npad, halo, PL);
+        else hipLaunchKernelGGL(wino2p_finish_kernel<false>, fgrid, dim3(256), flds, stream, p, npad, halo, PL);
+        if (launches) *launches = 2;
+        return hipGetLastError();
+    }
+    const int M = wino2_outputs(ax), G = p.Nh * p.Nw;
+    if (p.y_ds != p.y_hs * p.y_hs || p.y_cs != (p.Dout + 2 * halo) * p.y_ds || (size_t)M * p.y_ds * 4 > 64 * 1024) return hipErrorInvalidValue;
+    int SUB = 256 / G < 1 ? 1 : 256 / G;                   // (sample, depth group) pairs per finish workgroup
+    if (SUB > p.B * p.Nd) SUB = p.B * p.Nd;
+    while (SUB > 1 && (size_t)SUB * M * p.y_ds * 4 > 64 * 1024) --SUB;
+    const size_t flds = (size_t)SUB * M * p.y_ds * 4;
+    const FastDiv dNd((unsigned)p.Nd), dMS((unsigned)(M * p.y_ds));
+    const long long items = (long long)p.Cout * ((p.B * p.Nd + SUB - 1) / SUB);
+    const dim3 fgrid((unsigned)(items < 32768 ? items : 32768));
     if (form == 1) {
         if (ax != 0) return hipErrorInvalidValue;
         const dim3 grid(p.m_tiles * n_tiles * 6);
@@ -1126,7 +1359,7 @@ hipError_t launch_conv_wino2(ConvParams p, int ax, int form, hipStream_t stream,
         else hipLaunchKernelGGL((wino_kernel<1, 1, 2, false, false, false, true>), grid, dim3(256), lds, stream, p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(wino2s_finish_kernel, fgrid, dim3(256), 0, stream, p, n_tiles * WCN);
+        hipLaunchKernelGGL(wino2s_finish_kernel, fgrid, dim3(256), flds, stream, p, n_tiles * WCN, halo, SUB, dNd, dMS);
         if (launches) *launches = 2;
         return hipGetLastError();
     }
@@ -1135,8 +1368,11 @@ hipError_t launch_conv_wino2(ConvParams p, int ax, int form, hipStream_t stream,
     else hipLaunchKernelGGL((wino_kernel<1, 1, 2, true, false>), grid, dim3(256), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (ax == 0) hipLaunchKernelGGL(wino2_finish_kernel<0>, fgrid, dim3(256), 0, stream, p, n_tiles * WCN);
-    else hipLaunchKernelGGL(wino2_finish_kernel<1>, fgrid, dim3(256), 0, stream, p, n_tiles * WCN);
+    const long long total = (long long)p.Cout * p.Ntotal;
+    const long long blocks = (total + 255) / 256;
+    const dim3 flat((unsigned)(blocks < 8192 ? blocks : 8192));
+    if (ax == 0) hipLaunchKernelGGL(wino2_finish_flat_kernel<0>, flat, dim3(256), 0, stream, p, n_tiles * WCN);
+    else hipLaunchKernelGGL(wino2_finish_flat_kernel<1>, flat, dim3(256), 0, stream, p, n_tiles * WCN);
     if (launches) *launches = 2;
     return hipGetLastError();
 }

@@ -160,12 +160,14 @@ hipError_t launch_conv_wino(ConvParams p, const WinoLaunch& L, hipStream_t strea
 // Two-axis (D and H) class-parallel Winograd convolution of 3D layers with a small edge: ax = 0: F(4,3) on both axes (k3 p1, 36
 // classes per 4 x 4 outputs), 1: F(2,4) (k4 p0, 25 classes per 2 x 2 outputs).  x: (B, C, Dp, Hp, Wp) as the layer reads it;
 // V: [ncls][B][C][SD][SH][Wp]; slabs in p.part
-int wino2_classes(int ax);          // 36 / 25
+int wino2_classes(int ax);          // 36 / 25 (ax 0: 3D k3 p1 over D, H; 1: 3D k4 p0; 2: 2D k3 p1 over H, W)
 int wino2_outputs(int ax);          // outputs per group and axis: 4 / 2
 hipError_t launch_wino2_input(const float* x, float* V, int ax, long long planes, int Dp, int Hp, int Wp, int SD, int SH, hipStream_t s);
+hipError_t launch_wino2p_input(const float* x, float* V, int B, int Cin, int Hp, int Wp, int SH, int SW, long long npad, hipStream_t s);
 hipError_t launch_pack_wino2(const float* w, float* wp, int ax, int Cin, int Cout, int CoutPad, hipStream_t s);
 int wino2_form(int ax, int cout, int ntotal, int forced);                      // 0 class-parallel, 1 semi-fused (same bits)
 int64_t wino2_slab_elems(int ax, int cout, int ntotal, int form);
+int64_t wino2_npad(int64_t ntotal);                                           // positions rounded up to whole GEMM tiles
 hipError_t launch_conv_wino2(ConvParams p, int ax, int form, hipStream_t stream, int* launches);
 // the cost volume written as the 36 two-axis plane sets of its halo-1 padded form: V[36][B][2C][(D)/4][H/4][W+2]
 hipError_t launch_cost_volume_wino2(const float* fl, const float* fr, float* V, int B, int C, int D, int H, int W, hipStream_t s);

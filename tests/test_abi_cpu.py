@@ -69,6 +69,8 @@ def test_out_size_and_packed_elems(s3r, lib):
                     wino += 36 * 3 * l.cin * pad
                 if l.op == "conv3d" and l.s == 1 and l.k == 4 and l.p == 0:      # (v6: 25 F(2,4)^2 slabs of 4 taps)
                     wino += 25 * 4 * l.cin * pad
+                if l.op == "conv2d" and l.s == 1 and l.k == 3 and l.p == 1:      # a 2D one the 36 (H, W) slabs of a single tap
+                    wino += 36 * l.cin * pad
                 assert e.value == l.k ** nd * l.cin * pad + wino
 
 

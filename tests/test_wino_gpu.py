@@ -295,7 +295,7 @@ def test_winograd_on_offset_and_heavy_tailed_inputs(s3r):
         forms = [("direct", L.ALGO_DIRECT, -1)]
         if name != "v6":
             forms.append(("one-axis", L.ALGO_WINOGRAD, 0))
-        if l.op == "conv3d":
+        if l.op != "deconv3d":
             forms.append(("two-axis", L.ALGO_WINOGRAD, 3))
         for zero_sum in (False, True):
             ch = s3r.modules._HipChain([l], n_in, precision="fp32")
@@ -338,19 +338,22 @@ def test_winograd_on_offset_and_heavy_tailed_inputs(s3r):
 
 
 def test_two_axis_form_vs_oracle_and_invariants(s3r, oracle):
-    """The two-axis class-parallel form (tile = 3 under algo = WINOGRAD; what AUTO resolves v5 and v6 to): against the oracle at
-    1e-5, deterministic, batch-invariant, and — where the layer has both — within rounding of the one-axis kernel but not its
-    bits (another algorithm).  v3 and v1 are forced onto it too: the form is general, only its slabs make it a loss there."""
+    """The two-axis form (tile = 3 under algo = WINOGRAD; what AUTO resolves every stride-1 layer over an edge <= 28 to — over
+    D and H in 3D, over H and W in 2D, where the positions of a sub-batch lie flat): against the oracle at 1e-5, deterministic,
+    batch-invariant, the same bits from both launch forms, and — where the layer has both algorithms — within rounding of the
+    one-axis kernel but not its bits.  e4 (edge 56) is forced onto it too: the form is general, only its slabs make it a loss
+    there.  e7 at 3 samples: 147 positions, a ragged last GEMM tile."""
     dev, spec, L = "cuda:0", s3r.arch_spec, s3r._lib
-    dl = {l.name: (l, n_in) for l, n_in, _ in spec.trace(spec.DECODER, spec.MAX_DISP)}
-    for name, B in (("v5", 5), ("v6", 5), ("v3", 2), ("v1", 1)):
+    dl = {l.name: (l, n_in) for layers, n0 in ((spec.ENCODER, spec.IMG_HW), (spec.DECODER, spec.MAX_DISP))
+          for l, n_in, _ in spec.trace(layers, n0)}
+    for name, B in (("v5", 5), ("v6", 5), ("v3", 2), ("v1", 1), ("e7", 3), ("e6", 1), ("e4", 2)):
         l, n_in = dl[name]
         ch = s3r.modules._HipChain([l], n_in, precision="fp32")
         s3r.seed_module(ch, 21)
         blk = oracle._Block(l).eval()
         blk.load_state_dict(getattr(ch, l.name).state_dict())
         ch.to(dev)
-        x = torch.randn((B, l.cin) + (n_in,) * 3, generator=torch.Generator().manual_seed(8))
+        x = torch.randn((B, l.cin) + (n_in,) * spec.ndim(l), generator=torch.Generator().manual_seed(8))
         with torch.no_grad():
             want = blk(x)
         ch.algo_override[name], ch.tile_override[name] = L.ALGO_WINOGRAD, 3
