@@ -637,6 +637,7 @@ struct Plan {
     std::vector<Geo> g;
     std::vector<int64_t> off;         // workspace offset of layer i's OUTPUT (-1: the caller's y)
     std::vector<char> fuse_head;      // layer i is an MFMA conv whose epilogue also runs layer i+1 (1x1 head)
+    bool stem_wino = false;           // the stem writes layer 1's Winograd-transformed planes (launch_stem_wino), not its activation
     bool pad_input = false;
     int64_t pad_off = 0;
     int64_t scratch_off = 0, scratch_elems = 0;   // split-K slabs, shared by all layers of the chain
@@ -662,13 +663,24 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
     for (int i = 0; i < n; ++i) {
         if (i > 0) pl->d[i].in_halo = pl->d[i - 1].out_halo;
         if (i + 1 < n) pl->d[i].out_halo = need_halo(&pl->d[i + 1], pl->r[i + 1]);
+        if (i == 1 && pl->r[0] == R_STEM && pl->r[1] == R_MFMA && pl->d[1].dtype == S3R_F32 && pl->d[1].op == S3R_OP_CONV) {
+            // a stem feeding the one-axis Winograd kernel writes that kernel's planes itself (the same bits: the stem's values
+            // through wino_input_kernel's transform): no plain activation, no transform launch
+            static const int fuse = getenv("S3R_STEM_WINO") ? atoi(getenv("S3R_STEM_WINO")) : 1;      // A/B switch, read once
+            int alg, form;
+            if (fuse && resolve_algo(&pl->d[1], &alg, &form) == S3R_OK && alg == ALG_WINO && pl->d[1].in_size % wino_r(&pl->d[1]) == 0 &&
+                wino_bmax(&pl->d[1]) >= pl->d[1].batch) {
+                pl->stem_wino = true;
+                pl->d[1].in_layout = S3R_LAYOUT_WINO_H;
+            }
+        }
         int rc = geometry(&pl->d[i], &pl->g[i]);
         if (rc) return rc;
         if ((rc = check_halos(&pl->d[i], pl->r[i]))) return rc;
         if (pl->d[i].dtype != pl->d[0].dtype) return fail(S3R_ERR_INVALID, "all layers of a chain must share one dtype");
         if (i > 0) {   // shapes must chain
             const s3r_conv_desc& a = pl->d[i - 1];
-            const int64_t prev_out = (int64_t)a.cout * pl->g[i - 1].out_sp, cur_in = (int64_t)pl->d[i].cin * pl->g[i].in_sp;
+            const int64_t prev_out = (int64_t)a.cout * pl->g[i - 1].out_sp, cur_in = (int64_t)pl->d[i].cin * pl->g[i].in_sp;      // (logical sizes)
             if (prev_out != cur_in || a.batch != pl->d[i].batch)
                 return fail(S3R_ERR_INVALID, "layer %d input (%lld/sample) does not match layer %d output (%lld/sample)", i,
                             (long long)cur_in, i - 1, (long long)prev_out);
@@ -704,7 +716,8 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
     }
     for (int i = 0; i + 1 < n; ++i) {
         pl->off[i] = off;
-        if (!pl->fuse_head[i]) off = align_up(off + pl->g[i].y_store, 256);   // a fused conv's output does not exist
+        if (i == 0 && pl->stem_wino) off = align_up(off + pl->g[1].x_store, 256);      // layer 1's transformed planes
+        else if (!pl->fuse_head[i]) off = align_up(off + pl->g[i].y_store, 256);   // a fused conv's output does not exist
     }
     for (int i = 0; i < n; ++i) {
         const int64_t sc = s3r_conv_scratch_elems(&pl->d[i]);
@@ -1134,6 +1147,19 @@ int chain_forward_impl(const s3r_layer* layers, int n_layers, const void* x, con
             continue;
         }
         void* out = (i == n_layers - 1) ? y : static_cast<void*>(ws + pl.off[i]);
+        if (i == 0 && pl.stem_wino) {
+            const s3r_conv_desc& d0 = pl.d[0];
+            const Geo& g0 = pl.g[0];
+            if (!L.packed_w || !L.scale || !L.shift) return fail(S3R_ERR_INVALID, "stem needs packed weights, scale and shift");
+            if (x2 && (nsplit <= 0 || nsplit >= d0.batch)) return fail(S3R_ERR_INVALID, "split %d outside (0, batch=%d)", nsplit, d0.batch);
+            // bytes: the renders in (1 byte a sample when 8-bit), layer 1's six plane sets out
+            ProfScope ps(s, F_STEM, d0.tag, g0.flops, (x_u8 ? 1.0 : 4.0) * d0.batch * d0.cin * (double)g0.in_sp + 4.0 * (double)pl.g[1].x_elems);
+            hipError_t e = s3r::launch_stem_wino(cur, x2, x_u8, nsplit, static_cast<const float*>(L.packed_w), L.scale, L.shift,
+                                                 static_cast<float*>(out), d0.batch, g0.in, g0.in, g0.out, g0.out, s);
+            if (e != hipSuccess) return hip_fail(e, "stem (Winograd layout) launch");
+            cur = out;
+            continue;
+        }
         rc = conv_forward_impl(&pl.d[i], cur, i == 0 ? x2 : nullptr, nsplit, i == 0 ? x_u8 : 0, L.packed_w, L.scale, L.shift, out,
                                pl.scratch_elems ? ws + pl.scratch_off : nullptr, pl.scratch_elems, stream);
         if (rc) return rc;

@@ -180,6 +180,8 @@ hipError_t launch_deconv_wino(ConvParams p, const WinoLaunch& L, hipStream_t str
 // Images [0, nsplit) are read from x, images [nsplit, N) from x2 (the left / right renders of a stereo batch live in
 // two tensors: no concatenation copy); nsplit = N, x2 = null: one tensor.  u8 != 0: x / x2 are 8-bit renders (N,3,Hi,Wi)
 // uint8, scaled by 1/255 inside the kernel (render_f32); otherwise fp32.
+hipError_t launch_stem_wino(const void* x, const void* x2, int u8, int nsplit, const float* wt, const float* scale, const float* shift,
+                            float* V, int N, int Hi, int Wi, int Ho, int Wo, hipStream_t s);      // (the consumer's S3R_LAYOUT_WINO_H planes)
 hipError_t launch_stem(const void* x, const void* x2, int u8, int nsplit, const float* w, const float* scale,
                        const float* shift, float* y, int N, int Hi, int Wi, int Ho, int Wo, int y_cs, int y_hs, int y_org,
                        hipStream_t s);

@@ -75,6 +75,95 @@ __global__ __launch_bounds__(256) void stem_kernel(const TI* __restrict__ x, con
     for (int c = 0; c < 32; ++c) yn[(size_t)c * y_cs] = fmaxf(fmaf(acc[c], scale[c], shift[c]), 0.f);
 }
 
+// The stem written straight into the layout its consumer's one-axis Winograd kernel reads (S3R_LAYOUT_WINO_H: V_i[n][c][q][wp],
+// i = 0 .. 5, from the padded rows 4 q .. 4 q + 5 of the halo-1 activation through wino_rows_to_classes): the plain activation
+// (106 MB at 64 renders) is neither written nor re-read by a transform kernel.  One thread per (n, q, padded column, half of the
+// couts): the six rows of its column with the plain kernel's loop and summation order per value — the bits wino_input_kernel
+// makes of the plain stem's output.  Every output row is computed 1.5 times (groups overlap by two rows); the kernel stays
+// store-bound.
+template <typename TI>
+__global__ __launch_bounds__(256) void stem_wino_kernel(const TI* __restrict__ x, const TI* __restrict__ x2, int nsplit,
+                                                        const float* __restrict__ wt, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, float* __restrict__ V, int N, int Hi, int Wi,
+                                                        int Ho, int Wo, long long cls_stride) {
+    const int Wp = Wo + 2, HQ = Ho / 4;
+    const long long per_half = (long long)N * HQ * Wp;
+    const long long g2 = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g2 >= per_half) return;
+    const int half = blockIdx.y;                         // workgroup-uniform: the weights stay scalar loads
+    const int n = (int)(g2 / (HQ * Wp));
+    const int rem = (int)(g2 - (long long)n * HQ * Wp);
+    const int q = rem / Wp, wp = rem - q * Wp;
+    const int ow = wp - 1;
+    const bool col_in = (unsigned)ow < (unsigned)Wo;
+    const int iw0 = ow * 2 - 1;
+    const TI* __restrict__ xn = n < nsplit ? x + (size_t)n * 3 * Hi * Wi : x2 + (size_t)(n - nsplit) * 3 * Hi * Wi;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    float rows[6][16];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int oh = 4 * q + k - 1;                    // padded row 4 q + k
+        const bool in = col_in && (unsigned)oh < (unsigned)Ho;
+        const int ih0 = oh * 2 - 1;
+        f32x2 acc2[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc2[c] = (f32x2){0.f, 0.f};
+#pragma unroll 1
+        for (int ci = 0; ci < 3; ++ci) {
+#pragma unroll 1
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = ih0 + kh;
+                const bool vh = in && (unsigned)ih < (unsigned)Hi;
+                const TI* __restrict__ xrow = xn + ((size_t)ci * Hi + (vh ? ih : 0)) * Wi;
+                const float* __restrict__ wrow = wt + (ci * 3 + kh) * 96 + half * 16;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int iw = iw0 + kw;
+                    const bool v = vh && ((unsigned)iw < (unsigned)Wi);
+                    const float xv = v ? render_f32(xrow[iw]) : 0.f;
+                    const f32x2 xv2 = {xv, xv};
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        acc2[c] = __builtin_elementwise_fma(xv2, *reinterpret_cast<const f32x2*>(wrow + kw * 32 + 2 * c), acc2[c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int ch = half * 16 + 2 * c;
+            rows[k][2 * c] = in ? fmaxf(fmaf(acc2[c].x, scale[ch], shift[ch]), 0.f) : 0.f;
+            rows[k][2 * c + 1] = in ? fmaxf(fmaf(acc2[c].y, scale[ch + 1], shift[ch + 1]), 0.f) : 0.f;
+        }
+    }
+    float* __restrict__ o = V + (((size_t)n * 32 + half * 16) * HQ + q) * Wp + wp;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float r[6], v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) r[k] = rows[k][c];
+        wino_rows_to_classes<4>(r, v);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[(size_t)k * cls_stride + (size_t)c * HQ * Wp] = v[k];
+    }
+}
+
+hipError_t launch_stem_wino(const void* x, const void* x2, int u8, int nsplit, const float* wt, const float* scale, const float* shift,
+                            float* V, int N, int Hi, int Wi, int Ho, int Wo, hipStream_t s) {
+    if (Ho % 4 != 0) return hipErrorInvalidValue;
+    if (!x2) { x2 = x; nsplit = N; }
+    const int Wp = Wo + 2, HQ = Ho / 4;
+    const long long per_half = (long long)N * HQ * Wp;
+    const long long cls_stride = (long long)N * 32 * HQ * Wp;
+    const dim3 grid((unsigned)((per_half + 255) / 256), 2);
+    if (u8)
+        hipLaunchKernelGGL(stem_wino_kernel<unsigned char>, grid, dim3(256), 0, s, static_cast<const unsigned char*>(x),
+                           static_cast<const unsigned char*>(x2), nsplit, wt, scale, shift, V, N, Hi, Wi, Ho, Wo, cls_stride);
+    else
+        hipLaunchKernelGGL(stem_wino_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(x),
+                           static_cast<const float*>(x2), nsplit, wt, scale, shift, V, N, Hi, Wi, Ho, Wo, cls_stride);
+    return hipGetLastError();
+}
+
 __global__ void pack_stem_kernel(const float* __restrict__ w, float* __restrict__ wt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 27*32
     if (i < 27 * 32) {

@@ -84,9 +84,12 @@ def test_workspace_query(s3r, lib, monkeypatch):
         arr[i].desc = _desc(s3r, l, 4, n)
     need = lib.s3r_chain_workspace_elems(arr, len(rows))
     # every intermediate has its own region, stored with the zero halo its consumer's gather reads
-    # (3x3 pad-1 consumers: halo 1; the 1x1 e8: none), each region rounded up to 256 floats
-    want = 0
+    # (3x3 pad-1 consumers: halo 1; the 1x1 e8: none), each region rounded up to 256 floats — but the stem's, which
+    # holds the six F(4,3) plane sets its consumer e2 reads (the stem writes them itself: 6 x 4 x 32 x 28 groups x 114)
+    want = -(-(6 * 4 * 32 * (112 // 4) * 114) // 256) * 256
     for i, (l, n, m) in enumerate(rows[:-1]):
+        if i == 0:
+            continue
         halo = rows[i + 1][0].p
         want += -(-(4 * l.cout * (m + 2 * halo) ** 2) // 256) * 256
     # ... plus ONE split-K scratch region sized for the hungriest layer
@@ -94,6 +97,8 @@ def test_workspace_query(s3r, lib, monkeypatch):
     for i, (l, n, m) in enumerate(rows):
         d = _desc(s3r, l, 4, n)
         d.in_halo = l.p
+        if i == 1:
+            d.in_layout = s3r._lib.LAYOUT_WINO_H                  # (e2's planes come from the stem: not in its scratch)
         scratch = max(scratch, lib.s3r_conv_scratch_elems(C.byref(d)))
     assert need == want + -(-scratch // 256) * 256
     # a chain whose first layer gathers with padding pads an unpadded input itself: one more region

@@ -254,21 +254,23 @@ def test_whole_forward_is_form_invariant_at_every_batch(tmp_path):
     layer's last round is mostly empty; the transposed layers' depth differences materialised or formed in the kernel by
     input size; the two-axis layers class-parallel or semi-fused) equals the forward with every one-axis Winograd layer forced
     to the serial form, with the depth differences forced either way, and with the two-axis layers forced to either of their
-    forms — bitwise."""
+    forms, and with the stem writing its plain activation for a transform kernel instead of e2's planes itself — bitwise."""
     res = {}
     for flag, env_set in (("auto", {}), ("serial", {"S3R_WINO_FORM": "0"}), ("mat0", {"S3R_DWINO_MAT": "0"}),
-                          ("mat1", {"S3R_DWINO_MAT": "1"}), ("cp2", {"S3R_WINO2_FORM": "0"}), ("semi2", {"S3R_WINO2_FORM": "1"})):
+                          ("mat1", {"S3R_DWINO_MAT": "1"}), ("cp2", {"S3R_WINO2_FORM": "0"}), ("semi2", {"S3R_WINO2_FORM": "1"}),
+                          ("stem0", {"S3R_STEM_WINO": "0"})):
         path = str(tmp_path / f"forms_{flag}.pt")
         env = dict(os.environ)
         env.pop("S3R_WINO_FORM", None)
         env.pop("S3R_DWINO_MAT", None)
         env.pop("S3R_WINO2_FORM", None)
+        env.pop("S3R_STEM_WINO", None)
         env.update(env_set)
         r = subprocess.run([sys.executable, "-c", _FORMS_CHILD % {"root": ROOT}, path], capture_output=True, text=True,
                            timeout=900, cwd=ROOT, env=env)
         assert r.returncode == 0, r.stderr[-3000:]
         res[flag] = torch.load(path)
-    for flag in ("serial", "mat0", "mat1", "cp2", "semi2"):
+    for flag in ("serial", "mat0", "mat1", "cp2", "semi2", "stem0"):
         for a, b in zip(res["auto"], res[flag]):
             assert torch.equal(a, b), (flag, a.shape)
 
