@@ -2,7 +2,6 @@
 // shift-and-diff cost volume, the 1x1x1 occupancy head (+sigmoid), the point-head linear layers,
 // and the on-device thresholded IoU.  All are priced against the HBM roof.
 #include "s3r_kernels.h"
-#include <cstdlib>
 
 namespace s3r {
 
@@ -77,64 +76,105 @@ __global__ __launch_bounds__(256) void stem_kernel(const TI* __restrict__ x, con
 
 // The stem written straight into the layout its consumer's one-axis Winograd kernel reads (S3R_LAYOUT_WINO_H: V_i[n][c][q][wp],
 // i = 0 .. 5, from the padded rows 4 q .. 4 q + 5 of the halo-1 activation through wino_rows_to_classes): the plain activation
-// (106 MB at 64 renders) is neither written nor re-read by a transform kernel.  One thread per (n, q, padded column, half of the
-// couts): the six rows of its column with the plain kernel's loop and summation order per value — the bits wino_input_kernel
-// makes of the plain stem's output.  Every output row is computed 1.5 times (groups overlap by two rows); the kernel stays
-// store-bound.
+// (106 MB at 64 renders) is neither written nor re-read by a transform kernel.  One workgroup per (image, row group q): the 13
+// input rows 8 q - 3 .. 8 q + 9 of the three channels go to LDS once (zeros outside the image, even and odd columns apart so
+// that a wave's reads are stride-1), then a thread per (half of the couts, padded column) computes the six rows of its column
+// with the plain kernel's summation order per value — the bits wino_input_kernel makes of the plain stem's output — and
+// transforms them.  Every output row is computed 1.5 times (groups overlap by two rows).  Single v_fma_f32 here, not the plain
+// kernel's packed pairs (v_pk_fma_f32 issues about three times slower per FMA on gfx950: MI355X_MICROARCH.md, row 'F32').
+// 59 us at 64 renders (stores alone 26, staging 9, the FMAs 40, overlapped) against 37 + 45 for plain stem + transform.
+constexpr int STEM_W_ROWS = 13;
 template <typename TI>
 __global__ __launch_bounds__(256) void stem_wino_kernel(const TI* __restrict__ x, const TI* __restrict__ x2, int nsplit,
                                                         const float* __restrict__ wt, const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, float* __restrict__ V, int N, int Hi, int Wi,
+                                                        const float* __restrict__ shift, float* __restrict__ V, int Hi, int Wi,
                                                         int Ho, int Wo, long long cls_stride) {
+    extern __shared__ __attribute__((aligned(16))) float stem_sx[];      // [3][13][2][LH]: even columns, then odd, of iw + 3
     const int Wp = Wo + 2, HQ = Ho / 4;
-    const long long per_half = (long long)N * HQ * Wp;
-    const long long g2 = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (g2 >= per_half) return;
-    const int half = blockIdx.y;                         // workgroup-uniform: the weights stay scalar loads
-    const int n = (int)(g2 / (HQ * Wp));
-    const int rem = (int)(g2 - (long long)n * HQ * Wp);
-    const int q = rem / Wp, wp = rem - q * Wp;
-    const int ow = wp - 1;
-    const bool col_in = (unsigned)ow < (unsigned)Wo;
-    const int iw0 = ow * 2 - 1;
+    const int LW = 2 * Wp + 4, LH = LW / 2;              // columns iw = -3 .. 2 Wp (a thread reads 2 wp - 3 .. 2 wp - 1)
+    const int n = blockIdx.x / HQ, q = blockIdx.x - n * HQ;
+    const int tid = threadIdx.x;
     const TI* __restrict__ xn = n < nsplit ? x + (size_t)n * 3 * Hi * Wi : x2 + (size_t)(n - nsplit) * 3 * Hi * Wi;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // staging: 16-byte pieces of the 39 rows, every load of a thread issued before the first LDS store (a load-then-store loop
+    // with a runtime trip count compiles to one memory round trip per iteration: 36 in series, 30 us of this kernel)
+    constexpr int E = 16 / (int)sizeof(TI);              // samples per piece
+    constexpr int NV = sizeof(TI) == 4 ? 9 : 3;          // pieces per thread (Wi <= 236 / 304: the launcher checks)
+    typedef TI piece_t __attribute__((ext_vector_type(E)));
+    const int ppr = Wi / E;                              // pieces per row
+    piece_t pv[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int i = tid + u * 256;
+        const int r = i / ppr, c = i - r * ppr;
+        const int ci = r / STEM_W_ROWS, ih = 8 * q - 3 + (r - ci * STEM_W_ROWS);
+        const bool v = r < 3 * STEM_W_ROWS && (unsigned)ih < (unsigned)Hi;
+        pv[u] = *reinterpret_cast<const piece_t*>(xn + ((size_t)(v ? ci : 0) * Hi + (v ? ih : 0)) * Wi + (v ? c : 0) * E);
+        if (!v) pv[u] = piece_t{};
+    }
+    for (int i = tid; i < 3 * STEM_W_ROWS * (LW - Wi); i += 256) {       // the columns outside the image: iw = -3 .. -1, Wi ..
+        const int r = i / (LW - Wi), jj = i - r * (LW - Wi);
+        const int j = jj < 3 ? jj : Wi + jj;
+        stem_sx[r * LW + (j & 1) * LH + (j >> 1)] = 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int i = tid + u * 256;
+        const int r = i / ppr, c = i - r * ppr;
+        if (r < 3 * STEM_W_ROWS) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int j = c * E + e + 3;
+                stem_sx[r * LW + (j & 1) * LH + (j >> 1)] = render_f32(pv[u][e]);
+            }
+        }
+    }
+    __syncthreads();
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 7);           // waves 0, 1: couts 0 .. 15; waves 2, 3: 16 .. 31
+    const int wl = tid & 127;
+    const int wp = wl < Wp ? wl : Wp - 1;                // (lanes past the row compute its last column and store nothing)
+    const bool col_in = (unsigned)(wp - 1) < (unsigned)Wo;
+    float sc[16], sf[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { sc[c] = scale[half * 16 + c]; sf[c] = shift[half * 16 + c]; }
+    // The (channel, row) loops stay ROLLED, as in the plain kernel: one iteration holds the 48 weights of its three taps — and
+    // spends them on all six rows (a value's own summation order is untouched by what is interleaved with it)
     float rows[6][16];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) rows[k][c] = 0.f;
+#pragma unroll 1
+    for (int ci = 0; ci < 3; ++ci) {
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh) {
+            const float* __restrict__ wrow = wt + (ci * 3 + kh) * 96 + half * 16;
+            float xk[6][3];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float* __restrict__ xr = stem_sx + (ci * STEM_W_ROWS + 2 * k + kh) * LW + wp;      // input row 2 oh - 1 + kh
+                xk[k][0] = xr[0]; xk[k][1] = xr[LH]; xk[k][2] = xr[1];   // columns 2 ow - 1, 2 ow, 2 ow + 1
+            }
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const float wv = wrow[kw * 32 + c];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) rows[k][c] = fmaf(xk[k][kw], wv, rows[k][c]);
+                }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const int oh = 4 * q + k - 1;                    // padded row 4 q + k
         const bool in = col_in && (unsigned)oh < (unsigned)Ho;
-        const int ih0 = oh * 2 - 1;
-        f32x2 acc2[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc2[c] = (f32x2){0.f, 0.f};
-#pragma unroll 1
-        for (int ci = 0; ci < 3; ++ci) {
-#pragma unroll 1
-            for (int kh = 0; kh < 3; ++kh) {
-                const int ih = ih0 + kh;
-                const bool vh = in && (unsigned)ih < (unsigned)Hi;
-                const TI* __restrict__ xrow = xn + ((size_t)ci * Hi + (vh ? ih : 0)) * Wi;
-                const float* __restrict__ wrow = wt + (ci * 3 + kh) * 96 + half * 16;
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int iw = iw0 + kw;
-                    const bool v = vh && ((unsigned)iw < (unsigned)Wi);
-                    const float xv = v ? render_f32(xrow[iw]) : 0.f;
-                    const f32x2 xv2 = {xv, xv};
-#pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        acc2[c] = __builtin_elementwise_fma(xv2, *reinterpret_cast<const f32x2*>(wrow + kw * 32 + 2 * c), acc2[c]);
-                }
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int ch = half * 16 + 2 * c;
-            rows[k][2 * c] = in ? fmaxf(fmaf(acc2[c].x, scale[ch], shift[ch]), 0.f) : 0.f;
-            rows[k][2 * c + 1] = in ? fmaxf(fmaf(acc2[c].y, scale[ch + 1], shift[ch + 1]), 0.f) : 0.f;
+        for (int c = 0; c < 16; ++c) {
+            const float a = fmaxf(fmaf(rows[k][c], sc[c], sf[c]), 0.f);
+            rows[k][c] = in ? a : 0.f;
         }
     }
+    if (wl >= Wp) return;
     float* __restrict__ o = V + (((size_t)n * 32 + half * 16) * HQ + q) * Wp + wp;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
@@ -149,18 +189,20 @@ __global__ __launch_bounds__(256) void stem_wino_kernel(const TI* __restrict__ x
 
 hipError_t launch_stem_wino(const void* x, const void* x2, int u8, int nsplit, const float* wt, const float* scale, const float* shift,
                             float* V, int N, int Hi, int Wi, int Ho, int Wo, hipStream_t s) {
-    if (Ho % 4 != 0) return hipErrorInvalidValue;
-    if (!x2) { x2 = x; nsplit = N; }
     const int Wp = Wo + 2, HQ = Ho / 4;
-    const long long per_half = (long long)N * HQ * Wp;
+    const size_t lds = (size_t)3 * STEM_W_ROWS * (2 * Wp + 4) * sizeof(float);
+    const int pieces = 3 * STEM_W_ROWS * (Wi / (u8 ? 16 : 4));
+    if (Ho % 4 != 0 || Wp > 128 || Wi != 2 * Wo || Hi != 2 * Ho || lds > 64 * 1024 || Wi % 16 != 0 || pieces > 256 * (u8 ? 3 : 9))
+        return hipErrorInvalidValue;
+    if (!x2) { x2 = x; nsplit = N; }
     const long long cls_stride = (long long)N * 32 * HQ * Wp;
-    const dim3 grid((unsigned)((per_half + 255) / 256), 2);
+    const dim3 grid((unsigned)(N * HQ));
     if (u8)
-        hipLaunchKernelGGL(stem_wino_kernel<unsigned char>, grid, dim3(256), 0, s, static_cast<const unsigned char*>(x),
-                           static_cast<const unsigned char*>(x2), nsplit, wt, scale, shift, V, N, Hi, Wi, Ho, Wo, cls_stride);
+        hipLaunchKernelGGL(stem_wino_kernel<unsigned char>, grid, dim3(256), lds, s, static_cast<const unsigned char*>(x),
+                           static_cast<const unsigned char*>(x2), nsplit, wt, scale, shift, V, Hi, Wi, Ho, Wo, cls_stride);
     else
-        hipLaunchKernelGGL(stem_wino_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(x),
-                           static_cast<const float*>(x2), nsplit, wt, scale, shift, V, N, Hi, Wi, Ho, Wo, cls_stride);
+        hipLaunchKernelGGL(stem_wino_kernel<float>, grid, dim3(256), lds, s, static_cast<const float*>(x),
+                           static_cast<const float*>(x2), nsplit, wt, scale, shift, V, Hi, Wi, Ho, Wo, cls_stride);
     return hipGetLastError();
 }
 
