@@ -208,11 +208,12 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False,
             "kernel": "conv_bf16{,r,p}_kernel (bf16 MFMA implicit-GEMM conv, channels-last, LDS-DMA; "
                       "per-tap / row-reuse / plane-reuse gathers)" if bf
             else "the fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM convolution family, LDS-DMA operand staging: conv_glds_kernel / "
-                 "conv_glds_dual_kernel (direct form) + wino_kernel / wino_dual_kernel / wino_finish_kernel with their transform passes "
-                 "wino_input_kernel / wino_diff_kernel (Winograd: F(4,3)-along-H convolutions execute 1/2, F(2,2)-along-D-and-H transposed "
-                 "convolutions 9/16 of the direct form's multiplications; serial, class-parallel and dual launch forms, bit-identical) and "
-                 "the two-axis class-parallel form wino2_input_kernel / wino2_finish_kernel (F(4,3)xF(4,3) on v3 / v5: 1/4, F(2,4)xF(2,4) on "
-                 "v6: 25/64)",
+                 "conv_glds_dual_kernel (direct form) + the Winograd class kernel wino_kernel / wino_dual_kernel with its transform and "
+                 "finish passes (wino_input / wino_diff / wino_finish, wino2_input / wino2p_input, wino2s_finish / wino2p_finish / "
+                 "wino2_finish_flat).  One-axis forms: F(4,3) along H (1/2 of the direct multiplications), F(2,2) along D and H inside the "
+                 "parity classes of a transposed convolution (9/16).  Two-axis forms on every stride-1 layer with an edge <= 28: F(4,3)^2 "
+                 "over D, H (v1, v3, v5) or H, W (e6, e7): 1/4; F(2,4)^2 (v6): 25/64.  Launch forms (serial, class-parallel, dual, "
+                 "semi-fused) are bit-identical per algorithm",
             "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
             "achieved_credited": round(credited, 3),

@@ -557,7 +557,11 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(const ConvParams p, in
     }
 }
 
+static thread_local int g_launch_count = 0;          // kernels launched by the last launch_conv_mfma (split-K finish included)
+int conv_last_launch_count() { return g_launch_count; }
+
 hipError_t launch_conv_finish(const ConvParams& p, int npad, hipStream_t stream) {
+    g_launch_count += 1;
     const long long total = (long long)p.Cout * (npad >> 2);
     const long long blocks = (total + 255) / 256;
     hipLaunchKernelGGL(conv_finish_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096), p.transposed ? 8 : 1), dim3(256),
@@ -767,11 +771,8 @@ static hipError_t launch_vec(const ConvParams& p, int vec, hipStream_t stream) {
     }
 }
 
-static thread_local int g_launch_count = 0;
-int conv_last_launch_count() { return g_launch_count; }
-
 static hipError_t launch_tile(const ConvParams& p, int cfg, int vec, hipStream_t stream) {
-    g_launch_count += 1;      // launches of THIS kernel (the split-K finish kernel is not counted)
+    g_launch_count += 1;
     switch (cfg) {
         case 0: return launch_vec<2, 2, 2, 2>(p, vec, stream);
         case 1: return launch_vec<1, 4, 2, 2>(p, vec, stream);
