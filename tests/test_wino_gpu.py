@@ -379,3 +379,88 @@ def test_two_axis_form_vs_oracle_and_invariants(s3r, oracle):
             one = ch._run(x.to(dev))
             assert not torch.equal(one, got)
             assert float((one.double() - got.double()).norm() / got.double().norm()) < 1e-5
+
+
+def test_shapes_that_are_not_the_networks(s3r, oracle):
+    """The descriptors are general, the network's shapes are few: every algorithm and launch form on layer shapes the network does
+    not have — edges that are not multiples of the group size (ragged last groups along one or both axes), couts that fill
+    neither a 64-row tile nor a 128-row weight pad, position counts that end inside a GEMM tile — against the oracle block at
+    1e-5, all forms of one algorithm bitwise equal, AUTO equal to one of the forced algorithms."""
+    dev, spec, L = "cuda:0", s3r.arch_spec, s3r._lib
+    Layer = spec.Layer
+    cases = [  # (layer, edge, batch, algorithm / form codes it must support under algo = WINOGRAD)
+        (Layer("t2a", "conv2d", 32, 48), 6, 3, (0, 1, 2, 3, 4, 5)),
+        (Layer("t2b", "conv2d", 64, 96), 9, 2, (0, 1, 2, 3, 4, 5)),
+        (Layer("t2c", "conv2d", 32, 130), 30, 1, (0, 1, 2, 3, 4, 5)),
+        (Layer("t2d", "conv2d", 96, 64), 7, 5, (0, 1, 2, 3, 4, 5)),
+        (Layer("t2e", "conv2d", 32, 64), 28, 7, (0, 1, 2, 3, 4, 5)),
+        (Layer("t3d", "conv3d", 96, 32), 4, 2, (0, 1, 2, 3, 4, 5)),
+        (Layer("t3a", "conv3d", 32, 40), 5, 3, (0, 1, 2, 3, 4, 5)),
+        (Layer("t3b", "conv3d", 64, 72), 10, 1, (0, 1, 2, 3, 4, 5)),
+        (Layer("t3c", "conv3d", 32, 64), 12, 2, (0, 1, 2, 3, 4, 5)),
+        (Layer("t4a", "conv3d", 32, 48, 4, 1, 0), 5, 3, (3, 4)),
+        (Layer("t4b", "conv3d", 64, 20, 4, 1, 0), 8, 2, (3, 4)),
+        (Layer("tda", "deconv3d", 32, 24, 4, 2, 1), 4, 3, (0, 1, 2)),
+        (Layer("tdb", "deconv3d", 64, 72, 4, 2, 1), 8, 1, (0, 1, 2)),
+    ]
+    for l, n_in, B, forms in cases:
+        ch = s3r.modules._HipChain([l], n_in, precision="fp32")
+        s3r.seed_module(ch, 13)
+        blk = oracle._Block(l).eval()
+        blk.load_state_dict(getattr(ch, l.name).state_dict())
+        ch.to(dev)
+        x = torch.randn((B, l.cin) + (n_in,) * spec.ndim(l), generator=torch.Generator().manual_seed(17))
+        with torch.no_grad():
+            want = blk(x).double()
+        outs = {}
+        ch.algo_override[l.name] = L.ALGO_DIRECT
+        outs["direct"] = ch._run(x.to(dev)).clone()
+        ch.algo_override[l.name] = L.ALGO_WINOGRAD
+        for form in forms:
+            ch.tile_override[l.name] = form
+            outs[form] = ch._run(x.to(dev)).clone()
+        ch.tile_override.pop(l.name)
+        ch.algo_override.pop(l.name)
+        outs["auto"] = ch._run(x.to(dev)).clone()
+        for key, y in outs.items():
+            assert y.shape == want.shape, (l.name, key, y.shape, want.shape)
+            rel = float((y.cpu().double() - want).norm() / want.norm())
+            assert rel < 1e-5, (l.name, n_in, key, rel)
+        one_axis = [f for f in forms if f <= 2]
+        two_axis = [f for f in forms if f >= 3]
+        for group in (one_axis, two_axis):
+            for f in group[1:]:
+                assert torch.equal(outs[f], outs[group[0]]), (l.name, n_in, f, float((outs[f] - outs[group[0]]).abs().max()))
+        assert any(torch.equal(outs["auto"], outs[k]) for k in outs if k != "auto"), (l.name, "auto matches no forced algorithm")
+        # batch invariance of the library's own pick
+        assert torch.equal(ch._run(x[B - 1:].to(dev))[0], outs["auto"][B - 1]), (l.name, "batch")
+
+
+def test_stem_that_writes_its_consumers_planes_at_other_sizes(s3r, oracle):
+    """stem + e2 as a chain (the stem writes e2's six plane sets: `stem_wino_kernel`) against the same two layers run one by one
+    (plain stem activation, padded by the chain, transformed by `wino_input_kernel`): bitwise, at render sizes other than the
+    network's and with an odd number of images.  (8-bit renders take the same kernel with another sample type:
+    tests/test_ingest_soak_gpu.py compares the two entries bitwise on the whole tower.)"""
+    dev, spec = "cuda:0", s3r.arch_spec
+    e1, e2 = spec.ENCODER[0], spec.ENCODER[1]
+    for size, N in ((32, 3), (64, 5), (96, 2), (224, 1)):
+        pair = s3r.modules._HipChain([e1, e2], size, precision="fp32")
+        s3r.seed_module(pair, 31)
+        first = s3r.modules._HipChain([e1], size, precision="fp32")
+        second = s3r.modules._HipChain([e2], size // 2, precision="fp32")
+        first.load_state_dict({k: v for k, v in pair.state_dict().items() if k.startswith("e1.")})
+        second.load_state_dict({k: v for k, v in pair.state_dict().items() if k.startswith("e2.")})
+        blocks = [oracle._Block(l).eval() for l in (e1, e2)]
+        for l, blk in zip((e1, e2), blocks):
+            blk.load_state_dict(getattr(pair, l.name).state_dict())
+        for m in (pair, first, second):
+            m.to(dev)
+        u8 = torch.randint(0, 256, (N, 3, size, size), dtype=torch.uint8, generator=torch.Generator().manual_seed(size))
+        x = s3r.data.renders_to_float(u8)
+        with torch.no_grad():
+            want = blocks[1](blocks[0](x)).double()
+        got = pair._run(x.to(dev))
+        step = second._run(first._run(x.to(dev)))
+        assert torch.equal(got, step), (size, N, float((got - step).abs().max()))
+        rel = float((got.cpu().double() - want).norm() / want.norm())
+        assert rel < 1e-5, (size, rel)
