@@ -1168,10 +1168,11 @@ __global__ __launch_bounds__(64 * RW_WAVES) void conv_bf16w_kernel(const ConvPar
                 }
             }
             const int ybase = b * p.y_bs + p.y_org + (row0 + s * RW_R) * p.y_hs;
+            // the rows of step s + 1 (requested at the top of this step, a whole MFMA phase ago) and the previous step's stores are
+            // all that is outstanding here: wait for them BEFORE this step's stores go out, so that the wait does not have to know
+            // how many stores the epilogue issues (it used to be vmcnt(8) behind it: a count shared silently by two functions)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             epilogue_h<SH, 2, false, true>(p, acc, yoff, ep, stage + wave * (32 * ST_ROW), wave, li, lk, 0, n0, 0, 0, 0, ybase);
-            // the rows of step s + 1 were requested BEFORE this step's 8 stores: they have landed once at most those 8
-            // are outstanding (vmcnt retires in issue order, loads and stores alike)
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         }
     }
 }
