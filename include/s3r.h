@@ -74,8 +74,14 @@ typedef enum s3r_act { S3R_ACT_NONE = 0, S3R_ACT_RELU = 1, S3R_ACT_SIGMOID = 2 }
  * bit-identical, measured slower / no gain inside the forward in rounds 2 and 3, never planned by default; removed in ABI 7.) */
 /*   S3R_LAYOUT_WINO_DH the same for the TWO-AXIS kernel (Conv3d k3 s1 p1, edge a multiple of 4): 36 plane sets
  *                      (36, B, C, n/4, n/4, n+2), set 6 a + b = depth class a, row class b of the 6 x 6 window of padded depths
- *                      4 s .. 4 s + 5 and padded rows 4 q .. 4 q + 5 (rows first, then depths).  s3r_cost_volume_forward_wino2 writes it. */
-typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_WINO_H = 2, S3R_LAYOUT_WINO_DH = 3 } s3r_layout;
+ *                      4 s .. 4 s + 5 and padded rows 4 q .. 4 q + 5 (rows first, then depths).  s3r_cost_volume_forward_wino2 writes it.
+ *   S3R_LAYOUT_WINO_HW the two-axis kernel's input in 2D (Conv2d k3 s1 p1, edge n a multiple of 4): (36, C, P) with the positions
+ *                      of the whole batch flat, P = B (n/4)^2 rounded up to a multiple of 64, position (b, q, s); set 6 a + b =
+ *                      column class a, row class b of the 6 x 6 window of padded rows 4 q .. 4 q + 5 and padded columns
+ *                      4 s .. 4 s + 5 (rows first, then columns).  It is also the one OUTPUT layout other than PLAIN: a
+ *                      two-axis Conv2d whose consumer is another one writes these plane sets of its own (halo-1) output from
+ *                      its finish kernel — s3r_chain_forward plans that hand-off itself (e6 -> e7 of this network). */
+typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_WINO_H = 2, S3R_LAYOUT_WINO_DH = 3, S3R_LAYOUT_WINO_HW = 4 } s3r_layout;
 
 /* Which convolution algorithm a layer's forward runs (ABI 7).  The fp32 3 x 3 [x 3] stride-1 pad-1 convolutions and the
  * transposed convolutions have two kernels — the direct implicit GEMM and a Winograd form with 1/2 .. 9/16 of the
@@ -91,10 +97,11 @@ typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_WINO_H = 2, S3R_LAYOU
  *                      needs in_halo = 1, plain layouts — or S3R_LAYOUT_WINO_H input —, no split-K, no sigmoid).  `tile` >= 0 then
  *                      forces the launch FORM of the one-axis kernel (tuning / tests; every form gives the same bits, and the
  *                      library picks among them by batch): 0 serial, 1 class-parallel, 2 dual (bulk serial + remainder
- *                      class-parallel in one launch); `tile` = 3: the TWO-AXIS algorithm (Conv3d k3 s1 p1 as F(4,3) x F(4,3), k4 s1
- *                      p0 as F(2,4) x F(2,4), in_halo = pad; 4 / 5 force its class-parallel / semi-fused launch form: same
- *                      bits) — another algorithm, other bits than the one-axis kernel; AUTO takes it for every 3D stride-1
- *                      layer that has it (v1, v3, v5, v6 of this network).
+ *                      class-parallel in one launch); `tile` = 3: the TWO-AXIS algorithm (Conv3d k3 s1 p1 as F(4,3) x F(4,3) over D
+ *                      and H, Conv2d k3 s1 p1 as F(4,3) x F(4,3) over H and W, Conv3d k4 s1 p0 as F(2,4) x F(2,4); in_halo = pad;
+ *                      4 / 5 force its class-parallel / semi-fused launch form: same bits) — another algorithm, other bits than
+ *                      the one-axis kernel; AUTO takes it for every stride-1 layer that has it and an edge <= 28 (e6, e7, v1, v3,
+ *                      v5, v6 of this network).
  * A call whose scratch is smaller than s3r_conv_scratch_elems says for the RESOLVED algorithm fails with S3R_ERR_WORKSPACE; it
  * is never answered with the other kernel's bits. */
 typedef enum s3r_algo { S3R_ALGO_AUTO = 0, S3R_ALGO_DIRECT = 1, S3R_ALGO_WINOGRAD = 2 } s3r_algo;

@@ -124,7 +124,7 @@ def check(rc, what=""):
     return rc
 
 
-LAYOUT_PLAIN, LAYOUT_WINO_H, LAYOUT_WINO_DH = 0, 2, 3
+LAYOUT_PLAIN, LAYOUT_WINO_H, LAYOUT_WINO_DH, LAYOUT_WINO_HW = 0, 2, 3, 4
 
 
 def make_desc(layer, batch, in_size, tag=0, tile=-1, in_halo=0, out_halo=0, ksplit=0, dtype=0, in_layout=0, out_layout=0,

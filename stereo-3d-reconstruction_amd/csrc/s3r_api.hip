@@ -121,8 +121,8 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
     if (d->in_halo < 0 || d->out_halo < 0 || d->in_halo > 8 || d->out_halo > 8)
         return fail(S3R_ERR_INVALID, "halo must be in [0, 8]");
     if (d->dtype != S3R_F32 && d->dtype != S3R_BF16) return fail(S3R_ERR_INVALID, "unknown dtype %d", d->dtype);
-    if ((d->in_layout != S3R_LAYOUT_PLAIN && d->in_layout != S3R_LAYOUT_WINO_H && d->in_layout != S3R_LAYOUT_WINO_DH) ||
-        d->out_layout != S3R_LAYOUT_PLAIN)
+    if ((d->in_layout != S3R_LAYOUT_PLAIN && d->in_layout != S3R_LAYOUT_WINO_H && d->in_layout != S3R_LAYOUT_WINO_DH &&
+         d->in_layout != S3R_LAYOUT_WINO_HW) || (d->out_layout != S3R_LAYOUT_PLAIN && d->out_layout != S3R_LAYOUT_WINO_HW))
         return fail(S3R_ERR_INVALID, "unknown layout");
     if ((d->in_layout || d->out_layout) && d->op == S3R_OP_LINEAR)
         return fail(S3R_ERR_INVALID, "the transformed input layout exists on the convolution paths only");
@@ -165,6 +165,17 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
             d->in_halo != 1 || d->cin % 32 != 0 || d->cout <= 1)
             return fail(S3R_ERR_INVALID, "a two-axis Winograd-transformed input serves an fp32 Conv3d k=3 s=1 p=1 over an edge %% 4 == 0, in_halo = 1");
         g->x_elems = 36 * (int64_t)d->batch * d->cin * (g->in / 4) * (g->in / 4) * g->in_p;
+    }
+    if (d->in_layout == S3R_LAYOUT_WINO_HW) {    // the 36 two-axis plane sets of a 2D layer, positions flat
+        if (d->dtype != S3R_F32 || d->op != S3R_OP_CONV || d->ndim != 2 || d->stride != 1 || d->k != 3 || d->pad != 1 || (g->in & 3) ||
+            d->in_halo != 1 || d->cin % 32 != 0 || d->cout <= 1)
+            return fail(S3R_ERR_INVALID, "a two-axis Winograd-transformed input (2D) serves an fp32 Conv2d k=3 s=1 p=1 over an edge %% 4 == 0, in_halo = 1");
+        g->x_elems = 36 * (int64_t)d->cin * s3r::wino2_npad((int64_t)d->batch * (g->in / 4) * (g->in / 4));
+    }
+    if (d->out_layout == S3R_LAYOUT_WINO_HW) {   // ... written by the layer in front of it: the plane sets of THIS layer's halo-1 output
+        if (d->dtype != S3R_F32 || d->op != S3R_OP_CONV || d->ndim != 2 || (g->out & 3) || d->cout % 32 != 0 || d->act == S3R_ACT_SIGMOID)
+            return fail(S3R_ERR_INVALID, "the two-axis Winograd output layout is written by an fp32 Conv2d with an output edge %% 4 == 0 and cout %% 32 == 0");
+        g->y_elems = 36 * (int64_t)d->cout * s3r::wino2_npad((int64_t)d->batch * (g->out / 4) * (g->out / 4));
     }
     g->w_elems = (int64_t)d->cin * d->cout * ipow(d->k, g->nd);
     if (d->op == S3R_OP_DECONV)
@@ -258,8 +269,9 @@ int wino2_ax(const s3r_conv_desc* d) {
 }
 bool wino2_desc_ok(const s3r_conv_desc* d) {
     return wino2_ax(d) >= 0 && d->act != S3R_ACT_SIGMOID && d->in_halo == d->pad && d->ksplit <= 1 &&
-           (d->in_layout == S3R_LAYOUT_PLAIN || (d->in_layout == S3R_LAYOUT_WINO_DH && wino2_ax(d) == 0 && d->in_size % 4 == 0)) &&
-           d->out_layout == S3R_LAYOUT_PLAIN;
+           (d->in_layout == S3R_LAYOUT_PLAIN || (d->in_layout == S3R_LAYOUT_WINO_DH && wino2_ax(d) == 0 && d->in_size % 4 == 0) ||
+            (d->in_layout == S3R_LAYOUT_WINO_HW && wino2_ax(d) == 2 && d->in_size % 4 == 0)) &&
+           (d->out_layout == S3R_LAYOUT_PLAIN || (d->out_layout == S3R_LAYOUT_WINO_HW && wino2_ax(d) == 2 && d->in_size % 4 == 0));
 }
 // library policy: the two-axis form where the output is small enough for its class slabs (ncls / m^2 x the output) to be cheap
 // or, in its semi-fused launch form (6 / 4 x the output), worth the halved matrix work — v1 (edge 28), v3 (14), v5, v6 (7) of this
@@ -284,19 +296,21 @@ int resolve_algo(const s3r_conv_desc* d, int* alg, int* form) {
             return fail(S3R_ERR_INVALID, "algo = WINOGRAD: this layer / descriptor has no such Winograd form (one-axis: fp32 Conv k3 s1 p1 "
                         "with cin %% %d == 0 and edge >= 4, or ConvTranspose3d k4 s2 p1 over an edge %% 4 == 0, in_halo = 1; two-axis "
                         "(tile = 3): Conv3d k3 s1 p1 / k4 s1 p0, in_halo = pad; plain layouts, no split-K, no sigmoid)", s3r::wino_bk());
-        if (d->in_layout == S3R_LAYOUT_WINO_DH && !(two && (d->tile < 0 || d->tile >= 3)))
-            return fail(S3R_ERR_INVALID, "a two-axis transformed input runs the two-axis kernel only");
-        if (d->tile >= 3 || !one || d->in_layout == S3R_LAYOUT_WINO_DH ||
+        const bool two_io = d->in_layout == S3R_LAYOUT_WINO_DH || d->in_layout == S3R_LAYOUT_WINO_HW || d->out_layout == S3R_LAYOUT_WINO_HW;
+        if (two_io && !(two && (d->tile < 0 || d->tile >= 3)))
+            return fail(S3R_ERR_INVALID, "a two-axis transformed input / output runs the two-axis kernel only");
+        if (d->tile >= 3 || !one || two_io ||
             (d->tile < 0 && two && d->in_layout == S3R_LAYOUT_PLAIN && d->in_size <= wino2_max_edge())) {
             *alg = ALG_WINO2;
             *form = d->tile >= 4 ? d->tile - 4 : -1;
         } else { *alg = ALG_WINO; *form = d->tile; }
         return S3R_OK;
     }
-    if (d->in_layout == S3R_LAYOUT_WINO_DH) {            // only the two-axis kernel reads the 36 plane sets
+    if (d->in_layout == S3R_LAYOUT_WINO_DH || d->in_layout == S3R_LAYOUT_WINO_HW || d->out_layout == S3R_LAYOUT_WINO_HW) {
+        // only the two-axis kernel reads / writes the 36 plane sets
         if (d->algo == S3R_ALGO_DIRECT || !wino2_desc_ok(d) || d->tile >= 0)
-            return fail(S3R_ERR_INVALID, "a two-axis transformed input runs the two-axis kernel only: algo AUTO / WINOGRAD, no direct tile / "
-                        "split-K override, a plain output");
+            return fail(S3R_ERR_INVALID, "a two-axis transformed input / output runs the two-axis kernel only: algo AUTO / WINOGRAD, no direct "
+                        "tile / split-K override");
         *alg = ALG_WINO2;
         return S3R_OK;
     }
@@ -414,7 +428,7 @@ WinoNeed wino2_need(const s3r_conv_desc* d, int form) {
     WinoNeed w = {0, 0, 0};
     const Wino2Geo g2 = wino2_geo(d);
     if (d->batch <= 0 || g2.bmax <= 0) return w;
-    if (d->in_layout != S3R_LAYOUT_WINO_DH)
+    if (d->in_layout != S3R_LAYOUT_WINO_DH && d->in_layout != S3R_LAYOUT_WINO_HW)
         w.v = ((g2.ax == 2 ? g2.ncls * d->cin * s3r::wino2_npad(g2.pos_sample * g2.bmax) : g2.v_sample * g2.bmax) + 255) / 256 * 256;
     for (int b0 = 0; b0 < d->batch; b0 += g2.bmax) {              // (at most two different sub-batch sizes)
         const int nb = d->batch - b0 < g2.bmax ? d->batch - b0 : g2.bmax;
@@ -435,8 +449,9 @@ int wino2_run(const s3r_conv_desc* d, const Geo& g, s3r::ConvParams p, const flo
               int64_t scratch_elems, int form, hipStream_t s, int* launches) {
     const Wino2Geo g2 = wino2_geo(d);
     const WinoNeed need = wino2_need(d, form);
-    const bool pre = d->in_layout == S3R_LAYOUT_WINO_DH;             // the producer wrote the plane sets
-    if (g2.bmax <= 0 || (pre && g2.bmax < d->batch))
+    const bool pre = d->in_layout == S3R_LAYOUT_WINO_DH || d->in_layout == S3R_LAYOUT_WINO_HW;      // the producer wrote the plane sets
+    const bool to_v = d->out_layout == S3R_LAYOUT_WINO_HW;           // ... and this layer writes its consumer's
+    if (g2.bmax <= 0 || ((pre || to_v) && g2.bmax < d->batch))
         return fail(S3R_ERR_INVALID, "two-axis Winograd form: the transformed input of this batch exceeds 2 GiB (at most %d samples per "
                     "call with a producer-written input: s3r_conv_wino_input_elems)", g2.bmax);
     if (!scratch || scratch_elems < need.total)
@@ -482,7 +497,7 @@ int wino2_run(const s3r_conv_desc* d, const Geo& g, s3r::ConvParams p, const flo
         p.y = y + (int64_t)b0 * p.y_bs;
         p.y_bytes = (unsigned)(4 * (int64_t)nb * p.y_bs);
         int nl = 0;
-        e = s3r::launch_conv_wino2(p, g2.ax, s3r::wino2_form(g2.ax, d->cout, p.Ntotal, form), s, &nl);
+        e = s3r::launch_conv_wino2(p, g2.ax, s3r::wino2_form(g2.ax, d->cout, p.Ntotal, form), to_v, s, &nl);
         if (e != hipSuccess) return hip_fail(e, "two-axis Winograd conv launch");
         *launches += nl;
     }
@@ -672,6 +687,22 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
                 wino_bmax(&pl->d[1]) >= pl->d[1].batch) {
                 pl->stem_wino = true;
                 pl->d[1].in_layout = S3R_LAYOUT_WINO_H;
+            }
+        }
+        if (i > 0 && pl->r[i - 1] == R_MFMA && pl->r[i] == R_MFMA && pl->d[i].dtype == S3R_F32) {
+            // two-axis Conv2d -> two-axis Conv2d over the same edge: the first one's finish kernel writes the second one's plane sets
+            // (S3R_LAYOUT_WINO_HW: the bits wino2p_input_kernel makes of the plain activation)
+            static const int fuse = getenv("S3R_WINO_HANDOFF") ? atoi(getenv("S3R_WINO_HANDOFF")) : 1;      // A/B switch, read once
+            s3r_conv_desc& a = pl->d[i - 1];
+            s3r_conv_desc& b = pl->d[i];
+            int alg_a, alg_b, form;
+            if (fuse && wino2_ax(&a) == 2 && wino2_ax(&b) == 2 && a.cout == b.cin && out_size(&a) == b.in_size && b.in_size % 4 == 0 &&
+                resolve_algo(&a, &alg_a, &form) == S3R_OK && alg_a == ALG_WINO2 && resolve_algo(&b, &alg_b, &form) == S3R_OK &&
+                alg_b == ALG_WINO2 && wino2_geo(&a).bmax >= a.batch && wino2_geo(&b).bmax >= b.batch) {
+                a.out_layout = S3R_LAYOUT_WINO_HW;
+                b.in_layout = S3R_LAYOUT_WINO_HW;
+                const int rg = geometry(&a, &pl->g[i - 1]);              // (its output is now the plane sets)
+                if (rg) return rg;
             }
         }
         int rc = geometry(&pl->d[i], &pl->g[i]);
@@ -1278,6 +1309,13 @@ static int wino_input_layout(const s3r_conv_desc* d, int64_t* elems) {
         if (g2.bmax >= t.batch) {
             *elems = g2.v_sample * t.batch;
             return S3R_LAYOUT_WINO_DH;
+        }
+    }
+    if (alg == ALG_WINO2 && wino2_ax(&t) == 2 && t.in_size % 4 == 0) {
+        const Wino2Geo g2 = wino2_geo(&t);
+        if (g2.bmax >= t.batch) {
+            *elems = g2.ncls * t.cin * s3r::wino2_npad(g2.pos_sample * t.batch);
+            return S3R_LAYOUT_WINO_HW;
         }
     }
     return S3R_LAYOUT_PLAIN;

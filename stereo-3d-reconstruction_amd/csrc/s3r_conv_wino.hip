@@ -1225,13 +1225,16 @@ __global__ void pack_wino2p_kernel(const float* __restrict__ w, float* __restric
 }
 
 // 2D: one workgroup per (cout, PL consecutive samples): slabs -> PL whole padded planes.  SEMI: [a][row][Cout][npad] (A^T along H
-// already applied by the class kernel), otherwise [a 6 + b][Cout][npad]: A^T along H, then along W.  y_hs = W + 2 halo, y_cs = a plane
-template <bool SEMI>
+// already applied by the class kernel), otherwise [a 6 + b][Cout][npad]: A^T along H, then along W.  y_hs = W + 2 halo, y_cs = a plane.
+// TOV (S3R_LAYOUT_WINO_HW output; halo 1, edge a multiple of 4): the planes never leave LDS — the workgroup applies the NEXT layer's
+// input transform to them (wino2p_input_kernel's arithmetic on the values it would have read back) and writes that layer's 36
+// plane sets V[cls][cout][position]: the positions of its PL samples are one contiguous run per class
+template <bool SEMI, bool TOV>
 __global__ __launch_bounds__(256) void wino2p_finish_kernel(const ConvParams p, const int npad, const int halo, const int PL) {
     constexpr int N = 6, M = 4;
     extern __shared__ __attribute__((aligned(16))) float fsm[];          // PL planes of Hp x Wp
     const int tid = threadIdx.x;
-    const int G = p.Nh * p.Nw, Wp = p.y_hs, plane = p.y_cs;
+    const int G = p.Nh * p.Nw, Wp = TOV ? p.Hout + 2 : p.y_hs, plane = TOV ? Wp * Wp : p.y_cs;
     const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
     const size_t cstride = (size_t)p.Cout * npad;
     const int nbg = (p.B + PL - 1) / PL;
@@ -1276,8 +1279,36 @@ __global__ __launch_bounds__(256) void wino2p_finish_kernel(const ConvParams p, 
             }
         }
         __syncthreads();
-        for (int pl = 0; pl < npl; ++pl)
-            wino2_copy_out(fsm + pl * plane, p.y + (size_t)(b0 + pl) * p.y_bs + (size_t)mrow * p.y_cs, plane, tid);
+        if constexpr (TOV) {
+            for (int t = tid; t < npl * G; t += 256) {
+                const int pl = p.dS.div(t);
+                const int s = t - pl * G;
+                const int sh = p.dW.div(s);
+                const int sw = s - sh * p.Nw;
+                const float* __restrict__ win = fsm + pl * plane + M * sh * Wp + M * sw;     // 6 x 6 window of the padded plane
+                float tt[N][N];                                          // [row class][column]
+#pragma unroll
+                for (int jc = 0; jc < N; ++jc) {
+                    float r[N], v[N];
+#pragma unroll
+                    for (int ir = 0; ir < N; ++ir) r[ir] = win[ir * Wp + jc];
+                    wax_bt<0>(r, v);
+#pragma unroll
+                    for (int ir = 0; ir < N; ++ir) tt[ir][jc] = v[ir];
+                }
+                float* __restrict__ dst = p.y + (size_t)mrow * npad + (size_t)b0 * G + t;
+#pragma unroll
+                for (int bb = 0; bb < N; ++bb) {
+                    float v[N];
+                    wax_bt<0>(tt[bb], v);
+#pragma unroll
+                    for (int a = 0; a < N; ++a) dst[(size_t)(a * N + bb) * cstride] = v[a];
+                }
+            }
+        } else {
+            for (int pl = 0; pl < npl; ++pl)
+                wino2_copy_out(fsm + pl * plane, p.y + (size_t)(b0 + pl) * p.y_bs + (size_t)mrow * p.y_cs, plane, tid);
+        }
         __syncthreads();
     }
 }
@@ -1303,7 +1334,7 @@ int64_t wino2_slab_elems(int ax, int cout, int ntotal, int form) {
 
 // p: the CLASS convolution (wino_body): x = V, x_cs / x_ds / x_hs / x_cls its strides, Nd / Nh = depth / row groups, kd = kh = 1,
 // T = kw, ncls = the class count; part = slabs; y / Dout / Hout the layer's output
-hipError_t launch_conv_wino2(ConvParams p, int ax, int form, hipStream_t stream, int* launches) {
+hipError_t launch_conv_wino2(ConvParams p, int ax, int form, bool to_v, hipStream_t stream, int* launches) {
     if (p.Cin % WBK != 0 || p.stride != 1 || p.transposed || p.ksplit != 1 || p.head_w || p.act == ACT_SIGMOID || !p.part ||
         ax < 0 || ax > 2 || p.ncls != wino2_classes(ax))
         return hipErrorInvalidValue;
@@ -1313,12 +1344,13 @@ hipError_t launch_conv_wino2(ConvParams p, int ax, int form, hipStream_t stream,
     const int n_tiles = (p.Ntotal + WCN - 1) / WCN;
     const size_t lds = (size_t)WNB * WBK * (WBM + WCN) * sizeof(float);
     // finish kernels: whole padded slices / planes through LDS (the output's halo comes back from its strides)
-    const int halo = (p.y_hs - p.Hout) / 2;
-    if (halo < 0 || p.y_hs != p.Hout + 2 * halo) return hipErrorInvalidValue;
+    const int halo = to_v ? 1 : (p.y_hs - p.Hout) / 2;
+    if (to_v && (ax != 2 || p.Hout % 4 != 0)) return hipErrorInvalidValue;
+    if (!to_v && (halo < 0 || p.y_hs != p.Hout + 2 * halo)) return hipErrorInvalidValue;
     if (ax == 2) {
         // p describes the layer for the finish kernel (Nh x Nw groups per sample); the class GEMM runs over the flat positions
-        const int plane = p.y_hs * p.y_hs, G = p.Nh * p.Nw;
-        if (p.y_cs != plane || (size_t)plane * 4 > 64 * 1024) return hipErrorInvalidValue;
+        const int plane = to_v ? (p.Hout + 2) * (p.Hout + 2) : p.y_hs * p.y_hs, G = p.Nh * p.Nw;
+        if ((!to_v && p.y_cs != plane) || (size_t)plane * 4 > 64 * 1024) return hipErrorInvalidValue;
         int PL = 256 / G < 1 ? 1 : 256 / G;
         if (PL > p.B) PL = p.B;
         while (PL > 1 && (size_t)PL * plane * 4 > 64 * 1024) --PL;
@@ -1338,8 +1370,11 @@ hipError_t launch_conv_wino2(ConvParams p, int ax, int form, hipStream_t stream,
         const long long items = (long long)p.Cout * ((p.B + PL - 1) / PL);
         const dim3 fgrid((unsigned)(items < 16384 ? items : 16384));
         const size_t flds = (size_t)PL * plane * 4;
-        if (form == 1) hipLaunchKernelGGL(wino2p_finish_kernel<true>, fgrid, dim3(256), flds, stream, p, npad, halo, PL);
-        else hipLaunchKernelGGL(wino2p_finish_kernel<false>, fgrid, dim3(256), flds, stream, p, npad, halo, PL);
+        if (to_v) {
+            if (form == 1) hipLaunchKernelGGL((wino2p_finish_kernel<true, true>), fgrid, dim3(256), flds, stream, p, npad, halo, PL);
+            else hipLaunchKernelGGL((wino2p_finish_kernel<false, true>), fgrid, dim3(256), flds, stream, p, npad, halo, PL);
+        } else if (form == 1) hipLaunchKernelGGL((wino2p_finish_kernel<true, false>), fgrid, dim3(256), flds, stream, p, npad, halo, PL);
+        else hipLaunchKernelGGL((wino2p_finish_kernel<false, false>), fgrid, dim3(256), flds, stream, p, npad, halo, PL);
         if (launches) *launches = 2;
         return hipGetLastError();
     }

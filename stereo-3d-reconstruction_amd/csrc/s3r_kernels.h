@@ -168,7 +168,7 @@ hipError_t launch_pack_wino2(const float* w, float* wp, int ax, int Cin, int Cou
 int wino2_form(int ax, int cout, int ntotal, int forced);                      // 0 class-parallel, 1 semi-fused (same bits)
 int64_t wino2_slab_elems(int ax, int cout, int ntotal, int form);
 int64_t wino2_npad(int64_t ntotal);                                           // positions rounded up to whole GEMM tiles
-hipError_t launch_conv_wino2(ConvParams p, int ax, int form, hipStream_t stream, int* launches);
+hipError_t launch_conv_wino2(ConvParams p, int ax, int form, bool to_v, hipStream_t stream, int* launches);   // to_v: write the next layer's plane sets
 // the cost volume written as the 36 two-axis plane sets of its halo-1 padded form: V[36][B][2C][(D)/4][H/4][W+2]
 hipError_t launch_cost_volume_wino2(const float* fl, const float* fr, float* V, int B, int C, int D, int H, int W, hipStream_t s);
 int wino_bk();                      // channels per K tile of the Winograd kernels (Cin must be a multiple)

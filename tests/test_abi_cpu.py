@@ -90,6 +90,9 @@ def test_workspace_query(s3r, lib, monkeypatch):
     for i, (l, n, m) in enumerate(rows[:-1]):
         if i == 0:
             continue
+        if l.name == "e6":      # ... and e6's, which holds the 36 two-axis plane sets of e7 (written by e6's finish kernel):
+            want += 36 * l.cout * (-(-(4 * 7 * 7) // 64) * 64)      # positions of the 4 images flat, rounded up to a GEMM tile
+            continue
         halo = rows[i + 1][0].p
         want += -(-(4 * l.cout * (m + 2 * halo) ** 2) // 256) * 256
     # ... plus ONE split-K scratch region sized for the hungriest layer
@@ -99,6 +102,10 @@ def test_workspace_query(s3r, lib, monkeypatch):
         d.in_halo = l.p
         if i == 1:
             d.in_layout = s3r._lib.LAYOUT_WINO_H                  # (e2's planes come from the stem: not in its scratch)
+        if l.name == "e7":
+            d.in_layout = s3r._lib.LAYOUT_WINO_HW                 # (e7's from e6)
+        if l.name == "e6":
+            d.out_layout = s3r._lib.LAYOUT_WINO_HW
         scratch = max(scratch, lib.s3r_conv_scratch_elems(C.byref(d)))
     assert need == want + -(-scratch // 256) * 256
     # a chain whose first layer gathers with padding pads an unpadded input itself: one more region

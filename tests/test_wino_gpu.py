@@ -254,23 +254,25 @@ def test_whole_forward_is_form_invariant_at_every_batch(tmp_path):
     layer's last round is mostly empty; the transposed layers' depth differences materialised or formed in the kernel by
     input size; the two-axis layers class-parallel or semi-fused) equals the forward with every one-axis Winograd layer forced
     to the serial form, with the depth differences forced either way, and with the two-axis layers forced to either of their
-    forms, and with the stem writing its plain activation for a transform kernel instead of e2's planes itself — bitwise."""
+    forms, with the stem writing its plain activation for a transform kernel instead of e2's planes itself, and with e6 doing
+    the same instead of writing e7's — bitwise."""
     res = {}
     for flag, env_set in (("auto", {}), ("serial", {"S3R_WINO_FORM": "0"}), ("mat0", {"S3R_DWINO_MAT": "0"}),
                           ("mat1", {"S3R_DWINO_MAT": "1"}), ("cp2", {"S3R_WINO2_FORM": "0"}), ("semi2", {"S3R_WINO2_FORM": "1"}),
-                          ("stem0", {"S3R_STEM_WINO": "0"})):
+                          ("stem0", {"S3R_STEM_WINO": "0"}), ("handoff0", {"S3R_WINO_HANDOFF": "0"})):
         path = str(tmp_path / f"forms_{flag}.pt")
         env = dict(os.environ)
         env.pop("S3R_WINO_FORM", None)
         env.pop("S3R_DWINO_MAT", None)
         env.pop("S3R_WINO2_FORM", None)
         env.pop("S3R_STEM_WINO", None)
+        env.pop("S3R_WINO_HANDOFF", None)
         env.update(env_set)
         r = subprocess.run([sys.executable, "-c", _FORMS_CHILD % {"root": ROOT}, path], capture_output=True, text=True,
                            timeout=900, cwd=ROOT, env=env)
         assert r.returncode == 0, r.stderr[-3000:]
         res[flag] = torch.load(path)
-    for flag in ("serial", "mat0", "mat1", "cp2", "semi2", "stem0"):
+    for flag in ("serial", "mat0", "mat1", "cp2", "semi2", "stem0", "handoff0"):
         for a, b in zip(res["auto"], res[flag]):
             assert torch.equal(a, b), (flag, a.shape)
 
@@ -464,3 +466,38 @@ def test_stem_that_writes_its_consumers_planes_at_other_sizes(s3r, oracle):
         assert torch.equal(got, step), (size, N, float((got - step).abs().max()))
         rel = float((got.cpu().double() - want).norm() / want.norm())
         assert rel < 1e-5, (size, rel)
+
+
+def test_two_axis_conv2d_pairs_hand_over_transformed_planes(s3r, oracle):
+    """Two two-axis Conv2d layers in a row over an edge that is a multiple of 4: the first one's finish kernel writes the second
+    one's 36 plane sets (S3R_LAYOUT_WINO_HW) instead of its activation.  Against the two layers run one by one (plain
+    activation, padded, transformed by `wino2p_input_kernel`): bitwise, for both launch forms of the producer, at the network's
+    e6 -> e7 and at other sizes; an edge that is not a multiple of 4 takes the plain hand-off and must agree too."""
+    dev, spec, L = "cuda:0", s3r.arch_spec, s3r._lib
+    Layer = spec.Layer
+    enc = {l.name: l for l in spec.ENCODER}
+    for a, b, edge, B in ((enc["e6"], enc["e7"], 28, 3), (Layer("ha", "conv2d", 32, 64), Layer("hb", "conv2d", 64, 48), 8, 5),
+                          (Layer("ha", "conv2d", 64, 32), Layer("hb", "conv2d", 32, 32), 12, 1),
+                          (Layer("ha", "conv2d", 32, 32), Layer("hb", "conv2d", 32, 40), 10, 2)):
+        pair = s3r.modules._HipChain([a, b], edge, precision="fp32")
+        s3r.seed_module(pair, 41)
+        first = s3r.modules._HipChain([a], edge, precision="fp32")
+        second = s3r.modules._HipChain([b], edge, precision="fp32")
+        first.load_state_dict({k: v for k, v in pair.state_dict().items() if k.startswith(a.name + ".")})
+        second.load_state_dict({k: v for k, v in pair.state_dict().items() if k.startswith(b.name + ".")})
+        blocks = [oracle._Block(l).eval() for l in (a, b)]
+        for l, blk in zip((a, b), blocks):
+            blk.load_state_dict(getattr(pair, l.name).state_dict())
+        for m in (pair, first, second):
+            m.to(dev)
+        x = torch.randn((B, a.cin, edge, edge), generator=torch.Generator().manual_seed(edge))
+        with torch.no_grad():
+            want = blocks[1](blocks[0](x)).double()
+        step = second._run(first._run(x.to(dev)))
+        for form in (-1, 4, 5):                                      # the producer's launch form: the library's, class-parallel, semi-fused
+            if form >= 0:
+                pair.algo_override[a.name], pair.tile_override[a.name] = L.ALGO_WINOGRAD, form
+            got = pair._run(x.to(dev))
+            assert torch.equal(got, step), (a.name, edge, B, form, float((got - step).abs().max()))
+        rel = float((step.cpu().double() - want).norm() / want.norm())
+        assert rel < 1e-5, (edge, rel)
