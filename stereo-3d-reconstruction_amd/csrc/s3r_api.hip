@@ -261,7 +261,8 @@ bool wino_desc_ok(const s3r_conv_desc* d) {
 // -1: the layer has no such form
 int wino2_ax(const s3r_conv_desc* d) {
     if (d->dtype == S3R_BF16 || d->op != S3R_OP_CONV || d->stride != 1 || d->cin % s3r::wino_bk() != 0 || d->cout <= 1) return -1;
-    if (d->ndim == 2) return d->k == 3 && d->pad == 1 && d->in_size >= 4 ? 2 : -1;
+    // (2D: the finish kernel stages a whole padded output plane in 64 KiB of LDS)
+    if (d->ndim == 2) return d->k == 3 && d->pad == 1 && d->in_size >= 4 && d->in_size <= 124 ? 2 : -1;
     if (d->ndim != 3) return -1;
     if (d->k == 3 && d->pad == 1 && d->in_size >= 4) return 0;
     if (d->k == 4 && d->pad == 0 && d->in_size >= 5) return 1;
@@ -292,7 +293,7 @@ int resolve_algo(const s3r_conv_desc* d, int* alg, int* form) {
         // tile: -1 the library's pick between the forms the layer has; 0, 1, 2 a launch form of the one-axis kernel; 3 the two-axis
         // algorithm (4: its class-parallel form, 5: its semi-fused form)
         if ((d->tile >= 3 && !two) || (d->tile >= 0 && d->tile <= 2 && !one) || (!one && !two) || d->tile > 5 ||
-            (d->tile == 5 && wino2_ax(d) == 1))
+            (d->tile == 5 && (wino2_ax(d) == 1 || (wino2_ax(d) == 0 && d->in_size > 60))))      // (semi-fused 3D: four padded slices in LDS)
             return fail(S3R_ERR_INVALID, "algo = WINOGRAD: this layer / descriptor has no such Winograd form (one-axis: fp32 Conv k3 s1 p1 "
                         "with cin %% %d == 0 and edge >= 4, or ConvTranspose3d k4 s2 p1 over an edge %% 4 == 0, in_halo = 1; two-axis "
                         "(tile = 3): Conv3d k3 s1 p1 / k4 s1 p0, in_halo = pad; plain layouts, no split-K, no sigmoid)", s3r::wino_bk());
@@ -423,6 +424,12 @@ double wino_exec_flops(const s3r_conv_desc* d, const Geo& g) {
     return 2.0 * (double)wino_positions(d, d->batch) * d->cout * d->cin * taps;
 }
 
+// the launch form of a two-axis call (0 class-parallel, 1 semi-fused): the library's plan unless forced; a 3D layer whose four padded
+// output slices do not fit the semi-fused finish kernel's LDS stays class-parallel
+int wino2_form_of(const s3r_conv_desc* d, int ntotal, int forced) {
+    if (forced < 0 && wino2_ax(d) == 0 && d->in_size > 60) forced = 0;
+    return s3r::wino2_form(wino2_ax(d), d->cout, ntotal, forced);
+}
 // scratch of a two-axis call: [V of one sub-batch (unless the producer wrote it) | slabs of the launch form planned for the batch]
 WinoNeed wino2_need(const s3r_conv_desc* d, int form) {
     WinoNeed w = {0, 0, 0};
@@ -434,7 +441,7 @@ WinoNeed wino2_need(const s3r_conv_desc* d, int form) {
         const int nb = d->batch - b0 < g2.bmax ? d->batch - b0 : g2.bmax;
         if (b0 > 0 && nb == g2.bmax) continue;
         const int nt = (int)(g2.pos_sample * nb);
-        const int64_t sl = s3r::wino2_slab_elems(g2.ax, d->cout, nt, s3r::wino2_form(g2.ax, d->cout, nt, form));
+        const int64_t sl = s3r::wino2_slab_elems(g2.ax, d->cout, nt, wino2_form_of(d, nt, form));
         if (sl > w.slab) w.slab = sl;
     }
     w.total = w.v + w.slab;
@@ -497,7 +504,7 @@ int wino2_run(const s3r_conv_desc* d, const Geo& g, s3r::ConvParams p, const flo
         p.y = y + (int64_t)b0 * p.y_bs;
         p.y_bytes = (unsigned)(4 * (int64_t)nb * p.y_bs);
         int nl = 0;
-        e = s3r::launch_conv_wino2(p, g2.ax, s3r::wino2_form(g2.ax, d->cout, p.Ntotal, form), to_v, s, &nl);
+        e = s3r::launch_conv_wino2(p, g2.ax, wino2_form_of(d, p.Ntotal, form), to_v, s, &nl);
         if (e != hipSuccess) return hip_fail(e, "two-axis Winograd conv launch");
         *launches += nl;
     }

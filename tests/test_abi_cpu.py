@@ -294,3 +294,22 @@ def test_policy_override_is_read_once_at_load(s3r):
     assert r.returncode == 0, r.stderr[-2000:]
     a, b, c = [int(v) for v in r.stdout.split("RES")[1].split()]
     assert a == 0 and b == 0 and c > 0          # AUTO -> direct under S3R_WINO=0, also after the variable changed; WINOGRAD still runs
+
+
+def test_two_axis_forms_know_their_lds_limits(s3r, lib):
+    """The finish kernels of the two-axis forms stage whole padded planes (2D) / four padded slices (3D, semi-fused form) in
+    64 KiB of LDS: a layer too large for that has no such form — forcing it is S3R_ERR_INVALID at the scratch query already,
+    AUTO resolves to another algorithm, and a forced two-axis call on a large 3D layer plans its class-parallel form."""
+    L = s3r._lib
+    Layer = s3r.arch_spec.Layer
+    big2d = L.make_desc(Layer("b2", "conv2d", 32, 32), 1, 128, in_halo=1, algo=L.ALGO_WINOGRAD, tile=3)
+    assert lib.s3r_conv_scratch_elems(C.byref(big2d)) == -1
+    big2d.tile = -1                                                  # the one-axis form remains
+    assert lib.s3r_conv_scratch_elems(C.byref(big2d)) > 0
+    ok2d = L.make_desc(Layer("o2", "conv2d", 32, 32), 1, 124, in_halo=1, algo=L.ALGO_WINOGRAD, tile=3)
+    assert lib.s3r_conv_scratch_elems(C.byref(ok2d)) > 0
+    big3d = L.make_desc(Layer("b3", "conv3d", 32, 32), 1, 64, in_halo=1, algo=L.ALGO_WINOGRAD, tile=5)
+    assert lib.s3r_conv_scratch_elems(C.byref(big3d)) == -1
+    big3d.tile = 3                                                   # planned: class-parallel (36 slabs), not semi-fused (24)
+    n = 16 * 16 * 64
+    assert lib.s3r_conv_scratch_elems(C.byref(big3d)) == -(-(36 * 32 * 16 * 16 * 66) // 256) * 256 + 36 * 32 * n
