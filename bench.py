@@ -223,6 +223,10 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False,
             "what_ran": {names.get(t, str(t)): e["ran"] for t, e in sorted(per_layer.items())},
             "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
             "pmc_source": pmc,
+            # `peak` is the data-sheet figure at 2.4 GHz; the profiled box ran its kernels at pmc.shader_clock_ghz_pmc: the same
+            # executed rate over the peak AT THAT CLOCK is what the counters' busy-cycle ratio (mfma_utilisation_pmc) measures
+            "frac_at_pmc_clock": round(achieved / peak * 2.4 / pmc["shader_clock_ghz_pmc"], 4)
+            if pmc and pmc.get("shader_clock_ghz_pmc") else None,
             "layers_per_step": c["n"] // steps,
             "launches_per_step": c["launches"] // steps,
             "executed_gflop_per_launch": round(executed / c["launches"] / 1e9, 3),
