@@ -1,6 +1,13 @@
-// fp32 3 x 3 [x 3] stride-1 convolutions and ConvTranspose3d(k4 s2 p1) with FEWER multiplications: Winograd along the H axis only.
+// fp32 stride-1 convolutions and ConvTranspose3d(k4 s2 p1) with FEWER multiplications: the Winograd forms.  One class GEMM
+// (wino_body) serves all of them; what differs is how many classes a layer has, what is left of its kernel inside a class, and
+// who applies the output transform.  Map of this file:
+//   1. one axis, F(4,3) along H (six classes, half the multiplications): input transform, weight transform         (e2, e4)
+//   2. transposed convolutions, F(2,2) along D and H inside each output-parity class (nine classes, 9/16)       (d1, d2, d3)
+//   3. wino_body and its launch forms: serial / class-parallel / dual (one axis), semi-fused (two axes); wino_plan
+//   4. two axes, class-parallel or semi-fused: F(4,3) x F(4,3) over D, H (Conv3d k3: v1, v3, v5) or over H, W (Conv2d k3: e6, e7),
+//      F(2,4) x F(2,4) (Conv3d k4 valid: v6); their input transforms, weight transforms and finish kernels
 //
-// Convolutions, F(4, 3) (Lavin & Gray): four output rows (4q .. 4q + 3) of a column need the padded input rows r0..r5 = 4q .. 4q + 5
+// One axis, F(4, 3) (Lavin & Gray): four output rows (4q .. 4q + 3) of a column need the padded input rows r0..r5 = 4q .. 4q + 5
 // and the three kernel rows g0, g1, g2:
 //     v0 = 4 r0 - 5 r2 + r4             u0 = g0 / 4                          y0 = m0 + m1 + m2 + m3 + m4
 //     v1 = -4 r1 - 4 r2 + r3 + r4       u1 = -(g0 + g1 + g2) / 6             y1 = m1 - m2 + 2 m3 - 2 m4
@@ -11,12 +18,14 @@
 // so the layer becomes SIX convolutions with a (kd x 1 x kw) kernel — 9 taps instead of 27 in 3D, 3 instead of 9 in 2D, each over
 // its own transformed input plane set V_i and its own transformed weights U_i — whose results are combined in registers: HALF
 // the matrix work of the direct form for the same outputs (edges that are not a multiple of 4 compute a partial last group:
-// 16 rows for 14, 8 for 7).  Why only one axis: every further axis multiplies the transform-domain accumulators per output again
-// and shortens each GEMM's K to Cin; along H alone K stays Cin x 9 (or x 3), the W axis stays contiguous (16-byte gathers where
-// W % 4 == 0, whole-row stores), and the kernel below is the implicit GEMM of s3r_conv_glds.hip with a class loop around its
-// K loop.  In fp32 over 64-256 channels it is as accurate as the direct sum (4.9e-7 relative to an fp64 convolution against
-// 3.6e-7; north_star allows 1e-4) but it is a DIFFERENT summation: results are not bit-identical to the direct kernels', which
-// is why the choice between them is part of the layer descriptor (s3r_algo, include/s3r.h).
+// 16 rows for 14, 8 for 7).  Along H alone K stays Cin x 9 (or x 3), the W axis stays contiguous (16-byte gathers where
+// W % 4 == 0, whole-row stores), six classes' accumulators fit a workgroup's registers, and the kernel is the implicit GEMM of
+// s3r_conv_glds.hip with a class loop around its K loop.  Every further axis multiplies the classes (36 for two) and shortens
+// each class's K: a workgroup cannot hold them, so the two-axis forms (section 4) send class sums through slabs in HBM — which
+// pays where the output is small (an edge <= 28) and not for e2 / e4.  In fp32 over 64-256 channels the forms are as accurate as
+// the direct sum (rel-L2 against an fp64 convolution: direct 3e-7 .. 1e-6, one axis <= 2.3e-6, two axes <= 4.7e-6; north_star
+// allows 1e-4) but they are DIFFERENT summations: results are not bit-identical to the direct kernels' nor to each other's,
+// which is why the choice between them is part of the layer descriptor (s3r_algo, include/s3r.h).
 //
 //   wino_input_kernel   x (padded NC(D)HW, halo 1) -> V[6][B][C][Dp][ceil(H/4)][Wp]   (HBM-bound: reads x once, writes 1.5 x)
 //   pack_wino_kernel    w[Cout][Cin][kd][3][kw]    -> Up[6][(chunk*T' + tap')*32 + c][CoutPad],  T' = kd*kw, 32-channel chunks
