@@ -2,8 +2,10 @@
 """What a bf16 Winograd form would cost in accuracy, measured on the CPU in fp64 / fp32 arithmetic: a 3 x 3
 stride-1 pad-1 convolution computed (a) directly with operands rounded to bf16 and fp32 accumulation — what conv_bf16*_kernel
 does —, (b) as F(4,3) along H with the TRANSFORMED operands rounded to bf16 (the transform itself in fp32, rounded once: the
-best a bf16-MFMA Winograd kernel can do), (c) as F(4,3) x F(4,3), (d) as F(2,3) along H.  Errors are relative L2 against the
-fp64 convolution of the UNROUNDED operands; the bf16 path's bar is tests/test_bf16_gpu.py's.   python tools/bf16_wino_error.py"""
+best a bf16-MFMA Winograd kernel can do), (c) as F(4,3) x F(4,3), (d) as F(2,3) along H; and a 2 x 2 valid correlation — one
+parity class of a transposed k4 s2 convolution, two of its three axes — directly and as F(2,2) x F(2,2).  Errors are relative L2
+against the fp64 convolution of the UNROUNDED operands; the bf16 path's bar is tests/test_bf16_gpu.py's.
+    python tools/bf16_wino_error.py"""
 import torch
 
 torch.manual_seed(0)
@@ -70,3 +72,27 @@ for name, C, K, n in (("e4-like 64->128, 16^2", 64, 128, 16), ("e7-like 256->256
                "F(4,3) x F(4,3)": rel(wino(x, w, (BT4, G4, AT4), (2, 3)), want)}
         base = res["direct bf16"]
         print(f"{name}, {data}: " + "; ".join(f"{k} {v:.2e} ({v / base:.1f}x)" for k, v in res.items()))
+
+
+# ---- the transposed layers: one parity class is a 2 x 2 [x 2] correlation; F(2,2) along two of its axes
+BT22 = torch.tensor([[1, -1, 0], [0, 1, 0], [0, -1, 1]], dtype=torch.float64)
+G22 = torch.tensor([[1, 0], [1, 1], [0, 1]], dtype=torch.float64)
+AT22 = torch.tensor([[1, 1, 0], [0, 1, 1]], dtype=torch.float64)
+for name, C, K, n in (("d3-like 128->64, 16^2", 128, 64, 16), ("d2-like 256->128, 8^2", 256, 128, 8)):
+    for data in ("randn", "relu(randn)"):
+        x = torch.randn(2, C, n + 1, n + 1, dtype=torch.float64)
+        if data != "randn":
+            x = x.clamp_min(0)
+        w = torch.randn(K, C, 2, 2, dtype=torch.float64) / (2 * C ** .5)
+        want = torch.nn.functional.conv2d(x, w)
+        direct = torch.nn.functional.conv2d(bf(x), bf(w))
+        xb = bf(x)                                                    # the activation tensor IS bf16; differences formed in fp32
+        U = bf(torch.einsum("ak,bl,ockl->ocab", G22, G22, w))
+        y = torch.zeros_like(want)
+        for q in range(n // 2):
+            for s in range(n // 2):
+                V = bf(torch.einsum("ai,bj,xcij->xcab", BT22, BT22, xb[:, :, 2 * q:2 * q + 3, 2 * s:2 * s + 3]).float())
+                M = torch.einsum("ocab,xcab->xoab", U, V)
+                y[:, :, 2 * q:2 * q + 2, 2 * s:2 * s + 2] = torch.einsum("ua,vb,xoab->xouv", AT22, AT22, M.float().double())
+        print(f"{name}, {data}: direct bf16 {rel(direct, want):.2e}; F(2,2) x F(2,2) {rel(y, want):.2e} "
+              f"({rel(y, want) / rel(direct, want):.1f}x)")
