@@ -272,7 +272,7 @@ def eager_records(s3r, torch, model, left, right, gt_cloud, steps):
 # under any of them is not the configuration the committed counter passes were taken on
 _KERNEL_ENV = ("S3R_TILE_", "S3R_KSPLIT_", "S3R_ALGO_", "S3R_BF16_MFMA", "S3R_STEM_MFMA", "S3R_DEEP_RING", "S3R_LINEAR_NT",
                "S3R_NO_TAIL_CUT", "S3R_NO_FUSE", "S3R_LIB", "S3R_WINO", "S3R_DWINO_MAT", "S3R_WINO2_FORM", "S3R_WINO2_MAX_EDGE", "S3R_WINO_FORM", "S3R_ROWS", "S3R_NO_DUAL", "S3R_DUAL_MODEL",
-               "S3R_LINEAR_WGK", "S3R_STEM_WINO")
+               "S3R_LINEAR_WGK", "S3R_STEM_WINO", "S3R_WINO_HANDOFF")
 
 
 def kernel_env_overrides():

@@ -690,8 +690,10 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
             // through wino_input_kernel's transform): no plain activation, no transform launch
             static const int fuse = getenv("S3R_STEM_WINO") ? atoi(getenv("S3R_STEM_WINO")) : 1;      // A/B switch, read once
             int alg, form;
-            if (fuse && resolve_algo(&pl->d[1], &alg, &form) == S3R_OK && alg == ALG_WINO && pl->d[1].in_size % wino_r(&pl->d[1]) == 0 &&
-                wino_bmax(&pl->d[1]) >= pl->d[1].batch) {
+            // (launch_stem_wino's own limits: 13 input rows of three channels staged in LDS by at most 9 pieces per thread)
+            const bool fits = pl->d[0].in_size % 16 == 0 && pl->d[0].in_size <= 236;
+            if (fuse && fits && resolve_algo(&pl->d[1], &alg, &form) == S3R_OK && alg == ALG_WINO &&
+                pl->d[1].in_size % wino_r(&pl->d[1]) == 0 && wino_bmax(&pl->d[1]) >= pl->d[1].batch) {
                 pl->stem_wino = true;
                 pl->d[1].in_layout = S3R_LAYOUT_WINO_H;
             }

@@ -445,7 +445,7 @@ def test_stem_that_writes_its_consumers_planes_at_other_sizes(s3r, oracle):
     tests/test_ingest_soak_gpu.py compares the two entries bitwise on the whole tower.)"""
     dev, spec = "cuda:0", s3r.arch_spec
     e1, e2 = spec.ENCODER[0], spec.ENCODER[1]
-    for size, N in ((32, 3), (64, 5), (96, 2), (224, 1)):
+    for size, N in ((32, 3), (64, 5), (96, 2), (224, 1), (256, 1), (40, 2)):      # (256, 40: outside the fused kernel's limits)
         pair = s3r.modules._HipChain([e1, e2], size, precision="fp32")
         s3r.seed_module(pair, 31)
         first = s3r.modules._HipChain([e1], size, precision="fp32")
