@@ -313,3 +313,37 @@ def test_two_axis_forms_know_their_lds_limits(s3r, lib):
     big3d.tile = 3                                                   # planned: class-parallel (36 slabs), not semi-fused (24)
     n = 16 * 16 * 64
     assert lib.s3r_conv_scratch_elems(C.byref(big3d)) == -(-(36 * 32 * 16 * 16 * 66) // 256) * 256 + 36 * 32 * n
+
+
+def test_wino_hw_layout_rules(s3r, lib):
+    """S3R_LAYOUT_WINO_HW (the two-axis 2D kernel's plane sets, flat positions): accepted as the input of a Conv2d k3 s1 p1 over
+    an edge % 4 == 0 and as the output of a two-axis Conv2d in front of one; the descriptor must resolve to the two-axis
+    algorithm (never the direct kernel, never the one-axis form), and the consumer's scratch shrinks by the planes it no longer
+    makes itself."""
+    L = s3r._lib
+    enc = {l.name: (l, n) for l, n, _ in s3r.arch_spec.trace(s3r.arch_spec.ENCODER, s3r.arch_spec.IMG_HW)}
+    e6, n6 = enc["e6"]
+    e7, n7 = enc["e7"]
+    plain = L.make_desc(e7, 4, n7, in_halo=1)
+    pre = L.make_desc(e7, 4, n7, in_halo=1, in_layout=L.LAYOUT_WINO_HW)
+    assert lib.s3r_conv_wino_input_layout(C.byref(plain)) == L.LAYOUT_WINO_HW
+    planes = 36 * e7.cin * (-(-(4 * 7 * 7) // 64) * 64)
+    assert lib.s3r_conv_wino_input_elems(C.byref(plain)) == planes
+    assert lib.s3r_conv_scratch_elems(C.byref(plain)) - lib.s3r_conv_scratch_elems(C.byref(pre)) == -(-planes // 256) * 256
+    pre.algo = L.ALGO_DIRECT                                         # the direct kernel cannot read plane sets
+    assert lib.s3r_conv_scratch_elems(C.byref(pre)) == -1
+    pre.algo, pre.tile = L.ALGO_WINOGRAD, 0                          # ... nor can the one-axis form
+    assert lib.s3r_conv_scratch_elems(C.byref(pre)) == -1
+    out = L.make_desc(e6, 4, n6, in_halo=1)
+    out.out_layout = L.LAYOUT_WINO_HW
+    assert lib.s3r_conv_scratch_elems(C.byref(out)) > 0
+    out.algo = L.ALGO_DIRECT
+    assert lib.s3r_conv_scratch_elems(C.byref(out)) == -1
+    e4, n4 = enc["e4"]                                               # edge 56: AUTO alone picks the one-axis form there, but the
+    big = L.make_desc(e4, 4, n4, in_halo=1)                          # layout is a request for the two-axis algorithm, which the
+    big.out_layout = L.LAYOUT_WINO_HW                                # layer has (the chain never plans this hand-off itself)
+    assert lib.s3r_conv_scratch_elems(C.byref(big)) > 0
+    v5 = [l for l in s3r.arch_spec.DECODER if l.name == "v5"][0]     # a 3D layer has no such layout at all
+    d3 = L.make_desc(v5, 2, 7, in_halo=1)
+    d3.out_layout = L.LAYOUT_WINO_HW
+    assert lib.s3r_conv_scratch_elems(C.byref(d3)) == -1
