@@ -768,8 +768,9 @@ def test_bench_line_carries_roofline_border_excluded_and_secondaries(tmp_path):
     counter file matches the sources that ran, and the configs[2] / configs[3] measurements under `secondary`."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("S3R_")}      # the DEFAULT line: no kernel-policy overrides
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=500, cwd=root)
+                         capture_output=True, text=True, timeout=500, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     r = d["roofline"]
