@@ -132,8 +132,9 @@ typedef struct s3r_conv_desc {
     int32_t out_halo;  /* zero halo of the output buffer */
     int32_t ksplit;    /* 0: library picks; >=1: force the split-K factor (must divide cin/16; bf16: cin/32) */
     int32_t dtype;     /* s3r_dtype: which path (layout + matrix instruction) the layer runs on */
-    int32_t in_layout; /* s3r_layout of the input buffer  (WINO_H: fp32 k3 s1 p1 convolutions, in_halo must be 1) */
-    int32_t out_layout;/* s3r_layout of the output buffer (PLAIN) */
+    int32_t in_layout; /* s3r_layout of the input buffer: PLAIN, or the plane sets a producer wrote for this layer's Winograd kernel —
+                          WINO_H (one-axis), WINO_DH (two-axis Conv3d), WINO_HW (two-axis Conv2d); in_halo must be 1 for those */
+    int32_t out_layout;/* s3r_layout of the output buffer: PLAIN, or WINO_HW (a two-axis Conv2d writing its consumer's plane sets) */
     int32_t algo;      /* s3r_algo (ABI 7): AUTO = the library's geometry-only policy */
 } s3r_conv_desc;
 
@@ -151,9 +152,9 @@ const char* s3r_last_error(void);
 /* output edge of a layer: conv (n+2p-k)/s+1, deconv (n-1)s-2p+k, linear 1 */
 int s3r_conv_out_size(const s3r_conv_desc* d);
 /* size of the packed weight buffer for a layer IN 4-BYTE UNITS (>= the torch weight's numel on the fp32
- * path: couts are padded; about half of it on the bf16 path).  ABI 6: an fp32 3 x 3 [x 3] stride-1 pad-1 convolution packs
- * two forms, the direct slab and the six Winograd F(4,3)-along-H class slabs (csrc/s3r_conv_wino.hip: half the
- * multiplications) — a 3D stride-1 layer also the 36 (k3) / 25 (k4, valid) slabs of the two-axis form; which kernel a forward
+ * path: couts are padded; about half of it on the bf16 path).  An fp32 3 x 3 [x 3] stride-1 pad-1 convolution packs every
+ * form it has: the direct slab, the six Winograd F(4,3)-along-H class slabs (csrc/s3r_conv_wino.hip: half the
+ * multiplications) and the 36 slabs of the two-axis form (2D over H, W; 3D over D, H; a 3D k4 valid layer its 25); which kernel a forward
  * runs is the descriptor's `algo` (s3r_algo above).  The transposed convolutions likewise: 72 F(2,2) x F(2,2) (parity class, class) slabs
  * behind the direct ones. */
 int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems);

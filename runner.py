@@ -56,6 +56,9 @@ def main():
                     help="take the multi-rank code path (init_process_group, metric all-gather) even with one rank: a "
                          "world-size-1 RCCL rehearsal on a 1-GPU box")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="testing only: every rank uses cuda:0 (with --backend gloo) so the N>1 path — at the real world size of "
+                         "BASELINE configs[4] — runs on a 1-GPU box")
     ap.add_argument("--gpus", type=int, default=1,
                     help="evaluate on N GPUs of this node: the eval list is sharded over one process per GPU (RCCL "
                          "all-gather of the per-sample metrics); runner.py starts the ranks itself")
@@ -68,7 +71,9 @@ def main():
             port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={max(1, args.gpus)}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")).returncode)
+        # (one process per GPU shares the host: a few intra-op threads each, as bench.py's launcher sets)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+        sys.exit(subprocess.run(cmd, env=env).returncode)
     if args.suggest_keymap:
         import torch
         import s3r
@@ -87,10 +92,10 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("runner.py --test needs an MI355X: this path has no CPU fallback")
-    if world > 1 or local_rank != 0 or args.force_dist:
+    if (world > 1 and not args.same_device) or local_rank != 0 or args.force_dist:
         # (not in a plain single-process run: with the current device set explicitly the look-ahead page-locking of the eval
         #  loop no longer overlaps the GPU work on this runtime — bf16, 3072 pairs at batch 256: 22.0-24.5 k pairs/s with
         #  the call, 32.6 k without; same box, alternating runs)

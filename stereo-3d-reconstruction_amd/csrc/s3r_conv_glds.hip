@@ -800,22 +800,23 @@ static bool plan_tail_cut(const ConvParams& p, int cfg, int* n_cut) {
     const long bm = kTileDims[cfg][0], bn = kTileDims[cfg][1];
     const long m_tiles = (p.Cout + bm - 1) / bm, n_tiles = (p.Ntotal + bn - 1) / bn;
     const long W = m_tiles * n_tiles * classes;
-    const long rounds = W / 256, rem = W % 256;
+    const long CUS = cu_count();
+    const long rounds = W / CUS, rem = W % CUS;
     // where both parts share ONE launch (launch_dual) the remainder's small workgroups run beside the bulk's last round
     // instead of after it: its cost is its share of a round, not a round of its own, and the cut pays for longer launches
     static const int dual_model = getenv("S3R_DUAL_MODEL") ? atoi(getenv("S3R_DUAL_MODEL")) : 1;      // A/B switch
     const bool dual = dual_model && !p.transposed && (cfg == 0 || cfg == 1 || cfg == 4 || cfg == 7) &&
                       getenv("S3R_NO_DUAL") == nullptr;
     if (rounds < 1 || rounds >= (dual ? 64 : 16) || rem == 0) return false;
-    const long n_main = (rounds * 256) / (m_tiles * classes);          // whole N tiles in the bulk
+    const long n_main = (rounds * CUS) / (m_tiles * classes);          // whole N tiles in the bulk
     if (n_main < 1 || n_main >= n_tiles) return false;
     const long pos_tail = p.Ntotal - n_main * bn;
     const long W_tail = ((pos_tail + 63) / 64) * ((p.Cout + 63) / 64) * classes;
-    const double before = (double)((W + 255) / 256);
-    const double bulk = (double)((n_main * m_tiles * classes + 255) / 256);
+    const double before = (double)((W + CUS - 1) / CUS);
+    const double bulk = (double)((n_main * m_tiles * classes + CUS - 1) / CUS);
     const double small = (64.0 * 64.0) / (double)(bm * bn);
-    const double after = dual ? bulk + (double)W_tail / 256.0 * small / 0.85
-                              : bulk + (double)((W_tail + 255) / 256) * small / 0.8;
+    const double after = dual ? bulk + (double)W_tail / (double)CUS * small / 0.85
+                              : bulk + (double)((W_tail + CUS - 1) / CUS) * small / 0.8;
     if (after > (dual ? 0.99 : 0.97) * before) return false;
     *n_cut = (int)(n_main * bn);
     return true;

@@ -60,6 +60,12 @@ constexpr int WBM = 64, WBK = S3R_WBK, WNB = S3R_WNB;      // K tile: one tap x 
 constexpr int WNPA = WBK * WBM / 1024;                                // 1 KiB weight pieces per wave and K tile
 int wino_bk() { return WBK; }
 
+#ifdef S3R_ABLATE
+// S3R_ABL=7: per-workgroup timeline stamps (s_memrealtime, 100 MHz) of the class kernels, tools/timeline.py --wino:
+// [cu key, start, loop start, loop end, end, stores issued]
+__device__ unsigned long long s3r_wino_timeline[6 * 65536];
+#endif
+
 template <int BYTES>
 __device__ __forceinline__ void wdma(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, int voffset, int soffset) {
     static_assert(BYTES == 16 || BYTES == 4, "LDS-DMA width");
@@ -321,6 +327,10 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int j = lane & 31, h = lane >> 5;
+#ifdef S3R_ABLATE
+    unsigned long long tl0 = 0, tl1 = 0, tl2 = 0;
+    if (p.debug == 7) tl0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int n_tiles = (n_end - n_begin + BN - 1) / BN;
     int bid = bid_in, cls0 = 0, pc = 0;                  // cls0: the one class of a class-parallel workgroup; pc: output parity class
@@ -392,16 +402,27 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
     int c_cls = cls0, c_cc = 0, c_td = 0, c_tw = 0, c_tap = 0;
     int c_kt = (DECONV ? pc * NCLS + cls0 : cls0) * nkt;
     int c_a = cls0 / 3, c_b = cls0 - 3 * (cls0 / 3);     // (transposed form) the class's depth / row part
+#ifdef S3R_ABLATE   // diagnostic builds only (tools/README.md): what the operand DMAs of the K loop cost the matrix pipe
+    bool abl_loop = false;                               // set once the prologue's tiles are out
+#endif
     auto issue = [&](int buf) __attribute__((always_inline)) {
+#ifdef S3R_ABLATE
+        const bool skip_a = abl_loop && (p.debug == 3 || p.debug == 5), skip_b = abl_loop && (p.debug == 3 || p.debug == 4);
+#else
+        constexpr bool skip_a = false, skip_b = false;
+#endif
+        if (!skip_a) {
 #pragma unroll
-        for (int q = 0; q < WNPA; ++q)
-            wdma<16>(wrsrc, As + buf * WBK * WBM + (wave + 4 * q) * 256, avoff,
-                     (c_kt * WBK * p.CoutPad + m0) * 4 + (wave + 4 * q) * 4 * p.CoutPad * 4);
+            for (int q = 0; q < WNPA; ++q)
+                wdma<16>(wrsrc, As + buf * WBK * WBM + (wave + 4 * q) * 256, avoff,
+                         (c_kt * WBK * p.CoutPad + m0) * 4 + (wave + 4 * q) * 4 * p.CoutPad * 4);
+        }
         float* sb = Bs + buf * BSTG + b_lds0;
         if constexpr (DECONV) {
             // along an axis, F-class 0: differences at index R, 1: plain at R + 1, 2: differences at R + 1
             const int b_base = ((c_cc * WBK + b_row0) * p.x_cs + (c_a ? p.x_ds : 0) + (c_b ? p.x_hs : 0) + c_tap) * 4;
-            if constexpr (XM) {
+            if (skip_b) {
+            } else if constexpr (XM) {
                 // materialised differences: one tile of x / Dh / Dd / Ddh (a descriptor per K tile: the tensors together may pass
                 // 2 GiB, and a 4-way choice between ready-made descriptors makes the compiler build a lookup table in scratch)
                 const int t_idx = (c_a != 1 ? 2 : 0) + (c_b != 1 ? 1 : 0);          // 0: x, 1: Dh, 2: Dd, 3: Ddh
@@ -437,8 +458,10 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
             }
         } else {
             const int b_base = (c_cls * p.x_cls + (c_cc * WBK + b_row0) * p.x_cs + c_td * p.x_ds + c_tw) * 4;
+            if (!skip_b) {
 #pragma unroll
-            for (int q = 0; q < NPB; ++q) wdma<4 * VEC>(xrsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
+                for (int q = 0; q < NPB; ++q) wdma<4 * VEC>(xrsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);
+            }
             ++c_kt;
             if (++c_tw == p.kw) { c_tw = 0; ++c_td; }
             if (++c_tap == T) {
@@ -464,6 +487,10 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef S3R_ABLATE
+    abl_loop = true;
+    if (p.debug == 7) tl1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int a_off = h * WBM + wm * TM * 32 + j * TM;
     const int b_off = h * BN + wn * 32 + j;
@@ -508,6 +535,37 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
         for (int c = 0; c < NACC; ++c) run_class(acc[c], otf && c / 3 != 1);
     }
 
+#ifdef S3R_ABLATE
+    if (p.debug == 7) tl2 = __builtin_amdgcn_s_memrealtime();
+    auto tl_finish = [&]() __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the "=s" constraint below does not exist for the host pass)
+        if (p.debug == 7 && tid == 0 && blockIdx.x < 65536) {
+            const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* t = s3r_wino_timeline + 6 * (size_t)blockIdx.x;
+            t[5] = t_issued;
+            t[0] = ((unsigned long long)(xcc & 15u) << 8) | ((hw >> 8) & 0xffu);
+            t[1] = tl0; t[2] = tl1; t[3] = tl2; t[4] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
+    };
+#define S3R_TL_FINISH() tl_finish()
+#if defined(__HIP_DEVICE_COMPILE__)      // (the "v" constraint does not exist for the host pass)
+    if (p.debug == 1) {       // timing-only: no epilogue (accumulators kept live)
+#pragma unroll
+        for (int c = 0; c < NACC; ++c)
+#pragma unroll
+            for (int t = 0; t < TM; ++t) asm volatile("" ::"v"(acc[c][t]));
+        S3R_TL_FINISH();
+        return;
+    }
+#endif
+#else
+#define S3R_TL_FINISH() (void)0
+#endif
     // rows of this lane: cout m0 + mbase + dm, dm = ((r & 3) + 8 (r >> 2)) * TM + tm
     const int mbase = wm * TM * 32 + 4 * h * TM;
     const int mlimit = p.Cout - (m0 + mbase);
@@ -524,6 +582,7 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
                 if (dm >= mlimit) continue;
                 slab[(size_t)dm * npad] = acc[0][tm][r];
             }
+        S3R_TL_FINISH();
         return;
     } else if constexpr (SEMI) {
         // ---- semi-fused two-axis form: the four row outputs of this depth class, raw, to part[(a * 4 + row)][cout][n - n_begin]
@@ -544,6 +603,7 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
 #pragma unroll
                 for (int i = 0; i < R; ++i) slab[(size_t)i * rstride + (size_t)dm * npad] = y[i];
             }
+        S3R_TL_FINISH();
         return;
     } else {
         // ---- epilogue: per-cout constants through LDS (every wave is past the last barrier: the ring is idle)
@@ -638,8 +698,10 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
                     if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
         }
+        S3R_TL_FINISH();
     }
 }
+#undef S3R_TL_FINISH
 
 // registers: six classes of one 32 x 32 tile = 96 accumulators (109 in all: four workgroups per CU), nine = 144 (three per CU);
 // the class-parallel form 16
@@ -752,6 +814,12 @@ static hipError_t launch_wino_finish(const ConvParams& p, int n_begin, int n_end
 
 // ---- launch planning ---------------------------------------------------------------------------
 constexpr int WCN = 64;                                  // positions per tile of the serial / class-parallel forms (head: WBN)
+#ifdef S3R_ABLATE   // diagnostic builds: S3R_ABL=3 no operand DMA inside the K loop, 4 weights only, 5 activations only
+static int wabl_mode() { static const int m = getenv("S3R_ABL") ? atoi(getenv("S3R_ABL")) : 0; return m; }
+#define S3R_WABL(p) (p).debug = wabl_mode()
+#else
+#define S3R_WABL(p) (void)0
+#endif
 
 int64_t wino_slab_elems(int kind, int cout, int ntotal, const WinoLaunch& L) {
     if (L.mode == WINO_SERIAL) return 0;
@@ -781,7 +849,8 @@ WinoLaunch wino_plan(int kind, int cout, int kcls, int ntotal, bool head, int fo
         forced = env_mode;
     }
     const int occ = kind == 2 ? 3 : 4;                   // serial workgroups a CU holds at once (registers)
-    const double u = (double)W / 256.0;                  // serial workgroups per CU
+    const int CUS = cu_count();
+    const double u = (double)W / (double)CUS;            // serial workgroups per CU
     int kb = (int)u;                                     // bulk rounds of a dual launch: whole workgroups per CU
     if (forced >= 0) {
         L.mode = forced <= WINO_DUAL ? forced : WINO_SERIAL;
@@ -808,7 +877,7 @@ WinoLaunch wino_plan(int kind, int cout, int kcls, int ntotal, bool head, int fo
         }
     }
     if (L.mode == WINO_DUAL) {
-        const long n_main = ((long)kb * 256) / (m_tiles * pcs);                        // whole N tiles in the bulk
+        const long n_main = ((long)kb * CUS) / (m_tiles * pcs);                        // whole N tiles in the bulk
         L.n_cut = (int)(n_main * WCN);
         if (L.n_cut <= 0 || L.n_cut >= ntotal) { L.mode = L.n_cut <= 0 ? WINO_CP : WINO_SERIAL; L.n_cut = 0; }
     }
@@ -871,6 +940,7 @@ hipError_t launch_conv_wino(ConvParams p, const WinoLaunch& L, hipStream_t strea
     if (p.Cin % WBK != 0 || p.stride != 1 || p.transposed || p.ksplit != 1 || p.head_w || p.act == ACT_SIGMOID)
         return hipErrorInvalidValue;
     p.kh = 1;
+    S3R_WABL(p);
     p.m_tiles = (p.Cout + WBM - 1) / WBM;
     if (launches) *launches = L.mode == WINO_SERIAL ? 1 : 2;
     return p.Nw % 4 == 0 ? launch_wino_forms<4, 1>(p, L, stream) : launch_wino_forms<1, 1>(p, L, stream);
@@ -879,6 +949,7 @@ hipError_t launch_conv_wino(ConvParams p, const WinoLaunch& L, hipStream_t strea
 hipError_t launch_deconv_wino(ConvParams p, const WinoLaunch& L, hipStream_t stream, int* launches) {
     if (p.Cin % WBK != 0 || !p.transposed || p.ksplit != 1 || !p.xd || p.act == ACT_SIGMOID || (p.head_w && p.Cout > WBM))
         return hipErrorInvalidValue;
+    S3R_WABL(p);
     p.m_tiles = (p.Cout + WBM - 1) / WBM;
     if (launches) *launches = L.mode == WINO_SERIAL ? 1 : 2;
     if (p.Nw % 4 != 0) return hipErrorInvalidValue;       // (16-byte gathers only: the library's policy asks for an edge % 4 == 0)
@@ -1333,7 +1404,7 @@ int wino2_form(int ax, int cout, int ntotal, int forced) {
     const long semi_wgs = (long)((cout + WBM - 1) / WBM) * ((ntotal + WCN - 1) / WCN) * 6;
     // 3D: >= two rounds of the chip's four slots per CU.  2D: a class is Cin / 32 K tiles only, too short a workgroup on its own —
     // semi-fused from half a round on
-    return semi_wgs >= (ax == 2 ? 2 * 256 : 8 * 256) ? 1 : 0;
+    return semi_wgs >= (ax == 2 ? 2 : 8) * (long)cu_count() ? 1 : 0;
 }
 int64_t wino2_npad(int64_t ntotal) { return (ntotal + WCN - 1) / WCN * WCN; }
 int64_t wino2_slab_elems(int ax, int cout, int ntotal, int form) {
@@ -1348,6 +1419,7 @@ hipError_t launch_conv_wino2(ConvParams p, int ax, int form, bool to_v, hipStrea
         ax < 0 || ax > 2 || p.ncls != wino2_classes(ax))
         return hipErrorInvalidValue;
     p.kh = 1;
+    S3R_WABL(p);
     p.m_tiles = (p.Cout + WBM - 1) / WBM;
     p.n_begin = 0; p.n_end = p.Ntotal;
     const int n_tiles = (p.Ntotal + WCN - 1) / WCN;
@@ -1387,17 +1459,18 @@ hipError_t launch_conv_wino2(ConvParams p, int ax, int form, bool to_v, hipStrea
         if (launches) *launches = 2;
         return hipGetLastError();
     }
-    const int M = wino2_outputs(ax), G = p.Nh * p.Nw;
-    if (p.y_ds != p.y_hs * p.y_hs || p.y_cs != (p.Dout + 2 * halo) * p.y_ds || (size_t)M * p.y_ds * 4 > 64 * 1024) return hipErrorInvalidValue;
-    int SUB = 256 / G < 1 ? 1 : 256 / G;                   // (sample, depth group) pairs per finish workgroup
-    if (SUB > p.B * p.Nd) SUB = p.B * p.Nd;
-    while (SUB > 1 && (size_t)SUB * M * p.y_ds * 4 > 64 * 1024) --SUB;
-    const size_t flds = (size_t)SUB * M * p.y_ds * 4;
-    const FastDiv dNd((unsigned)p.Nd), dMS((unsigned)(M * p.y_ds));
-    const long long items = (long long)p.Cout * ((p.B * p.Nd + SUB - 1) / SUB);
-    const dim3 fgrid((unsigned)(items < 32768 ? items : 32768));
+    if (p.y_ds != p.y_hs * p.y_hs || p.y_cs != (p.Dout + 2 * halo) * p.y_ds) return hipErrorInvalidValue;
     if (form == 1) {
-        if (ax != 0) return hipErrorInvalidValue;
+        // (only this form's finish kernel stages output slices in LDS: the class-parallel form's flat kernel has no edge limit)
+        const int M = wino2_outputs(ax), G = p.Nh * p.Nw;
+        if (ax != 0 || (size_t)M * p.y_ds * 4 > 64 * 1024) return hipErrorInvalidValue;
+        int SUB = 256 / G < 1 ? 1 : 256 / G;               // (sample, depth group) pairs per finish workgroup
+        if (SUB > p.B * p.Nd) SUB = p.B * p.Nd;
+        while (SUB > 1 && (size_t)SUB * M * p.y_ds * 4 > 64 * 1024) --SUB;
+        const size_t flds = (size_t)SUB * M * p.y_ds * 4;
+        const FastDiv dNd((unsigned)p.Nd), dMS((unsigned)(M * p.y_ds));
+        const long long items = (long long)p.Cout * ((p.B * p.Nd + SUB - 1) / SUB);
+        const dim3 fgrid((unsigned)(items < 32768 ? items : 32768));
         const dim3 grid(p.m_tiles * n_tiles * 6);
         if (p.Nw % 4 == 0) hipLaunchKernelGGL((wino_kernel<4, 1, 2, false, false, false, true>), grid, dim3(256), lds, stream, p);
         else hipLaunchKernelGGL((wino_kernel<1, 1, 2, false, false, false, true>), grid, dim3(256), lds, stream, p);
@@ -1420,5 +1493,19 @@ hipError_t launch_conv_wino2(ConvParams p, int ax, int form, bool to_v, hipStrea
     if (launches) *launches = 2;
     return hipGetLastError();
 }
+
+#ifdef S3R_ABLATE
+}  // namespace s3r
+extern "C" int s3r_debug_read_timeline_wino(unsigned long long* out, int nblocks) {
+    if (nblocks > 65536) nblocks = 65536;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(s3r::s3r_wino_timeline), sizeof(unsigned long long) * 6 * (size_t)nblocks) == hipSuccess ? nblocks : -1;
+}
+extern "C" int s3r_debug_clear_timeline_wino() {
+    void* ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(s3r::s3r_wino_timeline)) != hipSuccess) return -1;
+    return hipMemset(ptr, 0, sizeof(unsigned long long) * 6 * 65536) == hipSuccess ? 0 : -1;
+}
+namespace s3r {
+#endif
 
 }  // namespace s3r

@@ -23,6 +23,33 @@ struct LdsAttr {
     }
 };
 
+// Compute units of the current device (256 on an unpartitioned MI355X; fewer in the CPX / partitioned modes): what the launch
+// planners (plan_tail_cut, wino_plan, wino2_form) count workgroup rounds against.  Read once per device; 256 where no device
+// answers (the host-only size queries of a CPU-only box, so that they plan what a full MI355X would).
+inline int cu_count() {
+    static std::atomic<int> cached[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) { (void)hipGetLastError(); return 256; }
+    const int slot = dev < 16 ? dev : 15;
+    int n = cached[slot].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+    cached[slot].store(n, std::memory_order_relaxed);
+    return n;
+}
+
+// Profiler hook for the launchers (s3r_prof.hip): brackets ONE pass that does no matrix work — an input transform, a difference
+// tensor, a finish kernel — with its algorithmic bytes, so that a profile shows the HBM-bound passes of a Winograd layer beside
+// its class GEMM (record family "aux", the tag of the layer being run).  Costs nothing unless s3r_profile_enable is on.
+struct AuxScope {
+    void* impl;
+    AuxScope(hipStream_t s, double bytes);
+    ~AuxScope();
+    AuxScope(const AuxScope&) = delete;
+    AuxScope& operator=(const AuxScope&) = delete;
+};
+
 // Division of a non-negative int (< 2^31) by a launch-invariant divisor, as mulhi + add + shift (Granlund &
 // Montgomery): the position decodes of the conv kernels did ~10 integer divisions per thread, ~40 instructions each.
 struct FastDiv {

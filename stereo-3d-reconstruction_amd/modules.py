@@ -254,13 +254,14 @@ class _HipChain(nn.Module):
         return arr, n_layers
 
     def _has_winograd_form(self, l: spec.Layer) -> bool:
-        if self.precision != "fp32":
+        """Whether the LIBRARY has a Winograd form for this layer at the size it has in this chain (edge >= 4, a transposed
+        layer's edge % 4 == 0, no sigmoid, ...: the rules live in s3r_api.hip, so the question is put to the scratch query of a
+        descriptor with algo = WINOGRAD instead of being mirrored here)."""
+        if self.precision != "fp32" or l.op not in ("conv2d", "conv3d", "deconv3d"):
             return False
-        if l.op == "deconv3d":
-            return l.k == 4 and l.s == 2 and l.p == 1 and l.cin % 32 == 0
-        if l.op == "conv3d" and l.k == 4 and l.s == 1 and l.p == 0 and l.cin % 32 == 0 and l.cout > 1:
-            return True                                  # (the two-axis F(2,4) x F(2,4) form)
-        return l.op in ("conv2d", "conv3d") and l.k == 3 and l.s == 1 and l.p == 1 and l.cin % 32 == 0 and l.cout > 1
+        n_in = self._sizes()[self.names.index(l.name)][0]
+        desc = _lib.make_desc(l, 1, n_in, in_halo=1 if l.op == "deconv3d" else l.p, dtype=self._dtype, algo=_lib.ALGO_WINOGRAD)
+        return _lib.load().s3r_conv_scratch_elems(C.byref(desc)) >= 0
 
     def _algo_of(self, l: spec.Layer) -> int:
         """s3r_algo of a layer's descriptor: a per-layer override, else the model's `winograd` switch (only layers that
@@ -272,7 +273,7 @@ class _HipChain(nn.Module):
             return int(env)
         if self.winograd is None:
             return _lib.ALGO_AUTO
-        if self.winograd and self._has_winograd_form(l) and l.act != "sigmoid":
+        if self.winograd and self._has_winograd_form(l):
             return _lib.ALGO_WINOGRAD
         return _lib.ALGO_DIRECT
 
@@ -658,9 +659,10 @@ class Stereo2Voxel(_DisparityMixin, nn.Module):
     nn.Parameters either way (same state_dict), the bf16 images of the weights are made at pack time."""
 
     def __init__(self, precision: str = "fp32", winograd=None):
-        """winograd: None = the library's policy (Winograd-along-H kernels on the layers they measured faster on at batch 32:
-        the throughput default — batches below 8 run ~2x..1.1x slower on it than on the direct kernels unless the
-        class-parallel forms cover them); False = the direct kernels only; True = every layer that has the form.
+        """winograd: None = the library's policy (S3R_ALGO_AUTO: every layer that has a Winograd form runs it — one-axis F(4,3) on
+        e2 / e4, two-axis F(4,3)^2 / F(2,4)^2 on the stride-1 layers with an edge <= 28, F(2,2)^2 inside the parity classes of the
+        transposed layers; each measured faster than the direct kernel at B = 1, 4, 8 and 32); False = the direct
+        kernels only; True = ask for the Winograd kernel on every layer the library has one for (direct elsewhere).
         Results differ between the settings at fp32 rounding level (never with the batch)."""
         super().__init__()
         self.precision = precision

@@ -210,6 +210,22 @@ def test_encoder_entry_takes_a_left_right_pair(s3r, lib):
     assert lib.s3r_encoder_forward(arr2, 1, one, one, one, one, 1 << 40, 0, None) == -1     # not an encoder chain
 
 
+def test_every_entry_that_reaches_a_stem_checks_render_alignment(s3r, lib):
+    """The stems read render rows with 16-byte loads from base + row * width.  The check lives in the chain implementation, so
+    s3r_chain_forward over a tower prefix (what Encoder.forward(upto=...) calls) refuses an unaligned pointer exactly like
+    s3r_encoder_forward[_u8] — argument validation only, nothing is launched."""
+    spec = s3r.arch_spec
+    rows = spec.stage_table("encoder")[:2]
+    arr = (s3r._lib.Layer * len(rows))()
+    for i, (l, n, m) in enumerate(rows):
+        arr[i].desc = _desc(s3r, l, 2, n)
+    ok, odd = C.c_void_p(64), C.c_void_p(68)
+    for fn, args in ((lib.s3r_chain_forward, (odd, ok)), (lib.s3r_encoder_forward, (odd, ok, ok)), (lib.s3r_encoder_forward, (ok, odd, ok)),
+                     (lib.s3r_encoder_forward_u8, (ok, C.c_void_p(65), ok))):
+        assert fn(arr, len(rows), *args, ok, 1 << 40, 0, None) == -1
+        assert b"16-byte aligned" in lib.s3r_last_error(), lib.s3r_last_error()
+
+
 def test_missing_library_fails_loudly(s3r, monkeypatch, tmp_path):
     monkeypatch.setattr(s3r._lib, "_lib", None)
     monkeypatch.setattr(s3r._lib, "LIB_PATH", str(tmp_path / "nope.so"))
@@ -347,3 +363,29 @@ def test_wino_hw_layout_rules(s3r, lib):
     d3 = L.make_desc(v5, 2, 7, in_halo=1)
     d3.out_layout = L.LAYOUT_WINO_HW
     assert lib.s3r_conv_scratch_elems(C.byref(d3)) == -1
+
+
+def test_winograd_switch_asks_the_library_which_layers_have_the_form(s3r, lib):
+    """`_HipChain(winograd=True)` runs the Winograd kernel wherever the layer has one — and the DIRECT kernel elsewhere, instead
+    of handing the library a descriptor it must refuse (ADVICE r04: the Python mirror of the rules knew k / s / p / cin only;
+    the library also wants edge >= 4, a transposed layer's edge % 4 == 0 and no sigmoid)."""
+    L = s3r._lib
+    Layer = s3r.arch_spec.Layer
+    cases = [  # (layer, edge, has a Winograd form)
+        (Layer("a", "conv2d", 32, 32), 8, True),
+        (Layer("a", "conv2d", 32, 32), 2, False),                    # edge < 4
+        (Layer("a", "conv3d", 32, 32), 3, False),
+        (Layer("a", "conv3d", 32, 32, 4, 1, 0), 7, True),            # F(2,4) x F(2,4)
+        (Layer("a", "deconv3d", 32, 32, 4, 2, 1), 8, True),
+        (Layer("a", "deconv3d", 32, 32, 4, 2, 1), 6, False),         # edge % 4 != 0
+        (Layer("a", "conv2d", 32, 32, 3, 1, 1, True, "sigmoid"), 8, False),
+        (Layer("a", "conv2d", 16, 32), 8, False),                    # cin % 32 != 0
+        (Layer("a", "conv2d", 32, 32, 3, 2, 1), 8, False),           # stride 2
+    ]
+    for l, edge, has in cases:
+        ch = s3r.modules._HipChain([l], edge, precision="fp32", winograd=True)
+        assert ch._has_winograd_form(l) == has, (l, edge)
+        assert ch._algo_of(l) == (L.ALGO_WINOGRAD if has else L.ALGO_DIRECT), (l, edge)
+        assert s3r.modules._HipChain([l], edge, precision="fp32", winograd=False)._algo_of(l) == L.ALGO_DIRECT
+        assert s3r.modules._HipChain([l], edge, precision="fp32")._algo_of(l) == L.ALGO_AUTO
+    assert not s3r.modules._HipChain([cases[0][0]], 8, precision="bf16", winograd=True)._has_winograd_form(cases[0][0])

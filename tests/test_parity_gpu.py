@@ -732,16 +732,17 @@ def test_dataset_eval_with_exr_disparity(s3r, models, tmp_path):
     assert a["epe_left"] > 0
 
 
-@pytest.mark.timeout(420)
-@pytest.mark.parametrize("launcher", ["self", "torchrun"])
-def test_bench_two_ranks_on_one_gpu(tmp_path, launcher):
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("launcher,world", [("self", 2), ("torchrun", 2), ("self", 8)])
+def test_bench_ranks_share_one_gpu(tmp_path, launcher, world):
     """bench.py's N>1 path (sharded batch, all-gather collation, barrier, max-over-ranks timing, rank-0 JSON) run
-    with two ranks sharing cuda:0 over gloo — the RCCL run itself needs a multi-GPU node.  "self": plain
-    `python bench.py --gpus 2 ...` as the driver invokes it (bench starts its own ranks as a child process);
-    "torchrun": under an external launcher, as the contract's N>1 command line does."""
+    with `world` ranks sharing cuda:0 over gloo — the RCCL run itself needs a multi-GPU node — at two ranks and at the
+    real world size of BASELINE configs[4] (eight processes, eight arenas, eight host launch threads on one device).
+    "self": plain `python bench.py --gpus N ...` as the driver invokes it (bench starts its own ranks as a child
+    process); "torchrun": under an external launcher, as the contract's N>1 command line does."""
     import json, os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    args = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--backend",
+    args = [os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", "4", "--backend",
             "gloo", "--same-device", "--no-cpu-baseline"]
     if launcher == "self":
         cmd = [sys.executable] + args
@@ -750,16 +751,16 @@ def test_bench_two_ranks_on_one_gpu(tmp_path, launcher):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                "127.0.0.1", "--master-port", str(port)] + args
         env = dict(os.environ)
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=root, env=env)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=580, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # exactly one JSON line, from rank 0
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak"
-    assert d["n_ranks_seen"] == 2 and d["collective_backend"] == "gloo"
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["config"]["global_batch"] == 4 * world and d["scaling"] == "weak"
+    assert d["n_ranks_seen"] == world and d["collective_backend"] == "gloo"
     assert d["value"] > 0 and "cpu_baseline" not in d and "secondary" not in d
 
 

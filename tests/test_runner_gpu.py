@@ -127,3 +127,23 @@ def test_runner_refuses_what_it_does_not_implement():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "runner.py"), "--test"], capture_output=True, text=True,
                            timeout=300, cwd=ROOT)
         assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_runner_eight_ranks_share_one_gpu():
+    """`runner.py --test --gpus 8` at the world size of BASELINE configs[4], eight ranks sharing cuda:0 over gloo (the RCCL run
+    needs an 8-GPU node): the eval list — 19 samples, so shards of 3 and 2 — is sharded over the ranks, the per-sample metrics are
+    all-gathered, and rank 0's line must carry exactly the single-process result on the same list."""
+    base = [sys.executable, os.path.join(ROOT, "runner.py"), "--test", "--samples", "19", "--batch", "4", "--seed", "3"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    one = subprocess.run(base, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    many = subprocess.run(base + ["--gpus", "8", "--backend", "gloo", "--same-device"], capture_output=True, text=True, timeout=580,
+                          cwd=ROOT, env=env)
+    assert many.returncode == 0, many.stderr[-2000:]
+    a = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in many.stdout.splitlines() if l.startswith("{")][-1])
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 8 and b["n_ranks_seen"] == 8 and b["collective_backend"] == "gloo"
+    assert a["samples"] == b["samples"] == 19
+    assert a["mean_iou"] == b["mean_iou"], (a["mean_iou"], b["mean_iou"])

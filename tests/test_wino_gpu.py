@@ -438,6 +438,43 @@ def test_shapes_that_are_not_the_networks(s3r, oracle):
         assert torch.equal(ch._run(x[B - 1:].to(dev))[0], outs["auto"][B - 1]), (l.name, "batch")
 
 
+def test_two_axis_class_parallel_form_has_no_edge_limit(s3r, oracle):
+    """A 3D layer whose four padded output slices do not fit the semi-fused finish kernel's 64 KiB of LDS (edge > 60) is planned
+    — and, forced, launched — in the class-parallel form, whose flat finish kernel stages nothing (the launcher applied
+    the semi-fused bound to both forms and failed with an opaque HIP error).  Edge 68, and edge 64 with the consumer's halo on the
+    output (66^2 x 4 slices > 64 KiB); the semi-fused form itself stays S3R_ERR_INVALID there."""
+    dev, spec, L = "cuda:0", s3r.arch_spec, s3r._lib
+    Layer = spec.Layer
+    a = Layer("ta", "conv3d", 32, 32)
+    for layers, edge in (([a], 68), ([a, Layer("tb", "conv3d", 32, 32, 3, 2, 1)], 64)):
+        ch = s3r.modules._HipChain(layers, edge, precision="fp32")
+        s3r.seed_module(ch, 5)
+        blocks = [oracle._Block(l).eval() for l in layers]
+        for l, blk in zip(layers, blocks):
+            blk.load_state_dict(getattr(ch, l.name).state_dict())
+        ch.to(dev)
+        x = torch.randn((1, 32) + (edge,) * 3, generator=torch.Generator().manual_seed(edge))
+        with torch.no_grad():
+            want = x
+            for blk in blocks:
+                want = blk(want)
+            want = want.double()
+        ch.algo_override["ta"] = L.ALGO_DIRECT
+        direct = ch._run(x.to(dev)).clone()
+        ch.algo_override["ta"] = L.ALGO_WINOGRAD
+        outs = []
+        for form in (3, 4):                                          # the two-axis algorithm: the library's plan, class-parallel
+            ch.tile_override["ta"] = form
+            outs.append(ch._run(x.to(dev)).clone())
+        assert torch.equal(outs[0], outs[1]), edge
+        for y in outs + [direct]:
+            rel = float((y.cpu().double() - want).norm() / want.norm())
+            assert rel < 1e-5, (edge, rel)
+        ch.tile_override["ta"] = 5                                   # semi-fused: no such form at this edge
+        with pytest.raises(s3r.S3RError):
+            ch._run(x.to(dev))
+
+
 def test_stem_that_writes_its_consumers_planes_at_other_sizes(s3r, oracle):
     """stem + e2 as a chain (the stem writes e2's six plane sets: `stem_wino_kernel`) against the same two layers run one by one
     (plain stem activation, padded by the chain, transformed by `wino_input_kernel`): bitwise, at render sizes other than the

@@ -13,6 +13,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--layer", default="e2")
 ap.add_argument("--tile", type=int, default=-1)
 ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--wino", action="store_true", help="the layer's Winograd class kernel (wino_body stamps) instead of the direct kernel")
+ap.add_argument("--form", type=int, default=-1, help="--wino: launch form code (layer_bench --algo 2 --tiles)")
 a = ap.parse_args()
 spec = s3r.arch_spec
 dev = torch.device("cuda:0")
@@ -26,12 +28,19 @@ s3r.seed_module(ch, 1)
 ch.to(dev)
 if a.tile >= 0:
     ch.tile_override[l.name] = a.tile
+if a.wino:
+    ch.algo_override[l.name] = s3r._lib.ALGO_WINOGRAD
+    ch.tile_override[l.name] = a.form
 x = torch.randn((B, l.cin) + (n_in,) * spec.ndim(l), device=dev).relu_()
 for _ in range(3):
     ch._run(x)
 torch.cuda.synchronize()
 lib = s3r.load_library()
-fn = lib.s3r_debug_read_timeline
+fn = lib.s3r_debug_read_timeline_wino if a.wino else lib.s3r_debug_read_timeline
+if a.wino:                                   # stamps of the last run only (the grid differs between the launch forms)
+    lib.s3r_debug_clear_timeline_wino()
+    ch._run(x)
+    torch.cuda.synchronize()
 fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]
 N = 65536
 buf = np.zeros((N, 6), dtype=np.uint64)
