@@ -37,6 +37,11 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (= fp32 vector peak)
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
+ACHIEVABLE_HBM_GBS = 6300.0       # what a float4 copy kernel reaches on this chip (MI355X_MICROARCH.md: 6.29 TB/s measured, 79 %)
+SCHEMA = 5                        # of the JSON line.  5 (r05): + `roofline.aux`, `gemm_ms_per_step`, `frac_gemm_only`, `frac_useful`.
+                                  # 4 (r04): `roofline.frac` = EXECUTED MFMA FLOPs / family kernel time / peak; through r03 (no
+                                  # schema key) `frac` charged the direct form's FLOPs, which r04+ reports as `speedup_vs_direct_form`
+                                  # (alias `frac_credited`): BENCH_r03 and BENCH_r04+ lines do not compare on `frac`
 
 
 def log(*a):
@@ -164,11 +169,26 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False,
     for r in records:
         if r["family"] == "conv_mfma":
             e = per_layer.setdefault(r["tag"], {"ms": 0.0, "flops": 0.0, "exec": 0.0, "n": 0, "ran": r.get("ran", "direct"),
-                                                "launches": 0})
+                                                "launches": 0, "aux_ms": 0.0, "aux_bytes": 0.0, "aux_n": 0})
             e["ms"] += r["ms"]; e["flops"] += r["flops"]; e["exec"] += r.get("exec_flops", r["flops"]); e["n"] += 1
             e["launches"] += r["launches"]
+    for r in records:       # the transform / finish passes of a layer, recorded INSIDE its conv_mfma record (same tag)
+        if r["family"] == "aux" and r["tag"] in per_layer:
+            e = per_layer[r["tag"]]
+            e["aux_ms"] += r["ms"]; e["aux_bytes"] += r["bytes"]; e["aux_n"] += 1
     names = {100 + i: l.name for i, l in enumerate(spec.ENCODER)}
     names.update({200 + i: l.name for i, l in enumerate(spec.DECODER)})
+    edge = {l.name: n_in for layers, n0 in ((spec.ENCODER, spec.IMG_HW), (spec.DECODER, spec.MAX_DISP)) for l, n_in, _ in spec.trace(layers, n0)}
+
+    def useful(tag, ran):
+        """Share of a layer's executed MFMA FLOPs that lands on outputs the layer has: a Winograd group is 4 outputs per
+        transformed axis, so an edge that is not a multiple of 4 computes a partial last group (v3: 16 rows for 14 on both
+        axes, v5: 8 for 7)."""
+        n = edge.get(names.get(tag), 0)
+        if not n or not ran.startswith("winograd") or names[tag].startswith("d") or names[tag] == "v6":
+            return 1.0
+        f = n / (4.0 * ((n + 3) // 4))
+        return f * f if ran == "winograd-2axis" else f
     bf = dtype == "bf16"
     peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_FP32_MFMA_TFLOPS
     if not quiet:
@@ -177,11 +197,14 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False,
             log(f"  {k:20s} {f['n']:8d} {f['ms'] / steps:9.3f} {f['flops'] / f['ms'] / 1e9 if f['ms'] else 0:9.2f} "
                 f"{f['bytes'] / f['ms'] / 1e6 if f['ms'] else 0:9.1f}")
         log(f"conv_mfma per layer:   ms/layer  launches  executed TFLOP/s  frac of {'bf16' if bf else 'fp32'} MFMA peak   "
-            f"credited TFLOP/s   what ran")
+            f"direct-form TFLOP/s   aux passes: n  ms   TB/s   GEMM-only frac   what ran")
         for tag, e in sorted(per_layer.items()):
             tf, tfe = e["flops"] / e["ms"] / 1e9, e["exec"] / e["ms"] / 1e9
+            gemm = max(e["ms"] - e["aux_ms"], 1e-9)
             log(f"  {names.get(tag, tag)!s:6s} {e['ms'] / e['n']:12.4f} {e['launches'] // e['n']:6d} {tfe:12.2f} {tfe / peak:12.3f} "
-                f"{tf:18.2f}   {e['ran']}")
+                f"{tf:18.2f}   {e['aux_n'] // e['n']:10d} {e['aux_ms'] / e['n']:6.4f} "
+                f"{(e['aux_bytes'] / e['aux_ms'] / 1e9 if e['aux_ms'] else 0.0):6.2f} {e['exec'] / gemm / 1e9 / peak:12.3f}   {e['ran']}")
+    aux = fam.pop("aux", None)      # (nested inside conv_mfma: reported under roofline.aux, never added to a sum of families)
     kernels = {k: {"ms_per_step": round(f["ms"] / steps, 4),
                    "tflops": round(f["flops"] / f["ms"] / 1e9, 2) if f["ms"] else None,
                    "algorithmic_gbs": round(f["bytes"] / f["ms"] / 1e6, 1) if f["ms"] else None,
@@ -198,12 +221,15 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False,
         log("conv_mfma kernel ms per eager step, in order: " + " ".join(f"{v:.3f}" for v in step_sums))
     step_sums.sort()
     executed = sum(e["exec"] for e in per_layer.values())
+    executed_useful = sum(e["exec"] * useful(t, e["ran"]) for t, e in per_layer.items())
+    aux_ms = aux["ms"] if aux else 0.0
+    gemm_ms = max(c["ms"] - aux_ms, 1e-9)
     credited = c["flops"] / c["ms"] / 1e9            # TFLOP/s on the direct form's count
     achieved = executed / c["ms"] / 1e9              # TFLOP/s the matrix cores execute
     # §8d's formulas count the taps that multiply padding zeros; without them (arch_spec.layer_macs_interior)
     ratio = spec.mfma_flops_per_pair(variant, interior=True) / spec.mfma_flops_per_pair(variant)
     pmc = pmc_summary(variant, dtype, B, plain_run)
-    all_ms = sum(f["ms"] for f in fam.values())
+    all_ms = sum(f["ms"] for f in fam.values())      # (`aux` was taken out above: its time is inside conv_mfma's)
     roof = {"bound": "mfma",
             "kernel": "conv_bf16{,r,p}_kernel (bf16 MFMA implicit-GEMM conv, channels-last, LDS-DMA; "
                       "per-tap / row-reuse / plane-reuse gathers)" if bf
@@ -216,8 +242,25 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False,
                  "semi-fused) are bit-identical per algorithm",
             "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
+            # executed minus the Winograd groups that lie beyond an edge (v3: 16 rows for 14, v5: 8 for 7): the pipe's USEFUL work
+            "frac_useful": round(executed_useful / c["ms"] / 1e9 / peak, 4),
+            # the same executed FLOPs over the family's time WITHOUT its transform / difference / finish / combine passes
+            # (`aux` below, timed in a second eager pass of the same K steps): the utilisation of the matrix pipe inside the
+            # kernels that use it
+            "gemm_ms_per_step": round(gemm_ms / steps, 4),
+            "frac_gemm_only": round(executed / gemm_ms / 1e9 / peak, 4),
+            # the family's HBM-bound passes, graded against their own roof: algorithmic bytes (what each pass must read and
+            # write) over its HIP-event time, against the 6.3 TB/s a streaming kernel reaches on this chip
+            "aux": ({"bound": "hbm", "ms_per_step": round(aux_ms / steps, 4), "passes_per_step": aux["n"] // steps,
+                     "algorithmic_gb_per_step": round(aux["bytes"] / steps / 1e9, 4),
+                     "achieved": round(aux["bytes"] / aux_ms / 1e6, 1) if aux_ms else None, "peak": ACHIEVABLE_HBM_GBS, "unit": "GB/s",
+                     "frac": round(aux["bytes"] / aux_ms / 1e6 / ACHIEVABLE_HBM_GBS, 4) if aux_ms else None,
+                     "share_of_family_time": round(aux_ms / c["ms"], 4)} if aux else None),
+            # NOT a roofline fraction: the same kernel time charged with the DIRECT form's FLOP count over the peak =
+            # how much faster than a direct-form kernel AT THE PEAK the family runs; > 1 because Winograd forms skip multiplications
             "achieved_credited": round(credited, 3),
-            "frac_credited": round(credited / peak, 4),
+            "speedup_vs_direct_form_at_peak": round(credited / peak, 4),
+            "frac_credited": round(credited / peak, 4),                       # (r04's name for the line above, kept for the driver)
             "frac_credited_border_excluded": round(credited / peak * ratio, 4),
             "executed_over_algorithmic_mfma_flops": round(executed / c["flops"], 4),
             "what_ran": {names.get(t, str(t)): e["ran"] for t, e in sorted(per_layer.items())},
@@ -242,7 +285,7 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False,
     return roof, kernels
 
 
-def eager_records(s3r, torch, model, left, right, gt_cloud, steps):
+def eager_records(s3r, torch, model, left, right, gt_cloud, steps, detail=False):
     """Per-kernel HIP events cannot bracket kernels inside a graph replay: run the same K steps eagerly (untimed).
     The chip needs a few steps of uninterrupted work to settle after the host-side pause that precedes this pass (the
     first three or four eager steps' kernels ran 2-14 % longer than the rest: clocks ramping back up), so six steps go
@@ -253,7 +296,8 @@ def eager_records(s3r, torch, model, left, right, gt_cloud, steps):
         yy = model(left, right)
         if gt_cloud is not None:
             s3r.chamfer_distance(yy, gt_cloud)
-    s3r.profile_enable(64 * steps + 64)
+    s3r.profile_detail(1 if detail else 0)          # (detail: + one record per transform / finish pass, nested in its layer's)
+    s3r.profile_enable(128 * steps + 64)
     for _ in range(6):
         one()
     s3r.profile_reset()                              # (host-side only: the queue stays full)
@@ -263,16 +307,25 @@ def eager_records(s3r, torch, model, left, right, gt_cloud, steps):
         one()
     e1.record()
     torch.cuda.synchronize()
-    records = s3r.profile_read(64 * steps + 64)
+    records = s3r.profile_read(128 * steps + 64)
     s3r.profile_enable(0)
+    s3r.profile_detail(0)
     return records, e0.elapsed_time(e1) / steps
+
+
+def aux_records(s3r, torch, model, left, right, gt_cloud, steps):
+    """A second eager pass with one record per aux pass (input transforms, difference tensors, finish / combine kernels).  Kept
+    apart from the pass that times the layers: every extra event pair between two kernels of a layer costs queue time (r05: 19
+    pairs a step made the family's kernel time read 5 % longer)."""
+    recs, _ = eager_records(s3r, torch, model, left, right, gt_cloud, steps, detail=True)
+    return [r for r in recs if r["family"] == "aux"]
 
 
 # environment switches that change which kernel (or which variant of one) runs without changing the kernel sources: a run
 # under any of them is not the configuration the committed counter passes were taken on
-_KERNEL_ENV = ("S3R_TILE_", "S3R_KSPLIT_", "S3R_ALGO_", "S3R_BF16_MFMA", "S3R_STEM_MFMA", "S3R_DEEP_RING", "S3R_LINEAR_NT",
-               "S3R_NO_TAIL_CUT", "S3R_NO_FUSE", "S3R_LIB", "S3R_WINO", "S3R_DWINO_MAT", "S3R_WINO2_FORM", "S3R_WINO2_MAX_EDGE", "S3R_WINO_FORM", "S3R_ROWS", "S3R_NO_DUAL", "S3R_DUAL_MODEL",
-               "S3R_LINEAR_WGK", "S3R_STEM_WINO", "S3R_WINO_HANDOFF")
+_KERNEL_ENV = ("S3R_TILE_", "S3R_KSPLIT_", "S3R_ALGO_", "S3R_LIB", "S3R_ABL", "S3R_BF16_MFMA", "S3R_STEM_MFMA", "S3R_DEEP_RING", "S3R_NO_TAIL_CUT",
+               "S3R_NO_DUAL", "S3R_WINO", "S3R_DWINO_MAT", "S3R_WINO_FORM", "S3R_WINO2_FORM", "S3R_WINO2_MAX_EDGE", "S3R_STEM_WINO",
+               "S3R_WINO_HANDOFF")      # (tools/README.md holds the table; tests/test_abi_cpu.py checks it against the sources)
 
 
 def kernel_env_overrides():
@@ -310,6 +363,7 @@ def secondary_config(s3r, torch, dev, variant, dtype, B, steps, warmup, plain_ru
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     records, eager_ms = eager_records(s3r, torch, model, left, right, gt_cloud, steps)
+    records = records + aux_records(s3r, torch, model, left, right, gt_cloud, steps)
     roof, kernels = roofline_of(records, steps, dtype, variant, B, spec, plain_run=plain_run, eager_step_ms=eager_ms)
     fl = spec.flops_per_pair(variant)
     out = {"workload": f"Stereo2{'Voxel' if variant == 'voxel' else 'Point'} forward"
@@ -474,7 +528,7 @@ def main():
 
     profiling = not args.no_profile
     if profiling and graphed is None:
-        s3r.profile_enable(64 * args.steps + 64)
+        s3r.profile_enable(128 * args.steps + 64)
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
@@ -493,7 +547,7 @@ def main():
 
     records = []
     if profiling and graphed is None:                     # eager launches: the timed region's own kernel events
-        records = s3r.profile_read(64 * args.steps + 64)
+        records = s3r.profile_read(128 * args.steps + 64)
         s3r.profile_enable(0)
 
     # per-step spread (untimed for `value`): the same K steps once more, each bracketed by its own pair of events on
@@ -512,6 +566,7 @@ def main():
     eager_ms = None
     if profiling and graphed is not None:                 # per-kernel HIP events: the same K steps again, eagerly (untimed)
         records, eager_ms = eager_records(s3r, torch, model, left, right, gt_cloud, args.steps)
+        records = records + aux_records(s3r, torch, model, left, right, gt_cloud, args.steps)
 
     if rank == 0:
         pairs = world * B * args.steps
@@ -529,6 +584,7 @@ def main():
             except Exception:
                 rccl = None
         out = {
+            "schema": SCHEMA,
             "metric": f"stereo pairs/s forward (batch {B}, 224x224 -> 32^3 voxel)" if args.variant == "voxel"
                       else f"stereo pairs/s forward (batch {B}, 224x224 -> 2048-pt cloud)",
             "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps,
@@ -552,6 +608,12 @@ def main():
             "autotuned": {k: [v["tile"], v["ksplit"]] for k, v in tuned.items()} if tuned else None,
             "roofline": roof, "kernels": kernels,
         }
+        if roof and eager_ms:
+            # two clocks: `ms_per_step` times K graph replays (no host launch gaps); the per-kernel events come from an EAGER re-run, where
+            # each record's interval runs from the previous kernel's end to its own end — launch gap included — so their sum tiles the
+            # eager step (<= eager_step_ms) and may exceed the graph step by what the graph saves in gaps
+            roof["graph_step_ms"] = round(ms_per_step, 4)
+            roof["eager_minus_graph_step_ms"] = round(eager_ms - ms_per_step, 4)
         if not dist_on and not args.no_secondary and args.variant == "voxel" and args.dtype == "f32" and \
                 not args.include_h2d and args.renders == "f32":
             # BASELINE.json configs[2] and configs[3], measured in the same process (never part of `value`)

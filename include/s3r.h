@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define S3R_ABI_VERSION 7
+#define S3R_ABI_VERSION 8
 
 typedef enum s3r_status {
     S3R_OK = 0,
@@ -258,7 +258,9 @@ int s3r_disparity_epe(const float* pred, const float* gt, float* epe, int32_t* c
 
 /* Kernel-level profiler: when enabled, every kernel the library launches is bracketed by HIP events
  * on the launch stream.  s3r_profile_read synchronises those events and returns, per launch, the
- * kernel family (0 mfma conv, 1 stem, 2 head, 3 cost volume, 4 linear, 5 chamfer, 6 iou, 7 pack, 8 pad copy, 9 disparity read-out / epe),
+ * kernel family (0 mfma conv, 1 stem, 2 head, 3 cost volume, 4 linear, 5 chamfer, 6 iou, 7 pack, 8 pad copy, 9 disparity read-out / epe,
+ * 10 aux: ONE transform / difference / finish / split-K-combine pass of a convolution layer — no matrix work, `bytes` = what it must
+ * read and write — recorded INSIDE that layer's family-0 record, same tag: the layer's record includes its aux passes' time),
  * the caller's tag, milliseconds, and the algorithmic flops / bytes of that launch. */
 typedef struct s3r_prof_record {
     int32_t family;
@@ -274,6 +276,10 @@ typedef struct s3r_prof_record {
 } s3r_prof_record;
 int s3r_profile_enable(int max_records);   /* 0 disables and frees the event pool */
 int s3r_profile_reset(void);
+/* ABI 8.  level 1: the aux passes of the convolution layers (record family 10) get records of their own, nested inside their layer's;
+ * 0 (default): layer records only — an event pair between two kernels of a layer costs queue time, which a profile taken for the
+ * layers' durations must not carry (bench.py runs one pass of each kind) */
+int s3r_profile_detail(int level);
 int s3r_profile_read(s3r_prof_record* out, int max_records);   /* returns the number of records */
 
 #ifdef __cplusplus

@@ -17,8 +17,8 @@ OP_CONV, OP_DECONV, OP_LINEAR = 0, 1, 2
 DTYPE = {"fp32": 0, "bf16": 1}
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}
 FAMILY = {0: "conv_mfma", 1: "stem", 2: "head", 3: "cost_volume", 4: "linear", 5: "chamfer", 6: "iou", 7: "pack",
-          8: "pad_copy", 9: "disparity"}
-ABI_VERSION = 7
+          8: "pad_copy", 9: "disparity", 10: "aux"}      # aux: transform / finish passes, nested inside their layer's conv_mfma record
+ABI_VERSION = 8
 ALGO_AUTO, ALGO_DIRECT, ALGO_WINOGRAD = 0, 1, 2
 ALGO = {None: 0, "auto": 0, "direct": 1, "winograd": 2, False: 1, True: 2}
 RAN = {0: "direct", 1: "winograd-serial", 2: "winograd-class-parallel", 3: "winograd-dual", 4: "winograd-2axis"}
@@ -88,6 +88,7 @@ SIGNATURES = {
     "s3r_disparity_epe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "s3r_profile_enable": (C.c_int, [C.c_int]),
     "s3r_profile_reset": (C.c_int, []),
+    "s3r_profile_detail": (C.c_int, [C.c_int]),
     "s3r_profile_read": (C.c_int, [C.POINTER(ProfRecord), C.c_int]),
 }
 
@@ -138,6 +139,11 @@ def make_desc(layer, batch, in_size, tag=0, tile=-1, in_halo=0, out_halo=0, kspl
 
 def profile_enable(max_records):
     check(load().s3r_profile_enable(int(max_records)), "profile_enable")
+
+
+def profile_detail(level):
+    """1: the transform / finish passes of the convolution layers get `aux` records of their own (nested in their layer's)."""
+    check(load().s3r_profile_detail(int(level)), "profile_detail")
 
 
 def profile_reset():

@@ -48,6 +48,8 @@ int wino2_run(const s3r_conv_desc* d, const Geo& g, s3r::ConvParams p, const flo
         const int nb = d->batch - b0 < g2.bmax ? d->batch - b0 : g2.bmax;
         hipError_t e = hipSuccess;
         if (!pre) {
+            // (aux pass: reads the padded input once, writes its ncls plane sets)
+            s3r::AuxScope aux(s, 4.0 * ((double)nb * x_sample + (double)(g2.ax == 2 ? g2.ncls * d->cin * s3r::wino2_npad(g2.pos_sample * nb) : g2.v_sample * nb)));
             if (g2.ax == 2)
                 e = s3r::launch_wino2p_input(x + (int64_t)b0 * x_sample, scratch, nb, d->cin, g2.wp, g2.wp, g2.sg, g2.sg,
                                              s3r::wino2_npad(g2.pos_sample * nb), s);
@@ -79,7 +81,12 @@ int dwino_run(const s3r_conv_desc* d, s3r::ConvParams p, const float* x, const f
                     "(s3r_conv_scratch_elems), got %lld", (long long)need.total, (long long)(scratch ? scratch_elems : 0));
     const int n = d->in_size;
     p.xd_mode = dwino_materialise(d) ? 1 : 0;
-    hipError_t e = s3r::launch_wino_diff(x, scratch, (long long)d->batch * d->cin, n + 2, n + 2, n + 2, p.xd_mode, s);
+    hipError_t e;
+    {
+        const double x_el = (double)d->batch * d->cin * (double)ipow(n + 2, 3);
+        s3r::AuxScope aux(s, 4.0 * x_el * (p.xd_mode ? 4.0 : 2.0));      // (reads x, writes Dh [, Dd, Ddh])
+        e = s3r::launch_wino_diff(x, scratch, (long long)d->batch * d->cin, n + 2, n + 2, n + 2, p.xd_mode, s);
+    }
     if (e != hipSuccess) return hip_fail(e, "Winograd difference-tensor launch");
     p.x = x;
     p.xd = scratch;
@@ -351,6 +358,7 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                 for (int b0 = 0; b0 < d->batch; b0 += bmax) {
                     const int nb = d->batch - b0 < bmax ? d->batch - b0 : bmax;
                     if (!pre) {
+                        s3r::AuxScope aux(s, 4.0 * ((double)nb * x_sample + (double)nb * v_sample));
                         e = s3r::launch_wino_input(x + (int64_t)b0 * x_sample, scratch, (long long)nb * d->cin * dp, n + 2, wp, h2, R, s);
                         if (e != hipSuccess) return hip_fail(e, "Winograd input transform launch");
                         ps.launches += 1;

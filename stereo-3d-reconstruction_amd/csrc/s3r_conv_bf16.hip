@@ -1405,8 +1405,7 @@ static hipError_t launch_tm(ConvParamsH p, bool kc32, hipStream_t stream) {
 // kernel is bit-identical to the plane family, so — unlike the choice of family — this may depend on the batch: it needs
 // >= 512 strips of >= 28 rows to fill 256 CUs with two work units each.
 static int rows_strips(const ConvParamsH& p) {
-    static const bool off = getenv("S3R_ROWS") && atoi(getenv("S3R_ROWS")) == 0;                   // A/B switch
-    if (off || p.transposed || p.stride != 1 || p.kd != 1 || p.kh != 3 || p.kw != 3 || p.Cin != 32 || p.Nd != 1 ||
+    if (p.transposed || p.stride != 1 || p.kd != 1 || p.kh != 3 || p.kw != 3 || p.Cin != 32 || p.Nd != 1 ||
         p.Nh != 112 || p.Nw != 112 || p.x_ws != 32 || p.x_hs != 114 * 32 || p.x_org != 0 || p.ksplit != 1 || p.head_w ||
         (p.Cout & 7) != 0 || p.act == ACT_SIGMOID)
         return 0;

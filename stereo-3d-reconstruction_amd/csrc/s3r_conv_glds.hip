@@ -564,6 +564,8 @@ hipError_t launch_conv_finish(const ConvParams& p, int npad, hipStream_t stream)
     g_launch_count += 1;
     const long long total = (long long)p.Cout * (npad >> 2);
     const long long blocks = (total + 255) / 256;
+    // (aux pass: reads the ksplit partial slabs, writes the outputs)
+    AuxScope aux(stream, 4.0 * (double)p.Cout * (p.transposed ? 8 : 1) * ((double)p.ksplit * npad + (double)p.Ntotal));
     hipLaunchKernelGGL(conv_finish_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096), p.transposed ? 8 : 1), dim3(256),
                        0, stream, p, npad);
     return hipGetLastError();
@@ -804,9 +806,7 @@ static bool plan_tail_cut(const ConvParams& p, int cfg, int* n_cut) {
     const long rounds = W / CUS, rem = W % CUS;
     // where both parts share ONE launch (launch_dual) the remainder's small workgroups run beside the bulk's last round
     // instead of after it: its cost is its share of a round, not a round of its own, and the cut pays for longer launches
-    static const int dual_model = getenv("S3R_DUAL_MODEL") ? atoi(getenv("S3R_DUAL_MODEL")) : 1;      // A/B switch
-    const bool dual = dual_model && !p.transposed && (cfg == 0 || cfg == 1 || cfg == 4 || cfg == 7) &&
-                      getenv("S3R_NO_DUAL") == nullptr;
+    const bool dual = !p.transposed && (cfg == 0 || cfg == 1 || cfg == 4 || cfg == 7) && getenv("S3R_NO_DUAL") == nullptr;
     if (rounds < 1 || rounds >= (dual ? 64 : 16) || rem == 0) return false;
     const long n_main = (rounds * CUS) / (m_tiles * classes);          // whole N tiles in the bulk
     if (n_main < 1 || n_main >= n_tiles) return false;

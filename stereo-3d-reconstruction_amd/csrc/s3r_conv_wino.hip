@@ -407,7 +407,9 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
 #endif
     auto issue = [&](int buf) __attribute__((always_inline)) {
 #ifdef S3R_ABLATE
-        const bool skip_a = abl_loop && (p.debug == 3 || p.debug == 5), skip_b = abl_loop && (p.debug == 3 || p.debug == 4);
+        // (6: the activation tile of a (class, chunk) fetched for its first column tap only — the traffic a tap-shared B tile would have)
+        const bool skip_a = abl_loop && (p.debug == 3 || p.debug == 5);
+        const bool skip_b = abl_loop && (p.debug == 3 || p.debug == 4 || (p.debug == 6 && (DECONV ? c_tap != 0 : c_tw != 0)));
 #else
         constexpr bool skip_a = false, skip_b = false;
 #endif
@@ -814,7 +816,7 @@ static hipError_t launch_wino_finish(const ConvParams& p, int n_begin, int n_end
 
 // ---- launch planning ---------------------------------------------------------------------------
 constexpr int WCN = 64;                                  // positions per tile of the serial / class-parallel forms (head: WBN)
-#ifdef S3R_ABLATE   // diagnostic builds: S3R_ABL=3 no operand DMA inside the K loop, 4 weights only, 5 activations only
+#ifdef S3R_ABLATE   // diagnostic builds: S3R_ABL=3 no operand DMA inside the K loop, 4 weights only, 5 activations only, 6 activations on a chunk's first column tap only
 static int wabl_mode() { static const int m = getenv("S3R_ABL") ? atoi(getenv("S3R_ABL")) : 0; return m; }
 #define S3R_WABL(p) (p).debug = wabl_mode()
 #else
@@ -932,6 +934,8 @@ static hipError_t launch_wino_forms(ConvParams p, const WinoLaunch& L, hipStream
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    // (aux pass: reads the class slabs of the class-parallel range, writes that range's outputs)
+    AuxScope aux(stream, 4.0 * (double)(ntotal - n0) * p.Cout * (pcs * NCLS + (p.head_w ? 0.0 : pcs * WinoKind<KIND>::R)));
     return launch_wino_finish<KIND>(p, n0, ntotal, cp_tiles * WCN, stream);
 }
 
@@ -1451,6 +1455,8 @@ hipError_t launch_conv_wino2(ConvParams p, int ax, int form, bool to_v, hipStrea
         const long long items = (long long)p.Cout * ((p.B + PL - 1) / PL);
         const dim3 fgrid((unsigned)(items < 16384 ? items : 16384));
         const size_t flds = (size_t)PL * plane * 4;
+        // (aux pass: reads the slabs, writes the output planes — or, to_v, the consumer's 36 plane sets)
+        AuxScope aux(stream, 4.0 * (double)p.Cout * ((double)(form == 1 ? 24 : 36) * npad + (to_v ? 36.0 * npad : (double)p.B * plane)));
         if (to_v) {
             if (form == 1) hipLaunchKernelGGL((wino2p_finish_kernel<true, true>), fgrid, dim3(256), flds, stream, p, npad, halo, PL);
             else hipLaunchKernelGGL((wino2p_finish_kernel<false, true>), fgrid, dim3(256), flds, stream, p, npad, halo, PL);
@@ -1476,6 +1482,7 @@ hipError_t launch_conv_wino2(ConvParams p, int ax, int form, bool to_v, hipStrea
         else hipLaunchKernelGGL((wino_kernel<1, 1, 2, false, false, false, true>), grid, dim3(256), lds, stream, p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
+        AuxScope aux(stream, 4.0 * (double)p.Cout * (24.0 * n_tiles * WCN + (double)p.B * p.y_cs));      // (slabs in, padded output out)
         hipLaunchKernelGGL(wino2s_finish_kernel, fgrid, dim3(256), flds, stream, p, n_tiles * WCN, halo, SUB, dNd, dMS);
         if (launches) *launches = 2;
         return hipGetLastError();
@@ -1488,6 +1495,7 @@ hipError_t launch_conv_wino2(ConvParams p, int ax, int form, bool to_v, hipStrea
     const long long total = (long long)p.Cout * p.Ntotal;
     const long long blocks = (total + 255) / 256;
     const dim3 flat((unsigned)(blocks < 8192 ? blocks : 8192));
+    AuxScope aux(stream, 4.0 * (double)p.Cout * ((double)p.ncls * n_tiles * WCN + (double)p.B * p.Dout * p.Hout * p.Nw));
     if (ax == 0) hipLaunchKernelGGL(wino2_finish_flat_kernel<0>, flat, dim3(256), 0, stream, p, n_tiles * WCN);
     else hipLaunchKernelGGL(wino2_finish_flat_kernel<1>, flat, dim3(256), 0, stream, p, n_tiles * WCN);
     if (launches) *launches = 2;

@@ -767,10 +767,9 @@ __global__ __launch_bounds__(64 * WGK_W) void linear_wgk_kernel(const float* __r
 // which layers the one-launch form serves: K small enough that a wave's quarter is a handful of blocks, tensors within
 // 32-bit byte offsets
 static bool linear_wgk_ok(int B, int Cin, int Cout) {
-    static const bool off = getenv("S3R_LINEAR_WGK") && atoi(getenv("S3R_LINEAR_WGK")) == 0;      // A/B switch
     // (>= 128 workgroups: p3's 192 take 14.5 us against 17.7 split over workgroups + finish; p2's 32 would take 12.6
     //  against 11.5 — too few waves in flight for a latency-bound stream of 4 MB: tools/point_bench.py, cold caches)
-    return !off && Cin % (32 * WGK_W) == 0 && Cin <= 4096 && (long long)Cin * Cout * 4 < (1ll << 31) &&
+    return Cin % (32 * WGK_W) == 0 && Cin <= 4096 && (long long)Cin * Cout * 4 < (1ll << 31) &&
            (long long)B * Cin * 4 < (1ll << 31) && (long)((Cout + 31) / 32) * ((B + 31) / 32) >= 128;
 }
 
@@ -815,18 +814,14 @@ hipError_t launch_linear(const float* x, const float* w, const float* scale, con
         hipLaunchKernelGGL(linear_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, scratch, B,
                            Cin, Cout);
     } else {
-        // weights are read once per forward; whether the non-temporal hint pays depends on what else runs between two
-        // forwards (MI355X_MICROARCH.md nt-weights): S3R_LINEAR_NT=0|1 overrides the measured default
-        static const int nt_env = getenv("S3R_LINEAR_NT") ? atoi(getenv("S3R_LINEAR_NT")) : -1;
-        const bool nt = nt_env >= 0 ? nt_env != 0 : true;
+        // weights are read once per forward, with the non-temporal hint (MI355X_MICROARCH.md nt-weights; measured faster than the
+        // default policy inside the forward, r02)
         const size_t lds = (size_t)LIN_NS * LIN_STAGE;
-        static LdsAttr attr_nt, attr_pl;
-        hipError_t e = nt ? attr_nt.ensure(reinterpret_cast<const void*>(&linear_stream_kernel<true>), (int)lds)
-                          : attr_pl.ensure(reinterpret_cast<const void*>(&linear_stream_kernel<false>), (int)lds);
+        static LdsAttr attr_nt;
+        hipError_t e = attr_nt.ensure(reinterpret_cast<const void*>(&linear_stream_kernel<true>), (int)lds);
         if (e != hipSuccess) return e;
         const dim3 grid((Cout + 127) / 128, ks, (B + 31) / 32);
-        if (nt) hipLaunchKernelGGL(linear_stream_kernel<true>, grid, dim3(256), lds, s, x, w, scratch, B, Cin, Cout, kper, ks);
-        else hipLaunchKernelGGL(linear_stream_kernel<false>, grid, dim3(256), lds, s, x, w, scratch, B, Cin, Cout, kper, ks);
+        hipLaunchKernelGGL(linear_stream_kernel<true>, grid, dim3(256), lds, s, x, w, scratch, B, Cin, Cout, kper, ks);
     }
     if (ks >= 16 && ks % 4 == 0)
         hipLaunchKernelGGL(linear_finish4_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, scratch, y, scale, bias,

@@ -356,9 +356,6 @@ static hipError_t launch_stem_bf16_mfma(const void* x, const void* x2, int nspli
     }
     const int blocks = N * (112 / STEM_ROWS);
     int wgs = blocks < resident[dev] ? blocks : resident[dev];
-#ifdef S3R_ABLATE
-    if (getenv("S3R_STEM_WGS")) wgs = atoi(getenv("S3R_STEM_WGS"));
-#endif
     hipLaunchKernelGGL(stem_bf16_mfma_kernel<U8>, dim3((unsigned)wgs), dim3(64 * STEM_WAVES), STEM_LDS_BYTES, s, x, x2, nsplit,
                        wt, scale, shift, reinterpret_cast<unsigned short*>(y), N, y_bs, y_hs, y_org
 #ifdef S3R_ABLATE

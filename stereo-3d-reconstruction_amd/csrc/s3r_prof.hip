@@ -19,6 +19,7 @@ struct Prof {
 } g_prof;
 
 thread_local int g_cur_tag = 0;      // tag of the innermost live F_MFMA scope on this thread: what its nested F_AUX passes carry
+std::atomic<int> g_detail{0};        // s3r_profile_detail: 1 = the aux passes get records of their own
 
 }  // namespace
 
@@ -60,7 +61,9 @@ namespace s3r {
 
 // the launchers' hook (s3r_kernels.h): one pass without matrix work, labelled with the layer being run
 AuxScope::AuxScope(hipStream_t s, double bytes) : impl(nullptr) {
-    impl = new s3rh::ProfScope(s, s3rh::F_AUX, s3rh::g_cur_tag, 0.0, bytes);
+    // (only on request: an event pair between two kernels of a layer costs a few microseconds of queue time in an eager run,
+    // which a profile taken for the LAYER's duration must not carry)
+    if (s3rh::g_detail.load(std::memory_order_relaxed)) impl = new s3rh::ProfScope(s, s3rh::F_AUX, s3rh::g_cur_tag, 0.0, bytes);
 }
 AuxScope::~AuxScope() { delete static_cast<s3rh::ProfScope*>(impl); }
 
@@ -93,6 +96,11 @@ int s3r_profile_enable(int max_records) {
     g_prof.rec.reserve(max_records);
     g_prof.cap = max_records;
     g_prof.on = true;
+    return S3R_OK;
+}
+
+int s3r_profile_detail(int level) {
+    g_detail.store(level > 0 ? 1 : 0, std::memory_order_relaxed);
     return S3R_OK;
 }
 

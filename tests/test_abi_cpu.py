@@ -26,7 +26,7 @@ def test_header_symbols_all_exported(s3r, lib):
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.s3r_abi_version() == 7
+    assert lib.s3r_abi_version() == 8
 
 
 def test_struct_layouts_match_header(s3r):
@@ -389,3 +389,21 @@ def test_winograd_switch_asks_the_library_which_layers_have_the_form(s3r, lib):
         assert s3r.modules._HipChain([l], edge, precision="fp32", winograd=False)._algo_of(l) == L.ALGO_DIRECT
         assert s3r.modules._HipChain([l], edge, precision="fp32")._algo_of(l) == L.ALGO_AUTO
     assert not s3r.modules._HipChain([cases[0][0]], 8, precision="bf16", winograd=True)._has_winograd_form(cases[0][0])
+
+
+def test_env_switch_table_matches_the_sources():
+    """tools/README.md lists EVERY environment switch the library reads (one table, checked against `grep getenv`): a
+    switch added to a kernel source without a row — or a row whose switch is gone — fails here."""
+    import glob, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = set()
+    for f in glob.glob(os.path.join(root, "stereo-3d-reconstruction_amd", "csrc", "*.hip")) + \
+            glob.glob(os.path.join(root, "stereo-3d-reconstruction_amd", "csrc", "*.h")):
+        found |= set(re.findall(r'getenv\("(S3R_[A-Z0-9_]+)"\)', open(f).read()))
+    readme = open(os.path.join(root, "tools", "README.md")).read()
+    table = set(re.findall(r"^\| `(S3R_[A-Z0-9_]+)` \|", readme, re.M))
+    assert found == table, (sorted(found - table), sorted(table - found))
+    assert len(found) <= 13                      # (18 in r04: new switches replace old ones, they do not pile up)
+    bench = open(os.path.join(root, "bench.py")).read()
+    for name in found:                           # ... and a bench run under any of them is marked as not the plain configuration
+        assert f'"{name}"' in bench, name
