@@ -171,7 +171,7 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False,
             e = per_layer.setdefault(r["tag"], {"ms": 0.0, "flops": 0.0, "exec": 0.0, "n": 0, "ran": r.get("ran", "direct"),
                                                 "launches": 0, "aux_ms": 0.0, "aux_bytes": 0.0, "aux_n": 0})
             e["ms"] += r["ms"]; e["flops"] += r["flops"]; e["exec"] += r.get("exec_flops", r["flops"]); e["n"] += 1
-            e["launches"] += r["launches"]
+            e["launches"] += r["launches"]; e["bytes"] = e.get("bytes", 0.0) + r["bytes"]
     for r in records:       # the transform / finish passes of a layer, recorded INSIDE its conv_mfma record (same tag)
         if r["family"] == "aux" and r["tag"] in per_layer:
             e = per_layer[r["tag"]]
@@ -205,6 +205,18 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False,
                 f"{tf:18.2f}   {e['aux_n'] // e['n']:10d} {e['aux_ms'] / e['n']:6.4f} "
                 f"{(e['aux_bytes'] / e['aux_ms'] / 1e9 if e['aux_ms'] else 0.0):6.2f} {e['exec'] / gemm / 1e9 / peak:12.3f}   {e['ran']}")
     aux = fam.pop("aux", None)      # (nested inside conv_mfma: reported under roofline.aux, never added to a sum of families)
+    # every layer against its OWN roof: the matrix pipe (executed FLOPs over the peak) or HBM (algorithmic bytes — input + output +
+    # weights, each once — over the 6.3 TB/s a streaming kernel reaches): the larger fraction names the bound
+    layers = {}
+    for tag, e in sorted(per_layer.items()):
+        fm = e["exec"] / e["ms"] / 1e9 / peak
+        fh = e.get("bytes", 0.0) / e["ms"] / 1e6 / ACHIEVABLE_HBM_GBS
+        layers[names.get(tag, str(tag))] = {"ms": round(e["ms"] / e["n"], 4), "bound": "hbm" if fh > fm else "mfma",
+                                            "frac_mfma": round(fm, 3), "frac_hbm": round(fh, 3),
+                                            "algorithmic_gbs": round(e.get("bytes", 0.0) / e["ms"] / 1e6, 1)}
+    if not quiet:
+        log("per layer against its own roof (mfma: executed FLOPs / peak; hbm: algorithmic bytes / 6.3 TB/s): " +
+            "  ".join(f"{k} {v['bound']} {max(v['frac_mfma'], v['frac_hbm']):.2f}" for k, v in layers.items()))
     kernels = {k: {"ms_per_step": round(f["ms"] / steps, 4),
                    "tflops": round(f["flops"] / f["ms"] / 1e9, 2) if f["ms"] else None,
                    "algorithmic_gbs": round(f["bytes"] / f["ms"] / 1e6, 1) if f["ms"] else None,
@@ -264,6 +276,7 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False,
             "frac_credited_border_excluded": round(credited / peak * ratio, 4),
             "executed_over_algorithmic_mfma_flops": round(executed / c["flops"], 4),
             "what_ran": {names.get(t, str(t)): e["ran"] for t, e in sorted(per_layer.items())},
+            "layers": layers,
             "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
             "pmc_source": pmc,
             # `peak` is the data-sheet figure at 2.4 GHz; the profiled box ran its kernels at pmc.shader_clock_ghz_pmc: the same

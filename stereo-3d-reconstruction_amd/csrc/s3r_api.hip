@@ -107,6 +107,35 @@ int dwino_run(const s3r_conv_desc* d, s3r::ConvParams p, const float* x, const f
     *ran = 1 + L.mode;
     return S3R_OK;
 }
+// the three-axis form: difference tensors (all three materialised) + the class kernel (serial form only)
+int dwino3_run(const s3r_conv_desc* d, s3r::ConvParams p, const float* x, const float* packed_w, float* scratch, int64_t scratch_elems,
+               hipStream_t s, int* launches) {
+    const int n = d->in_size;
+    const int64_t need = (3 * (int64_t)d->batch * d->cin * ipow(n + 2, 3) + 255) / 256 * 256;
+    if (!scratch || scratch_elems < need)
+        return fail(S3R_ERR_WORKSPACE, "the three-axis Winograd form of this transposed convolution needs %lld floats of scratch "
+                    "(s3r_conv_scratch_elems), got %lld", (long long)need, (long long)(scratch ? scratch_elems : 0));
+    hipError_t e;
+    {
+        s3r::AuxScope aux(s, 4.0 * 4.0 * (double)d->batch * d->cin * (double)ipow(n + 2, 3));
+        e = s3r::launch_wino_diff(x, scratch, (long long)d->batch * d->cin, n + 2, n + 2, n + 2, 1, s);
+    }
+    if (e != hipSuccess) return hip_fail(e, "Winograd difference-tensor launch");
+    p.x = x;
+    p.xd = scratch;
+    p.w = packed_w + dwino3_w_offset(d);
+    p.Nd = p.Nh = p.Nw = n / 2;
+    p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
+    p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
+    p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
+    p.dW = s3r::FastDiv((unsigned)p.Nw);
+    p.ksplit = 1;
+    e = s3r::launch_deconv_wino3(p, s);
+    if (e != hipSuccess) return hip_fail(e, "three-axis Winograd transposed-conv launch");
+    *launches = 2;
+    return S3R_OK;
+}
+
 // MFMA conv with the following 1x1 single-channel head folded into its epilogue (plan_chain decides)
 int conv_head_fused(const s3r_conv_desc* d, const Geo& g, const s3r_conv_desc* hd, const Geo& hg, const float* x,
                     const s3r_layer& L, const s3r_layer& H, float* out, float* scratch, int64_t scratch_elems, hipStream_t s) {
@@ -122,6 +151,14 @@ int conv_head_fused(const s3r_conv_desc* d, const Geo& g, const s3r_conv_desc* h
     int alg, form;
     int rc = resolve_algo(d, &alg, &form);
     if (rc) return rc;
+    if (alg == ALG_WINO3) {
+        if (d->cout > 64) return fail(S3R_ERR_INVALID, "the fused head rides on the transposed Winograd kernel with <= 64 couts only");
+        ProfScope ps(s, F_MFMA, d->tag, g.flops + hg.flops, g.bytes - 4.0 * d->batch * d->cout * (double)g.out_sp +
+                     4.0 * d->batch * (double)hg.out_sp);
+        ps.exec = g.flops * (27.0 / 64.0) + hg.flops;
+        ps.algo = 5;
+        return dwino3_run(d, p, x, static_cast<const float*>(L.packed_w), scratch, scratch_elems, s, &ps.launches);
+    }
     if (alg != ALG_DIRECT) {
         if (alg != ALG_WINO || d->op != S3R_OP_DECONV || d->cout > 64) return fail(S3R_ERR_INVALID, "the fused head rides on the transposed Winograd kernel with <= 64 couts only");
         ProfScope ps(s, F_MFMA, d->tag, g.flops + hg.flops, g.bytes - 4.0 * d->batch * d->cout * (double)g.out_sp +
@@ -200,6 +237,8 @@ int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, void* packedv,
                                               cout_pad(d->cout), g.nd == 3 ? 3 : 1, 3, wino_r(d), s);
                 if (e == hipSuccess && dwino_layer(d))
                     e = s3r::launch_pack_wino_deconv(w, packed + 64 * (int64_t)d->cin * cout_pad(d->cout), d->cin, d->cout, cout_pad(d->cout), s);
+                if (e == hipSuccess && dwino3_layer(d))
+                    e = s3r::launch_pack_dwino3(w, packed + dwino3_w_offset(d), d->cin, d->cout, s);
                 if (e == hipSuccess && wino2_ax(d) >= 0)
                     e = s3r::launch_pack_wino2(w, packed + ipow(d->k, g.nd) * d->cin * cout_pad(d->cout) + (wino_layer(d) ? wino_w_elems(d) : 0),
                                                wino2_ax(d), d->cin, d->cout, cout_pad(d->cout), s);
@@ -320,6 +359,12 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                 ps.exec = wino2_exec_flops(d);
                 ps.algo = 4;
                 return wino2_run(d, g, p, x, packed_w, y, scratch, scratch_elems, form, s, &ps.launches);
+            }
+            if (alg == ALG_WINO3) {
+                ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
+                ps.exec = g.flops * (27.0 / 64.0);
+                ps.algo = 5;
+                return dwino3_run(d, p, x, packed_w, scratch, scratch_elems, s, &ps.launches);
             }
             if (wino && d->op == S3R_OP_DECONV) {
                 ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);

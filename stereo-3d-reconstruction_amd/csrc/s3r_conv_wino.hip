@@ -572,26 +572,31 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
     const int mbase = wm * TM * 32 + 4 * h * TM;
     const int mlimit = p.Cout - (m0 + mbase);
     if constexpr (CP) {
-        // ---- class-parallel: the raw class sums to the slab [class][cout][n - n_begin]; every lane of the tile has a slot
-        const int npad = n_tiles * BN;
+        // ---- class-parallel: the raw class sums to the slab, blocked [cout][64-position tile][class][64]: all classes of a tile's
+        // positions are one contiguous run (what the finish kernel reads per position); every lane of the tile has a slot
+        static_assert(BN == 64 || !CP, "class-parallel slabs are blocked in 64-position tiles");
         const int cg = DECONV ? pc * NCLS + cls0 : cls0;
-        float* __restrict__ slab = p.part + ((size_t)cg * p.Cout + (m0 + mbase)) * npad + (n0 - n_begin) + wn * 32 + j;
+        const int nblk = DECONV ? 8 * NCLS : (p.ncls ? p.ncls : NCLS);       // classes per block
+        float* __restrict__ slab = p.part + (((size_t)(m0 + mbase) * n_tiles + n_tile) * nblk + cg) * 64 + wn * 32 + j;
+        const size_t mstride = (size_t)n_tiles * nblk * 64;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dm = ((r & 3) + 8 * (r >> 2)) * TM + tm;
                 if (dm >= mlimit) continue;
-                slab[(size_t)dm * npad] = acc[0][tm][r];
+                slab[(size_t)dm * mstride] = acc[0][tm][r];
             }
         S3R_TL_FINISH();
         return;
     } else if constexpr (SEMI) {
         // ---- semi-fused two-axis form: the four row outputs of this depth class, raw, to part[(a * 4 + row)][cout][n - n_begin]
-        const int npad = n_tiles * BN;
+        // blocked by (cout, tile): the 24 partial rows of a tile's 64 positions are one 6 KiB run, so the finish kernel — which
+        // needs all 24 of a position — reads a few contiguous blocks instead of 24 streams 11 MB apart
         const int a = cls0 / NCLS;
-        float* __restrict__ slab = p.part + ((size_t)a * R * p.Cout + (m0 + mbase)) * npad + (n0 - n_begin) + wn * 32 + j;
-        const size_t rstride = (size_t)p.Cout * npad;
+        static_assert(BN == 64 || !SEMI, "semi-fused slabs are blocked in 64-position tiles");
+        float* __restrict__ slab = p.part + (((size_t)(m0 + mbase) * n_tiles + n_tile) * (6 * R) + a * R) * 64 + wn * 32 + j;
+        const size_t mstride = (size_t)n_tiles * (6 * R) * 64;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -603,7 +608,7 @@ __device__ __forceinline__ void wino_body(const ConvParams& p, const int bid_in,
                 for (int c = 0; c < NCLS; ++c) m[c] = acc[c][tm][r];
                 wino_out<KIND>(m, y);
 #pragma unroll
-                for (int i = 0; i < R; ++i) slab[(size_t)i * rstride + (size_t)dm * npad] = y[i];
+                for (int i = 0; i < R; ++i) slab[(size_t)dm * mstride + i * 64] = y[i];
             }
         S3R_TL_FINISH();
         return;
@@ -736,8 +741,11 @@ __global__ __launch_bounds__(256) void wino_finish_kernel(const ConvParams p, co
     const int pc = DECONV ? (int)blockIdx.y : 0;
     const int rd = (pc >> 2) & 1, rh = (pc >> 1) & 1, rw = pc & 1;
     const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
-    const size_t cstride = (size_t)p.Cout * npad;                            // between class slabs
-    const float* __restrict__ base = p.part + (size_t)pc * NCLS * cstride;    // (pc = 0 for convolutions)
+    // slabs blocked [cout][64-position tile][class][64] (wino_body, CP): class c of (cout mm, position nl) at blk(mm, nl)[c * 64]
+    constexpr int NBLK = DECONV ? 8 * NCLS : NCLS;
+    const int ntl = npad >> 6;
+    const float* __restrict__ base = p.part + (size_t)pc * NCLS * 64;       // (pc = 0 for convolutions)
+    auto blk = [&](int mm, int nl) { return base + ((size_t)mm * ntl + (nl >> 6)) * (NBLK * 64) + (nl & 63); };
     const long long total = HEAD ? nn : (long long)p.Cout * nn;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int mrow = HEAD ? 0 : (int)(i / nn);
@@ -773,7 +781,7 @@ __global__ __launch_bounds__(256) void wino_finish_kernel(const ConvParams p, co
                         const float sc = p.scale ? p.scale[mm] : 1.f, sf = p.shift ? p.shift[mm] : 0.f, hw = p.head_w[mm];
                         float m[NCLS], y[R];
 #pragma unroll
-                        for (int c = 0; c < NCLS; ++c) m[c] = base[(size_t)c * cstride + (size_t)mm * npad + nl];
+                        for (int c = 0; c < NCLS; ++c) m[c] = blk(mm, nl)[c * 64];
                         wino_out<KIND>(m, y);
 #pragma unroll
                         for (int k = 0; k < R; ++k) th[hh][k] = fmaf(wino_act(y[k], sc, sf, lo), hw, th[hh][k]);
@@ -790,7 +798,7 @@ __global__ __launch_bounds__(256) void wino_finish_kernel(const ConvParams p, co
             const float sc = p.scale ? p.scale[mrow] : 1.f, sf = p.shift ? p.shift[mrow] : 0.f;
             float m[NCLS], y[R];
 #pragma unroll
-            for (int c = 0; c < NCLS; ++c) m[c] = base[(size_t)c * cstride + (size_t)mrow * npad + nl];
+            for (int c = 0; c < NCLS; ++c) m[c] = blk(mrow, nl)[c * 64];
             wino_out<KIND>(m, y);
             float* __restrict__ yo = p.y + (size_t)mrow * p.y_cs + e0;
 #pragma unroll
@@ -1129,7 +1137,6 @@ __global__ __launch_bounds__(256) void wino2s_finish_kernel(const ConvParams p, 
     const int tid = threadIdx.x;
     const int G = p.Nh * p.Nw, Wp = p.y_hs, slice = p.y_ds, MS = M * slice;
     const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
-    const size_t cstride = (size_t)p.Cout * npad;
     const int per_c = p.B * p.Nd;
     const int nrg = (per_c + SUB - 1) / SUB;
     const bool vec = (slice & 3) == 0 && (reinterpret_cast<size_t>(p.y) & 15) == 0;
@@ -1147,13 +1154,14 @@ __global__ __launch_bounds__(256) void wino2s_finish_kernel(const ConvParams p, 
             const int pw = g - sh * p.Nw;
             const int r = r0 + sub;
             const int sd = r - dNd.div(r) * p.Nd;
-            const float* __restrict__ src = p.part + (size_t)mrow * npad + (size_t)r0 * G + t;
+            const int n = r0 * G + t;                                  // (slabs blocked by (cout, 64-position tile): wino_body, SEMI)
+            const float* __restrict__ src = p.part + ((size_t)mrow * (npad >> 6) + (n >> 6)) * (N * M * 64) + (n & 63);
             float* __restrict__ o = fsm + sub * MS + (halo + M * sh) * Wp + halo + pw;
 #pragma unroll
             for (int v = 0; v < M; ++v) {
                 float m[N], y[M];
 #pragma unroll
-                for (int a = 0; a < N; ++a) m[a] = src[(size_t)(a * M + v) * cstride];
+                for (int a = 0; a < N; ++a) m[a] = src[(a * M + v) * 64];
                 wax_at<0>(m, y);
 #pragma unroll
                 for (int u = 0; u < M; ++u)
@@ -1197,7 +1205,6 @@ __global__ __launch_bounds__(256) void wino2_finish_flat_kernel(const ConvParams
     const int S = p.Nd * p.Nh * p.Nw;
     const int nn = p.Ntotal;
     const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
-    const size_t cstride = (size_t)p.Cout * npad;
     const long long total = (long long)p.Cout * nn;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int mrow = (int)(i / nn);
@@ -1208,13 +1215,13 @@ __global__ __launch_bounds__(256) void wino2_finish_flat_kernel(const ConvParams
         rem -= sd * p.Nh * p.Nw;
         const int sh = p.dW.div(rem);
         const int pw = rem - sh * p.Nw;
-        const float* __restrict__ src = p.part + (size_t)mrow * npad + n;
+        const float* __restrict__ src = p.part + ((size_t)mrow * (npad >> 6) + (n >> 6)) * (N * N * 64) + (n & 63);     // (blocked slabs)
         float t[N][M];                                                   // [depth class][output row]
 #pragma unroll
         for (int a = 0; a < N; ++a) {
             float m[N], y[M];
 #pragma unroll
-            for (int c = 0; c < N; ++c) m[c] = src[(size_t)(a * N + c) * cstride];
+            for (int c = 0; c < N; ++c) m[c] = src[(a * N + c) * 64];
             wax_at<AX>(m, y);
 #pragma unroll
             for (int v = 0; v < M; ++v) t[a][v] = y[v];
@@ -1334,17 +1341,18 @@ __global__ __launch_bounds__(256) void wino2p_finish_kernel(const ConvParams p, 
             const int s = t - pl * G;
             const int sh = p.dW.div(s);
             const int sw = s - sh * p.Nw;
-            const float* __restrict__ src = p.part + (size_t)mrow * npad + (size_t)b0 * G + t;
+            const int n = b0 * G + t;
+            const float* __restrict__ src = p.part + ((size_t)mrow * (npad >> 6) + (n >> 6)) * ((SEMI ? N * M : N * N) * 64) + (n & 63);
             float tt[N][M];                                              // [column class][output row]
 #pragma unroll
             for (int a = 0; a < N; ++a) {
-                if constexpr (SEMI) {
+                if constexpr (SEMI) {                                    // (slabs blocked by (cout, 64-position tile))
 #pragma unroll
-                    for (int v = 0; v < M; ++v) tt[a][v] = src[(size_t)(a * M + v) * cstride];
+                    for (int v = 0; v < M; ++v) tt[a][v] = src[(a * M + v) * 64];
                 } else {
                     float m[N], y[M];
 #pragma unroll
-                    for (int c = 0; c < N; ++c) m[c] = src[(size_t)(a * N + c) * cstride];
+                    for (int c = 0; c < N; ++c) m[c] = src[(a * N + c) * 64];
                     wax_at<0>(m, y);
 #pragma unroll
                     for (int v = 0; v < M; ++v) tt[a][v] = y[v];

@@ -54,7 +54,7 @@ struct Geo {
 
 enum Route { R_STEM, R_HEAD, R_MFMA, R_LINEAR };
 
-enum { ALG_DIRECT = 0, ALG_WINO = 1, ALG_WINO2 = 2 };
+enum { ALG_DIRECT = 0, ALG_WINO = 1, ALG_WINO2 = 2, ALG_WINO3 = 3 };      // (WINO3: the three-axis form of the transposed layers)
 
 struct Wino2Geo { int ax, m, n, ncls, out, sg, wp, kw, bmax; int64_t w_elems, v_sample, pos_sample; };
 
@@ -91,6 +91,9 @@ int cout_pad(int cout);
 int wino_mode();
 bool wino_layer(const s3r_conv_desc* d);
 bool dwino_layer(const s3r_conv_desc* d);
+bool dwino3_layer(const s3r_conv_desc* d);
+bool dwino3_desc_ok(const s3r_conv_desc* d);
+int64_t dwino3_w_offset(const s3r_conv_desc* d);
 bool wino_desc_ok(const s3r_conv_desc* d);
 int wino2_ax(const s3r_conv_desc* d);
 bool wino2_desc_ok(const s3r_conv_desc* d);

@@ -181,6 +181,19 @@ bool dwino_layer(const s3r_conv_desc* d) {
     return d->dtype != S3R_BF16 && d->op == S3R_OP_DECONV && d->ndim == 3 && d->k == 4 && d->stride == 2 && d->pad == 1 &&
            d->cin % s3r::wino_bk() == 0 && d->in_size >= 4 && (d->in_size & 3) == 0;
 }
+// the three-axis form of a transposed layer (s3r_deconv_wino3.hip): whole padded rows per 64-position tile
+bool dwino3_layer(const s3r_conv_desc* d) {
+    return d->dtype != S3R_BF16 && d->op == S3R_OP_DECONV && d->ndim == 3 && d->k == 4 && d->stride == 2 && d->pad == 1 &&
+           d->cin % 16 == 0 && d->cout > 1 && s3r::dwino3_edge_ok(d->in_size);
+}
+bool dwino3_desc_ok(const s3r_conv_desc* d) {
+    return dwino3_layer(d) && d->act != S3R_ACT_SIGMOID && d->in_halo == 1 && d->ksplit <= 1 && d->in_layout == S3R_LAYOUT_PLAIN &&
+           d->out_layout == S3R_LAYOUT_PLAIN;
+}
+// its 8 x 27 class slabs sit behind the direct slab and the two-axis form's
+int64_t dwino3_w_offset(const s3r_conv_desc* d) {
+    return 64 * (int64_t)d->cin * cout_pad(d->cout) + (dwino_layer(d) ? dwino_w_elems(d) : 0);
+}
 // the descriptor can run its layer's Winograd form
 bool wino_desc_ok(const s3r_conv_desc* d) {
     if (!(wino_layer(d) || dwino_layer(d)) || d->act == S3R_ACT_SIGMOID || d->in_halo != 1 || d->ksplit > 1) return false;
@@ -218,6 +231,13 @@ int resolve_algo(const s3r_conv_desc* d, int* alg, int* form) {
     *form = -1;
     if (d->algo != S3R_ALGO_AUTO && d->algo != S3R_ALGO_DIRECT && d->algo != S3R_ALGO_WINOGRAD)
         return fail(S3R_ERR_INVALID, "unknown algo %d", d->algo);
+    if (d->algo == S3R_ALGO_WINOGRAD && d->tile == 6) {        // the three-axis form of a transposed layer
+        if (!dwino3_desc_ok(d))
+            return fail(S3R_ERR_INVALID, "algo = WINOGRAD, tile = 6: the three-axis form serves an fp32 ConvTranspose3d k4 s2 p1 over an edge of "
+                        "8, 16 or 32 with cin %% 16 == 0 (in_halo = 1, plain layouts, no split-K, no sigmoid)");
+        *alg = ALG_WINO3;
+        return S3R_OK;
+    }
     if (d->algo == S3R_ALGO_WINOGRAD) {
         const bool one = wino_desc_ok(d), two = wino2_desc_ok(d);
         // tile: -1 the library's pick between the forms the layer has; 0, 1, 2 a launch form of the one-axis kernel; 3 the two-axis
@@ -625,7 +645,7 @@ int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems) {
             const int64_t taps = d->op == S3R_OP_DECONV ? 64 : ipow(d->k, g.nd);
             if (d->dtype == S3R_BF16) *elems = (taps * d->cin * cout_pad_h(d->cout) + 1) / 2;   // bf16, in float units
             else *elems = taps * d->cin * cout_pad(d->cout) + (wino_layer(d) ? wino_w_elems(d) : 0) + (dwino_layer(d) ? dwino_w_elems(d) : 0) +
-                          (wino2_ax(d) >= 0 ? wino2_geo(d).w_elems : 0);
+                          (wino2_ax(d) >= 0 ? wino2_geo(d).w_elems : 0) + (dwino3_layer(d) ? s3r::dwino3_w_elems(d->cin, d->cout) : 0);
             break;
         }
     }
@@ -647,6 +667,7 @@ int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d) {
     }
     int alg, form;
     if ((rc = resolve_algo(d, &alg, &form))) return rc;
+    if (alg == ALG_WINO3) return (3 * (int64_t)d->batch * d->cin * ipow(d->in_size + 2, 3) + 255) / 256 * 256;      // Dh, Dd, Ddh
     if (alg == ALG_WINO) return wino_need(d, form, false).total;
     if (alg == ALG_WINO2) return wino2_need(d, form).total;
     s3r::ConvParams p = make_params(d, g);
