@@ -228,16 +228,27 @@ __global__ __launch_bounds__(256, 2) void dwino3_kernel(const ConvParams p) {
                 if (more) issue(cur == 0 ? D3_NST - 1 : cur - 1);    // into the stage tile g - 1 was read from
                 const float* A = ring + cur * G::STAGE + a_off;
                 const float* B = ring + cur * G::STAGE + D3_A + b_off;
+                // software pipeline over the k-steps: the fragments of step ks + 2 are requested in front of the matrix
+                // instructions of step ks (two waves per SIMD do not hide an LDS round trip per step on their own)
+                struct Frag { d3f2 P; float X2, a0, a1, a2; };
+                auto fetch = [&](int ks) __attribute__((always_inline)) {
+                    Frag f;
+                    f.P = *reinterpret_cast<const d3f2*>(B + ks * 2 * G::ROWS * G::RS);
+                    f.X2 = B[ks * 2 * G::ROWS * G::RS + 2];
+                    f.a0 = A[ks * 128]; f.a1 = A[D3_CK * 64 + ks * 128]; f.a2 = A[2 * D3_CK * 64 + ks * 128];
+                    return f;
+                };
+                Frag f0 = fetch(0), f1 = fetch(1);
 #pragma unroll
                 for (int ks = 0; ks < D3_CK / 2; ++ks) {
-                    const d3f2 P = *reinterpret_cast<const d3f2*>(B + ks * 2 * G::ROWS * G::RS);
-                    const float X2 = B[ks * 2 * G::ROWS * G::RS + 2];
-                    const float b0 = P[0] - P[1], b1 = P[1], b2 = P[1] - X2;
-                    const float a0 = A[ks * 128], a1 = A[D3_CK * 64 + ks * 128], a2 = A[2 * D3_CK * 64 + ks * 128];
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1], 0, 0, 0);
-                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc[2], 0, 0, 0);
-                    if (ks & 1) __builtin_amdgcn_sched_barrier(0);       // (fragments of two k-steps in flight, not of eight)
+                    Frag f2 = f1;
+                    if (ks + 2 < D3_CK / 2) f2 = fetch(ks + 2);
+                    const float b0 = f0.P[0] - f0.P[1], b1 = f0.P[1], b2 = f0.P[1] - f0.X2;
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.a0, b0, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.a1, b1, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.a2, b2, acc[2], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    f0 = f1; f1 = f2;
                 }
                 if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D3_NST - 2) * NPD) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

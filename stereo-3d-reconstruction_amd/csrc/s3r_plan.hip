@@ -274,6 +274,10 @@ int resolve_algo(const s3r_conv_desc* d, int* alg, int* form) {
     }
     if (d->algo == S3R_ALGO_DIRECT || d->tile >= 0 || d->ksplit >= 1 || wino_mode() <= 0) return S3R_OK;
     if (wino2_desc_ok(d) && d->in_size <= wino2_max_edge()) *alg = ALG_WINO2;
+    // transposed layers with an edge >= 16: the three-axis form (27 / 64 of the multiplications).  r05, d3 (16^3 -> 32^3, fused head)
+    // inside the forward: 0.694 -> 0.622 ms at B = 32, -4 % at B = 8 / 16, equal at 4, +5 % at B = 1 / 2 (serial form only: 64
+    // workgroups); at edge 8 (d2) its one round of long workgroups loses to the two-axis form's dual launch (0.438 vs 0.380 ms)
+    else if (d->op == S3R_OP_DECONV && dwino3_desc_ok(d) && d->in_size >= 16) *alg = ALG_WINO3;
     else if (wino_desc_ok(d)) *alg = ALG_WINO;
     return S3R_OK;
 }

@@ -65,6 +65,8 @@ def test_out_size_and_packed_elems(s3r, lib):
                 wino = 6 * 3 ** (nd - 1) * l.cin * pad if (l.op != "deconv3d" and l.k == 3 and l.s == 1 and l.p == 1) else 0
                 if l.op == "deconv3d":            # ... and a transposed convolution its 72 F(2,2)^2 (parity class, class) slabs of 2 taps
                     wino = 72 * 2 * l.cin * pad
+                    if n in (8, 16, 32):          # ... + the 8 x 27 slabs of the three-axis form (64-cout tiles)
+                        wino += 8 * 27 * l.cin * ((l.cout + 63) // 64 * 64)
                 if l.op == "conv3d" and l.s == 1 and l.k == 3 and l.p == 1:      # ... a 3D one also the 36 two-axis F(4,3)^2 slabs
                     wino += 36 * 3 * l.cin * pad
                 if l.op == "conv3d" and l.s == 1 and l.k == 4 and l.p == 0:      # (v6: 25 F(2,4)^2 slabs of 4 taps)

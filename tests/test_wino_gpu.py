@@ -538,3 +538,47 @@ def test_two_axis_conv2d_pairs_hand_over_transformed_planes(s3r, oracle):
             assert torch.equal(got, step), (a.name, edge, B, form, float((got - step).abs().max()))
         rel = float((step.cpu().double() - want).norm() / want.norm())
         assert rel < 1e-5, (edge, rel)
+
+
+def test_three_axis_transposed_form_vs_oracle_and_invariants(s3r, oracle):
+    """ConvTranspose3d k4 s2 p1 as F(2,2) along D, H AND W inside the parity classes (csrc/s3r_deconv_wino3.hip: 27 / 64 of the direct
+    multiplications; algo = WINOGRAD, tile = 6): against the oracle block at 1e-5 on layer shapes that fill neither a 64-cout tile nor
+    a 64-position tile, at edges 8 / 16 / 32, with and without the fused 1 x 1 x 1 head; deterministic; a sample's bits do not depend
+    on its batch; AUTO takes the form from edge 16 up (the network's d3) and the two-axis form below (d2)."""
+    dev, spec, L = "cuda:0", s3r.arch_spec, s3r._lib
+    Layer = spec.Layer
+    dec = {l.name: l for l in spec.DECODER}
+    cases = [([Layer("ta", "deconv3d", 32, 64, 4, 2, 1)], 8, 1), ([Layer("tb", "deconv3d", 64, 72, 4, 2, 1)], 8, 3),
+             ([Layer("tc", "deconv3d", 32, 24, 4, 2, 1)], 16, 2), ([Layer("td", "deconv3d", 16, 40, 4, 2, 1, True, "none")], 32, 1),
+             ([dec["d2"]], 8, 2), ([dec["d3"]], 16, 2), ([dec["d3"], dec["d4"]], 16, 3)]
+    for layers, n_in, B in cases:
+        first = layers[0].name
+        ch = s3r.modules._HipChain(layers, n_in, precision="fp32")
+        s3r.seed_module(ch, 7)
+        blocks = [oracle._Block(l).eval() for l in layers]
+        for l, blk in zip(layers, blocks):
+            blk.load_state_dict(getattr(ch, l.name).state_dict())
+        ch.to(dev)
+        x = torch.randn((B, layers[0].cin) + (n_in,) * 3, generator=torch.Generator().manual_seed(3))
+        with torch.no_grad():
+            want = x
+            for blk in blocks:
+                want = blk(want)
+            want = want.double()
+        auto = ch._run(x.to(dev)).clone()
+        ch.algo_override[first], ch.tile_override[first] = L.ALGO_WINOGRAD, 6
+        three = ch._run(x.to(dev)).clone()
+        assert torch.equal(three, ch._run(x.to(dev))), (first, "determinism")
+        assert torch.equal(ch._run(x[B - 1:].to(dev))[0], three[B - 1]), (first, "batch")
+        rel = float((three.cpu().double() - want).norm() / want.norm())
+        assert rel < 1e-5, (first, n_in, rel)
+        ch.tile_override[first] = -1                                 # algo = WINOGRAD, the library's pick: the two-axis form
+        two = ch._run(x.to(dev)).clone()
+        assert float((two.cpu().double() - want).norm() / want.norm()) < 1e-5
+        assert torch.equal(auto, three if n_in >= 16 else two), (first, n_in, "AUTO: three axes from edge 16 up")
+    bad = s3r.modules._HipChain([Layer("te", "deconv3d", 32, 32, 4, 2, 1)], 12, precision="fp32")      # edge 12: no such form
+    s3r.seed_module(bad, 1)
+    bad.to(dev)
+    bad.algo_override["te"], bad.tile_override["te"] = L.ALGO_WINOGRAD, 6
+    with pytest.raises(s3r.S3RError):
+        bad._run(torch.randn(1, 32, 12, 12, 12, device=dev))
