@@ -572,10 +572,13 @@ def test_three_axis_transposed_form_vs_oracle_and_invariants(s3r, oracle):
         assert torch.equal(ch._run(x[B - 1:].to(dev))[0], three[B - 1]), (first, "batch")
         rel = float((three.cpu().double() - want).norm() / want.norm())
         assert rel < 1e-5, (first, n_in, rel)
-        ch.tile_override[first] = -1                                 # algo = WINOGRAD, the library's pick: the two-axis form
-        two = ch._run(x.to(dev)).clone()
-        assert float((two.cpu().double() - want).norm() / want.norm()) < 1e-5
-        assert torch.equal(auto, three if n_in >= 16 else two), (first, n_in, "AUTO: three axes from edge 16 up")
+        if n_in >= 16:
+            assert torch.equal(auto, three), (first, n_in, "AUTO: three axes from edge 16 up")
+        elif layers[0].cin % 32 == 0:                                # (the two-axis form wants 32-channel K tiles)
+            ch.tile_override[first] = -1                             # algo = WINOGRAD, the library's pick: the two-axis form
+            two = ch._run(x.to(dev)).clone()
+            assert float((two.cpu().double() - want).norm() / want.norm()) < 1e-5
+            assert torch.equal(auto, two), (first, n_in, "AUTO: two axes below edge 16")
     bad = s3r.modules._HipChain([Layer("te", "deconv3d", 32, 32, 4, 2, 1)], 12, precision="fp32")      # edge 12: no such form
     s3r.seed_module(bad, 1)
     bad.to(dev)
