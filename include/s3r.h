@@ -60,7 +60,8 @@ typedef enum s3r_dtype {
                                  writes fp32 probabilities */
 } s3r_dtype;
 
-typedef enum s3r_act { S3R_ACT_NONE = 0, S3R_ACT_RELU = 1, S3R_ACT_SIGMOID = 2 } s3r_act;
+typedef enum s3r_act { S3R_ACT_NONE = 0, S3R_ACT_RELU = 1, S3R_ACT_SIGMOID = 2,
+                       S3R_ACT_LEAKY_RELU = 3, S3R_ACT_ELU = 4, S3R_ACT_TANH = 5 /* ABI 8: fp32 convolution layers only */ } s3r_act;
 
 /* Memory layout of an activation buffer (beyond NCHW vs channels-last, which the dtype fixes):
  *   S3R_LAYOUT_PLAIN   the (halo-padded) tensor as described under "Halos" below;
@@ -138,6 +139,15 @@ typedef struct s3r_conv_desc {
                           WINO_H (one-axis), WINO_DH (two-axis Conv3d), WINO_HW (two-axis Conv2d); in_halo must be 1 for those */
     int32_t out_layout;/* s3r_layout of the output buffer: PLAIN, or WINO_HW (a two-axis Conv2d writing its consumer's plane sets) */
     int32_t algo;      /* s3r_algo (ABI 7): AUTO = the library's geometry-only policy */
+    /* ABI 8 — parameter-general layers (fp32 path).  The shapes this build's network has keep their tuned kernels; any other
+     * (k, stride, pad, dilation) convolution with cin % 16 == 0 runs the direct kernel; everything else listed here goes through
+     * the direct kernel behind a staging pass (correct first, untuned): cin % 16 != 0 (channels zero-padded), ConvTranspose2d / 3d
+     * with any k / stride / pad / dilation / output padding (the input zero-stuffed at the stride, the kernel flipped), and the
+     * activations below (a pass of their own behind the convolution).  0 / 0 / 0.f are NOT the neutral values of `dilation`:
+     * a zero-initialised ABI-7 descriptor means dilation 1 and is read so. */
+    int32_t dilation;  /* >= 1 (0 is read as 1) */
+    int32_t out_pad;   /* ConvTranspose output_padding (< max(stride, dilation)) */
+    float act_param;   /* S3R_ACT_LEAKY_RELU: negative slope; S3R_ACT_ELU: alpha */
 } s3r_conv_desc;
 
 /* One layer of a stage: geometry + its packed weights + folded epilogue vectors (device pointers). */

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("S3R_LIB") or os.path.join(_HERE, "csrc", "libs3r_hip.
 
 OP_CONV, OP_DECONV, OP_LINEAR = 0, 1, 2
 DTYPE = {"fp32": 0, "bf16": 1}
-ACT = {"none": 0, "relu": 1, "sigmoid": 2}
+ACT = {"none": 0, "relu": 1, "sigmoid": 2, "leaky_relu": 3, "elu": 4, "tanh": 5}
 FAMILY = {0: "conv_mfma", 1: "stem", 2: "head", 3: "cost_volume", 4: "linear", 5: "chamfer", 6: "iou", 7: "pack",
           8: "pad_copy", 9: "disparity", 10: "aux"}      # aux: transform / finish passes, nested inside their layer's conv_mfma record
 ABI_VERSION = 8
@@ -27,7 +27,8 @@ RAN = {0: "direct", 1: "winograd-serial", 2: "winograd-class-parallel", 3: "wino
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("op", "ndim", "batch", "cin", "cout", "in_size", "k", "stride", "pad", "act", "tag", "tile",
-                 "in_halo", "out_halo", "ksplit", "dtype", "in_layout", "out_layout", "algo")]
+                 "in_halo", "out_halo", "ksplit", "dtype", "in_layout", "out_layout", "algo", "dilation", "out_pad")] + \
+               [("act_param", C.c_float)]
 
 
 class Layer(C.Structure):
@@ -131,10 +132,12 @@ LAYOUT_PLAIN, LAYOUT_WINO_H, LAYOUT_WINO_DH, LAYOUT_WINO_HW = 0, 2, 3, 4
 def make_desc(layer, batch, in_size, tag=0, tile=-1, in_halo=0, out_halo=0, ksplit=0, dtype=0, in_layout=0, out_layout=0,
               algo=0):
     """arch_spec.Layer -> ConvDesc.  algo: ALGO_AUTO (the library's geometry-only policy), ALGO_DIRECT, ALGO_WINOGRAD."""
-    op = {"conv2d": OP_CONV, "conv3d": OP_CONV, "deconv3d": OP_DECONV, "linear": OP_LINEAR}[layer.op]
-    nd = {"conv2d": 2, "conv3d": 3, "deconv3d": 3, "linear": 0}[layer.op]
+    from . import arch_spec as _spec
+    op = {"conv2d": OP_CONV, "conv3d": OP_CONV, "deconv3d": OP_DECONV, "deconv2d": OP_DECONV, "linear": OP_LINEAR}[layer.op]
+    nd = _spec.ndim(layer)
     return ConvDesc(op, nd, batch, layer.cin, layer.cout, in_size, layer.k, layer.s, layer.p, ACT[layer.act], tag,
-                    tile, in_halo, out_halo, ksplit, dtype, in_layout, out_layout, algo)
+                    tile, in_halo, out_halo, ksplit, dtype, in_layout, out_layout, algo, getattr(layer, "dil", 1),
+                    getattr(layer, "opad", 0), _spec.act_param(layer))
 
 
 def profile_enable(max_records):

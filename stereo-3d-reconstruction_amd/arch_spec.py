@@ -50,6 +50,12 @@ class Layer:
     p: int = 1
     bn: bool = True
     act: str = "relu"
+    # parameter-general layers (r05: what a reference layer table may hold beyond this build's own shapes; the network above uses
+    # none of them).  dil: dilation; opad: ConvTranspose output_padding; act also "leaky_relu" | "elu" | "tanh", act_param its
+    # slope / alpha (None: torch's default, 0.01 / 1.0); op also "deconv2d"
+    dil: int = 1
+    opad: int = 0
+    act_param: float = None
 
     def as_dict(self):
         return asdict(self)
@@ -93,15 +99,22 @@ POINT_HEAD: Tuple[Layer, ...] = (
 
 
 def out_size(layer: Layer, n: int) -> int:
-    if layer.op == "deconv3d":
-        return (n - 1) * layer.s - 2 * layer.p + layer.k
+    if layer.op in ("deconv3d", "deconv2d"):
+        return (n - 1) * layer.s - 2 * layer.p + layer.dil * (layer.k - 1) + layer.opad + 1
     if layer.op == "linear":
         return 1
-    return (n + 2 * layer.p - layer.k) // layer.s + 1
+    return (n + 2 * layer.p - layer.dil * (layer.k - 1) - 1) // layer.s + 1
 
 
 def ndim(layer: Layer) -> int:
-    return {"conv2d": 2, "conv3d": 3, "deconv3d": 3, "linear": 0}[layer.op]
+    return {"conv2d": 2, "conv3d": 3, "deconv3d": 3, "deconv2d": 2, "linear": 0}[layer.op]
+
+
+def act_param(layer: Layer) -> float:
+    """Slope of leaky_relu / alpha of elu (torch's defaults when the layer does not say)."""
+    if layer.act_param is not None:
+        return float(layer.act_param)
+    return {"leaky_relu": 0.01, "elu": 1.0}.get(layer.act, 0.0)
 
 
 def trace(layers, n_in: int) -> List[Tuple[Layer, int, int]]:
@@ -119,7 +132,7 @@ def layer_macs(layer: Layer, n_in: int) -> int:
     d, n_out = ndim(layer), out_size(layer, n_in)
     if layer.op == "linear":
         return layer.cin * layer.cout
-    if layer.op == "deconv3d":   # every input voxel meets every kernel tap once
+    if layer.op in ("deconv3d", "deconv2d"):   # every input voxel meets every kernel tap once
         return layer.cin * n_in ** d * layer.cout * layer.k ** d
     return layer.cout * n_out ** d * layer.cin * layer.k ** d
 

@@ -229,7 +229,10 @@ int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, void* packedv,
             if (d->dtype == S3R_BF16)
                 e = s3r::launch_pack_bf16(w, packed, d->cin, d->cout, cout_pad_h(d->cout),
                                           d->op == S3R_OP_DECONV ? 8 : (int)ipow(d->k, g.nd), d->op == S3R_OP_DECONV, s);
-            else {
+            else if (staged_layer(d)) {
+                e = s3r::launch_pack_general(w, packed, d->cin, staged_geo(d).cin_pad, d->cout, cout_pad(d->cout), (int)ipow(d->k, g.nd),
+                                             d->op == S3R_OP_DECONV, s);
+            } else {
                 e = s3r::launch_pack_conv(w, packed, d->cin, d->cout, cout_pad(d->cout),
                                           d->op == S3R_OP_DECONV ? 8 : (int)ipow(d->k, g.nd), d->op == S3R_OP_DECONV, s);
                 if (e == hipSuccess && wino_layer(d))
@@ -349,10 +352,45 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
             break;
         }
         case R_MFMA: {
-            s3r::ConvParams p = make_params(d, g);
-            p.x = x; p.w = packed_w; p.scale = scale; p.shift = shift; p.y = y;
             int alg, form;
             if ((rc = resolve_algo(d, &alg, &form))) return rc;
+            if (staged_layer(d) || d->act > S3R_ACT_SIGMOID) {
+                // ---- parameter-general layer: [staged copy ->] direct kernel [-> activation pass]
+                s3r::ConvParams q = staged_layer(d) ? make_params_staged(d, g) : make_params(d, g);
+                q.x = x; q.w = packed_w; q.scale = scale; q.shift = shift; q.y = y;
+                ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
+                ps.launches = 0;
+                if (staged_layer(d)) {
+                    const StagedGeo sg = staged_geo(d);
+                    const int64_t need = (sg.elems + 255) / 256 * 256;
+                    if (!scratch || scratch_elems < need)
+                        return fail(S3R_ERR_WORKSPACE, "a parameter-general layer stages its input in %lld floats of scratch "
+                                    "(s3r_conv_scratch_elems), got %lld", (long long)need, (long long)(scratch ? scratch_elems : 0));
+                    if (sg.elems * 4 >= kMaxBytes) return fail(S3R_ERR_INVALID, "staged input too large for one call: split the batch");
+                    s3r::AuxScope aux(s, 4.0 * ((double)g.x_elems + (double)sg.elems));
+                    e = s3r::launch_stage(x, scratch, d->batch, d->cin, sg.cin_pad, g.nd, d->in_size, d->in_halo, sg.sp, sg.pe, sg.step, s);
+                    if (e != hipSuccess) return hip_fail(e, "staging launch");
+                    q.x = scratch;
+                    ps.launches += 2;
+                    ps.exec = 2.0 * d->batch * (double)d->cout * (double)g.out_sp * sg.cin_pad * (double)ipow(d->k, g.nd);
+                }
+                Launch L;
+                s3r_conv_desc dd = *d;
+                dd.ksplit = 1;                                   // (no split-K slabs behind the staged copy)
+                if ((rc = resolve_launch(&dd, &q, &L))) return rc;
+                e = s3r::launch_conv_mfma(q, L.cfg + 16 * L.vec, s);
+                if (e != hipSuccess) return hip_fail(e, "conv forward launch");
+                ps.launches += s3r::conv_last_launch_count();
+                if (d->act > S3R_ACT_SIGMOID) {
+                    s3r::AuxScope aux(s, 8.0 * (double)g.y_elems);
+                    e = s3r::launch_act(y, g.y_elems, d->act, d->act_param, s);
+                    if (e != hipSuccess) return hip_fail(e, "activation launch");
+                    ps.launches += 1;
+                }
+                return S3R_OK;
+            }
+            s3r::ConvParams p = make_params(d, g);
+            p.x = x; p.w = packed_w; p.scale = scale; p.shift = shift; p.y = y;
             const bool wino = alg == ALG_WINO;
             if (alg == ALG_WINO2) {
                 ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);

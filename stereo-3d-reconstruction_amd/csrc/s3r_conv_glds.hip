@@ -215,7 +215,7 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, const int bi
         }
         // ---- gathered input: 16 channels of chunk c_cc at tap (c_td, c_th, c_tw)
         float* sb = Bs + buf * BK * BN + b_lds0;
-        const int b_base = ((c_cc * BK + b_row0) * p.x_cs + c_td * p.x_ds + c_th * p.x_hs + c_tw) * 4;
+        const int b_base = ((c_cc * BK + b_row0) * p.x_cs + (c_td * p.x_ds + c_th * p.x_hs + c_tw) * p.dil) * 4;
 #pragma unroll
         for (int q = 0; q < NPB; ++q)
             dma_to_lds<4 * VEC>(xrsrc, sb + q * B_LDS_STEP, bvoff, b_base + q * B_ROW_STEP * cs4);

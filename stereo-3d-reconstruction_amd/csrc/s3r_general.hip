@@ -1,0 +1,93 @@
+// Parameter-general layers (ABI 8), correctness first: what lets ANY fp32 Conv / ConvTranspose (2D or 3D; k, stride, pad, dilation,
+// output padding; any channel count; LeakyReLU / ELU / Tanh) run on the direct implicit-GEMM kernel of s3r_conv_glds.hip.
+//
+//   stage_kernel         x (B, Cin, n [+ 2 halo] ...) -> staged (B, CinPad, U + 2 pe, ...), zero everywhere else: channels padded to a
+//                        multiple of 16, the convolution's zero padding pe materialised as a halo, and — transposed layers — the input
+//                        ZERO-STUFFED at the stride (sample i at position pe + i * stride).  A ConvTranspose(k, s, p, d, op) is then
+//                        the stride-1 convolution of the stuffed tensor (edge (n - 1) s + 1 + op) with the flipped kernel, dilation d
+//                        and padding d (k - 1) - p: s^ndim times the multiplications of the parity-class form the tuned k4 s2 p1
+//                        path uses, which is the price of "any".
+//   pack_general_kernel  torch weights -> the direct kernel's packed K order with CinPad rows (zeros beyond Cin), flipped for
+//                        transposed layers
+//   act_kernel           LeakyReLU / ELU / Tanh in place (the MFMA epilogues know none / ReLU / sigmoid); act(0) = 0 keeps halos zero
+#include "s3r_kernels.h"
+
+namespace s3r {
+
+__global__ __launch_bounds__(256) void stage_kernel(const float* __restrict__ x, float* __restrict__ y, long long total, int Cin, int CinPad,
+                                                    int nd, int n, int x_hs, int x_ds, int x_cs, int x_org, int sp, int pe, int step) {
+    // one thread per INPUT element (b, c, d, h, w): scattered to its staged position; the rest of y was zeroed by the caller
+    const long long S = nd == 3 ? (long long)n * n * n : (long long)n * n;
+    const long long y_cs = nd == 3 ? (long long)sp * sp * sp : (long long)sp * sp;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long bc = i / S;
+        long long r = i - bc * S;
+        const int w = (int)(r % n); r /= n;
+        const int hh = (int)(r % n); r /= n;
+        const int dd = (int)r;                                   // (0 in 2D)
+        const long long b = bc / Cin;
+        const int c = (int)(bc - b * Cin);
+        const float v = x[bc * x_cs + x_org + (long long)dd * x_ds + (long long)hh * x_hs + w];
+        long long o = (b * CinPad + c) * y_cs + (long long)(pe + hh * step) * sp + (pe + w * step);
+        if (nd == 3) o += (long long)(pe + dd * step) * sp * sp;
+        y[o] = v;
+    }
+}
+
+hipError_t launch_stage(const float* x, float* y, int B, int Cin, int CinPad, int nd, int n, int in_halo, int sp, int pe, int step,
+                        hipStream_t s) {
+    const long long S = nd == 3 ? (long long)n * n * n : (long long)n * n;
+    const long long total = (long long)B * Cin * S;
+    const long long y_elems = (long long)B * CinPad * (nd == 3 ? (long long)sp * sp * sp : (long long)sp * sp);
+    hipError_t e = hipMemsetAsync(y, 0, (size_t)y_elems * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    const int np = n + 2 * in_halo;
+    const int x_hs = np, x_ds = nd == 3 ? np * np : 0, x_cs = nd == 3 ? np * np * np : np * np;
+    const int x_org = in_halo * (x_ds + x_hs + 1);
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(stage_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, x, y, total, Cin, CinPad, nd, n,
+                       x_hs, x_ds, x_cs, x_org, sp, pe, step);
+    return hipGetLastError();
+}
+
+// wp[(chunk * T + tap) * 16 + c][CoutPad]; conv: w[Cout][Cin][taps]; transposed: w[Cin][Cout][taps] read at the FLIPPED tap
+__global__ void pack_general_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int CinPad, int Cout, int CoutPad, int T,
+                                    int flip) {
+    const size_t total = (size_t)T * CinPad * CoutPad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int co = (int)(r % CoutPad); r /= CoutPad;
+        const int c = (int)(r & 15); r >>= 4;
+        const int tap = (int)(r % T);
+        const int cin = (int)(r / T) * 16 + c;
+        float v = 0.f;
+        if (co < Cout && cin < Cin)
+            v = flip ? w[((size_t)cin * Cout + co) * T + (T - 1 - tap)] : w[((size_t)co * Cin + cin) * T + tap];
+        wp[i] = v;
+    }
+}
+
+hipError_t launch_pack_general(const float* w, float* wp, int Cin, int CinPad, int Cout, int CoutPad, int T, int flip, hipStream_t s) {
+    hipLaunchKernelGGL(pack_general_kernel, dim3(1024), dim3(256), 0, s, w, wp, Cin, CinPad, Cout, CoutPad, T, flip);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void act_kernel(float* __restrict__ y, long long total, int act, float param) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const float v = y[i];
+        float o;
+        if (act == 3) o = v > 0.f ? v : v * param;                       // LeakyReLU
+        else if (act == 4) o = v > 0.f ? v : param * expm1f(v);          // ELU
+        else o = tanhf(v);                                               // Tanh
+        y[i] = o;
+    }
+}
+
+hipError_t launch_act(float* y, long long total, int act, float param, hipStream_t s) {
+    if (act < 3 || act > 5) return hipErrorInvalidValue;
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(act_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, y, total, act, param);
+    return hipGetLastError();
+}
+
+}  // namespace s3r

@@ -83,6 +83,11 @@ int hip_fail(hipError_t e, const char* what);
 int64_t ipow(int64_t b, int e);
 int wino_r(const s3r_conv_desc*);
 int out_size(const s3r_conv_desc* d);
+int dil_of(const s3r_conv_desc* d);
+bool staged_layer(const s3r_conv_desc* d);
+struct StagedGeo { int cin_pad, step, pe, sp; int64_t elems; };
+StagedGeo staged_geo(const s3r_conv_desc* d);
+s3r::ConvParams make_params_staged(const s3r_conv_desc* d, const Geo& g);
 int geometry(const s3r_conv_desc* d, Geo* g);
 int route(const s3r_conv_desc* d, Route* r);
 int need_halo(const s3r_conv_desc* d, Route r);

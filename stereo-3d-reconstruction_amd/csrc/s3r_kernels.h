@@ -95,6 +95,7 @@ struct ConvParams {
     FastDiv dS, dHW, dW;  // fast division by Nd*Nh*Nw, Nh*Nw, Nw
     int kd, kh, kw, T;    // taps per axis and in total (transposed k4s2p1: 2,2,2 per parity class)
     int stride;           // input step per position (transposed: 1)
+    int dil;              // dilation: taps are dil input elements apart (the direct kernel only; >= 1)
     int x_cs, x_ds, x_hs; // input element strides: channel, depth, row   (batch stride = Cin * x_cs)
     int x_org;            // element offset of tap (0,0,0) of position (0,0,0): (halo_in - pad) per axis
     int y_cs, y_ds, y_hs; // output element strides
@@ -163,7 +164,7 @@ struct ConvParamsH {
     int head_act;
 };
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };      // (the epilogues'; LeakyReLU / ELU / Tanh run as launch_act behind ACT_NONE)
 
 // launchers (defined in the .hip files); every launcher enqueues on `stream` and returns hipGetLastError()
 hipError_t launch_conv_mfma(const ConvParams& p, int tile_code, hipStream_t stream);   // code = cfg + 16*vec
@@ -222,6 +223,12 @@ hipError_t launch_cost_volume(const float* fl, const float* fr, float* vol, int 
                               int halo, hipStream_t s);
 // the same volume written as the Winograd F(R,3)-along-H plane sets of its halo-1 padded form: V[R+2][B][2C][D+2][H/R][W+2]
 hipError_t launch_cost_volume_wino(const float* fl, const float* fr, float* V, int B, int C, int D, int H, int W, int R, hipStream_t s);
+// parameter-general layers (s3r_general.hip): staged input (channel padding, padding halo, zero-stuffing), general weight packing,
+// LeakyReLU / ELU / Tanh as a pass of their own
+hipError_t launch_stage(const float* x, float* y, int B, int Cin, int CinPad, int nd, int n, int in_halo, int sp, int pe, int step,
+                        hipStream_t s);
+hipError_t launch_pack_general(const float* w, float* wp, int Cin, int CinPad, int Cout, int CoutPad, int T, int flip, hipStream_t s);
+hipError_t launch_act(float* y, long long total, int act, float param, hipStream_t s);
 hipError_t launch_pad_copy(const float* x, float* y, int64_t planes, int D, int H, int W, int hd, int hh, int hw,
                            hipStream_t s);
 hipError_t launch_pack_stem(const float* w, float* wt, hipStream_t s);

@@ -41,10 +41,46 @@ const char* last_error() { return g_err; }
 
 // ---------------------------------------------------------------- layer geometry
 
+int dil_of(const s3r_conv_desc* d) { return d->dilation > 0 ? d->dilation : 1; }      // (a zero-initialised ABI-7 descriptor: 1)
+
 int out_size(const s3r_conv_desc* d) {
     if (d->op == S3R_OP_LINEAR) return 1;
-    if (d->op == S3R_OP_DECONV) return (d->in_size - 1) * d->stride - 2 * d->pad + d->k;
-    return (d->in_size + 2 * d->pad - d->k) / d->stride + 1;
+    if (d->op == S3R_OP_DECONV) return (d->in_size - 1) * d->stride - 2 * d->pad + dil_of(d) * (d->k - 1) + d->out_pad + 1;
+    const int span = d->in_size + 2 * d->pad - dil_of(d) * (d->k - 1) - 1;
+    return span < 0 ? 0 : span / d->stride + 1;
+}
+
+// the transposed layer the tuned kernels serve (8 output-parity classes of 2 x 2 x 2 taps; Winograd forms)
+static bool deconv_fast(const s3r_conv_desc* d) {
+    return d->op == S3R_OP_DECONV && d->ndim == 3 && d->k == 4 && d->stride == 2 && d->pad == 1 && dil_of(d) == 1 && d->out_pad == 0;
+}
+static bool stem_shape(const s3r_conv_desc* d) {
+    return d->op == S3R_OP_CONV && d->ndim == 2 && d->cin == 3 && d->cout == 32 && d->k == 3 && d->stride == 2 && d->pad == 1 &&
+           d->act == S3R_ACT_RELU && dil_of(d) == 1;
+}
+static bool head_shape(const s3r_conv_desc* d) {
+    return d->op == S3R_OP_CONV && d->cout == 1 && d->k == 1 && d->stride == 1 && d->pad == 0 && d->act <= S3R_ACT_SIGMOID &&
+           (ipow(d->in_size, d->ndim) % 4) == 0;
+}
+// Parameter-general layers (ABI 8, s3r_general.hip): an fp32 convolution whose channel count is not a multiple of 16, or any
+// transposed convolution but the tuned one, runs the direct kernel over a STAGED copy of its input (channels zero-padded, the
+// padding as a halo, transposed: zero-stuffed at the stride).  Correct first; the network's own shapes never take this path.
+bool staged_layer(const s3r_conv_desc* d) {
+    if (d->dtype != S3R_F32 || (d->op != S3R_OP_CONV && d->op != S3R_OP_DECONV) || (d->ndim != 2 && d->ndim != 3)) return false;
+    if (stem_shape(d) || head_shape(d)) return false;
+    if (d->op == S3R_OP_DECONV) return !(deconv_fast(d) && d->cin % 16 == 0);
+    return d->cin % 16 != 0;
+}
+StagedGeo staged_geo(const s3r_conv_desc* d) {
+    StagedGeo s;
+    s.cin_pad = (d->cin + 15) / 16 * 16;
+    const bool tr = d->op == S3R_OP_DECONV;
+    s.step = tr ? d->stride : 1;
+    s.pe = tr ? dil_of(d) * (d->k - 1) - d->pad : d->pad;
+    const int u = tr ? (d->in_size - 1) * d->stride + 1 + d->out_pad : d->in_size;
+    s.sp = u + 2 * s.pe;
+    s.elems = (int64_t)d->batch * s.cin_pad * ipow(s.sp, d->ndim);
+    return s;
 }
 
 int geometry(const s3r_conv_desc* d, Geo* g) {
@@ -73,8 +109,20 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
     if (d->op != S3R_OP_CONV && d->op != S3R_OP_DECONV) return fail(S3R_ERR_INVALID, "unknown op %d", d->op);
     if (d->ndim != 2 && d->ndim != 3) return fail(S3R_ERR_INVALID, "ndim must be 2 or 3");
     if (d->in_size <= 0 || d->k <= 0 || d->stride <= 0 || d->pad < 0) return fail(S3R_ERR_INVALID, "bad size/k/stride/pad");
-    if (d->op == S3R_OP_DECONV && !(d->ndim == 3 && d->k == 4 && d->stride == 2 && d->pad == 1))
-        return fail(S3R_ERR_INVALID, "ConvTranspose is supported for ndim=3,k=4,s=2,p=1 only");
+    if (d->dilation < 0 || d->out_pad < 0) return fail(S3R_ERR_INVALID, "dilation / out_pad must not be negative");
+    if (d->act < S3R_ACT_NONE || d->act > S3R_ACT_TANH) return fail(S3R_ERR_INVALID, "unknown activation %d", d->act);
+    if (d->dtype == S3R_BF16 && (dil_of(d) != 1 || d->out_pad != 0 || d->act > S3R_ACT_SIGMOID || (d->op == S3R_OP_DECONV && !deconv_fast(d))))
+        return fail(S3R_ERR_INVALID, "bf16 path: Conv with dilation 1 / ConvTranspose3d k4 s2 p1 and none / relu / sigmoid only (the "
+                    "parameter-general layers are fp32)");
+    if (d->op == S3R_OP_CONV && d->out_pad != 0) return fail(S3R_ERR_INVALID, "out_pad belongs to transposed convolutions");
+    if (d->op == S3R_OP_DECONV && !deconv_fast(d)) {
+        if (dil_of(d) * (d->k - 1) - d->pad < 0)
+            return fail(S3R_ERR_INVALID, "ConvTranspose with pad %d > dilation * (k - 1) = %d crops more than the kernel reaches: not supported",
+                        d->pad, dil_of(d) * (d->k - 1));
+        if (d->out_pad >= (d->stride > dil_of(d) ? d->stride : dil_of(d)))
+            return fail(S3R_ERR_INVALID, "out_pad %d must be smaller than max(stride, dilation)", d->out_pad);
+    }
+    if (staged_layer(d) && staged_geo(d).pe > 8) return fail(S3R_ERR_INVALID, "effective padding %d > 8", staged_geo(d).pe);
     g->nd = d->ndim;
     g->in = d->in_size;
     g->out = out_size(d);
@@ -131,18 +179,16 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
 // which kernel serves a layer shape (halos are checked separately, by check_halos)
 int route(const s3r_conv_desc* d, Route* r) {
     if (d->op == S3R_OP_LINEAR) { *r = R_LINEAR; return S3R_OK; }
-    if (d->op == S3R_OP_CONV && d->ndim == 2 && d->cin == 3 && d->cout == 32 && d->k == 3 && d->stride == 2 &&
-        d->pad == 1 && d->act == S3R_ACT_RELU) { *r = R_STEM; return S3R_OK; }
-    if (d->op == S3R_OP_CONV && d->cout == 1 && d->k == 1 && d->stride == 1 && d->pad == 0 &&
-        (ipow(d->in_size, d->ndim) % 4) == 0) { *r = R_HEAD; return S3R_OK; }
-    if (d->dtype == S3R_BF16 ? d->cin % 32 == 0 : d->cin % 16 == 0) { *r = R_MFMA; return S3R_OK; }
+    if (stem_shape(d)) { *r = R_STEM; return S3R_OK; }
+    if (head_shape(d)) { *r = R_HEAD; return S3R_OK; }
+    if (d->dtype == S3R_BF16 ? d->cin % 32 == 0 : (d->cin % 16 == 0 || staged_layer(d))) { *r = R_MFMA; return S3R_OK; }
     return fail(S3R_ERR_INVALID, "no kernel for this layer shape (cin=%d cout=%d k=%d s=%d p=%d ndim=%d): the MFMA path "
                 "needs cin %% 16 == 0", d->cin, d->cout, d->k, d->stride, d->pad, d->ndim);
 }
 
 // input halo the layer's kernel needs (the MFMA gather reads its zero padding from memory)
 int need_halo(const s3r_conv_desc* d, Route r) {
-    if (r != R_MFMA) return 0;
+    if (r != R_MFMA || staged_layer(d)) return 0;          // (a staged layer builds its own padded copy)
     return d->op == S3R_OP_DECONV ? 1 : d->pad;
 }
 
@@ -178,16 +224,14 @@ bool wino_layer(const s3r_conv_desc* d) {
            d->pad == 1 && d->cin % s3r::wino_bk() == 0 && d->cout > 1 && d->in_size >= 4;
 }
 bool dwino_layer(const s3r_conv_desc* d) {
-    return d->dtype != S3R_BF16 && d->op == S3R_OP_DECONV && d->ndim == 3 && d->k == 4 && d->stride == 2 && d->pad == 1 &&
-           d->cin % s3r::wino_bk() == 0 && d->in_size >= 4 && (d->in_size & 3) == 0;
+    return d->dtype != S3R_BF16 && deconv_fast(d) && d->cin % s3r::wino_bk() == 0 && d->in_size >= 4 && (d->in_size & 3) == 0;
 }
 // the three-axis form of a transposed layer (s3r_deconv_wino3.hip): whole padded rows per 64-position tile
 bool dwino3_layer(const s3r_conv_desc* d) {
-    return d->dtype != S3R_BF16 && d->op == S3R_OP_DECONV && d->ndim == 3 && d->k == 4 && d->stride == 2 && d->pad == 1 &&
-           d->cin % 16 == 0 && d->cout > 1 && s3r::dwino3_edge_ok(d->in_size);
+    return d->dtype != S3R_BF16 && deconv_fast(d) && d->cin % 16 == 0 && d->cout > 1 && s3r::dwino3_edge_ok(d->in_size);
 }
 bool dwino3_desc_ok(const s3r_conv_desc* d) {
-    return dwino3_layer(d) && d->act != S3R_ACT_SIGMOID && d->in_halo == 1 && d->ksplit <= 1 && d->in_layout == S3R_LAYOUT_PLAIN &&
+    return dwino3_layer(d) && d->act < S3R_ACT_SIGMOID && d->in_halo == 1 && d->ksplit <= 1 && d->in_layout == S3R_LAYOUT_PLAIN &&
            d->out_layout == S3R_LAYOUT_PLAIN;
 }
 // its 8 x 27 class slabs sit behind the direct slab and the two-axis form's
@@ -196,7 +240,7 @@ int64_t dwino3_w_offset(const s3r_conv_desc* d) {
 }
 // the descriptor can run its layer's Winograd form
 bool wino_desc_ok(const s3r_conv_desc* d) {
-    if (!(wino_layer(d) || dwino_layer(d)) || d->act == S3R_ACT_SIGMOID || d->in_halo != 1 || d->ksplit > 1) return false;
+    if (!(wino_layer(d) || dwino_layer(d)) || d->act >= S3R_ACT_SIGMOID || d->in_halo != 1 || d->ksplit > 1 || dil_of(d) != 1) return false;
     if (d->out_layout != S3R_LAYOUT_PLAIN) return false;
     return d->in_layout == S3R_LAYOUT_PLAIN || (d->in_layout == S3R_LAYOUT_WINO_H && wino_layer(d));
 }
@@ -213,7 +257,7 @@ int wino2_ax(const s3r_conv_desc* d) {
     return -1;
 }
 bool wino2_desc_ok(const s3r_conv_desc* d) {
-    return wino2_ax(d) >= 0 && d->act != S3R_ACT_SIGMOID && d->in_halo == d->pad && d->ksplit <= 1 &&
+    return wino2_ax(d) >= 0 && d->act < S3R_ACT_SIGMOID && dil_of(d) == 1 && d->in_halo == d->pad && d->ksplit <= 1 &&
            (d->in_layout == S3R_LAYOUT_PLAIN || (d->in_layout == S3R_LAYOUT_WINO_DH && wino2_ax(d) == 0 && d->in_size % 4 == 0) ||
             (d->in_layout == S3R_LAYOUT_WINO_HW && wino2_ax(d) == 2 && d->in_size % 4 == 0)) &&
            (d->out_layout == S3R_LAYOUT_PLAIN || (d->out_layout == S3R_LAYOUT_WINO_HW && wino2_ax(d) == 2 && d->in_size % 4 == 0));
@@ -231,6 +275,13 @@ int resolve_algo(const s3r_conv_desc* d, int* alg, int* form) {
     *form = -1;
     if (d->algo != S3R_ALGO_AUTO && d->algo != S3R_ALGO_DIRECT && d->algo != S3R_ALGO_WINOGRAD)
         return fail(S3R_ERR_INVALID, "unknown algo %d", d->algo);
+    if (staged_layer(d) || d->act > S3R_ACT_SIGMOID || dil_of(d) != 1) {      // parameter-general layers: the direct kernel
+        if (d->algo == S3R_ALGO_WINOGRAD) return fail(S3R_ERR_INVALID, "algo = WINOGRAD: a parameter-general layer (staged input, dilation, "
+                                                      "LeakyReLU / ELU / Tanh) has no Winograd form");
+        if (d->in_layout != S3R_LAYOUT_PLAIN || d->out_layout != S3R_LAYOUT_PLAIN)
+            return fail(S3R_ERR_INVALID, "a parameter-general layer reads and writes plain layouts");
+        return S3R_OK;
+    }
     if (d->algo == S3R_ALGO_WINOGRAD && d->tile == 6) {        // the three-axis form of a transposed layer
         if (!dwino3_desc_ok(d))
             return fail(S3R_ERR_INVALID, "algo = WINOGRAD, tile = 6: the three-axis form serves an fp32 ConvTranspose3d k4 s2 p1 over an edge of "
@@ -485,11 +536,34 @@ s3r::ConvParams make_params(const s3r_conv_desc* d, const Geo& g) {
         p.stride = d->stride;
         p.x_org = (d->in_halo - d->pad) * (p.x_ds + p.x_hs + 1);
     }
+    p.dil = dil_of(d);
+    if (p.act > S3R_ACT_SIGMOID) p.act = S3R_ACT_NONE;     // (LeakyReLU / ELU / Tanh: launch_act behind the convolution)
     p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
     p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
     p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
     p.dW = s3r::FastDiv((unsigned)p.Nw);
     p.ksplit = 1;
+    return p;
+}
+
+// a staged layer as the direct kernel sees it: a convolution (stride 1 if the layer is transposed) over the staged tensor, whose
+// halo is exactly the effective padding
+s3r::ConvParams make_params_staged(const s3r_conv_desc* d, const Geo& g) {
+    s3r::ConvParams p = make_params(d, g);
+    const StagedGeo sg = staged_geo(d);
+    const bool is3 = d->ndim == 3;
+    p.Cin = sg.cin_pad;
+    p.transposed = 0;
+    p.x_hs = sg.sp; p.x_ds = is3 ? sg.sp * sg.sp : 0; p.x_cs = (int)ipow(sg.sp, g.nd);
+    p.x_org = 0;
+    p.x_bytes = (unsigned)(sg.elems * 4);
+    p.Nd = is3 ? g.out : 1; p.Nh = g.out; p.Nw = g.out;
+    p.kd = is3 ? d->k : 1; p.kh = d->k; p.kw = d->k; p.T = p.kd * p.kh * p.kw;
+    p.stride = d->op == S3R_OP_DECONV ? 1 : d->stride;
+    p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
+    p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
+    p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
+    p.dW = s3r::FastDiv((unsigned)p.Nw);
     return p;
 }
 
@@ -580,7 +654,7 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
     // 1x1 single-channel head, runs the head inside its epilogue; its own output is never materialised
     for (int i = 0; i + 1 < n; ++i) {
         if (pl->r[i] != R_MFMA || pl->r[i + 1] != R_HEAD || pl->d[i].cout > 64) continue;
-        if (pl->d[i + 1].cin != pl->d[i].cout || pl->d[i].out_halo != 0 || pl->d[i].act == S3R_ACT_SIGMOID) continue;
+        if (pl->d[i + 1].cin != pl->d[i].cout || pl->d[i].out_halo != 0 || pl->d[i].act >= S3R_ACT_SIGMOID || staged_layer(&pl->d[i])) continue;
         if (pl->d[i].op == S3R_OP_CONV && resolves_to_wino(&pl->d[i])) continue;     // (the Winograd conv kernel has no fused-head epilogue)
         if (pl->d[i].dtype == S3R_BF16) {
             s3r::ConvParamsH ph = make_params_h(&pl->d[i], pl->g[i]);
@@ -646,6 +720,7 @@ int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems) {
         case R_HEAD: *elems = d->cin; break;
         case R_LINEAR: *elems = g.w_elems; break;
         case R_MFMA: {
+            if (staged_layer(d)) { *elems = ipow(d->k, g.nd) * staged_geo(d).cin_pad * cout_pad(d->cout); break; }
             const int64_t taps = d->op == S3R_OP_DECONV ? 64 : ipow(d->k, g.nd);
             if (d->dtype == S3R_BF16) *elems = (taps * d->cin * cout_pad_h(d->cout) + 1) / 2;   // bf16, in float units
             else *elems = taps * d->cin * cout_pad(d->cout) + (wino_layer(d) ? wino_w_elems(d) : 0) + (dwino_layer(d) ? dwino_w_elems(d) : 0) +
@@ -671,6 +746,7 @@ int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d) {
     }
     int alg, form;
     if ((rc = resolve_algo(d, &alg, &form))) return rc;
+    if (staged_layer(d)) return (staged_geo(d).elems + 255) / 256 * 256;          // the staged copy (no split-K behind it)
     if (alg == ALG_WINO3) return (3 * (int64_t)d->batch * d->cin * ipow(d->in_size + 2, 3) + 255) / 256 * 256;      // Dh, Dd, Ddh
     if (alg == ALG_WINO) return wino_need(d, form, false).total;
     if (alg == ALG_WINO2) return wino2_need(d, form).total;

@@ -123,14 +123,19 @@ class _Block(nn.Module):
         super().__init__()
         self.layer = layer
         if layer.op == "conv2d":
-            self.conv = nn.Conv2d(layer.cin, layer.cout, layer.k, layer.s, layer.p, bias=True)
+            self.conv = nn.Conv2d(layer.cin, layer.cout, layer.k, layer.s, layer.p, dilation=layer.dil, bias=True)
             self.bn = nn.BatchNorm2d(layer.cout, eps=spec.BN_EPS) if layer.bn else None
         elif layer.op == "conv3d":
-            self.conv = nn.Conv3d(layer.cin, layer.cout, layer.k, layer.s, layer.p, bias=True)
+            self.conv = nn.Conv3d(layer.cin, layer.cout, layer.k, layer.s, layer.p, dilation=layer.dil, bias=True)
             self.bn = nn.BatchNorm3d(layer.cout, eps=spec.BN_EPS) if layer.bn else None
         elif layer.op == "deconv3d":
-            self.conv = nn.ConvTranspose3d(layer.cin, layer.cout, layer.k, layer.s, layer.p, bias=True)
+            self.conv = nn.ConvTranspose3d(layer.cin, layer.cout, layer.k, layer.s, layer.p, output_padding=layer.opad,
+                                           dilation=layer.dil, bias=True)
             self.bn = nn.BatchNorm3d(layer.cout, eps=spec.BN_EPS) if layer.bn else None
+        elif layer.op == "deconv2d":
+            self.conv = nn.ConvTranspose2d(layer.cin, layer.cout, layer.k, layer.s, layer.p, output_padding=layer.opad,
+                                           dilation=layer.dil, bias=True)
+            self.bn = nn.BatchNorm2d(layer.cout, eps=spec.BN_EPS) if layer.bn else None
         elif layer.op == "linear":
             self.conv = nn.Linear(layer.cin, layer.cout, bias=True)
             self.bn = None

@@ -30,12 +30,12 @@ def test_header_symbols_all_exported(s3r, lib):
 
 
 def test_struct_layouts_match_header(s3r):
-    assert C.sizeof(s3r._lib.ConvDesc) == 19 * 4     # ABI 7: + algo
-    assert C.sizeof(s3r._lib.Layer) == 20 * 4 + 3 * 8       # (the descriptor padded to the pointers' alignment)
+    assert C.sizeof(s3r._lib.ConvDesc) == 22 * 4     # ABI 7: + algo; ABI 8: + dilation, out_pad, act_param
+    assert C.sizeof(s3r._lib.Layer) == 22 * 4 + 3 * 8
     assert C.sizeof(s3r._lib.ProfRecord) == 48      # 4 x 4 bytes + 3 doubles + algo + reserved
     header = open(os.path.join(ROOT, "include", "s3r.h")).read()
     body = header[header.index("typedef struct s3r_conv_desc {"):header.index("} s3r_conv_desc;")]
-    fields = re.findall(r"int32_t\s+([a-z_, ]+);", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    fields = re.findall(r"(?:int32_t|float)\s+([a-z_, ]+);", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
     names = [n.strip() for f in fields for n in f.split(",")]
     assert names == [n for n, _ in s3r._lib.ConvDesc._fields_]
 
@@ -159,10 +159,12 @@ def test_halo_contract(s3r, lib):
 def test_invalid_arguments_are_reported_not_crashed(s3r, lib):
     spec = s3r.arch_spec
     e = C.c_int64(0)
-    bad = _desc(s3r, spec.Layer("x", "conv2d", 5, 8, 3, 1, 1), 1, 8)       # cin % 16 != 0
+    bad = _desc(s3r, spec.Layer("x", "conv2d", 5, 8, 3, 1, 1), 1, 8)       # cin % 16 != 0: fp32 stages it (ABI 8), bf16 cannot
+    assert lib.s3r_conv_packed_elems(C.byref(bad), C.byref(e)) == 0 and e.value == 9 * 16 * 128
+    bad.dtype = 1
     assert lib.s3r_conv_packed_elems(C.byref(bad), C.byref(e)) == -1
     assert b"cin" in lib.s3r_last_error()
-    bad = _desc(s3r, spec.Layer("x", "deconv3d", 16, 8, 3, 1, 1), 1, 8)    # unsupported transposed shape
+    bad = _desc(s3r, spec.Layer("x", "deconv3d", 16, 8, 3, 1, 3), 1, 8)    # a transposed layer that crops more than its kernel reaches
     assert lib.s3r_conv_packed_elems(C.byref(bad), C.byref(e)) == -1
     bad = _desc(s3r, spec.Layer("x", "conv3d", 16, 8, 3, 1, 1), 0, 8)      # empty batch at the ABI
     assert lib.s3r_conv_packed_elems(C.byref(bad), C.byref(e)) == -1
@@ -409,3 +411,32 @@ def test_env_switch_table_matches_the_sources():
     bench = open(os.path.join(root, "bench.py")).read()
     for name in found:                           # ... and a bench run under any of them is marked as not the plain configuration
         assert f'"{name}"' in bench, name
+
+
+def test_parameter_general_descriptors_plan_without_a_gpu(s3r, lib):
+    """ABI 8: sizes of the parameter-general layers (host-side planning only): output edges follow torch's formulas with dilation and
+    output padding; a layer the tuned kernels do not serve packs K rows for its channel count rounded up to 16 and asks for the scratch
+    of its staged copy; nonsense is refused, not planned."""
+    L = s3r._lib
+    Layer = s3r.arch_spec.Layer
+    import torch
+    for layer, n in ((Layer("a", "conv2d", 3, 8, 7, 2, 3), 33), (Layer("a", "conv3d", 16, 16, 3, 1, 3, True, "none", 3), 9),
+                     (Layer("a", "deconv2d", 12, 20, 3, 2, 1, True, "relu", 1, 1), 6), (Layer("a", "deconv3d", 16, 8, 5, 3, 2, True, "tanh", 1, 2), 4),
+                     (Layer("a", "deconv2d", 16, 16, 3, 2, 2, True, "none", 2, 1), 6)):
+        d = L.make_desc(layer, 2, n)
+        blk = s3r.modules._Block(layer)
+        nd = s3r.arch_spec.ndim(layer)
+        want = blk.conv(torch.zeros((1, layer.cin) + (n,) * nd)).shape[-1]
+        assert lib.s3r_conv_out_size(C.byref(d)) == want == s3r.arch_spec.out_size(layer, n), (layer, want)
+    staged = L.make_desc(Layer("a", "conv2d", 20, 40, 3, 2, 1), 2, 15)
+    e = C.c_int64(0)
+    assert lib.s3r_conv_packed_elems(C.byref(staged), C.byref(e)) == 0 and e.value == 9 * 32 * 128
+    assert lib.s3r_conv_scratch_elems(C.byref(staged)) == -(-(2 * 32 * 17 * 17) // 256) * 256       # (B, 32, 15 + 2, 15 + 2)
+    up = L.make_desc(Layer("a", "deconv2d", 16, 8, 4, 2, 1), 1, 7)                                   # stuffed edge 13, halo 2
+    assert lib.s3r_conv_scratch_elems(C.byref(up)) == -(-(16 * 17 * 17) // 256) * 256
+    for bad in (Layer("a", "deconv2d", 16, 8, 3, 2, 3), Layer("a", "deconv2d", 16, 8, 3, 2, 1, True, "relu", 1, 2)):
+        assert lib.s3r_conv_scratch_elems(C.byref(L.make_desc(bad, 1, 7))) == -1                    # pad > k - 1; out_pad >= stride
+    wino = L.make_desc(Layer("a", "conv3d", 32, 32, 3, 1, 1, True, "elu"), 1, 8, in_halo=1, algo=L.ALGO_WINOGRAD)
+    assert lib.s3r_conv_scratch_elems(C.byref(wino)) == -1 and b"no Winograd form" in lib.s3r_last_error()
+    bf = L.make_desc(Layer("a", "conv2d", 32, 32, 3, 1, 2, True, "relu", 2), 1, 8, in_halo=2, dtype=1)
+    assert lib.s3r_conv_scratch_elems(C.byref(bf)) == -1 and b"bf16" in lib.s3r_last_error()

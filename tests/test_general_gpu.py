@@ -1,0 +1,92 @@
+"""Parameter-general layers (ABI 8, csrc/s3r_general.hip): any fp32 Conv2d / Conv3d / ConvTranspose2d / ConvTranspose3d — kernel size,
+stride, padding, dilation, output padding, channel counts that are not multiples of 16, LeakyReLU / ELU / Tanh — runs through the
+direct kernel (behind a staging pass where the tuned paths do not reach) and must agree with the oracle's block, i.e. with
+torch.nn on the CPU, at the path's fp32 tolerance.  The shapes are NOT this build's network: they are what a reference layer table
+may hold the day tools/resurvey.py prints it."""
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def _check(s3r, oracle, layers, n_in, B, seed=0):
+    dev, spec = "cuda:0", s3r.arch_spec
+    ch = s3r.modules._HipChain(layers, n_in, precision="fp32")
+    s3r.seed_module(ch, 11 + seed)
+    blocks = [oracle._Block(l).eval() for l in layers]
+    for l, blk in zip(layers, blocks):
+        blk.load_state_dict(getattr(ch, l.name).state_dict())
+    ch.to(dev)
+    x = torch.randn((B, layers[0].cin) + (n_in,) * spec.ndim(layers[0]), generator=torch.Generator().manual_seed(seed))
+    with torch.no_grad():
+        want = x
+        for blk in blocks:
+            want = blk(want)
+    got = ch._run(x.to(dev))
+    assert tuple(got.shape) == tuple(want.shape), (layers, n_in, got.shape, want.shape)
+    assert torch.equal(got, ch._run(x.to(dev))), (layers, "determinism")
+    assert torch.equal(ch._run(x[B - 1:].to(dev))[0], got[B - 1]), (layers, "batch invariance")
+    rel = _rel(got.cpu(), want)
+    assert rel < 1e-5, (layers, n_in, rel)
+
+
+def test_named_shapes(s3r, oracle):
+    L = s3r.arch_spec.Layer
+    cases = [
+        ([L("a", "conv2d", 3, 8, 7, 2, 3)], 33, 2),                                   # a ResNet-style stem: k7 s2 p3, Cin = 3
+        ([L("a", "conv2d", 16, 24, 5, 1, 2)], 12, 3),                                 # k5
+        ([L("a", "conv2d", 32, 32, 3, 1, 2, True, "relu", 2)], 16, 2),                 # dilation 2 (same size)
+        ([L("a", "conv3d", 16, 16, 3, 1, 3, True, "none", 3)], 9, 1),                  # dilation 3 in 3D
+        ([L("a", "conv3d", 5, 7, 1, 1, 0)], 6, 2),                                    # 1 x 1 x 1, odd channels
+        ([L("a", "conv2d", 20, 40, 3, 2, 1, True, "leaky_relu")], 15, 2),              # Cin % 16 != 0, LeakyReLU (default slope)
+        ([L("a", "conv2d", 16, 16, 3, 1, 1, False, "leaky_relu", 1, 0, 0.2)], 8, 1),   # slope 0.2, no BN
+        ([L("a", "conv3d", 32, 32, 3, 1, 1, True, "elu")], 8, 2),                      # ELU on a layer that otherwise has Winograd forms
+        ([L("a", "conv2d", 32, 16, 3, 1, 1, True, "tanh")], 8, 2),
+        ([L("a", "deconv2d", 16, 8, 4, 2, 1)], 7, 2),                                 # the usual 2D upsampler
+        ([L("a", "deconv2d", 12, 20, 3, 2, 1, True, "relu", 1, 1)], 6, 3),             # k3 s2 p1 output_padding 1
+        ([L("a", "deconv2d", 8, 8, 2, 2, 0)], 5, 1),                                  # k2 s2 p0
+        ([L("a", "deconv3d", 16, 16, 3, 1, 1)], 6, 2),                                # stride 1 (a flipped convolution)
+        ([L("a", "deconv3d", 8, 12, 4, 2, 1)], 5, 2),                                 # the network's shape but Cin % 16 != 0
+        ([L("a", "deconv3d", 16, 8, 5, 3, 2, True, "tanh", 1, 2)], 4, 1),              # k5 s3 p2 output_padding 2
+        ([L("a", "deconv2d", 16, 16, 3, 2, 2, True, "none", 2, 1)], 6, 2),             # dilation 2, p2, output_padding 1
+        ([L("a", "conv2d", 3, 16, 3, 1, 1), L("b", "conv2d", 16, 10, 3, 2, 1, True, "elu"), L("c", "deconv2d", 10, 6, 4, 2, 1)], 16, 2),
+        ([L("a", "conv3d", 4, 16, 3, 1, 1), L("b", "conv3d", 16, 16, 3, 1, 1), L("c", "deconv3d", 16, 4, 2, 2, 0, False, "tanh")], 8, 2),
+    ]
+    for i, (layers, n_in, B) in enumerate(cases):
+        _check(s3r, oracle, layers, n_in, B, seed=i)
+
+
+def test_random_sweep(s3r, oracle):
+    """A seeded sweep over the parameter space (what a property-based run would draw; kept deterministic so that a failure names
+    its case)."""
+    L = s3r.arch_spec.Layer
+    rng = random.Random(2025)
+    done = 0
+    while done < 48:
+        nd = rng.choice((2, 3))
+        tr = rng.random() < 0.4
+        k = rng.choice((1, 2, 3, 4, 5, 7) if nd == 2 else (1, 2, 3, 4, 5))
+        s = rng.choice((1, 2, 3) if tr else (1, 2))
+        dil = rng.choice((1, 1, 1, 2))
+        cin = rng.choice((1, 3, 8, 16, 20, 32, 48))
+        cout = rng.choice((2, 7, 16, 33, 64, 70))
+        act = rng.choice(("none", "relu", "sigmoid", "leaky_relu", "elu", "tanh"))
+        if tr:
+            p = rng.randrange(0, dil * (k - 1) + 1)
+            op = rng.randrange(0, max(s, dil))
+            layer = L("g", "deconv%dd" % nd, cin, cout, k, s, p, rng.random() < 0.7, act, dil, op)
+        else:
+            p = rng.randrange(0, min(4, dil * (k - 1)) + 1)
+            layer = L("g", "conv%dd" % nd, cin, cout, k, s, p, rng.random() < 0.7, act, dil)
+        n_in = rng.randrange(3, 13 if nd == 3 else 24)
+        n_out = s3r.arch_spec.out_size(layer, n_in)
+        if n_out < 1 or n_out > (40 if nd == 3 else 96) or (cout == 1 and k == 1):
+            continue
+        _check(s3r, oracle, [layer], n_in, rng.choice((1, 2, 3)), seed=done)
+        done += 1
