@@ -38,6 +38,9 @@
 extern "C" {
 #endif
 
+/* ABI 8 (r05) over ABI 7: s3r_conv_desc grew `dilation`, `out_pad`, `act_param` and three activations — the parameter-general
+ * fp32 layers; `tile` = 6 under S3R_ALGO_WINOGRAD names the three-axis form of a transposed convolution (AUTO takes it from edge
+ * 16 up: other bits than ABI 7 for such a layer); s3r_profile_detail and record family 10 (aux passes). */
 #define S3R_ABI_VERSION 8
 
 typedef enum s3r_status {
@@ -49,7 +52,8 @@ typedef enum s3r_status {
 
 typedef enum s3r_op {
     S3R_OP_CONV = 0,          /* Conv2d / Conv3d (ndim selects) */
-    S3R_OP_DECONV = 1,        /* ConvTranspose3d, k=4 s=2 p=1 only */
+    S3R_OP_DECONV = 1,        /* ConvTranspose2d / 3d.  3D k4 s2 p1 has the tuned kernels (parity classes, Winograd forms); every
+                                 other (k, stride, pad, dilation, out_pad) runs zero-stuffed through the direct kernel (fp32) */
     S3R_OP_LINEAR = 2         /* nn.Linear on the flattened input */
 } s3r_op;
 
