@@ -77,6 +77,16 @@ def test_arch_spec_flops_match_parameter_count(s3r, oracle):
     assert abs(f["total"] - (f["encoder"] + f["cost_volume"] + f["decoder"])) < 1
     assert 20e9 < f["total"] < 30e9
     assert spec.mfma_flops_per_pair("voxel") < f["total"]
+    # the numbers every roofline figure is priced with, written out (SURVEY §8d's formulas over the frozen table above, added up
+    # by hand once): an edit of a formula in arch_spec.py moves bench.py's algorithmic FLOPs, and this line with it
+    assert (f["encoder"], f["cost_volume"], f["decoder"]) == (5618106368.0, 1404928.0, 18911920128.0)
+    assert spec.mfma_flops_per_pair("voxel") == 24486674432.0 and spec.mfma_flops_per_pair("voxel", True) == 22032875520.0
+    assert spec.flops_per_pair("point")["total"] == 17092833280.0
+    assert (spec.params_total("voxel"), spec.params_total("point")) == (24011105, 53901408)
+    # the same encoder figure from the table's rows alone: 2 views x 2 x cout x out^2 x cin x k^2
+    rows = [(3, 32, 3, 112), (32, 64, 3, 112), (64, 64, 3, 56), (64, 128, 3, 56), (128, 128, 3, 28), (128, 256, 3, 28),
+            (256, 256, 3, 28), (256, 32, 1, 28)]
+    assert 2 * 2 * sum(co * o * o * ci * k * k for ci, co, k, o in rows) == f["encoder"]
 
 
 def test_layer_macs_follow_survey_formulas(s3r):
