@@ -391,6 +391,48 @@ def secondary_config(s3r, torch, dev, variant, dtype, B, steps, warmup, plain_ru
     return out
 
 
+def in_flight_config(s3r, torch, dev, B, steps, warmup, streams=3):
+    """The headline workload with `streams` independent batches in flight: each HIP stream replays its own model's graph (own
+    arena, same weights) back to back, nothing joins them until the end.  Kernels of different batches share the chip — a finish /
+    transform pass (HBM-bound) beside another batch's class GEMM (MFMA-bound) — which is how a serving loop would run the path;
+    never part of `value`, whose steps run one after the other on one stream."""
+    models = [s3r.Stereo2Voxel("fp32") for _ in range(streams)]
+    s3r.seed_module(models[0], 0)
+    for m in models[1:]:
+        m.load_state_dict(models[0].state_dict())
+    graphs, sts = [], []
+    for i, m in enumerate(models):
+        m.to(dev)
+        g = s3r.GraphedForward(m, B, dev)
+        l, r = s3r.synthetic_pairs(B, seed=3000 + i)
+        g.left.copy_(l.to(dev)); g.right.copy_(r.to(dev))
+        graphs.append(g); sts.append(torch.cuda.Stream(device=dev))
+    cur = torch.cuda.current_stream(dev)
+
+    def run(n):
+        for st in sts:
+            st.wait_stream(cur)
+        for _ in range(n):
+            for g, st in zip(graphs, sts):
+                with torch.cuda.stream(st):
+                    g()
+        for st in sts:
+            cur.wait_stream(st)
+
+    run(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    out = {"workload": f"Stereo2Voxel forward, batch={B}, fp32, 1 GPU, {streams} independent batches in flight on {streams} HIP streams",
+           "value": round(B * steps * streams / elapsed, 2), "unit": "stereo pairs/s", "steps": steps * streams, "streams": streams,
+           "ms_per_step": round(1e3 * elapsed / (steps * streams), 4), "dtype": "f32"}
+    del graphs, models
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -640,6 +682,11 @@ def main():
                 except Exception as e:
                     log(f"secondary {name} failed: {type(e).__name__}: {e}")
                     sec[name] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                sec["in_flight3_b32"] = in_flight_config(s3r, torch, dev, 32, k2, 2)
+            except Exception as e:
+                log(f"secondary in_flight3_b32 failed: {type(e).__name__}: {e}")
+                sec["in_flight3_b32"] = {"error": f"{type(e).__name__}: {e}"}
             out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline and not args.force_dist:
             out["cpu_baseline"] = cpu_baseline(32)

@@ -1,5 +1,2 @@
-mkdir -p gpurun_out/r5v
-for w in 0 1; do S3R_WINO_FOLD=$w python tools/alt/hash.py > gpurun_out/r5v/hash$w.log 2>&1; done
-for i in 1 2 3; do for w in 0 1; do
- S3R_WINO_FOLD=$w python bench.py --no-secondary --no-cpu-baseline > gpurun_out/r5v/b$w$i.json 2> gpurun_out/r5v/b$w$i.err
-done; done
+mkdir -p gpurun_out/r5w
+for s in 4 6 8; do python tools/two_stream_exp.py --batch 32 --streams $s --stagger-ms 0.9 --steps 30 > gpurun_out/r5w/n$s.log 2>&1; done

@@ -13,6 +13,7 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--streams", type=int, default=2)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--half", action="store_true")
+ap.add_argument("--stagger-ms", type=float, default=0.0, help="free-running streams, the second started this much later (no joins between steps)")
 ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -45,6 +46,37 @@ def concurrent():
     for st in streams:
         cur.wait_stream(st)
 
+
+def free_running(steps):
+    """Each stream replays its own graph back to back; stream i starts i * stagger later (host busy-wait), nothing joins them
+    until the end: a phase offset between two identical kernel sequences persists while both queues stay full."""
+    cur = torch.cuda.current_stream(dev)
+    for st in streams:
+        st.wait_stream(cur)
+    for i, (g, st) in enumerate(zip(graphs, streams)):
+        if i:
+            t1 = time.perf_counter() + a.stagger_ms * 1e-3
+            while time.perf_counter() < t1:
+                pass
+        with torch.cuda.stream(st):
+            g()
+    for _ in range(steps - 1):
+        for g, st in zip(graphs, streams):
+            with torch.cuda.stream(st):
+                g()
+    for st in streams:
+        cur.wait_stream(st)
+
+
+if a.stagger_ms > 0:
+    free_running(3)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        t0 = time.perf_counter()
+        free_running(a.steps)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
+        print(f"free-running, stagger {a.stagger_ms} ms: {dt * 1e3:7.3f} ms per {per * S} pairs  {per * S / dt:8.1f} pairs/s")
 
 for fn in (sequential, concurrent):
     for _ in range(3):
