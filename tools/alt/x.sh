@@ -1,2 +1,5 @@
-mkdir -p gpurun_out/r5w
-for s in 4 6 8; do python tools/two_stream_exp.py --batch 32 --streams $s --stagger-ms 0.9 --steps 30 > gpurun_out/r5w/n$s.log 2>&1; done
+mkdir -p gpurun_out/r5z
+for v in base exp1 exp2; do S3R_LIB=$PWD/tools/alt/$v.so python tools/alt/hash.py > gpurun_out/r5z/hash_$v.log 2>&1; done
+for i in 1 2 3; do for v in base exp1 exp2; do
+ S3R_LIB=$PWD/tools/alt/$v.so python bench.py --no-secondary --no-cpu-baseline > gpurun_out/r5z/$v$i.json 2> gpurun_out/r5z/$v$i.err
+done; done
