@@ -793,6 +793,8 @@ def test_bench_line_carries_roofline_border_excluded_and_secondaries(tmp_path):
     assert sec["bf16_b256"]["dtype"] == "bf16" and sec["bf16_b256"]["value"] > d["value"]
     assert sec["bf16_b256"]["roofline"]["peak"] == 2500.0
     assert sec["point_b32"]["value"] > 0 and "chamfer" in sec["point_b32"]["kernels"] and "linear" in sec["point_b32"]["kernels"]
+    # three independent batches in flight on three streams: the same work per step, never the headline; not slower than 0.9 x it
+    assert sec["in_flight3_b32"]["streams"] == 3 and sec["in_flight3_b32"]["value"] > 0.9 * d["value"]
 
 
 def test_maximum_sizes_chunking_and_limits(s3r, models):
