@@ -611,7 +611,7 @@ static const Tuned kTuned[] = {
     {32,  64,  9, 1, 12544, 0, 7, 1},   // e2  112^2   (r03 re-tune, three A/B pairs of bench.py: e2 1 -> 7, e4 2 -> 4, d1 2 -> 7: -0.5 % per step)
     {64,  64,  9, 2,  3136, 0, 1, 1},   // e3  -> 56^2  (with the remainder inside the bulk's launch, r03: e3 3 -> 1, v2 / v3 3 -> 7: -0.7 %)
     {64, 128,  9, 1,  3136, 0, 4, 1},   // e4
-    {128, 128, 9, 2,   784, 0, 3, 1},   // e5  -> 28^2
+    {128, 128, 9, 2,   784, 0, 7, 1},   // e5  -> 28^2  (r05 re-sweep: 64 x 128, 784 workgroups, 0.137 -> 0.130 alone)
     {128, 256, 9, 1,   784, 0, 1, 1},   // e6  (64x256 bulk + 64x64 remainder, see plan_tail_cut)
     {256, 256, 9, 1,   784, 0, 1, 1},   // e7
     {256, 32,  1, 1,   784, 0, 2, 1},   // e8

@@ -1,5 +1,5 @@
-mkdir -p gpurun_out/r5z
-for v in base exp1 exp2; do S3R_LIB=$PWD/tools/alt/$v.so python tools/alt/hash.py > gpurun_out/r5z/hash_$v.log 2>&1; done
-for i in 1 2 3; do for v in base exp1 exp2; do
- S3R_LIB=$PWD/tools/alt/$v.so python bench.py --no-secondary --no-cpu-baseline > gpurun_out/r5z/$v$i.json 2> gpurun_out/r5z/$v$i.err
-done; done
+mkdir -p gpurun_out/r5ab
+for i in 1 2 3; do
+S3R_LIB=$PWD/tools/alt/base.so python bench.py --no-secondary --no-cpu-baseline > gpurun_out/r5ab/base$i.json 2> gpurun_out/r5ab/base$i.err
+python bench.py --no-secondary --no-cpu-baseline > gpurun_out/r5ab/new$i.json 2> gpurun_out/r5ab/new$i.err
+done
