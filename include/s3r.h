@@ -103,8 +103,8 @@ typedef enum s3r_layout { S3R_LAYOUT_PLAIN = 0, S3R_LAYOUT_WINO_H = 2, S3R_LAYOU
  *                      forces the launch FORM of the one-axis kernel (tuning / tests; every form gives the same bits, and the
  *                      library picks among them by batch): 0 serial, 1 class-parallel, 2 dual (bulk serial + remainder
  *                      class-parallel in one launch); `tile` = 6 (ABI 8): the THREE-AXIS form of a ConvTranspose3d k4 s2 p1 over an edge
- *                      of 8, 16 or 32 (F(2,2) along D, H and W: 27 / 64 of the multiplications, serial form only; AUTO takes it from
- *                      edge 16 up); `tile` = 3: the TWO-AXIS algorithm (Conv3d k3 s1 p1 as F(4,3) x F(4,3) over D
+ *                      of 8, 16 or 32 (F(2,2) along D, H and W: 27 / 64 of the multiplications; AUTO takes it from edge 16 up;
+ *                      7 / 8 force its class-parallel / serial launch form: same bits, the library picks by batch); `tile` = 3: the TWO-AXIS algorithm (Conv3d k3 s1 p1 as F(4,3) x F(4,3) over D
  *                      and H, Conv2d k3 s1 p1 as F(4,3) x F(4,3) over H and W, Conv3d k4 s1 p0 as F(2,4) x F(2,4); in_halo = pad;
  *                      4 / 5 force its class-parallel / semi-fused launch form: same bits) — another algorithm, other bits than
  *                      the one-axis kernel; AUTO takes it for every stride-1 layer that has it and an edge <= 28 (e6, e7, v1, v3,
@@ -288,7 +288,7 @@ typedef struct s3r_prof_record {
     double exec_flops;  /* FLOPs the kernel that ran EXECUTES on the matrix cores (= flops for the direct kernels; 1/2 .. 9/16 of it
                            for the Winograd forms) */
     int32_t algo;       /* what ran: 0 direct, 1 Winograd serial form, 2 class-parallel form, 3 dual form, 4 two-axis form, 5 three-axis
-                           form (transposed layers) */
+                           form (transposed layers), 6 its class-parallel launch form */
     int32_t reserved;
 } s3r_prof_record;
 int s3r_profile_enable(int max_records);   /* 0 disables and frees the event pool */

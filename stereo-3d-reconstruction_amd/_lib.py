@@ -21,7 +21,7 @@ FAMILY = {0: "conv_mfma", 1: "stem", 2: "head", 3: "cost_volume", 4: "linear", 5
 ABI_VERSION = 8
 ALGO_AUTO, ALGO_DIRECT, ALGO_WINOGRAD = 0, 1, 2
 ALGO = {None: 0, "auto": 0, "direct": 1, "winograd": 2, False: 1, True: 2}
-RAN = {0: "direct", 1: "winograd-serial", 2: "winograd-class-parallel", 3: "winograd-dual", 4: "winograd-2axis", 5: "winograd-3axis"}
+RAN = {0: "direct", 1: "winograd-serial", 2: "winograd-class-parallel", 3: "winograd-dual", 4: "winograd-2axis", 5: "winograd-3axis", 6: "winograd-3axis-class-parallel"}
 
 
 class ConvDesc(C.Structure):

@@ -107,11 +107,13 @@ int dwino_run(const s3r_conv_desc* d, s3r::ConvParams p, const float* x, const f
     *ran = 1 + L.mode;
     return S3R_OK;
 }
-// the three-axis form: difference tensors (all three materialised) + the class kernel (serial form only)
+// the three-axis form: difference tensors (all three materialised) + the class kernel (serial, or class-parallel over the depth
+// class with a finish kernel: same bits)
 int dwino3_run(const s3r_conv_desc* d, s3r::ConvParams p, const float* x, const float* packed_w, float* scratch, int64_t scratch_elems,
-               hipStream_t s, int* launches) {
+               hipStream_t s, int form, int* launches, int* ran) {
     const int n = d->in_size;
-    const int64_t need = (3 * (int64_t)d->batch * d->cin * ipow(n + 2, 3) + 255) / 256 * 256;
+    const Dwino3Need nd = dwino3_need(d, form);
+    const int64_t need = nd.total;
     if (!scratch || scratch_elems < need)
         return fail(S3R_ERR_WORKSPACE, "the three-axis Winograd form of this transposed convolution needs %lld floats of scratch "
                     "(s3r_conv_scratch_elems), got %lld", (long long)need, (long long)(scratch ? scratch_elems : 0));
@@ -130,9 +132,11 @@ int dwino3_run(const s3r_conv_desc* d, s3r::ConvParams p, const float* x, const 
     p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
     p.dW = s3r::FastDiv((unsigned)p.Nw);
     p.ksplit = 1;
-    e = s3r::launch_deconv_wino3(p, s);
+    p.part = nd.split ? scratch + nd.diff : nullptr;
+    e = s3r::launch_deconv_wino3(p, nd.split, s);
     if (e != hipSuccess) return hip_fail(e, "three-axis Winograd transposed-conv launch");
-    *launches = 2;
+    *launches = nd.split ? 3 : 2;
+    *ran = nd.split ? 6 : 5;
     return S3R_OK;
 }
 
@@ -157,7 +161,7 @@ int conv_head_fused(const s3r_conv_desc* d, const Geo& g, const s3r_conv_desc* h
                      4.0 * d->batch * (double)hg.out_sp);
         ps.exec = g.flops * (27.0 / 64.0) + hg.flops;
         ps.algo = 5;
-        return dwino3_run(d, p, x, static_cast<const float*>(L.packed_w), scratch, scratch_elems, s, &ps.launches);
+        return dwino3_run(d, p, x, static_cast<const float*>(L.packed_w), scratch, scratch_elems, s, form, &ps.launches, &ps.algo);
     }
     if (alg != ALG_DIRECT) {
         if (alg != ALG_WINO || d->op != S3R_OP_DECONV || d->cout > 64) return fail(S3R_ERR_INVALID, "the fused head rides on the transposed Winograd kernel with <= 64 couts only");
@@ -402,7 +406,7 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                 ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
                 ps.exec = g.flops * (27.0 / 64.0);
                 ps.algo = 5;
-                return dwino3_run(d, p, x, packed_w, scratch, scratch_elems, s, &ps.launches);
+                return dwino3_run(d, p, x, packed_w, scratch, scratch_elems, s, form, &ps.launches, &ps.algo);
             }
             if (wino && d->op == S3R_OP_DECONV) {
                 ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);

@@ -22,6 +22,10 @@
 //   dwino3_kernel        grid = m tiles x position tiles x 8 parity classes; 256 threads as 2 x 2 waves; tile 64 couts x 64 positions
 //                        (position = (sample, depth pair, row pair, column pair)); stage = one (a, b, 16-channel chunk): 12 KiB of
 //                        weights + the input tile, LDS-DMA, three stages in flight
+//                        SPLIT (class-parallel over the depth class): x 3 the workgroups, each walks ONE a and writes its H-complete
+//                        sums z[v][w], raw, to the slab part[cout][tile][(pc, a, v, w)][64]; dwino3_finish_kernel forms
+//                        y(0) = z0 + z1, y(1) = z1 - z2 and the epilogue with the serial form's operations in the serial form's
+//                        order: the same bits, a third of the serial chain (64 workgroups of 72 stages at B = 1 otherwise)
 #include "s3r_kernels.h"
 
 namespace s3r {
@@ -53,8 +57,8 @@ template <int NWP> int dwino3_lds_bytes() { return (D3_NST * D3Geo<NWP>::STAGE +
 
 // p: make_params of the transposed layer; Nd = Nh = Nw = n / 2 (pairs per axis), p.x = padded input, p.xd = [Dh | Dd | Ddh],
 // p.w = the 8 x 27 class slabs, p.m_tiles = ceil(Cout / 64).  HEAD: the fused 1 x 1 x 1 head (Cout <= 64): y is the head's output.
-template <int NWP, bool HEAD>
-__global__ __launch_bounds__(256, 2) void dwino3_kernel(const ConvParams p) {
+template <int NWP, bool HEAD, bool SPLIT>
+__global__ __launch_bounds__(256, SPLIT ? 3 : 2) void dwino3_kernel(const ConvParams p) {
     typedef D3Geo<NWP> G;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const ring = smem;                                    // [D3_NST][A | B]
@@ -69,14 +73,16 @@ __global__ __launch_bounds__(256, 2) void dwino3_kernel(const ConvParams p) {
     // workgroup -> (m tile, position tile, parity class): an XCD walks a contiguous run of (tile, class) items, the 8 classes of a
     // tile back to back (they read the same input rows)
     const int nwg = (int)gridDim.x >> 3;
-    const int item = ((int)blockIdx.x & 7) * nwg + ((int)blockIdx.x >> 3);
+    int item = ((int)blockIdx.x & 7) * nwg + ((int)blockIdx.x >> 3);
+    int a0 = 0;                                                  // SPLIT: the one depth class of this workgroup
+    if constexpr (SPLIT) { a0 = item % 3; item /= 3; }
     const int pc = item & 7, tile = item >> 3;
     const int rd = (pc >> 2) & 1, rh = (pc >> 1) & 1, rw = pc & 1;
     const int m_tile = tile % p.m_tiles, n_tile = tile / p.m_tiles;
     const int m0 = m_tile * 64, n0 = n_tile * 64;
     const int S = p.Nd * p.Nh * p.Nw;                            // pair positions per sample
     const int chunks = p.Cin / D3_CK;
-    const int total = 9 * chunks;
+    const int total = (SPLIT ? 3 : 9) * chunks;
 
     // ---- per-lane DMA offsets of the input tile: slot s = (i * 4 + wave) * 64 + lane -> (channel k, tile row rho, piece pi)
     int bvo[G::NBI];
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void dwino3_kernel(const ConvParams p) {
         const_cast<float*>(p.w), 0, (int)(8u * 27u * (unsigned)p.Cin * (unsigned)p.m_tiles * 64u * 4u), 0x00020000);
 
     // cursor of the NEXT stage to fetch
-    int c_ab = 0, c_cc = 0;
+    int c_ab = 3 * a0, c_cc = 0;
     auto issue = [&](int buf) __attribute__((always_inline)) {
         float* sa = ring + buf * G::STAGE;
         const int wbase = (((pc * 9 + c_ab) * p.m_tiles + m_tile) * chunks + c_cc) * D3_A * 4;
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void dwino3_kernel(const ConvParams p) {
 
     int cur = 0, g = 0;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
+    for (int a = 0; a < (SPLIT ? 1 : 3); ++a) {
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
             // ---- the three W classes of (a, b): K = Cin in 16-channel stages (accumulators zeroed HERE, not behind the fold: they
@@ -271,6 +277,22 @@ __global__ __launch_bounds__(256, 2) void dwino3_kernel(const ConvParams p) {
                 for (int r = 0; r < 16; ++r) { z[1][0][r] -= acc[0][r] + acc[1][r]; z[1][1][r] -= acc[1][r] - acc[2][r]; }
             }
         }
+        if constexpr (SPLIT) {
+            // ---- class-parallel: the H-complete sums of depth class a0, raw, to the slab (blocked like the other forms' slabs)
+            const int n_tiles = (p.Ntotal + 63) / 64;
+            const int mbase = wm * 32 + 4 * h;
+            float* __restrict__ slab = p.part + (((size_t)(m0 + mbase) * n_tiles + n_tile) * 96 + (pc * 3 + a0) * 4) * 64 + jt;
+            const size_t mstride = (size_t)n_tiles * 96 * 64;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dm = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                for (int v = 0; v < 2; ++v)
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) slab[(size_t)dm * mstride + (v * 2 + w) * 64] = z[v][w][r];
+            }
+            (void)store_u;
+        } else
         // ---- H-complete sums of depth class a, folded into the depth transform
         if (a == 0) {
 #pragma unroll
@@ -341,33 +363,154 @@ hipError_t launch_pack_dwino3(const float* w, float* wp, int Cin, int Cout, hipS
 int64_t dwino3_w_elems(int Cin, int Cout) { return (int64_t)8 * 27 * Cin * ((Cout + 63) / 64) * 64; }
 bool dwino3_edge_ok(int n) { return n == 8 || n == 16 || n == 32; }
 
+// ---- class-parallel finish: the depth transform of the three slabs of each (parity class, v, w), then the serial epilogue's
+// operations in its order.  Plain: one thread per (cout, pair position), the 8 parity classes in turn.  HEAD: a wave per (parity
+// class, 16 positions), lane = (position, chain): the four 16-cout chains of a position (wave row wm, lane half h of the class
+// kernel; r = 0 .. 15) run in four lanes, their halves' sums and then the two wave rows' sum by two shuffles — the serial kernel's
+// shfl_xor 32 and LDS exchange
+__device__ __forceinline__ int d3_out_elem(const ConvParams& p, int n, int S) {
+    const int b = p.dS.div(n);
+    int rem = n - b * S;
+    const int pd = p.dHW.div(rem);
+    rem -= pd * p.Nh * p.Nw;
+    const int ph = p.dW.div(rem);
+    const int pw = rem - ph * p.Nw;
+    return b * p.y_bs + p.y_org + (2 * pd * p.y_ds + 2 * ph * p.y_hs + 2 * pw) * 2;
+}
+
+__global__ __launch_bounds__(256) void dwino3_finish_kernel(const ConvParams p, const int n_tiles) {
+    const int S = p.Nd * p.Nh * p.Nw;
+    const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+    const size_t mstride = (size_t)n_tiles * 96 * 64;
+    const long long total = (long long)p.Cout * p.Ntotal;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / p.Ntotal), n = (int)(i - (long long)m * p.Ntotal);
+        const int e00 = d3_out_elem(p, n, S);
+        const float sc = p.scale ? p.scale[m] : 1.f, sf = p.shift ? p.shift[m] : 0.f;
+        const float* __restrict__ blk = p.part + (size_t)m * mstride + ((size_t)(n >> 6) * 96) * 64 + (n & 63);
+#pragma unroll 1
+        for (int pc = 0; pc < 8; ++pc) {
+            const float* __restrict__ zz = blk + (size_t)(pc * 12) * 64;
+            float* __restrict__ yo = p.y + (size_t)m * p.y_cs + e00 + ((pc >> 2) & 1) * p.y_ds + ((pc >> 1) & 1) * p.y_hs + (pc & 1);
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const float z0 = zz[(0 * 4 + v * 2 + w) * 64], z1 = zz[(1 * 4 + v * 2 + w) * 64], z2 = zz[(2 * 4 + v * 2 + w) * 64];
+                    yo[v * 2 * p.y_hs + w * 2] = fmaxf(fmaf(z0 + z1, sc, sf), lo);
+                    yo[2 * p.y_ds + v * 2 * p.y_hs + w * 2] = fmaxf(fmaf(z1 - z2, sc, sf), lo);
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dwino3_finish_head_kernel(const ConvParams p, const int n_tiles) {
+    const int S = p.Nd * p.Nh * p.Nw;
+    const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+    const size_t mstride = (size_t)n_tiles * 96 * 64;
+    const int lane = threadIdx.x & 63;
+    const int nb16 = (p.Ntotal + 15) / 16;
+    const long long waves = (long long)nb16 * 8;
+    for (long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); q < waves; q += (long long)gridDim.x * 4) {
+        const int pc = (int)(q & 7), n = (int)(q >> 3) * 16 + (lane & 15);
+        const int g = lane >> 4;                                 // chain: wave row wm = g >> 1, lane half h = g & 1
+        const bool ok = n < p.Ntotal;
+        const int nn = ok ? n : p.Ntotal - 1;
+        const float* __restrict__ blk = p.part + ((size_t)(nn >> 6) * 96 + pc * 12) * 64 + (nn & 63);
+        float t[2][2][2];                                        // [u][v][w]
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int w = 0; w < 2; ++w) t[u][v][w] = 0.f;
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) {
+            const int dm = (g >> 1) * 32 + 4 * (g & 1) + (r & 3) + 8 * (r >> 2);
+            const float sc = (p.scale && dm < p.Cout) ? p.scale[dm] : 1.f, sf = (p.shift && dm < p.Cout) ? p.shift[dm] : 0.f;
+            const float hw = (p.head_w && dm < p.Cout) ? p.head_w[dm] : 0.f;
+            const float* __restrict__ zz = blk + (size_t)dm * mstride;
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const float z0 = zz[(0 * 4 + v * 2 + w) * 64], z1 = zz[(1 * 4 + v * 2 + w) * 64], z2 = zz[(2 * 4 + v * 2 + w) * 64];
+                    t[0][v][w] = fmaf(fmaxf(fmaf(z0 + z1, sc, sf), lo), hw, t[0][v][w]);
+                    t[1][v][w] = fmaf(fmaxf(fmaf(z1 - z2, sc, sf), lo), hw, t[1][v][w]);
+                }
+        }
+        const float hsc = p.head_scale ? p.head_scale[0] : 1.f, hsf = p.head_shift ? p.head_shift[0] : 0.f;
+        const int e0 = d3_out_elem(p, nn, S) + ((pc >> 2) & 1) * p.y_ds + ((pc >> 1) & 1) * p.y_hs + (pc & 1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    float s = t[u][v][w];
+                    s += __shfl_xor(s, 16, 64);                  // the lane halves' sum (h = 0 + h = 1)
+                    s += __shfl_xor(s, 32, 64);                  // wave row 0's + wave row 1's
+                    float o = fmaf(s, hsc, hsf);
+                    if (p.head_act == ACT_RELU) o = fmaxf(o, 0.f);
+                    else if (p.head_act == ACT_SIGMOID) o = __builtin_amdgcn_rcpf(1.f + __expf(-o));
+                    if (g == 0 && ok) p.y[e0 + u * 2 * p.y_ds + v * 2 * p.y_hs + w * 2] = o;
+                }
+    }
+}
+
+int64_t dwino3_slab_elems(int cout, int ntotal) { return (int64_t)((cout + 63) / 64) * 64 * ((ntotal + 63) / 64) * 96 * 64; }
+
+// class-parallel when the serial form's grid leaves half the CUs without a workgroup (d3: B <= 2); forced: 0 serial, 1
+// class-parallel, < 0 the rule (S3R_WINO_FORM, read once, overrides it like the other forms' plans)
+bool dwino3_split(int cout, int ntotal, int forced) {
+    if (forced < 0) {
+        static const int env_mode = getenv("S3R_WINO_FORM") ? atoi(getenv("S3R_WINO_FORM")) : -1;      // A/B switch, read once
+        forced = env_mode == 0 || env_mode == 1 ? env_mode : -1;
+    }
+    if (forced >= 0) return forced == 1;
+    const long W = (long)((cout + 63) / 64) * ((ntotal + 63) / 64) * 8;
+    return 2 * W <= cu_count();          // (d3: B <= 2 — 0.101 -> 0.053, 0.104 -> 0.070 ms; B = 4: 0.110 -> 0.120)
+}
+
 template <int NWP>
-static hipError_t launch_dwino3_t(const ConvParams& p, hipStream_t stream) {
+static hipError_t launch_dwino3_t(const ConvParams& p, bool split, hipStream_t stream) {
     const int n_tiles = (p.Ntotal + 63) / 64;
-    const dim3 grid(p.m_tiles * n_tiles * 8);
+    const dim3 grid(p.m_tiles * n_tiles * 8 * (split ? 3 : 1));
     const int lds = dwino3_lds_bytes<NWP>();
-    static LdsAttr attr_h, attr_p;
-    if (p.head_w) {
-        hipError_t e = attr_h.ensure(reinterpret_cast<const void*>(&dwino3_kernel<NWP, true>), lds);
+    static LdsAttr attr_h, attr_p, attr_s;
+    if (split) {
+        hipError_t e = attr_s.ensure(reinterpret_cast<const void*>(&dwino3_kernel<NWP, false, true>), lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((dwino3_kernel<NWP, true>), grid, dim3(256), lds, stream, p);
+        hipLaunchKernelGGL((dwino3_kernel<NWP, false, true>), grid, dim3(256), lds, stream, p);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        // (aux pass: reads the 96 slab rows of every position, writes the layer's — or the head's — output)
+        AuxScope aux(stream, 4.0 * (double)p.Ntotal * (96.0 * p.Cout + 64.0 * (p.head_w ? 1 : p.Cout)));
+        const long long blocks = p.head_w ? ((long long)((p.Ntotal + 15) / 16) * 8 + 3) / 4 : ((long long)p.Cout * p.Ntotal + 255) / 256;
+        const dim3 fgrid((unsigned)(blocks < 32768 ? blocks : 32768));
+        if (p.head_w) hipLaunchKernelGGL(dwino3_finish_head_kernel, fgrid, dim3(256), 0, stream, p, n_tiles);
+        else hipLaunchKernelGGL(dwino3_finish_kernel, fgrid, dim3(256), 0, stream, p, n_tiles);
+    } else if (p.head_w) {
+        hipError_t e = attr_h.ensure(reinterpret_cast<const void*>(&dwino3_kernel<NWP, true, false>), lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((dwino3_kernel<NWP, true, false>), grid, dim3(256), lds, stream, p);
     } else {
-        hipError_t e = attr_p.ensure(reinterpret_cast<const void*>(&dwino3_kernel<NWP, false>), lds);
+        hipError_t e = attr_p.ensure(reinterpret_cast<const void*>(&dwino3_kernel<NWP, false, false>), lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((dwino3_kernel<NWP, false>), grid, dim3(256), lds, stream, p);
+        hipLaunchKernelGGL((dwino3_kernel<NWP, false, false>), grid, dim3(256), lds, stream, p);
     }
     return hipGetLastError();
 }
 
 // p: the transposed layer's parameters with Nd = Nh = Nw = n / 2 and Ntotal = B (n / 2)^3 pair positions; p.xd = [Dh | Dd | Ddh]
-hipError_t launch_deconv_wino3(ConvParams p, hipStream_t stream) {
-    if (p.Cin % D3_CK != 0 || !p.transposed || !p.xd || p.act == ACT_SIGMOID || (p.head_w && p.Cout > 64) || p.Nd != p.Nw || p.Nh != p.Nw)
+hipError_t launch_deconv_wino3(ConvParams p, bool split, hipStream_t stream) {
+    if (p.Cin % D3_CK != 0 || !p.transposed || !p.xd || p.act == ACT_SIGMOID || (p.head_w && p.Cout > 64) || p.Nd != p.Nw || p.Nh != p.Nw ||
+        (split && !p.part))
         return hipErrorInvalidValue;
     p.m_tiles = (p.Cout + 63) / 64;
     switch (p.Nw) {
-        case 4: return launch_dwino3_t<4>(p, stream);
-        case 8: return launch_dwino3_t<8>(p, stream);
-        case 16: return launch_dwino3_t<16>(p, stream);
+        case 4: return launch_dwino3_t<4>(p, split, stream);
+        case 8: return launch_dwino3_t<8>(p, split, stream);
+        case 16: return launch_dwino3_t<16>(p, split, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -99,6 +99,8 @@ bool dwino_layer(const s3r_conv_desc* d);
 bool dwino3_layer(const s3r_conv_desc* d);
 bool dwino3_desc_ok(const s3r_conv_desc* d);
 int64_t dwino3_w_offset(const s3r_conv_desc* d);
+struct Dwino3Need { int64_t diff, total; bool split; };
+Dwino3Need dwino3_need(const s3r_conv_desc* d, int form);
 bool wino_desc_ok(const s3r_conv_desc* d);
 int wino2_ax(const s3r_conv_desc* d);
 bool wino2_desc_ok(const s3r_conv_desc* d);

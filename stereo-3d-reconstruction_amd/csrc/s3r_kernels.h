@@ -205,11 +205,14 @@ hipError_t launch_wino_diff(const float* x, float* D, long long planes, int Dp, 
 hipError_t launch_pack_wino_deconv(const float* w, float* wp, int Cin, int Cout, int CoutPad, hipStream_t s);
 hipError_t launch_deconv_wino(ConvParams p, const WinoLaunch& L, hipStream_t stream, int* launches);
 // Winograd F(2,2) along D, H AND W inside the parity classes (s3r_deconv_wino3.hip: 27 / 64 of the direct multiplications): positions
-// are (sample, depth pair, row pair, column pair), p.Nd = p.Nh = p.Nw = n / 2, p.xd = [Dh | Dd | Ddh]; serial form only
+// are (sample, depth pair, row pair, column pair), p.Nd = p.Nh = p.Nw = n / 2, p.xd = [Dh | Dd | Ddh]; split: the class-parallel form
+// (p.part = dwino3_slab_elems floats of slabs), same bits as the serial one
 hipError_t launch_pack_dwino3(const float* w, float* wp, int Cin, int Cout, hipStream_t s);
 int64_t dwino3_w_elems(int Cin, int Cout);
 bool dwino3_edge_ok(int n);
-hipError_t launch_deconv_wino3(ConvParams p, hipStream_t stream);
+int64_t dwino3_slab_elems(int cout, int ntotal);
+bool dwino3_split(int cout, int ntotal, int forced);
+hipError_t launch_deconv_wino3(ConvParams p, bool split, hipStream_t stream);
 // y (N,32,Ho+2h,Wo+2h) <- stem conv of x (N,3,Hi,Wi); y_hs / y_cs / y_org describe the padded output.
 // Images [0, nsplit) are read from x, images [nsplit, N) from x2 (the left / right renders of a stereo batch live in
 // two tensors: no concatenation copy); nsplit = N, x2 = null: one tensor.  u8 != 0: x / x2 are 8-bit renders (N,3,Hi,Wi)

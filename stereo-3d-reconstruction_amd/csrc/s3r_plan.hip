@@ -235,6 +235,15 @@ bool dwino3_desc_ok(const s3r_conv_desc* d) {
            d->out_layout == S3R_LAYOUT_PLAIN;
 }
 // its 8 x 27 class slabs sit behind the direct slab and the two-axis form's
+// scratch of the three-axis form: [Dh | Dd | Ddh] then, class-parallel form only, the slabs
+Dwino3Need dwino3_need(const s3r_conv_desc* d, int form) {
+    Dwino3Need n;
+    n.diff = (3 * (int64_t)d->batch * d->cin * ipow(d->in_size + 2, 3) + 255) / 256 * 256;
+    const int ntotal = d->batch * (int)ipow(d->in_size / 2, 3);
+    n.split = s3r::dwino3_split(d->cout, ntotal, form);
+    n.total = n.diff + (n.split ? (s3r::dwino3_slab_elems(d->cout, ntotal) + 255) / 256 * 256 : 0);
+    return n;
+}
 int64_t dwino3_w_offset(const s3r_conv_desc* d) {
     return 64 * (int64_t)d->cin * cout_pad(d->cout) + (dwino_layer(d) ? dwino_w_elems(d) : 0);
 }
@@ -282,11 +291,12 @@ int resolve_algo(const s3r_conv_desc* d, int* alg, int* form) {
             return fail(S3R_ERR_INVALID, "a parameter-general layer reads and writes plain layouts");
         return S3R_OK;
     }
-    if (d->algo == S3R_ALGO_WINOGRAD && d->tile == 6) {        // the three-axis form of a transposed layer
+    if (d->algo == S3R_ALGO_WINOGRAD && d->tile >= 6 && d->tile <= 8) {        // the three-axis form of a transposed layer
         if (!dwino3_desc_ok(d))
             return fail(S3R_ERR_INVALID, "algo = WINOGRAD, tile = 6: the three-axis form serves an fp32 ConvTranspose3d k4 s2 p1 over an edge of "
                         "8, 16 or 32 with cin %% 16 == 0 (in_halo = 1, plain layouts, no split-K, no sigmoid)");
         *alg = ALG_WINO3;
+        *form = d->tile == 6 ? -1 : d->tile == 7 ? 1 : 0;      // 6: the library's launch form; 7: class-parallel; 8: serial (same bits)
         return S3R_OK;
     }
     if (d->algo == S3R_ALGO_WINOGRAD) {
@@ -661,9 +671,13 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
             LaunchH Lh;
             if (resolve_launch_h(&pl->d[i], &ph, &Lh) != S3R_OK || Lh.ksplit != 1) continue;
         } else {
-            s3r::ConvParams p = make_params(&pl->d[i], pl->g[i]);
-            Launch L;
-            if (resolve_launch(&pl->d[i], &p, &L) != S3R_OK || L.ksplit != 1) continue;
+            int alg, form;
+            if (resolve_algo(&pl->d[i], &alg, &form) != S3R_OK) continue;
+            if (alg == ALG_DIRECT) {                     // (a Winograd form's `tile` is a launch-form code, not a tile of the direct kernel)
+                s3r::ConvParams p = make_params(&pl->d[i], pl->g[i]);
+                Launch L;
+                if (resolve_launch(&pl->d[i], &p, &L) != S3R_OK || L.ksplit != 1) continue;
+            }
         }
         pl->fuse_head[i] = 1;
     }
@@ -747,7 +761,7 @@ int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d) {
     int alg, form;
     if ((rc = resolve_algo(d, &alg, &form))) return rc;
     if (staged_layer(d)) return (staged_geo(d).elems + 255) / 256 * 256;          // the staged copy (no split-K behind it)
-    if (alg == ALG_WINO3) return (3 * (int64_t)d->batch * d->cin * ipow(d->in_size + 2, 3) + 255) / 256 * 256;      // Dh, Dd, Ddh
+    if (alg == ALG_WINO3) return dwino3_need(d, form).total;      // Dh, Dd, Ddh (+ the class-parallel form's slabs)
     if (alg == ALG_WINO) return wino_need(d, form, false).total;
     if (alg == ALG_WINO2) return wino2_need(d, form).total;
     s3r::ConvParams p = make_params(d, g);

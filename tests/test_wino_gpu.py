@@ -544,7 +544,8 @@ def test_three_axis_transposed_form_vs_oracle_and_invariants(s3r, oracle):
     """ConvTranspose3d k4 s2 p1 as F(2,2) along D, H AND W inside the parity classes (csrc/s3r_deconv_wino3.hip: 27 / 64 of the direct
     multiplications; algo = WINOGRAD, tile = 6): against the oracle block at 1e-5 on layer shapes that fill neither a 64-cout tile nor
     a 64-position tile, at edges 8 / 16 / 32, with and without the fused 1 x 1 x 1 head; deterministic; a sample's bits do not depend
-    on its batch; AUTO takes the form from edge 16 up (the network's d3) and the two-axis form below (d2)."""
+    on its batch — nor on the launch form (serial / class-parallel over the depth class); AUTO takes the form from edge 16 up (the
+    network's d3) and the two-axis form below (d2)."""
     dev, spec, L = "cuda:0", s3r.arch_spec, s3r._lib
     Layer = spec.Layer
     dec = {l.name: l for l in spec.DECODER}
@@ -570,6 +571,13 @@ def test_three_axis_transposed_form_vs_oracle_and_invariants(s3r, oracle):
         three = ch._run(x.to(dev)).clone()
         assert torch.equal(three, ch._run(x.to(dev))), (first, "determinism")
         assert torch.equal(ch._run(x[B - 1:].to(dev))[0], three[B - 1]), (first, "batch")
+        # launch forms: class-parallel over the depth class (tile 7: slabs + dwino3_finish_kernel) and serial (tile 8) give the
+        # plan's bits (tile 6 picks between them by batch), with and without the fused head
+        for code in (7, 8):
+            ch.tile_override[first] = code
+            assert torch.equal(ch._run(x.to(dev)), three), (first, n_in, "launch form", code)
+            assert torch.equal(ch._run(x[:1].to(dev))[0], three[0]), (first, n_in, "launch form, batch 1", code)
+        ch.tile_override[first] = 6
         rel = float((three.cpu().double() - want).norm() / want.norm())
         assert rel < 1e-5, (first, n_in, rel)
         if n_in >= 16:
