@@ -365,7 +365,8 @@ hipError_t launch_cost_volume_wino(const float* fl, const float* fr, float* V, i
 // ... and as the 36 TWO-AXIS plane sets (F(4,3) along D and H: s3r_conv_wino.hip, wino2_input_kernel, S3R_LAYOUT_WINO_DH):
 // V[6 a + b][bb][ch][sd][sh][wp] from the 6 x 6 window of padded depths 4 sd .. 4 sd + 5 and padded rows 4 sh .. 4 sh + 5 at column
 // wp of the halo-1 volume — rows first, then depths, through the same wino_rows_to_classes: bit-identical to the transform
-// kernel applied to the padded volume.  One workgroup per (b, c); a thread per (sd, sh, wp) and slab half.
+// kernel applied to the padded volume.  One workgroup per (b, c); a thread per (sd, sh, wp) and slab half.  Small batches
+// (gridDim.y = 2 or 2 SD): a workgroup per (b, c, slab half[, depth group]) — 32 workgroups of 12 serial passes are 46 us at B = 1.
 __global__ __launch_bounds__(256) void cost_volume_wino2_kernel(const float* __restrict__ fl, const float* __restrict__ fr,
                                                                 float* __restrict__ V, int C, int D, int H, int W,
                                                                 long long cls_stride, FastDiv dPlane, FastDiv dRow) {
@@ -385,9 +386,13 @@ __global__ __launch_bounds__(256) void cost_volume_wino2_kernel(const float* __r
     const int Wp = W + 2, SH = H / 4, SD = (D + 3) / 4;
     const int ds = SH * Wp;                              // one depth group of a class
     const int run = SD * ds;
-    for (int half = 0; half < 2; ++half) {               // the L - R(shifted) slab, then the R - L(shifted) slab
+    const int ny = (int)gridDim.y, pph = ny > 1 ? ny / 2 : 1;           // parts per slab half
+    const int half0 = ny > 1 ? (int)blockIdx.y / pph : 0, half1 = ny > 1 ? half0 + 1 : 2;
+    const int part = ny > 1 ? (int)blockIdx.y - half0 * pph : 0;
+    const int e0 = (part * SD / pph) * ds, e1 = ((part + 1) * SD / pph) * ds;
+    for (int half = half0; half < half1; ++half) {       // the L - R(shifted) slab, then the R - L(shifted) slab
         float* __restrict__ o = V + ((size_t)b * 2 * C + half * C + c) * run;
-        for (int e = threadIdx.x; e < run; e += 256) {
+        for (int e = e0 + threadIdx.x; e < e1; e += 256) {
             const int sd = dPlane.div(e);                // e / (SH*Wp)
             const int rem = e - sd * ds;
             const int sh = dRow.div(rem);                // rem / Wp
@@ -426,7 +431,8 @@ hipError_t launch_cost_volume_wino2(const float* fl, const float* fr, float* V, 
     const size_t lds = (size_t)2 * H * W * sizeof(float);
     const int Wp = W + 2, SH = H / 4, SD = (D + 3) / 4;
     const long long cls_stride = (long long)B * 2 * C * SD * SH * Wp;
-    hipLaunchKernelGGL(cost_volume_wino2_kernel, dim3(B * C), dim3(256), lds, s, fl, fr, V, C, D, H, W, cls_stride,
+    const int ny = B * C <= 128 ? 2 * SD : B * C <= 512 ? 2 : 1;      // (same bits: the split only re-distributes elements)
+    hipLaunchKernelGGL(cost_volume_wino2_kernel, dim3(B * C, ny), dim3(256), lds, s, fl, fr, V, C, D, H, W, cls_stride,
                        FastDiv((unsigned)(SH * Wp)), FastDiv((unsigned)Wp));
     return hipGetLastError();
 }
