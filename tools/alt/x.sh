@@ -1,5 +1,6 @@
-mkdir -p gpurun_out/r5ah
-python -m pytest tests/test_wino_gpu.py tests/test_parity_gpu.py -x -q -m gpu -k "cost_volume or form_invariant or stage_by_stage or batch32" > gpurun_out/r5ah/test.txt 2>&1
-for b in 1 2 4 8 16 32; do
-python bench.py --no-secondary --no-cpu-baseline --batch $b > gpurun_out/r5ah/auto_b$b.json 2> gpurun_out/r5ah/auto_b$b.err
-done
+mkdir -p gpurun_out/r5ai
+python bench.py --no-secondary --no-cpu-baseline > gpurun_out/r5ai/def.json 2> gpurun_out/r5ai/def.err
+S3R_WINO2_MAX_EDGE=56 python bench.py --no-secondary --no-cpu-baseline > gpurun_out/r5ai/edge56.json 2> gpurun_out/r5ai/edge56.err
+S3R_DWINO_MAT=0 python bench.py --no-secondary --no-cpu-baseline > gpurun_out/r5ai/mat0.json 2> gpurun_out/r5ai/mat0.err
+S3R_DWINO_MAT=1 python bench.py --no-secondary --no-cpu-baseline > gpurun_out/r5ai/mat1.json 2> gpurun_out/r5ai/mat1.err
+python bench.py --no-secondary --no-cpu-baseline > gpurun_out/r5ai/def2.json 2> gpurun_out/r5ai/def2.err
