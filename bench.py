@@ -336,13 +336,30 @@ def aux_records(s3r, torch, model, left, right, gt_cloud, steps):
 
 # environment switches that change which kernel (or which variant of one) runs without changing the kernel sources: a run
 # under any of them is not the configuration the committed counter passes were taken on
-_KERNEL_ENV = ("S3R_TILE_", "S3R_KSPLIT_", "S3R_ALGO_", "S3R_LIB", "S3R_ABL", "S3R_BF16_MFMA", "S3R_STEM_MFMA", "S3R_DEEP_RING", "S3R_NO_TAIL_CUT",
+_KERNEL_ENV = ("S3R_LIB", "S3R_ABL", "S3R_BF16_MFMA", "S3R_STEM_MFMA", "S3R_DEEP_RING", "S3R_NO_TAIL_CUT",
                "S3R_NO_DUAL", "S3R_WINO", "S3R_DWINO_MAT", "S3R_WINO_FORM", "S3R_WINO2_FORM", "S3R_WINO2_MAX_EDGE", "S3R_STEM_WINO",
                "S3R_WINO_HANDOFF")      # (tools/README.md holds the table; tests/test_abi_cpu.py checks it against the sources)
 
 
-def kernel_env_overrides():
-    return sorted(k for k in os.environ if k.startswith(_KERNEL_ENV))
+def kernel_env_overrides(s3r=None):
+    """... plus whatever an open s3r.debug_overrides(...) context forces (`--override`): per-layer descriptor fields"""
+    found = sorted(k for k in os.environ if k.startswith(_KERNEL_ENV))
+    if s3r is not None:
+        found += [f"{kind}.{name}={v}" for kind, d in sorted(s3r.debug_overrides.active().items()) for name, v in sorted(d.items())]
+    return found
+
+
+def parse_overrides(items):
+    """--override tile.v2=2 ksplit.v4=2 algo.e6=1  ->  kwargs of s3r.debug_overrides"""
+    kw = {"tile": {}, "ksplit": {}, "algo": {}}
+    for it in items or []:
+        try:
+            key, val = it.split("=")
+            kind, name = key.split(".")
+            kw[kind][name] = int(val)
+        except (ValueError, KeyError):
+            sys.exit(f"--override wants tile|ksplit|algo.<layer>=<int>, got {it!r}")
+    return kw
 
 
 def secondary_config(s3r, torch, dev, variant, dtype, B, steps, warmup, plain_run):
@@ -467,14 +484,23 @@ def main():
                          "(8-bit renders, scaled by 1/255 inside the first kernel)")
     ap.add_argument("--autotune", action="store_true",
                     help="time tile / split-K candidates per layer in warm-up instead of using the library's table")
+    ap.add_argument("--override", nargs="*", default=[], metavar="KIND.LAYER=INT",
+                    help="tuning / diagnosis only: force descriptor fields of named layers for the whole run through "
+                         "s3r.debug_overrides (tile.v2=2 ksplit.v4=2 algo.e6=1); the line is marked as not the plain configuration")
     args = ap.parse_args()
+    forced = parse_overrides(args.override)
 
+    if args.same_device and args.backend == "nccl" and max(args.gpus, int(os.environ.get("WORLD_SIZE", "1"))) > 1:
+        sys.exit("--same-device puts every rank on cuda:0, which RCCL refuses (one communicator rank per device): "
+                 "use --backend gloo with it")
     if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))              # nothing has touched the GPU in this process
 
     import torch
     import s3r
     spec = s3r.arch_spec
+    if any(forced.values()):
+        s3r.debug_overrides(**forced).__enter__()      # for the whole process: every model of this run is built under it
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -628,7 +654,7 @@ def main():
         value = pairs / elapsed
         ms_per_step = 1e3 * elapsed / args.steps
         fl = spec.flops_per_pair(args.variant)
-        overrides = kernel_env_overrides()
+        overrides = kernel_env_overrides(s3r)
         plain_run = not args.autotune and not args.no_graph and not overrides and not args.include_h2d and \
             args.renders == "f32"
         roof, kernels = roofline_of(records, args.steps, args.dtype, args.variant, B, spec, plain_run, eager_step_ms=eager_ms)
@@ -675,7 +701,9 @@ def main():
             graphed = None                           # (its buffers stay with the model; the secondaries build their own)
             sec = {}
             k2 = max(5, min(args.steps, 10))
-            for name, (v, d, b) in {"bf16_b256": ("voxel", "bf16", 256), "point_b32": ("point", "f32", 32)}.items():
+            # (fp32_b256: the per-rank workload of configs[4]'s 8 x 256 — the N = 1 anchor a 1 -> 8 weak-scaling curve divides by)
+            for name, (v, d, b) in {"bf16_b256": ("voxel", "bf16", 256), "point_b32": ("point", "f32", 32),
+                                    "fp32_b256": ("voxel", "f32", 256)}.items():
                 try:
                     sec[name] = secondary_config(s3r, torch, dev, v, d, b, k2, max(2, min(args.warmup, 3)),
                                                  plain_run=not overrides)

@@ -26,7 +26,11 @@
  *   - `stream` is a hipStream_t (NULL = the default stream); work is enqueued, not waited for;
  *   - return value: S3R_OK (0) or a negative s3r_status; s3r_last_error() gives a message for the
  *     calling thread; nothing throws across the ABI;
- *   - every tensor of one call must be < 2^31 elements and < 4 GiB (32-bit buffer offsets).
+ *   - every tensor of one call must be < 2^31 elements and < 4 GiB (32-bit buffer offsets);
+ *   - size queries (s3r_conv_scratch_elems, s3r_chain_workspace_elems, ...) and the forward they size must be made with the SAME
+ *     current HIP device: launch forms (bit-identical among themselves) are planned against that device's compute-unit count and
+ *     have different scratch footprints.  A mismatch is S3R_ERR_WORKSPACE from the forward, never a wrong result.  A process with no
+ *     device (host-only planning) plans for an unpartitioned MI355X (256 CUs).
  */
 #ifndef S3R_H
 #define S3R_H
@@ -151,7 +155,8 @@ typedef struct s3r_conv_desc {
      * a zero-initialised ABI-7 descriptor means dilation 1 and is read so. */
     int32_t dilation;  /* >= 1 (0 is read as 1) */
     int32_t out_pad;   /* ConvTranspose output_padding (< max(stride, dilation)) */
-    float act_param;   /* S3R_ACT_LEAKY_RELU: negative slope; S3R_ACT_ELU: alpha */
+    float act_param;   /* S3R_ACT_LEAKY_RELU: negative slope; S3R_ACT_ELU: alpha (S3R_OP_LINEAR descriptors take the three too: a pass behind
+                          the layer; the flat s3r_linear_forward entry, which has no parameter argument, takes none / relu / sigmoid) */
 } s3r_conv_desc;
 
 /* One layer of a stage: geometry + its packed weights + folded epilogue vectors (device pointers). */

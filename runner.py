@@ -63,6 +63,9 @@ def main():
                     help="evaluate on N GPUs of this node: the eval list is sharded over one process per GPU (RCCL "
                          "all-gather of the per-sample metrics); runner.py starts the ranks itself")
     args = ap.parse_args()
+    if args.same_device and args.backend == "nccl" and max(args.gpus, int(os.environ.get("WORLD_SIZE", "1"))) > 1:
+        sys.exit("--same-device puts every rank on cuda:0, which RCCL refuses (one communicator rank per device): "
+                 "use --backend gloo with it")
     if args.test and (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         # single-process entry point (README.md:85,91) kept: the ranks are a CHILD process started before anything
         # here touches the GPU (never exec from a process that has); rank 0's JSON line reaches our stdout

@@ -352,25 +352,27 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                 return fail(S3R_ERR_WORKSPACE, "linear layer needs %lld floats of scratch (s3r_conv_scratch_elems), got %lld",
                             (long long)need, (long long)(scratch ? scratch_elems : 0));
             ProfScope ps(s, F_LINEAR, d->tag, g.flops, g.bytes);
-            e = s3r::launch_linear(x, packed_w, scale, shift, y, d->batch, d->cin, d->cout, d->act, scratch, s);
+            // (the linear epilogue knows none / ReLU / sigmoid; LeakyReLU / ELU / Tanh are a pass behind it, as on the convolutions)
+            e = s3r::launch_linear(x, packed_w, scale, shift, y, d->batch, d->cin, d->cout, d->act > S3R_ACT_SIGMOID ? S3R_ACT_NONE : d->act,
+                                   scratch, s);
+            if (e == hipSuccess && d->act > S3R_ACT_SIGMOID) e = s3r::launch_act(y, g.y_elems, d->act, d->act_param, s);
             break;
         }
         case R_MFMA: {
             int alg, form;
             if ((rc = resolve_algo(d, &alg, &form))) return rc;
-            if (staged_layer(d) || d->act > S3R_ACT_SIGMOID) {
-                // ---- parameter-general layer: [staged copy ->] direct kernel [-> activation pass]
-                s3r::ConvParams q = staged_layer(d) ? make_params_staged(d, g) : make_params(d, g);
+            if (staged_layer(d)) {
+                // ---- parameter-general layer behind a staged copy: staged copy -> direct kernel [-> activation pass]
+                s3r::ConvParams q = make_params_staged(d, g);
                 q.x = x; q.w = packed_w; q.scale = scale; q.shift = shift; q.y = y;
                 ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
                 ps.launches = 0;
-                if (staged_layer(d)) {
+                {
                     const StagedGeo sg = staged_geo(d);
                     const int64_t need = (sg.elems + 255) / 256 * 256;
                     if (!scratch || scratch_elems < need)
                         return fail(S3R_ERR_WORKSPACE, "a parameter-general layer stages its input in %lld floats of scratch "
                                     "(s3r_conv_scratch_elems), got %lld", (long long)need, (long long)(scratch ? scratch_elems : 0));
-                    if (sg.elems * 4 >= kMaxBytes) return fail(S3R_ERR_INVALID, "staged input too large for one call: split the batch");
                     s3r::AuxScope aux(s, 4.0 * ((double)g.x_elems + (double)sg.elems));
                     e = s3r::launch_stage(x, scratch, d->batch, d->cin, sg.cin_pad, g.nd, d->in_size, d->in_halo, sg.sp, sg.pe, sg.step, s);
                     if (e != hipSuccess) return hip_fail(e, "staging launch");
@@ -477,6 +479,11 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
             ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
             e = s3r::launch_conv_mfma(p, L.cfg + 16 * L.vec, s);
             ps.launches = s3r::conv_last_launch_count();
+            if (e == hipSuccess && d->act > S3R_ACT_SIGMOID) {       // (make_params ran the kernel with ACT_NONE; split-K as the descriptor says)
+                s3r::AuxScope aux(s, 8.0 * (double)g.y_elems);
+                e = s3r::launch_act(y, g.y_elems, d->act, d->act_param, s);
+                ps.launches += 1;
+            }
             break;
         }
     }
@@ -711,6 +718,9 @@ int s3r_linear_forward(const float* x, const float* w, const float* bias, float*
                        int act, float* scratch, int64_t scratch_elems, void* stream) {
     if (!x || !w || !y) return fail(S3R_ERR_INVALID, "null tensor pointer");
     if (batch <= 0 || cin <= 0 || cout <= 0) return fail(S3R_ERR_INVALID, "linear dims must be positive");
+    if (act < S3R_ACT_NONE || act > S3R_ACT_SIGMOID)
+        return fail(S3R_ERR_INVALID, "s3r_linear_forward takes none / relu / sigmoid (act %d): LeakyReLU / ELU / Tanh carry a parameter — "
+                    "run the layer as an S3R_OP_LINEAR descriptor through s3r_conv_forward / s3r_chain_forward", act);
     if (!scratch || scratch_elems < s3r::linear_scratch_elems(batch, cin, cout))
         return fail(S3R_ERR_WORKSPACE, "linear needs %lld floats of scratch (s3r_linear_scratch_elems)",
                     (long long)s3r::linear_scratch_elems(batch, cin, cout));

@@ -27,15 +27,14 @@ struct LdsAttr {
 // planners (plan_tail_cut, wino_plan, wino2_form) count workgroup rounds against.  Read once per device; 256 where no device
 // answers (the host-only size queries of a CPU-only box, so that they plan what a full MI355X would).
 inline int cu_count() {
-    static std::atomic<int> cached[16];
+    static std::atomic<int> cached[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) { (void)hipGetLastError(); return 256; }
-    const int slot = dev < 16 ? dev : 15;
-    int n = cached[slot].load(std::memory_order_relaxed);
+    int n = dev < 64 ? cached[dev].load(std::memory_order_relaxed) : 0;      // (a device beyond the table is asked every time: never another's answer)
     if (n > 0) return n;
     n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
-    cached[slot].store(n, std::memory_order_relaxed);
+    if (dev < 64) cached[dev].store(n, std::memory_order_relaxed);
     return n;
 }
 

@@ -96,6 +96,7 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
         return fail(S3R_ERR_INVALID, "the transformed input layout exists on the convolution paths only");
     if (d->op == S3R_OP_LINEAR) {
         if (d->in_halo || d->out_halo) return fail(S3R_ERR_INVALID, "linear layers take no halo");
+        if (d->act < S3R_ACT_NONE || d->act > S3R_ACT_TANH) return fail(S3R_ERR_INVALID, "unknown activation %d", d->act);
         g->nd = 0; g->in = g->out = g->in_p = g->out_p = 1; g->in_sp = 1; g->out_sp = 1;
         g->x_elems = (int64_t)d->batch * d->cin;
         g->y_elems = (int64_t)d->batch * d->cout;
@@ -122,7 +123,16 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
         if (d->out_pad >= (d->stride > dil_of(d) ? d->stride : dil_of(d)))
             return fail(S3R_ERR_INVALID, "out_pad %d must be smaller than max(stride, dilation)", d->out_pad);
     }
-    if (staged_layer(d) && staged_geo(d).pe > 8) return fail(S3R_ERR_INVALID, "effective padding %d > 8", staged_geo(d).pe);
+    // (a staged layer builds its own halo of any width — pe is not bounded by the caller-halo limit above; what bounds it is the size
+    // of the staged copy, checked HERE so that planning and the forward agree: ADVICE r05)
+    if (staged_layer(d)) {
+        const bool tr = d->op == S3R_OP_DECONV;      // (in double first: the int64 product of staged_geo may not exist)
+        const double pe = tr ? (double)dil_of(d) * (d->k - 1) - d->pad : d->pad;
+        const double sp = (tr ? ((double)d->in_size - 1) * d->stride + 1 + d->out_pad : d->in_size) + 2 * pe;
+        const double est = (double)d->batch * ((d->cin + 15) / 16 * 16) * (d->ndim == 3 ? sp * sp * sp : sp * sp);
+        if (est >= (double)kMaxElems || est * 4 >= (double)kMaxBytes)
+            return fail(S3R_ERR_INVALID, "staged input too large for one call (>= 2^31 elements / 4 GiB): split the batch");
+    }
     g->nd = d->ndim;
     g->in = d->in_size;
     g->out = out_size(d);

@@ -22,6 +22,44 @@ from . import arch_spec as spec
 
 MAX_CHUNK = 256      # pairs per C-ABI call: keeps every activation < 2^31 elements / 4 GiB
 
+# Per-layer descriptor overrides of tuning / diagnosis runs: layer name -> value, for every module of the process, while a
+# `debug_overrides(...)` context is open.  The release path consults nothing else: no environment variable reaches a descriptor
+# (r05 read S3R_TILE_<layer> / S3R_KSPLIT_<layer> / S3R_ALGO_<layer> on every forward).
+_DEBUG = {"tile": {}, "ksplit": {}, "algo": {}}
+
+
+class debug_overrides:
+    """`with s3r.debug_overrides(tile={"v2": 2}, ksplit={"v4": 2}, algo={"e6": s3r.ALGO_DIRECT}): ...`
+
+    Forces descriptor fields of named layers — the direct kernel's tile code, the split-K factor, the algorithm — for every
+    forward enqueued inside the context.  These CHANGE RESULT BITS (another summation order / another algorithm): a tuning and
+    diagnosis facility (tools/layer_bench.py, tools/ab_*.py), never set on a deployment path.  Nesting merges; leaving restores.
+    A module captured in a HIP graph keeps the plan it was captured with."""
+
+    def __init__(self, tile=None, ksplit=None, algo=None):
+        self._new = {"tile": dict(tile or {}), "ksplit": dict(ksplit or {}), "algo": dict(algo or {})}
+        for kind, d in self._new.items():
+            for name, v in d.items():
+                if not isinstance(name, str) or not isinstance(v, int):
+                    raise TypeError(f"debug_overrides({kind}=...): layer name -> int, got {name!r}: {v!r}")
+
+    def __enter__(self):
+        self._saved = {k: dict(v) for k, v in _DEBUG.items()}
+        for k, d in self._new.items():
+            _DEBUG[k].update(d)
+        return self
+
+    def __exit__(self, *exc):
+        for k in _DEBUG:
+            _DEBUG[k].clear()
+            _DEBUG[k].update(self._saved[k])
+        return False
+
+    @staticmethod
+    def active() -> dict:
+        """what is in force now ({} x 3 on a release path; bench.py marks a run under any of it as not the plain configuration)"""
+        return {k: dict(v) for k, v in _DEBUG.items() if v}
+
 
 def _to_channels_last_physical(x: torch.Tensor) -> torch.Tensor:
     """logical (B,C,...) tensor -> contiguous physical (B,...,C) tensor (no copy if already channels-last)."""
@@ -245,8 +283,7 @@ class _HipChain(nn.Module):
         arr = (_lib.Layer * n_layers)()
         for i, (l, (n_in, _)) in enumerate(zip(self._layers[:n_layers], self._sizes())):
             pw, scale, shift, _ = packed[i]
-            tile = int(os.environ.get(f"S3R_TILE_{l.name}", self.tile_override.get(l.name, -1)))
-            ksplit = int(os.environ.get(f"S3R_KSPLIT_{l.name}", self.ksplit_override.get(l.name, 0)))
+            tile, ksplit = self._tile_ksplit_of(l)
             algo = self._algo_of(l)
             # only the chain's own input / output halos are the caller's to state (the output is always
             # a plain contiguous tensor); the library plans the intermediates
@@ -268,14 +305,19 @@ class _HipChain(nn.Module):
         desc = _lib.make_desc(l, 1, n_in, in_halo=1 if l.op == "deconv3d" else l.p, dtype=self._dtype, algo=_lib.ALGO_WINOGRAD)
         return _lib.load().s3r_conv_scratch_elems(C.byref(desc)) >= 0
 
+    def _tile_ksplit_of(self, l: spec.Layer):
+        """(tile, ksplit) of a layer's descriptor: an open `debug_overrides` context, else this module's tuning tables
+        (`autotune`), else the library's own choice (-1, 0)."""
+        return (int(_DEBUG["tile"].get(l.name, self.tile_override.get(l.name, -1))),
+                int(_DEBUG["ksplit"].get(l.name, self.ksplit_override.get(l.name, 0))))
+
     def _algo_of(self, l: spec.Layer) -> int:
         """s3r_algo of a layer's descriptor: a per-layer override, else the model's `winograd` switch (only layers that
         have the Winograd form can be asked for it), else AUTO."""
+        if l.name in _DEBUG["algo"]:
+            return int(_DEBUG["algo"][l.name])
         if l.name in self.algo_override:
             return int(self.algo_override[l.name])
-        env = os.environ.get(f"S3R_ALGO_{l.name}")
-        if env is not None:
-            return int(env)
         if self.winograd is None:
             return _lib.ALGO_AUTO
         if self.winograd and self._has_winograd_form(l):
@@ -289,8 +331,7 @@ class _HipChain(nn.Module):
         if self.precision != "fp32" or batch <= 0:
             return _lib.LAYOUT_PLAIN
         l, (n_in, _) = self._layers[0], self._sizes()[0]
-        tile = int(os.environ.get(f"S3R_TILE_{l.name}", self.tile_override.get(l.name, -1)))
-        ksplit = int(os.environ.get(f"S3R_KSPLIT_{l.name}", self.ksplit_override.get(l.name, 0)))
+        tile, ksplit = self._tile_ksplit_of(l)
         desc = _lib.make_desc(l, batch, n_in, tile=tile, in_halo=1, ksplit=ksplit, dtype=self._dtype, algo=self._algo_of(l))
         return _lib.check(_lib.load().s3r_conv_wino_input_layout(C.byref(desc)), "wino_input_layout")
 

@@ -440,3 +440,27 @@ def test_parameter_general_descriptors_plan_without_a_gpu(s3r, lib):
     assert lib.s3r_conv_scratch_elems(C.byref(wino)) == -1 and b"no Winograd form" in lib.s3r_last_error()
     bf = L.make_desc(Layer("a", "conv2d", 32, 32, 3, 1, 2, True, "relu", 2), 1, 8, in_halo=2, dtype=1)
     assert lib.s3r_conv_scratch_elems(C.byref(bf)) == -1 and b"bf16" in lib.s3r_last_error()
+
+
+def test_release_path_reads_no_kernel_policy_from_the_environment(s3r, monkeypatch):
+    """descriptor fields come from the model, its tuning tables or an explicit s3r.debug_overrides(...)
+    context — never from os.environ (r05 read S3R_TILE_ / S3R_KSPLIT_ / S3R_ALGO_<layer> on every forward)."""
+    import re
+    src = open(os.path.join(ROOT, "stereo-3d-reconstruction_amd", "modules.py")).read()
+    uses = [l.strip() for l in src.split("\n") if "os.environ" in l and not l.strip().startswith("#")]
+    assert len(uses) == 1 and "S3R_BF16_MFMA" in uses[0] and "_cache_key" in src[:src.index(uses[0])].rsplit("def ", 1)[1]
+    for name in ("S3R_TILE_v2", "S3R_KSPLIT_v2", "S3R_ALGO_v2"):
+        monkeypatch.setenv(name, "3")
+    dec = s3r.Decoder()
+    v2 = dec._layers[1]
+    assert dec._tile_ksplit_of(v2) == (-1, 0) and dec._algo_of(v2) == s3r.ALGO_AUTO
+    dec.tile_override["v2"] = 1
+    with s3r.debug_overrides(tile={"v2": 2}, algo={"v2": s3r.ALGO_DIRECT}):
+        assert dec._tile_ksplit_of(v2) == (2, 0) and dec._algo_of(v2) == s3r.ALGO_DIRECT
+        with s3r.debug_overrides(ksplit={"v2": 4}):
+            assert dec._tile_ksplit_of(v2) == (2, 4)
+            assert s3r.debug_overrides.active() == {"tile": {"v2": 2}, "ksplit": {"v2": 4}, "algo": {"v2": 1}}
+        assert dec._tile_ksplit_of(v2) == (2, 0)
+    assert dec._tile_ksplit_of(v2) == (1, 0) and s3r.debug_overrides.active() == {}
+    with pytest.raises(TypeError):
+        s3r.debug_overrides(tile={"v2": "2"})

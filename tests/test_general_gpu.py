@@ -62,6 +62,47 @@ def test_named_shapes(s3r, oracle):
         _check(s3r, oracle, layers, n_in, B, seed=i)
 
 
+def test_linear_layers_take_every_activation(s3r, oracle):
+    """a linear layer with LeakyReLU / ELU / Tanh ran with NO activation (the LINEAR branch of geometry() returned before
+    the range check and the linear epilogue knows none / ReLU / sigmoid only).  They are a pass behind the layer now."""
+    L = s3r.arch_spec.Layer
+    for i, (act, par) in enumerate((("leaky_relu", None), ("leaky_relu", 0.3), ("elu", 0.7), ("tanh", None), ("relu", None), ("sigmoid", None),
+                                    ("none", None))):
+        _check(s3r, oracle, [L("a", "linear", 96, 40, 1, 1, 0, False, act, 1, 0, par)], 1, 3, seed=40 + i)
+    _check(s3r, oracle, [L("a", "linear", 64, 64, 1, 1, 0, False, "elu"), L("b", "linear", 64, 10, 1, 1, 0, False, "tanh")], 1, 2, seed=50)
+    # the flat entry has no parameter argument: it refuses what it cannot express instead of dropping it
+    import ctypes as C
+    lib = s3r.load_library()
+    x = torch.zeros(2, 16, device="cuda:0"); w = torch.zeros(8, 16, device="cuda:0"); y = torch.zeros(2, 8, device="cuda:0")
+    sc = torch.zeros(max(1, lib.s3r_linear_scratch_elems(2, 16, 8)), device="cuda:0")
+    rc = lib.s3r_linear_forward(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), 2, 16, 8, 3, sc.data_ptr(), sc.numel(), None)
+    assert rc == -1 and b"LeakyReLU" in lib.s3r_last_error()
+
+
+def test_staged_layers_build_halos_of_any_width(s3r, oracle):
+    """the staged copy builds its own halo, so its effective padding is not bound by the caller-halo limit of 8"""
+    L = s3r.arch_spec.Layer
+    _check(s3r, oracle, [L("a", "deconv2d", 16, 8, 7, 1, 0, True, "relu", 2)], 6, 2, seed=60)          # pe = 2 * 6 - 0 = 12
+    _check(s3r, oracle, [L("a", "conv2d", 10, 12, 7, 1, 9, True, "none", 3)], 9, 1, seed=61)           # cin % 16 != 0, pad 9
+    _check(s3r, oracle, [L("a", "deconv3d", 8, 8, 5, 2, 0, False, "tanh", 3)], 3, 1, seed=62)          # pe = 12 in 3D
+
+
+def test_split_k_is_honoured_on_general_layers_that_are_not_staged(s3r, oracle):
+    """a caller-forced split-K on a cin % 16 == 0 layer with LeakyReLU / ELU / Tanh was silently ignored by the forward
+    while the scratch query planned its slabs; now the layer runs the normal direct path (split as asked) + the activation pass"""
+    import ctypes as C
+    L = s3r.arch_spec.Layer
+    layer = L("a", "conv3d", 64, 32, 3, 2, 1, True, "elu")
+    lib = s3r.load_library()
+    d1 = s3r._lib.make_desc(layer, 2, 9, in_halo=1)
+    d4 = s3r._lib.make_desc(layer, 2, 9, in_halo=1, ksplit=4)
+    assert lib.s3r_conv_scratch_elems(C.byref(d4)) > lib.s3r_conv_scratch_elems(C.byref(d1)) >= 0
+    with s3r.debug_overrides(ksplit={"a": 4}):
+        _check(s3r, oracle, [layer], 9, 2, seed=70)
+    with s3r.debug_overrides(ksplit={"a": 1}):
+        _check(s3r, oracle, [layer], 9, 2, seed=70)
+
+
 def test_random_sweep(s3r, oracle):
     """A seeded sweep over the parameter space (what a property-based run would draw; kept deterministic so that a failure names
     its case)."""
