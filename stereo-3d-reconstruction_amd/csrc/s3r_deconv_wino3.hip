@@ -38,6 +38,13 @@ __device__ __forceinline__ void d3dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, S3R_LDS_PTR_D(lds_dst), 16, voffset, soffset, 0, 0);
 }
 
+// AGPR residency for the running transform sums (z, Y: 8 tiles of 16).  They are touched by the folds at the end of an (a, b) only,
+// never by a matrix instruction, so they live in the accumulation half of the unified register file, which the VGPR-form MFMAs of
+// the K loop leave empty: 128 AGPRs + ~120 VGPRs at two waves per SIMD instead of 256 VGPRs + 72 spilled dwords (r05: the spills'
+// reloads sat in one phase's DMA issue path behind s_waitcnt vmcnt(0)).  Same operations in the same order: same bits.
+__device__ __forceinline__ float d3_put(float v) { float a; asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); return a; }
+__device__ __forceinline__ float d3_get(float a) { float v; asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; }
+
 constexpr int D3_CK = 16;          // channels per stage
 constexpr int D3_NST = 3;          // LDS stages
 constexpr int D3_A = 3 * D3_CK * 64;                     // weight floats per stage
@@ -159,7 +166,8 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void dwino3_kernel(const ConvPa
     }
     const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
 
-    d3f16 acc[3], z[2][2], Y[2][2];
+    d3f16 acc[3];
+    float z[2][2][16], Y[2][2][16];                              // AGPR-resident (d3_put / d3_get)
 
     // outputs of depth u: Y[v][w] -> (2 (2 pd + u) + rd, 2 (2 ph + v) + rh, 2 (2 pw + w) + rw)
     auto store_u = [&](const int u) __attribute__((always_inline)) {
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void dwino3_kernel(const ConvPa
 #pragma unroll
                 for (int v = 0; v < 2; ++v)
 #pragma unroll
-                    for (int w = 0; w < 2; ++w) t[v][w] = fmaf(fmaxf(fmaf(Y[v][w][r], sc, sf), lo), hw, t[v][w]);
+                    for (int w = 0; w < 2; ++w) t[v][w] = fmaf(fmaxf(fmaf(d3_get(Y[v][w][r]), sc, sf), lo), hw, t[v][w]);
                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
             float* ex = ep + 192 + jt * 4;
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void dwino3_kernel(const ConvPa
                 for (int v = 0; v < 2; ++v)
 #pragma unroll
                     for (int w = 0; w < 2; ++w) {
-                        const float o = fmaxf(fmaf(Y[v][w][r], sc, sf), lo);
+                        const float o = fmaxf(fmaf(d3_get(Y[v][w][r]), sc, sf), lo);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), yrsrc, yvo + (v * 2 * p.y_hs + w * 2) * 4,
                                                               dm * p.y_cs * 4, 0);
                     }
@@ -265,16 +273,20 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void dwino3_kernel(const ConvPa
             // ---- W transform of (a, b), folded into the H transform's sums z[v][w]
             if (b == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { z[0][0][r] = acc[0][r] + acc[1][r]; z[0][1][r] = acc[1][r] - acc[2][r]; }
+                for (int r = 0; r < 16; ++r) { z[0][0][r] = d3_put(acc[0][r] + acc[1][r]); z[0][1][r] = d3_put(acc[1][r] - acc[2][r]); }
             } else if (b == 1) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float t0 = acc[0][r] + acc[1][r], t1 = acc[1][r] - acc[2][r];
-                    z[0][0][r] += t0; z[0][1][r] += t1; z[1][0][r] = t0; z[1][1][r] = t1;
+                    z[0][0][r] = d3_put(d3_get(z[0][0][r]) + t0); z[0][1][r] = d3_put(d3_get(z[0][1][r]) + t1);
+                    z[1][0][r] = d3_put(t0); z[1][1][r] = d3_put(t1);
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { z[1][0][r] -= acc[0][r] + acc[1][r]; z[1][1][r] -= acc[1][r] - acc[2][r]; }
+                for (int r = 0; r < 16; ++r) {
+                    z[1][0][r] = d3_put(d3_get(z[1][0][r]) - (acc[0][r] + acc[1][r]));
+                    z[1][1][r] = d3_put(d3_get(z[1][1][r]) - (acc[1][r] - acc[2][r]));
+                }
             }
         }
         if constexpr (SPLIT) {
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void dwino3_kernel(const ConvPa
 #pragma unroll
                 for (int v = 0; v < 2; ++v)
 #pragma unroll
-                    for (int w = 0; w < 2; ++w) slab[(size_t)dm * mstride + (v * 2 + w) * 64] = z[v][w][r];
+                    for (int w = 0; w < 2; ++w) slab[(size_t)dm * mstride + (v * 2 + w) * 64] = d3_get(z[v][w][r]);
             }
             (void)store_u;
         } else
@@ -298,26 +310,30 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void dwino3_kernel(const ConvPa
 #pragma unroll
             for (int v = 0; v < 2; ++v)
 #pragma unroll
-                for (int w = 0; w < 2; ++w) Y[v][w] = z[v][w];
+                for (int w = 0; w < 2; ++w)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Y[v][w][r] = z[v][w][r];
         } else if (a == 1) {
 #pragma unroll
             for (int v = 0; v < 2; ++v)
 #pragma unroll
                 for (int w = 0; w < 2; ++w)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Y[v][w][r] += z[v][w][r];
+                    for (int r = 0; r < 16; ++r) Y[v][w][r] = d3_put(d3_get(Y[v][w][r]) + d3_get(z[v][w][r]));
             store_u(0);
 #pragma unroll
             for (int v = 0; v < 2; ++v)
 #pragma unroll
-                for (int w = 0; w < 2; ++w) Y[v][w] = z[v][w];   // depth output 1 starts from the same class: y(1) = z1 - z2
+                for (int w = 0; w < 2; ++w)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Y[v][w][r] = z[v][w][r];   // depth output 1 starts from the same class: y(1) = z1 - z2
         } else {
 #pragma unroll
             for (int v = 0; v < 2; ++v)
 #pragma unroll
                 for (int w = 0; w < 2; ++w)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Y[v][w][r] -= z[v][w][r];
+                    for (int r = 0; r < 16; ++r) Y[v][w][r] = d3_put(d3_get(Y[v][w][r]) - d3_get(z[v][w][r]));
             store_u(1);
         }
     }
