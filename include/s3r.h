@@ -57,7 +57,9 @@ typedef enum s3r_status {
 typedef enum s3r_op {
     S3R_OP_CONV = 0,          /* Conv2d / Conv3d (ndim selects) */
     S3R_OP_DECONV = 1,        /* ConvTranspose2d / 3d.  3D k4 s2 p1 has the tuned kernels (parity classes, Winograd forms); every
-                                 other (k, stride, pad, dilation, out_pad) runs zero-stuffed through the direct kernel (fp32) */
+                                 other (k, stride, pad, out_pad) with dilation 1 runs as stride^ndim residue classes, each a stride-1
+                                 launch of the direct kernel over a halo-padded copy (the algorithmic multiplications); dilation > 1
+                                 runs zero-stuffed (stride^ndim times as many) (fp32) */
     S3R_OP_LINEAR = 2         /* nn.Linear on the flattened input */
 } s3r_op;
 
@@ -149,9 +151,9 @@ typedef struct s3r_conv_desc {
     int32_t algo;      /* s3r_algo (ABI 7): AUTO = the library's geometry-only policy */
     /* ABI 8 — parameter-general layers (fp32 path).  The shapes this build's network has keep their tuned kernels; any other
      * (k, stride, pad, dilation) convolution with cin % 16 == 0 runs the direct kernel; everything else listed here goes through
-     * the direct kernel behind a staging pass (correct first, untuned): cin % 16 != 0 (channels zero-padded), ConvTranspose2d / 3d
-     * with any k / stride / pad / dilation / output padding (the input zero-stuffed at the stride, the kernel flipped), and the
-     * activations below (a pass of their own behind the convolution).  0 / 0 / 0.f are NOT the neutral values of `dilation`:
+     * the direct kernel behind a staging pass: cin % 16 != 0 (channels zero-padded), ConvTranspose2d / 3d with any k / stride / pad /
+     * output padding (dilation 1: one stride-1 convolution launch per output residue class over the halo-padded copy; dilation > 1:
+     * the input zero-stuffed at the stride, the kernel flipped), and the activations below (a pass of their own behind the layer).  0 / 0 / 0.f are NOT the neutral values of `dilation`:
      * a zero-initialised ABI-7 descriptor means dilation 1 and is read so. */
     int32_t dilation;  /* >= 1 (0 is read as 1) */
     int32_t out_pad;   /* ConvTranspose output_padding (< max(stride, dilation)) */

@@ -233,7 +233,15 @@ int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, void* packedv,
             if (d->dtype == S3R_BF16)
                 e = s3r::launch_pack_bf16(w, packed, d->cin, d->cout, cout_pad_h(d->cout),
                                           d->op == S3R_OP_DECONV ? 8 : (int)ipow(d->k, g.nd), d->op == S3R_OP_DECONV, s);
-            else if (staged_layer(d)) {
+            else if (tclass_layer(d)) {
+                for (int cls = 0; cls < (int)ipow(d->stride, g.nd) && e == hipSuccess; ++cls) {
+                    const int rw = cls % d->stride, rh = (cls / d->stride) % d->stride, rd = g.nd == 3 ? cls / (d->stride * d->stride) : 0;
+                    s3r::ConvParams q; int64_t w_off; double macs;
+                    (void)make_params_tclass(d, g, rd, rh, rw, &q, &w_off, &macs);      // (the slab is packed whether or not this size uses it)
+                    e = s3r::launch_pack_tclass(w, packed + w_off, d->cin, staged_geo(d).cin_pad, d->cout, cout_pad(d->cout), g.nd, d->k,
+                                                d->stride, rd, rh, rw, s);
+                }
+            } else if (staged_layer(d)) {
                 e = s3r::launch_pack_general(w, packed, d->cin, staged_geo(d).cin_pad, d->cout, cout_pad(d->cout), (int)ipow(d->k, g.nd),
                                              d->op == S3R_OP_DECONV, s);
             } else {
@@ -383,10 +391,28 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                 Launch L;
                 s3r_conv_desc dd = *d;
                 dd.ksplit = 1;                                   // (no split-K slabs behind the staged copy)
-                if ((rc = resolve_launch(&dd, &q, &L))) return rc;
-                e = s3r::launch_conv_mfma(q, L.cfg + 16 * L.vec, s);
-                if (e != hipSuccess) return hip_fail(e, "conv forward launch");
-                ps.launches += s3r::conv_last_launch_count();
+                if (tclass_layer(d)) {
+                    // ---- ConvTranspose, dilation 1: one stride-1 convolution launch per residue class of the output
+                    double macs_all = 0.0;
+                    dd.tile = -1;
+                    for (int cls = 0; cls < (int)ipow(d->stride, g.nd); ++cls) {
+                        const int rw = cls % d->stride, rh = (cls / d->stride) % d->stride, rd = g.nd == 3 ? cls / (d->stride * d->stride) : 0;
+                        s3r::ConvParams c; int64_t w_off; double macs;
+                        if (!make_params_tclass(d, g, rd, rh, rw, &c, &w_off, &macs)) continue;
+                        c.x = scratch; c.w = packed_w + w_off; c.scale = scale; c.shift = shift; c.y = y;
+                        if ((rc = resolve_launch(&dd, &c, &L))) return rc;
+                        e = s3r::launch_conv_mfma(c, L.cfg + 16 * L.vec, s);
+                        if (e != hipSuccess) return hip_fail(e, "conv forward launch (transposed class)");
+                        ps.launches += s3r::conv_last_launch_count();
+                        macs_all += macs;
+                    }
+                    ps.exec = 2.0 * macs_all;
+                } else {
+                    if ((rc = resolve_launch(&dd, &q, &L))) return rc;
+                    e = s3r::launch_conv_mfma(q, L.cfg + 16 * L.vec, s);
+                    if (e != hipSuccess) return hip_fail(e, "conv forward launch");
+                    ps.launches += s3r::conv_last_launch_count();
+                }
                 if (d->act > S3R_ACT_SIGMOID) {
                     s3r::AuxScope aux(s, 8.0 * (double)g.y_elems);
                     e = s3r::launch_act(y, g.y_elems, d->act, d->act_param, s);

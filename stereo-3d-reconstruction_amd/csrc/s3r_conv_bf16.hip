@@ -741,7 +741,28 @@ __global__ __launch_bounds__(256, 2) void conv_bf16r_kernel(const ConvParamsH p,
 // stream through a 3-slot ring with one barrier per tap.
 constexpr int NPA_PL = 15;     // 8-row A pieces per wave, upper bound (registers), 128-byte rows
 constexpr int NPA_PL32 = 12;   // 16-row pieces, 64-byte rows
-constexpr int PL_NB = 3;       // weight ring slots
+// weight ring slots of the plane kernel: a tap's weights are requested pl_nb - 1 taps ahead.  Three slots (two taps of lead) is the
+// measured optimum: r06 built the ring for any depth and five slots (four taps of lead; + 8 KiB per workgroup, which takes e4 / v3 /
+// v5 / d3 from three workgroups per CU to two) measured e4 + 19 %, d3 + 17 %, v3 + 11 %, v5 + 13 % SLOWER at B = 256, e7 / d1 / d2
+// - 2 ... - 3 % (gpurun_out/r6e/ab, A/B on one device): occupancy, not the weights' latency, is what these loops live on.
+#ifndef S3R_PL_NB32
+#define S3R_PL_NB32 3
+#endif
+constexpr int pl_nb(int kc) { return kc == 32 ? S3R_PL_NB32 : 3; }
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vm_n(int n) {      // n is wave-uniform and small: one immediate form per value
+    switch (n) {
+        case 0: wait_vm<0>(); break;
+        case 1: wait_vm<1>(); break;
+        case 2: wait_vm<2>(); break;
+        case 3: wait_vm<3>(); break;
+        case 4: wait_vm<4>(); break;
+        case 5: wait_vm<5>(); break;
+        case 6: wait_vm<6>(); break;
+        case 7: wait_vm<7>(); break;
+        default: wait_vm<8>(); break;
+    }
+}
 
 // KC = 64: 128-byte image rows (whole lines), two workgroups per CU; KC = 32: 64-byte rows, half the LDS, three
 // workgroups per CU (and the only form for Cin = 32).
@@ -765,6 +786,9 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
     constexpr int B_BYTES = BNW * ROWB;            // one tap's weight tile
     constexpr int NPB = B_BYTES / 4096;            // its pieces per wave
     constexpr int NPA_CAP = KC == 64 ? NPA_PL : NPA_PL32;
+    constexpr int PL_NB = pl_nb(KC);               // weight ring slots; a tap's weights are requested PL_D taps ahead
+    constexpr int PL_D = PL_NB - 1;
+    static_assert(NPB * (PL_D - 1) <= 8, "wait_vm_n covers 0 .. 8");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int a_bytes = r_max * ROWB;
     char* Bs = smem + a_bytes;                                        // [PL_NB][64][ROWB]
@@ -866,8 +890,9 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
         if (++b_tap == T) { b_tap = 0; ++b_cc; }
         if (++b_slot == PL_NB) b_slot = 0;
     };
-    issue_b();
-    if (total > 1) issue_b();
+#pragma unroll
+    for (int i = 0; i < PL_D; ++i)
+        if (i < total) issue_b();
 
     for (int t = tid; t < BM; t += 256) {
         const int n = m0 + t;
@@ -953,14 +978,18 @@ __global__ __launch_bounds__(256, (KC == 64 || NH == 2) ? 2 : 3) void conv_bf16p
             // this tap's weights (and, at t == 0, the image) have landed; the next tap's may still be in flight.
             // (s_barrier as inline asm: the compiler drains vmcnt before every barrier it knows about, which
             // would cut the weight prefetch back to one tap)
-            if (t == 0 || tt + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (NPB == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            asm volatile("s_barrier" ::: "memory");           // ... for every wave; ring slot (tt+2)%3 is free
+            // (the taps tt + 1 .. tt + PL_D - 1 requested behind it may still be in flight; at t == 0 the image, requested last, must
+            // have landed too)
+            {
+                const int ahead = total - 1 - tt < PL_D - 1 ? total - 1 - tt : PL_D - 1;
+                if (t == 0) wait_vm<0>();
+                else wait_vm_n(NPB * ahead);
+            }
+            asm volatile("s_barrier" ::: "memory");           // ... for every wave; ring slot (tt + PL_D) % PL_NB is free
 #ifdef S3R_ABLATE
             if (p.debug == 7 && tt == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
 #endif
-            if (tt + 2 < total && !S3R_ABLH(p, 3)) issue_b();
+            if (tt + PL_D < total && !S3R_ABLH(p, 3)) issue_b();
             const char* b = Bs + c_slot * B_BYTES;
             int a_off[NPT];
 #pragma unroll
@@ -1330,7 +1359,7 @@ static hipError_t launch_tm_plane(ConvParamsH p, hipStream_t stream) {
     if (r_max == 0 || r_max > (KC == 64 ? 32 * NPA_PL : 64 * NPA_PL32) || (p.Cin / KC) % p.ksplit != 0)
         return hipErrorInvalidValue;
     if (NH == 2 && (p.n_tiles % 2 != 0 || p.head_w)) return hipErrorInvalidValue;
-    const size_t lds = (size_t)r_max * KC * 2 + PL_NB * HBN * NH * KC * 2 + 2 * BM * sizeof(int) + EP_BYTES * NH;
+    const size_t lds = (size_t)r_max * KC * 2 + pl_nb(KC) * HBN * NH * KC * 2 + 2 * BM * sizeof(int) + EP_BYTES * NH;
     if (lds > 160 * 1024 || r_max * 4 > HBN * NH * KC * 2) return hipErrorInvalidValue;
     static LdsAttr lds_attr;
     dim3 grid(p.m_tiles * (p.n_tiles / NH) * (p.transposed ? 8 : 1), 1, p.ksplit);      // (class inside blockIdx.x: see the kernel)

@@ -354,8 +354,8 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, const int bi
     // ---- epilogue: y = act(acc * scale[cout] + shift[cout]) into the (halo-padded) NC(D)HW output;
     // a lane's TN positions are consecutive in one output row when Nw % TN == 0 (convolutions).
     const int nl = n0 + wn * TN * 32 + j * TN;          // this lane's first position
-    const int ostep = p.transposed ? 2 : 1;
-    const bool vec_ok = !p.transposed && (p.Nw % TN == 0);
+    const int ostep = p.transposed ? 2 : (p.y_step > 1 ? p.y_step : 1);
+    const bool vec_ok = !p.transposed && p.y_step <= 1 && (p.Nw % TN == 0);
     int yoff[TN];
     bool yok[TN];
 #pragma unroll
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(const ConvParams p, in
     const int rd = (cls >> 2) & 1, rh = (cls >> 1) & 1, rw = cls & 1;
     const int nq = npad >> 2;
     const long long total = (long long)p.Cout * nq;
-    const int ostep = p.transposed ? 2 : 1;
+    const int ostep = p.transposed ? 2 : (p.y_step > 1 ? p.y_step : 1);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int m = (int)(i / nq);
         const int n = (int)(i - (long long)m * nq) * 4;

@@ -2,11 +2,15 @@
 // output padding; any channel count; LeakyReLU / ELU / Tanh) run on the direct implicit-GEMM kernel of s3r_conv_glds.hip.
 //
 //   stage_kernel         x (B, Cin, n [+ 2 halo] ...) -> staged (B, CinPad, U + 2 pe, ...), zero everywhere else: channels padded to a
-//                        multiple of 16, the convolution's zero padding pe materialised as a halo, and — transposed layers — the input
-//                        ZERO-STUFFED at the stride (sample i at position pe + i * stride).  A ConvTranspose(k, s, p, d, op) is then
-//                        the stride-1 convolution of the stuffed tensor (edge (n - 1) s + 1 + op) with the flipped kernel, dilation d
-//                        and padding d (k - 1) - p: s^ndim times the multiplications of the parity-class form the tuned k4 s2 p1
-//                        path uses, which is the price of "any".
+//                        multiple of 16, the zero padding pe materialised as a halo.
+//   ConvTranspose(k, s, p, op), dilation 1 (r06): s^ndim RESIDUE CLASSES, each a stride-1 convolution launch of the direct kernel over
+//                        the halo-padded (NOT stuffed) input: output o = s q + r - p of class r takes the taps t = r, r + s, ... < k from
+//                        inputs q, q - 1, ...; the class kernel is that tap subset in correlation order (pack_tclass_kernel), its
+//                        positions are the q with 0 <= o < n_out, its outputs go out s elements apart (ConvParams::y_step).  Executes
+//                        the algorithmic multiplications (x CinPad / Cin, + the taps that meet the halo) where r05's zero-stuffed form
+//                        executed s^ndim times as many.
+//   ConvTranspose with dilation > 1: still the zero-stuffed form — the input stuffed at the stride (sample i at pe + i * stride),
+//                        a stride-1 convolution with the flipped kernel, dilation d and padding d (k - 1) - p.
 //   pack_general_kernel  torch weights -> the direct kernel's packed K order with CinPad rows (zeros beyond Cin), flipped for
 //                        transposed layers
 //   act_kernel           LeakyReLU / ELU / Tanh in place (the MFMA epilogues know none / ReLU / sigmoid); act(0) = 0 keeps halos zero
@@ -69,6 +73,38 @@ __global__ void pack_general_kernel(const float* __restrict__ w, float* __restri
 
 hipError_t launch_pack_general(const float* w, float* wp, int Cin, int CinPad, int Cout, int CoutPad, int T, int flip, hipStream_t s) {
     hipLaunchKernelGGL(pack_general_kernel, dim3(1024), dim3(256), 0, s, w, wp, Cin, CinPad, Cout, CoutPad, T, flip);
+    return hipGetLastError();
+}
+
+// taps of residue r along one axis: kernel indices r, r + s, ... < k
+__host__ __device__ inline int tclass_taps(int k, int s, int r) { return r < k ? (k - r + s - 1) / s : 0; }
+
+__global__ void pack_tclass_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int CinPad, int Cout, int CoutPad, int nd,
+                                   int k, int stride, int rd, int rh, int rw) {
+    const int krd = nd == 3 ? tclass_taps(k, stride, rd) : 1, krh = tclass_taps(k, stride, rh), krw = tclass_taps(k, stride, rw);
+    const int ed = krd > 0 ? krd : 1, eh = krh > 0 ? krh : 1, ew = krw > 0 ? krw : 1;      // (an empty axis: one zero tap)
+    const int T = ed * eh * ew, KT = nd == 3 ? k * k * k : k * k;
+    const size_t total = (size_t)T * CinPad * CoutPad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int co = (int)(r % CoutPad); r /= CoutPad;
+        const int c = (int)(r & 15); r >>= 4;
+        const int tap = (int)(r % T);
+        const int cin = (int)(r / T) * 16 + c;
+        const int jw = tap % ew, jh = (tap / ew) % eh, jd = tap / (ew * eh);
+        float v = 0.f;
+        if (co < Cout && cin < Cin && krh > 0 && krw > 0 && (nd != 3 || krd > 0)) {
+            const int tw = rw + stride * (krw - 1 - jw), th = rh + stride * (krh - 1 - jh);
+            const int td = nd == 3 ? rd + stride * (krd - 1 - jd) : 0;
+            v = w[((size_t)cin * Cout + co) * KT + ((size_t)td * k + th) * k + tw];
+        }
+        wp[i] = v;
+    }
+}
+
+hipError_t launch_pack_tclass(const float* w, float* wp, int Cin, int CinPad, int Cout, int CoutPad, int nd, int k, int stride,
+                              int rd, int rh, int rw, hipStream_t s) {
+    hipLaunchKernelGGL(pack_tclass_kernel, dim3(256), dim3(256), 0, s, w, wp, Cin, CinPad, Cout, CoutPad, nd, k, stride, rd, rh, rw);
     return hipGetLastError();
 }
 

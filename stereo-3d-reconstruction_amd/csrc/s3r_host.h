@@ -88,6 +88,16 @@ bool staged_layer(const s3r_conv_desc* d);
 struct StagedGeo { int cin_pad, step, pe, sp; int64_t elems; };
 StagedGeo staged_geo(const s3r_conv_desc* d);
 s3r::ConvParams make_params_staged(const s3r_conv_desc* d, const Geo& g);
+// residue classes of a general ConvTranspose with dilation 1 (s3r_general.hip): class r of an axis = the outputs o with
+// (o + pad) % stride == r; kr taps (0: none of that residue), ke >= 1 taps packed, positions q = qmin .. qmin + nq - 1 (nq <= 0: no output)
+struct TClassAxis { int kr, ke, qmin, nq; };
+bool tclass_layer(const s3r_conv_desc* d);
+TClassAxis tclass_axis(const s3r_conv_desc* d, int r);
+int tclass_halo(const s3r_conv_desc* d);
+int64_t tclass_w_elems(const s3r_conv_desc* d);                      // the s^nd class slabs, in class order
+// class (rd, rh, rw) as the direct kernel sees it: a stride-1 convolution over the staged tensor; false: the class has no output.
+// *w_off = floats from the start of the packed image to the class's slab; *macs = its multiply-adds (CinPad channels)
+bool make_params_tclass(const s3r_conv_desc* d, const Geo& g, int rd, int rh, int rw, s3r::ConvParams* q, int64_t* w_off, double* macs);
 int geometry(const s3r_conv_desc* d, Geo* g);
 int route(const s3r_conv_desc* d, Route* r);
 int need_halo(const s3r_conv_desc* d, Route r);

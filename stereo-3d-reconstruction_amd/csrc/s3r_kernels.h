@@ -100,6 +100,8 @@ struct ConvParams {
     int y_cs, y_ds, y_hs; // output element strides
     int y_bs;             // output batch stride (Cout * y_cs; the fused head's single-channel output: y_cs)
     int y_org;            // element offset of output (0,0,0): halo_out per axis
+    int y_step;           // output elements between consecutive positions along every axis (0 / 1: dense; s: one residue class of a
+                          // general ConvTranspose of stride s, run as a stride-1 convolution — s3r_general.hip; transposed = 1 implies 2)
     unsigned x_bytes;     // size of the input buffer (buffer descriptor range)
     unsigned y_bytes;     // size of the output buffer
     int transposed;       // 0: convolution, 1: ConvTranspose3d(k=4,s=2,p=1) split into 8 parity classes
@@ -230,6 +232,11 @@ hipError_t launch_cost_volume_wino(const float* fl, const float* fr, float* V, i
 hipError_t launch_stage(const float* x, float* y, int B, int Cin, int CinPad, int nd, int n, int in_halo, int sp, int pe, int step,
                         hipStream_t s);
 hipError_t launch_pack_general(const float* w, float* wp, int Cin, int CinPad, int Cout, int CoutPad, int T, int flip, hipStream_t s);
+// one residue class of a general ConvTranspose (w[Cin][Cout][k^nd]) as a stride-1 correlation kernel of kd x kh x kw taps: tap j of an
+// axis with residue r and kr taps reads kernel index r + stride * (kr - 1 - j); an axis with NO tap of that residue (kr = 0: stride > k)
+// packs one zero tap (the class's outputs are act(shift))
+hipError_t launch_pack_tclass(const float* w, float* wp, int Cin, int CinPad, int Cout, int CoutPad, int nd, int k, int stride,
+                              int rd, int rh, int rw, hipStream_t s);
 hipError_t launch_act(float* y, long long total, int act, float param, hipStream_t s);
 hipError_t launch_pad_copy(const float* x, float* y, int64_t planes, int D, int H, int W, int hd, int hh, int hw,
                            hipStream_t s);

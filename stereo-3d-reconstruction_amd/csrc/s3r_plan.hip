@@ -71,9 +71,44 @@ bool staged_layer(const s3r_conv_desc* d) {
     if (d->op == S3R_OP_DECONV) return !(deconv_fast(d) && d->cin % 16 == 0);
     return d->cin % 16 != 0;
 }
+// A staged ConvTranspose with dilation 1 runs as stride^ndim residue classes over the halo-padded (not stuffed) input
+bool tclass_layer(const s3r_conv_desc* d) { return d->op == S3R_OP_DECONV && staged_layer(d) && dil_of(d) == 1; }
+TClassAxis tclass_axis(const s3r_conv_desc* d, int r) {
+    TClassAxis a;
+    const int k = d->k, s = d->stride, p = d->pad, n_out = out_size(d);
+    a.kr = r < k ? (k - r + s - 1) / s : 0;
+    a.ke = a.kr > 0 ? a.kr : 1;
+    a.qmin = p > r ? (p - r + s - 1) / s : 0;                       // first q with s q + r - p >= 0
+    const int top = n_out - 1 + p - r;                               // last q: s q + r - p <= n_out - 1
+    a.nq = top < 0 ? 0 : top / s - a.qmin + 1;
+    return a;
+}
+int tclass_halo(const s3r_conv_desc* d) {
+    int h = 0;
+    for (int r = 0; r < d->stride; ++r) {
+        const TClassAxis a = tclass_axis(d, r);
+        if (a.nq <= 0) continue;
+        const int lo = (a.ke - 1) - a.qmin, hi = a.qmin + a.nq - 1 - (d->in_size - 1);      // inputs q - (ke - 1) .. q
+        if (lo > h) h = lo;
+        if (hi > h) h = hi;
+    }
+    return h;
+}
+int64_t tclass_w_elems(const s3r_conv_desc* d) {
+    int64_t per_axis = 0;
+    for (int r = 0; r < d->stride; ++r) per_axis += tclass_axis(d, r).ke;
+    return ipow(per_axis, d->ndim) * ((d->cin + 15) / 16 * 16) * cout_pad(d->cout);      // sum over classes of prod ke = (sum ke)^nd
+}
 StagedGeo staged_geo(const s3r_conv_desc* d) {
     StagedGeo s;
     s.cin_pad = (d->cin + 15) / 16 * 16;
+    if (tclass_layer(d)) {
+        s.step = 1;
+        s.pe = tclass_halo(d);
+        s.sp = d->in_size + 2 * s.pe;
+        s.elems = (int64_t)d->batch * s.cin_pad * ipow(s.sp, d->ndim);
+        return s;
+    }
     const bool tr = d->op == S3R_OP_DECONV;
     s.step = tr ? d->stride : 1;
     s.pe = tr ? dil_of(d) * (d->k - 1) - d->pad : d->pad;
@@ -126,8 +161,9 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
     // (a staged layer builds its own halo of any width — pe is not bounded by the caller-halo limit above; what bounds it is the size
     // of the staged copy, checked HERE so that planning and the forward agree: ADVICE r05)
     if (staged_layer(d)) {
-        const bool tr = d->op == S3R_OP_DECONV;      // (in double first: the int64 product of staged_geo may not exist)
-        const double pe = tr ? (double)dil_of(d) * (d->k - 1) - d->pad : d->pad;
+        const bool tr = d->op == S3R_OP_DECONV && !tclass_layer(d);      // (in double first: the int64 product of staged_geo may not exist)
+        if (d->stride > 64 || d->k > 1024) return fail(S3R_ERR_INVALID, "stride / kernel size out of range");
+        const double pe = tclass_layer(d) ? (double)tclass_halo(d) : tr ? (double)dil_of(d) * (d->k - 1) - d->pad : d->pad;
         const double sp = (tr ? ((double)d->in_size - 1) * d->stride + 1 + d->out_pad : d->in_size) + 2 * pe;
         const double est = (double)d->batch * ((d->cin + 15) / 16 * 16) * (d->ndim == 3 ? sp * sp * sp : sp * sp);
         if (est >= (double)kMaxElems || est * 4 >= (double)kMaxBytes)
@@ -587,6 +623,47 @@ s3r::ConvParams make_params_staged(const s3r_conv_desc* d, const Geo& g) {
     return p;
 }
 
+bool make_params_tclass(const s3r_conv_desc* d, const Geo& g, int rd, int rh, int rw, s3r::ConvParams* q, int64_t* w_off, double* macs) {
+    const bool is3 = d->ndim == 3;
+    const StagedGeo sg = staged_geo(d);
+    const int s = d->stride, h = sg.pe;
+    const TClassAxis ad = is3 ? tclass_axis(d, rd) : TClassAxis{1, 1, 0, 1}, ah = tclass_axis(d, rh), aw = tclass_axis(d, rw);
+    // slab offset: classes in (rd, rh, rw) order, each prod(ke) taps
+    int64_t taps_before = 0;
+    {
+        int64_t sum_ke = 0;
+        for (int r = 0; r < s; ++r) sum_ke += tclass_axis(d, r).ke;
+        int64_t kd_before = 0, kh_before = 0, kw_before = 0;
+        for (int r = 0; r < rd; ++r) kd_before += tclass_axis(d, r).ke;
+        for (int r = 0; r < rh; ++r) kh_before += tclass_axis(d, r).ke;
+        for (int r = 0; r < rw; ++r) kw_before += tclass_axis(d, r).ke;
+        // classes before (rd, rh, rw): all (rd' < rd, *, *), then (rd, rh' < rh, *), then (rd, rh, rw' < rw)
+        taps_before = (is3 ? kd_before * sum_ke * sum_ke : 0) + (int64_t)ad.ke * kh_before * sum_ke + (int64_t)ad.ke * ah.ke * kw_before;
+    }
+    *w_off = taps_before * sg.cin_pad * cout_pad(d->cout);
+    if (ad.nq <= 0 || ah.nq <= 0 || aw.nq <= 0) return false;
+    s3r::ConvParams p = make_params(d, g);
+    p.Cin = sg.cin_pad;
+    p.transposed = 0;
+    p.x_hs = sg.sp; p.x_ds = is3 ? sg.sp * sg.sp : 0; p.x_cs = (int)ipow(sg.sp, g.nd);
+    p.x_bytes = (unsigned)(sg.elems * 4);
+    p.Nd = is3 ? ad.nq : 1; p.Nh = ah.nq; p.Nw = aw.nq;
+    p.kd = is3 ? ad.ke : 1; p.kh = ah.ke; p.kw = aw.ke; p.T = p.kd * p.kh * p.kw;
+    p.stride = 1; p.dil = 1;
+    // position u of an axis is q = qmin + u: it reads staged indices h + q - (ke - 1) .. h + q and writes output s q + r - pad
+    p.x_org = (is3 ? (h + ad.qmin - (ad.ke - 1)) * p.x_ds : 0) + (h + ah.qmin - (ah.ke - 1)) * p.x_hs + (h + aw.qmin - (aw.ke - 1));
+    p.y_step = s;
+    p.y_org += (is3 ? (s * ad.qmin + rd - d->pad) * p.y_ds : 0) + (s * ah.qmin + rh - d->pad) * p.y_hs + (s * aw.qmin + rw - d->pad);
+    p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
+    p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
+    p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
+    p.dW = s3r::FastDiv((unsigned)p.Nw);
+    p.ksplit = 1;
+    *macs = (double)p.Ntotal * p.T * (double)sg.cin_pad * d->cout;
+    *q = p;
+    return true;
+}
+
 // (tile cfg, gather width, split-K) of an MFMA-route layer: the caller's forced values or the heuristics
 
 int resolve_launch(const s3r_conv_desc* d, s3r::ConvParams* p, Launch* L) {
@@ -744,6 +821,7 @@ int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems) {
         case R_HEAD: *elems = d->cin; break;
         case R_LINEAR: *elems = g.w_elems; break;
         case R_MFMA: {
+            if (tclass_layer(d)) { *elems = tclass_w_elems(d); break; }
             if (staged_layer(d)) { *elems = ipow(d->k, g.nd) * staged_geo(d).cin_pad * cout_pad(d->cout); break; }
             const int64_t taps = d->op == S3R_OP_DECONV ? 64 : ipow(d->k, g.nd);
             if (d->dtype == S3R_BF16) *elems = (taps * d->cin * cout_pad_h(d->cout) + 1) / 2;   // bf16, in float units

@@ -432,8 +432,15 @@ def test_parameter_general_descriptors_plan_without_a_gpu(s3r, lib):
     e = C.c_int64(0)
     assert lib.s3r_conv_packed_elems(C.byref(staged), C.byref(e)) == 0 and e.value == 9 * 32 * 128
     assert lib.s3r_conv_scratch_elems(C.byref(staged)) == -(-(2 * 32 * 17 * 17) // 256) * 256       # (B, 32, 15 + 2, 15 + 2)
-    up = L.make_desc(Layer("a", "deconv2d", 16, 8, 4, 2, 1), 1, 7)                                   # stuffed edge 13, halo 2
-    assert lib.s3r_conv_scratch_elems(C.byref(up)) == -(-(16 * 17 * 17) // 256) * 256
+    # a ConvTranspose with dilation 1 runs as stride^ndim residue classes over the halo-padded (NOT zero-stuffed) input: k4 s2 p1 reads
+    # one element beyond each side (halo 1) and packs its 2 x 2 classes of 2 x 2 taps; k2 s3 p0 has a class WITHOUT a tap (one zero tap)
+    up = L.make_desc(Layer("a", "deconv2d", 16, 8, 4, 2, 1), 1, 7)
+    assert lib.s3r_conv_scratch_elems(C.byref(up)) == -(-(16 * 9 * 9) // 256) * 256
+    assert lib.s3r_conv_packed_elems(C.byref(up), C.byref(e)) == 0 and e.value == 16 * 16 * 128
+    gap = L.make_desc(Layer("a", "deconv2d", 8, 8, 2, 3, 0), 1, 5)
+    assert lib.s3r_conv_packed_elems(C.byref(gap), C.byref(e)) == 0 and e.value == 9 * 16 * 128
+    dil = L.make_desc(Layer("a", "deconv2d", 16, 8, 3, 2, 2, True, "none", 2, 1), 1, 7)             # dilation 2: still stuffed (edge 14, halo 2)
+    assert lib.s3r_conv_scratch_elems(C.byref(dil)) == -(-(16 * 18 * 18) // 256) * 256
     for bad in (Layer("a", "deconv2d", 16, 8, 3, 2, 3), Layer("a", "deconv2d", 16, 8, 3, 2, 1, True, "relu", 1, 2)):
         assert lib.s3r_conv_scratch_elems(C.byref(L.make_desc(bad, 1, 7))) == -1                    # pad > k - 1; out_pad >= stride
     wino = L.make_desc(Layer("a", "conv3d", 32, 32, 3, 1, 1, True, "elu"), 1, 8, in_halo=1, algo=L.ALGO_WINOGRAD)

@@ -62,6 +62,53 @@ def test_named_shapes(s3r, oracle):
         _check(s3r, oracle, layers, n_in, B, seed=i)
 
 
+def _exec_ratio(s3r, layer, n_in, B):
+    """FLOPs the layer's kernels execute on the matrix cores / its algorithmic FLOPs (the library's own profiler record)"""
+    ch = s3r.modules._HipChain([layer], n_in, precision="fp32")
+    s3r.seed_module(ch, 3)
+    ch.to("cuda:0")
+    x = torch.randn((B, layer.cin) + (n_in,) * s3r.arch_spec.ndim(layer), device="cuda:0")
+    s3r.profile_enable(16)
+    ch._run(x)
+    rec = [r for r in s3r.profile_read(16) if r["family"] == "conv_mfma"]
+    s3r.profile_enable(0)
+    return sum(r["exec_flops"] for r in rec) / sum(r["flops"] for r in rec), rec
+
+
+def test_transposed_layers_run_as_residue_classes(s3r, oracle):
+    """r06 (VERDICT r05 #5c): ANY ConvTranspose with dilation 1 is stride^ndim residue classes, each a stride-1 convolution launch over
+    the halo-padded input — not a zero-stuffed tensor convolved with the whole kernel (stride^ndim times the multiplications).  Values
+    against torch.nn for kernels smaller / equal / larger than the stride, strides 1-4, output padding, classes without a tap; and the
+    executed multiplications stay within 5 % of the algorithmic count (channel counts that are multiples of 16)."""
+    L = s3r.arch_spec.Layer
+    cases = [
+        ([L("a", "deconv2d", 64, 32, 4, 2, 1)], 16, 2),                                # the usual upsampler, cin % 16 == 0
+        ([L("a", "deconv2d", 32, 32, 2, 2, 0)], 9, 2),                                 # k = s: one tap per class
+        ([L("a", "deconv2d", 16, 16, 2, 3, 0)], 5, 2),                                 # k < s: one class per axis has NO tap (bias only)
+        ([L("a", "deconv2d", 16, 16, 1, 2, 0, True, "relu", 1, 1)], 6, 1),              # k1 s2 + output padding
+        ([L("a", "deconv2d", 16, 24, 5, 2, 2, True, "relu", 1, 1)], 7, 3),              # k5 s2 p2 op1 (3 + 2 taps)
+        ([L("a", "deconv2d", 32, 16, 7, 4, 3, True, "none", 1, 3)], 5, 1),              # k7 s4 p3 op3
+        ([L("a", "deconv3d", 32, 32, 2, 2, 0)], 6, 2),                                 # 3D k2 s2
+        ([L("a", "deconv3d", 16, 16, 3, 2, 1, True, "relu", 1, 1)], 5, 2),              # 3D k3 s2 p1 op1
+        ([L("a", "deconv3d", 16, 8, 4, 3, 0)], 4, 1),                                  # 3D k4 s3
+        ([L("a", "deconv3d", 48, 32, 3, 1, 1)], 7, 2),                                 # stride 1: a flipped convolution, one class
+        ([L("a", "deconv2d", 20, 12, 4, 2, 1, False, "elu")], 11, 2),                  # odd channels + ELU + no BN
+    ]
+    for i, (layers, n_in, B) in enumerate(cases):
+        _check(s3r, oracle, layers, n_in, B, seed=80 + i)
+    for layer, n_in, B in ((L("a", "deconv2d", 64, 32, 4, 2, 1), 32, 4), (L("a", "deconv2d", 32, 32, 2, 2, 0), 28, 4),
+                           (L("a", "deconv3d", 32, 32, 2, 2, 0), 14, 2), (L("a", "deconv3d", 16, 16, 3, 2, 1, True, "relu", 1, 1), 14, 2),
+                           (L("a", "deconv2d", 48, 48, 3, 2, 1, True, "relu", 1, 1), 28, 4)):
+        ratio, rec = _exec_ratio(s3r, layer, n_in, B)
+        assert ratio <= 1.05, (layer, n_in, ratio)
+    # channel counts that are not multiples of 16 pay their zero rows: 24 -> 32 is 4/3, no more
+    ratio, _ = _exec_ratio(s3r, L("a", "deconv2d", 24, 24, 4, 2, 1), 28, 4)
+    assert ratio <= 1.05 * 32 / 24
+    # dilation > 1 keeps the zero-stuffed form (documented in include/s3r.h): stride^ndim
+    ratio, _ = _exec_ratio(s3r, L("a", "deconv2d", 16, 16, 3, 2, 2, True, "none", 2, 1), 12, 2)
+    assert 3.0 < ratio < 5.0
+
+
 def test_linear_layers_take_every_activation(s3r, oracle):
     """a linear layer with LeakyReLU / ELU / Tanh ran with NO activation (the LINEAR branch of geometry() returned before
     the range check and the linear epilogue knows none / ReLU / sigmoid only).  They are a pass behind the layer now."""

@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Shape-robustness sweep of the fp32 layer entry under the library's AUTO policy: the REAL layer table of the reference is unknown
+(/root/reference/README.md:5), so what survives a re-mount is how the library treats shapes that are NOT this build's network.
+
+    python tools/shape_sweep.py [--out profiles/r06_shape_sweep.csv] [--quick] [--ops conv2d,deconv3d]
+
+Sweeps Conv2d / Conv3d / ConvTranspose2d / ConvTranspose3d over channel counts {16 .. 512} (equal and 1:2 / 2:1 pairs), edges
+{7 .. 112} (3D: .. 32), kernels {1, 3, 4, 5, 7} (transposed: 2, 3, 4), strides {1, 2}.  Batch: the library's nominal 32 samples (what
+its split-K and tile rules are keyed to), raised to at most 256 while the shape holds less than 10 GFLOP of direct-form work, lowered
+to fit 1.5 GB of tensors.  A shape whose roof at that batch is under 20 us is marked `tiny` (a launch costs 5-10 us: such a layer is
+launch-bound whatever the kernel) and left out of the summary's criterion.  Each shape is run through `_HipChain` (pack, plan, forward: what a model does), timed by
+the library's own profiler record (median of 5), and graded against ITS OWN roof:
+
+    roof_ms = max(direct-form FLOPs / 157.3 TFLOP/s, algorithmic bytes (input + output + weights) / 6.3 TB/s);  frac = roof_ms / ms
+
+`exec_ratio` = FLOPs the kernels that ran execute on the matrix cores / direct-form FLOPs (Winograd forms < 1; a zero-stuffed or
+channel-padded layer > 1: VERDICT r05 #5's "no transposed shape executes more than 1.05 x its algorithmic multiplications").
+"""
+import argparse
+import csv
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import s3r  # noqa: E402
+
+PEAK_TF, PEAK_TB = 157.3, 6.3
+PAIRS = [(16, 16), (24, 24), (32, 32), (48, 48), (64, 64), (96, 96), (128, 128), (256, 256), (512, 512),
+         (32, 64), (64, 128), (128, 256), (256, 512), (64, 32), (256, 128), (24, 48), (48, 96)]
+
+
+def shapes(ops, quick):
+    L = s3r.arch_spec.Layer
+    for op in ops:
+        nd = 3 if op.endswith("3d") else 2
+        edges = (7, 8, 14, 16, 28, 32) if nd == 3 else (7, 8, 14, 16, 28, 32, 56, 112)
+        if op.startswith("conv"):
+            geo = [(k, s, {1: 0, 3: 1, 4: 1, 5: 2, 7: 3}[k], 0) for k in (1, 3, 4, 5, 7) for s in (1, 2)]
+        else:   # ConvTranspose: (k, stride, pad, output_padding) — the upsamplers and flipped convolutions a decoder holds
+            geo = [(2, 2, 0, 0), (3, 1, 1, 0), (3, 2, 1, 1), (4, 2, 1, 0), (4, 1, 1, 0), (2, 1, 0, 0)]
+        for cin, cout in PAIRS:
+            for n in edges:
+                for k, s, p, opad in geo:
+                    if quick and (cin, cout) not in ((32, 32), (64, 128), (48, 48), (256, 256)):
+                        continue
+                    if k > n + 2 * p:
+                        continue
+                    yield L("s", op, cin, cout, k, s, p, True, "relu", 1, opad), n, nd
+
+
+def pick_batch(layer, n, nd):
+    spec = s3r.arch_spec
+    m = spec.out_size(layer, n)
+    if m < 1:
+        return 0
+    flops = 2.0 * spec.layer_macs(layer, n)
+    per_sample = 4.0 * (layer.cin * (n + 4) ** nd + layer.cout * (m + 2) ** nd) * 3      # tensors + staged / transformed copies
+    b = 32
+    while b < 256 and b * flops < 10e9:
+        b *= 2
+    cap_mem = int(1.5e9 // max(per_sample, 1))
+    cap_idx = int((2 ** 31 - 1) // max(layer.cin * (n + 4) ** nd, layer.cout * (m + 2) ** nd, 1))
+    return max(0, min(b, cap_mem, cap_idx))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_shape_sweep.csv"))
+    ap.add_argument("--ops", default="conv2d,conv3d,deconv2d,deconv3d")
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--rounds", type=int, default=5)
+    args = ap.parse_args()
+    spec, dev = s3r.arch_spec, torch.device("cuda:0")
+    rows = []
+    for layer, n, nd in shapes(args.ops.split(","), args.quick):
+        B = pick_batch(layer, n, nd)
+        if B < 1:
+            continue
+        ch = s3r.modules._HipChain([layer], n)
+        s3r.seed_module(ch, 1)
+        ch.to(dev)
+        x = torch.randn((B, layer.cin) + (n,) * nd, device=dev)
+        ms, rec = [], None
+        try:
+            for it in range(args.rounds + 2):
+                s3r.profile_enable(16)
+                ch._run(x)
+                r = [q for q in s3r.profile_read(16) if q["family"] in ("conv_mfma", "stem", "head")]
+                s3r.profile_enable(0)
+                if it >= 2:
+                    ms.append(sum(q["ms"] for q in r))
+                    rec = r
+        except s3r.S3RError as e:
+            s3r.profile_enable(0)
+            rows.append(dict(op=layer.op, cin=layer.cin, cout=layer.cout, edge=n, k=layer.k, stride=layer.s, pad=layer.p, opad=layer.opad,
+                             batch=B, ms="", roof_ms="", tiny="", ran="error: " + str(e)[:80], frac="", bound="", exec_ratio=""))
+            continue
+        del x, ch
+        ms.sort()
+        med = ms[len(ms) // 2]
+        m = spec.out_size(layer, n)
+        flops = 2.0 * spec.layer_macs(layer, n) * B
+        bytes_ = 4.0 * (B * (layer.cin * n ** nd + layer.cout * m ** nd) + layer.cin * layer.cout * layer.k ** nd)
+        t_m, t_h = flops / PEAK_TF / 1e9, bytes_ / PEAK_TB / 1e9
+        roof = max(t_m, t_h)
+        ex = sum(q["exec_flops"] for q in rec)
+        rows.append(dict(op=layer.op, cin=layer.cin, cout=layer.cout, edge=n, k=layer.k, stride=layer.s, pad=layer.p, opad=layer.opad,
+                         batch=B, ms=round(med, 5), roof_ms=round(roof, 5), tiny=int(roof < 0.02), ran="+".join(sorted({q["ran"] for q in rec})) + f"/{sum(q['launches'] for q in rec)}",
+                         frac=round(roof / med, 4), bound="mfma" if t_m >= t_h else "hbm", exec_ratio=round(ex / flops, 4) if flops else ""))
+        print(rows[-1], flush=True)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
+    ok = [r for r in rows if r["frac"] != ""]
+    print(f"\n{len(rows)} shapes, {len(rows) - len(ok)} refused; wrote {args.out}")
+    graded = [r for r in ok if r["cin"] >= 32 and not r["tiny"]]
+    worst = sorted(graded, key=lambda r: r["frac"])[:25]
+    print("lowest against their own roof (cin >= 32, roof >= 20 us):")
+    for r in worst:
+        print("  ", {k: r[k] for k in ("op", "cin", "cout", "edge", "k", "stride", "batch", "ms", "ran", "frac", "bound", "exec_ratio")})
+    under = [r for r in graded if r["frac"] < 0.35]
+    tr = [r for r in ok if r["op"].startswith("deconv") and r["exec_ratio"] != ""]
+    over = [r for r in tr if r["exec_ratio"] > 1.05]
+    # what a transposed layer executes beyond its (input-centric) algorithmic count: zero channels up to a multiple of 16, and the taps
+    # of border outputs that read the zero halo — an output-stationary kernel computes n_out positions per axis, the count has n_in
+    over_other = [r for r in over if r["cin"] % 16 == 0 and r["stride"] > 1]
+    print(f"cin >= 32, roof >= 20 us, under 0.35 of their roof: {len(under)} of {len(graded)} ({sum(1 for r in ok if r['tiny'])} tiny shapes not graded)")
+    print(f"transposed shapes executing > 1.05 x their algorithmic multiplications: {len(over)} of {len(tr)}; of those with cin % 16 == 0 and "
+          f"stride > 1: {len(over_other)}")
+    import collections
+    by = collections.Counter((r["op"], r["k"], r["stride"]) for r in under)
+    print("under 0.35 by (op, k, stride):", sorted(by.items(), key=lambda kv: -kv[1])[:20])
+
+
+if __name__ == "__main__":
+    main()
