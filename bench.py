@@ -37,6 +37,7 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (= fp32 vector peak)
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
+PEAK_VALU_TLANE_INSTR = 78.6      # fp32 VALU issue: 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz (= the 157.3 TFLOP/s vector peak / 2 FLOPs per FMA)
 ACHIEVABLE_HBM_GBS = 6300.0       # what a float4 copy kernel reaches on this chip (MI355X_MICROARCH.md: 6.29 TB/s measured, 79 %)
 SCHEMA = 5                        # of the JSON line.  5 (r05): + `roofline.aux`, `gemm_ms_per_step`, `frac_gemm_only`, `frac_useful`.
                                   # 4 (r04): `roofline.frac` = EXECUTED MFMA FLOPs / family kernel time / peak; through r03 (no
@@ -221,6 +222,22 @@ def roofline_of(records, steps, dtype, variant, B, spec, plain_run, quiet=False,
                    "tflops": round(f["flops"] / f["ms"] / 1e9, 2) if f["ms"] else None,
                    "algorithmic_gbs": round(f["bytes"] / f["ms"] / 1e6, 1) if f["ms"] else None,
                    "launches_per_step": f["launches"] // steps} for k, f in fam.items()}
+    # the other kernel families against THEIR roofs: the streaming ones (stem, cost volume, the point head's linear
+    # layers: 168 MB of weights read once) against the 6.3 TB/s a streaming kernel reaches; Chamfer against VALU issue — the oracle's
+    # formula is 8 fp32 instructions per pair and direction (3 sub, 3 mul, 2 add, no FMA: three roundings each) = the record's
+    # `flops`, against the 78.6 T lane-instructions/s the SIMDs issue (the fp32 vector peak counted in instructions, not FMAs)
+    for k, v in kernels.items():
+        f = fam[k]
+        if not f["ms"]:
+            continue
+        if k in ("stem", "cost_volume", "linear", "head", "pad_copy", "iou", "disparity"):
+            v["roofline"] = {"bound": "hbm", "achieved": round(f["bytes"] / f["ms"] / 1e6, 1), "peak": ACHIEVABLE_HBM_GBS, "unit": "GB/s",
+                             "frac": round(f["bytes"] / f["ms"] / 1e6 / ACHIEVABLE_HBM_GBS, 4)}
+        elif k == "chamfer":
+            v["roofline"] = {"bound": "valu_issue", "achieved": round(f["flops"] / f["ms"] / 1e9, 2), "peak": PEAK_VALU_TLANE_INSTR,
+                             "unit": "T lane-instructions/s", "frac": round(f["flops"] / f["ms"] / 1e9 / PEAK_VALU_TLANE_INSTR, 4),
+                             "note": "8 instructions per pair and direction (no FMA in the oracle's formula) + the running minimum "
+                                     "and index select (2-3 more per pair: not in the count), so ~0.75 is this formula's ceiling"}
     c = fam.get("conv_mfma")
     if not c or c["ms"] <= 0:
         return None, kernels

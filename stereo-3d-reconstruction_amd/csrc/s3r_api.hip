@@ -375,7 +375,8 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                 q.x = x; q.w = packed_w; q.scale = scale; q.shift = shift; q.y = y;
                 ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
                 ps.launches = 0;
-                {
+                const bool in_place = tclass_direct(d);       // (a residue-class layer whose input already carries its halo)
+                if (!in_place) {
                     const StagedGeo sg = staged_geo(d);
                     const int64_t need = (sg.elems + 255) / 256 * 256;
                     if (!scratch || scratch_elems < need)
@@ -399,7 +400,7 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                         const int rw = cls % d->stride, rh = (cls / d->stride) % d->stride, rd = g.nd == 3 ? cls / (d->stride * d->stride) : 0;
                         s3r::ConvParams c; int64_t w_off; double macs;
                         if (!make_params_tclass(d, g, rd, rh, rw, &c, &w_off, &macs)) continue;
-                        c.x = scratch; c.w = packed_w + w_off; c.scale = scale; c.shift = shift; c.y = y;
+                        c.x = in_place ? x : scratch; c.w = packed_w + w_off; c.scale = scale; c.shift = shift; c.y = y;
                         if ((rc = resolve_launch(&dd, &c, &L))) return rc;
                         e = s3r::launch_conv_mfma(c, L.cfg + 16 * L.vec, s);
                         if (e != hipSuccess) return hip_fail(e, "conv forward launch (transposed class)");

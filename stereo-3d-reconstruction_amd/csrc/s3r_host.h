@@ -92,6 +92,8 @@ s3r::ConvParams make_params_staged(const s3r_conv_desc* d, const Geo& g);
 // (o + pad) % stride == r; kr taps (0: none of that residue), ke >= 1 taps packed, positions q = qmin .. qmin + nq - 1 (nq <= 0: no output)
 struct TClassAxis { int kr, ke, qmin, nq; };
 bool tclass_layer(const s3r_conv_desc* d);
+bool tclass_direct(const s3r_conv_desc* d);
+int want_halo(const s3r_conv_desc* d, Route r);
 TClassAxis tclass_axis(const s3r_conv_desc* d, int r);
 int tclass_halo(const s3r_conv_desc* d);
 int64_t tclass_w_elems(const s3r_conv_desc* d);                      // the s^nd class slabs, in class order

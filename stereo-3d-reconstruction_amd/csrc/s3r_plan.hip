@@ -73,6 +73,11 @@ bool staged_layer(const s3r_conv_desc* d) {
 }
 // A staged ConvTranspose with dilation 1 runs as stride^ndim residue classes over the halo-padded (not stuffed) input
 bool tclass_layer(const s3r_conv_desc* d) { return d->op == S3R_OP_DECONV && staged_layer(d) && dil_of(d) == 1; }
+// ... and WITHOUT the staged copy when its input already carries the halo the classes read and whole 16-channel K tiles: what
+// s3r_chain_forward plans for such a layer behind another one (want_halo), or a caller states with in_halo
+bool tclass_direct(const s3r_conv_desc* d) {
+    return tclass_layer(d) && d->cin % 16 == 0 && d->in_halo >= tclass_halo(d) && d->in_layout == S3R_LAYOUT_PLAIN;
+}
 TClassAxis tclass_axis(const s3r_conv_desc* d, int r) {
     TClassAxis a;
     const int k = d->k, s = d->stride, p = d->pad, n_out = out_size(d);
@@ -236,6 +241,13 @@ int route(const s3r_conv_desc* d, Route* r) {
 int need_halo(const s3r_conv_desc* d, Route r) {
     if (r != R_MFMA || staged_layer(d)) return 0;          // (a staged layer builds its own padded copy)
     return d->op == S3R_OP_DECONV ? 1 : d->pad;
+}
+
+// the halo a chain gives the layer's input when it can choose (>= need_halo): a residue-class ConvTranspose with whole K tiles reads
+// its border from the producer's zero halo instead of staging a padded copy
+int want_halo(const s3r_conv_desc* d, Route r) {
+    if (r == R_MFMA && tclass_layer(d) && d->cin % 16 == 0 && tclass_halo(d) <= 8) return tclass_halo(d);
+    return need_halo(d, r);
 }
 
 int check_halos(const s3r_conv_desc* d, Route r) {
@@ -625,7 +637,12 @@ s3r::ConvParams make_params_staged(const s3r_conv_desc* d, const Geo& g) {
 
 bool make_params_tclass(const s3r_conv_desc* d, const Geo& g, int rd, int rh, int rw, s3r::ConvParams* q, int64_t* w_off, double* macs) {
     const bool is3 = d->ndim == 3;
-    const StagedGeo sg = staged_geo(d);
+    StagedGeo sg = staged_geo(d);
+    if (tclass_direct(d)) {                       // the layer's own input, read in place: its halo is the classes' border
+        sg.pe = d->in_halo;
+        sg.sp = d->in_size + 2 * d->in_halo;
+        sg.elems = (int64_t)d->batch * sg.cin_pad * ipow(sg.sp, d->ndim);
+    }
     const int s = d->stride, h = sg.pe;
     const TClassAxis ad = is3 ? tclass_axis(d, rd) : TClassAxis{1, 1, 0, 1}, ah = tclass_axis(d, rh), aw = tclass_axis(d, rw);
     // slab offset: classes in (rd, rh, rw) order, each prod(ke) taps
@@ -703,7 +720,7 @@ int plan_chain(const s3r_layer* layers, int n, Plan* pl) {
     if (pl->pad_input) pl->d[0].in_halo = need0;
     for (int i = 0; i < n; ++i) {
         if (i > 0) pl->d[i].in_halo = pl->d[i - 1].out_halo;
-        if (i + 1 < n) pl->d[i].out_halo = need_halo(&pl->d[i + 1], pl->r[i + 1]);
+        if (i + 1 < n) pl->d[i].out_halo = want_halo(&pl->d[i + 1], pl->r[i + 1]);
         if (i == 1 && pl->r[0] == R_STEM && pl->r[1] == R_MFMA && pl->d[1].dtype == S3R_F32 && pl->d[1].op == S3R_OP_CONV) {
             // a stem feeding the one-axis Winograd kernel writes that kernel's planes itself (the same bits: the stem's values
             // through wino_input_kernel's transform): no plain activation, no transform launch
@@ -848,6 +865,7 @@ int64_t s3r_conv_scratch_elems(const s3r_conv_desc* d) {
     }
     int alg, form;
     if ((rc = resolve_algo(d, &alg, &form))) return rc;
+    if (tclass_direct(d)) return 0;                                                // (reads the producer's halo: nothing staged)
     if (staged_layer(d)) return (staged_geo(d).elems + 255) / 256 * 256;          // the staged copy (no split-K behind it)
     if (alg == ALG_WINO3) return dwino3_need(d, form).total;      // Dh, Dd, Ddh (+ the class-parallel form's slabs)
     if (alg == ALG_WINO) return wino_need(d, form, false).total;

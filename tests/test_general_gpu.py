@@ -109,6 +109,34 @@ def test_transposed_layers_run_as_residue_classes(s3r, oracle):
     assert 3.0 < ratio < 5.0
 
 
+def test_residue_class_layers_read_their_producers_halo_in_place(s3r, oracle):
+    """Behind another layer of a chain a residue-class ConvTranspose with cin % 16 == 0 is NOT staged: the chain gives its input
+    the halo the classes read (want_halo) and the class kernels read it in place — same values, no staging pass, no scratch."""
+    import ctypes as C
+    L = s3r.arch_spec.Layer
+    lib = s3r.load_library()
+    chains = [
+        ([L("a", "conv2d", 16, 32, 3, 1, 1), L("b", "deconv2d", 32, 16, 4, 2, 1), L("c", "deconv2d", 16, 8, 2, 2, 0, True, "none")], 12, 2),
+        ([L("a", "conv3d", 16, 32, 3, 1, 1), L("b", "deconv3d", 32, 16, 2, 2, 0), L("c", "deconv3d", 16, 16, 3, 2, 1, True, "tanh", 1, 1)], 6, 2),
+        ([L("a", "deconv2d", 32, 32, 5, 3, 1), L("b", "deconv2d", 32, 16, 3, 1, 1)], 5, 1),
+    ]
+    for i, (layers, n_in, B) in enumerate(chains):
+        _check(s3r, oracle, layers, n_in, B, seed=90 + i)
+    d = s3r._lib.make_desc(L("b", "deconv2d", 32, 16, 4, 2, 1), 2, 12, in_halo=1)
+    assert lib.s3r_conv_scratch_elems(C.byref(d)) == 0                       # halo 1 is what k4 s2 p1 reads: in place
+    d0 = s3r._lib.make_desc(L("b", "deconv2d", 32, 16, 4, 2, 1), 2, 12, in_halo=0)
+    assert lib.s3r_conv_scratch_elems(C.byref(d0)) == -(-(2 * 32 * 14 * 14) // 256) * 256      # unpadded input: the staged copy
+    # the profile of the chain's second layer: class launches only (4), no staging pass
+    ch = s3r.modules._HipChain(chains[0][0], 12, precision="fp32")
+    s3r.seed_module(ch, 1)
+    ch.to("cuda:0")
+    s3r.profile_enable(32)
+    ch._run(torch.randn(2, 16, 12, 12, device="cuda:0"))
+    rec = [r for r in s3r.profile_read(32) if r["family"] == "conv_mfma"]
+    s3r.profile_enable(0)
+    assert [r["launches"] for r in rec][1:] == [4, 4], rec
+
+
 def test_linear_layers_take_every_activation(s3r, oracle):
     """a linear layer with LeakyReLU / ELU / Tanh ran with NO activation (the LINEAR branch of geometry() returned before
     the range check and the linear epilogue knows none / ReLU / sigmoid only).  They are a pass behind the layer now."""
