@@ -233,7 +233,10 @@ int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, void* packedv,
             if (d->dtype == S3R_BF16)
                 e = s3r::launch_pack_bf16(w, packed, d->cin, d->cout, cout_pad_h(d->cout),
                                           d->op == S3R_OP_DECONV ? 8 : (int)ipow(d->k, g.nd), d->op == S3R_OP_DECONV, s);
-            else if (tclass_layer(d)) {
+            else if (tshuf_layer(d)) {      // w[Cin][Cout][k^nd] IS [Cin][cout x taps]: pad the rows to 16 and the columns to the tile
+                const int rows = d->cout * (int)ipow(d->stride, g.nd);
+                e = s3r::launch_pack_general(w, packed, d->cin, staged_geo(d).cin_pad, rows, cout_pad(rows), 1, 1, s);
+            } else if (tclass_layer(d)) {
                 for (int cls = 0; cls < (int)ipow(d->stride, g.nd) && e == hipSuccess; ++cls) {
                     const int rw = cls % d->stride, rh = (cls / d->stride) % d->stride, rd = g.nd == 3 ? cls / (d->stride * d->stride) : 0;
                     s3r::ConvParams q; int64_t w_off; double macs;
@@ -392,7 +395,18 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                 Launch L;
                 s3r_conv_desc dd = *d;
                 dd.ksplit = 1;                                   // (no split-K slabs behind the staged copy)
-                if (tclass_layer(d)) {
+                if (tshuf_layer(d)) {
+                    // ---- ConvTranspose with k == stride: ONE 1 x 1 GEMM over (cout, tap) rows, depth-to-space store
+                    s3r::ConvParams c = make_params_tshuf(d, g);
+                    c.x = in_place ? x : scratch; c.w = packed_w; c.scale = scale; c.shift = shift; c.y = y;
+                    dd.tile = -1;
+                    dd.cout = c.Cout;
+                    if ((rc = resolve_launch(&dd, &c, &L))) return rc;
+                    e = s3r::launch_conv_mfma(c, L.cfg + 16 * L.vec, s);
+                    if (e != hipSuccess) return hip_fail(e, "conv forward launch (depth-to-space)");
+                    ps.launches += s3r::conv_last_launch_count();
+                    ps.exec = 2.0 * (double)c.Ntotal * c.Cin * (double)c.Cout;
+                } else if (tclass_layer(d)) {
                     // ---- ConvTranspose, dilation 1: one stride-1 convolution launch per residue class of the output
                     double macs_all = 0.0;
                     dd.tile = -1;

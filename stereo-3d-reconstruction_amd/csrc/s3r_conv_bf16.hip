@@ -392,6 +392,10 @@ __global__ __launch_bounds__(256, NH == 2 ? (KC == 64 ? 2 : 3) : min_waves_h(TM,
     const int T = p.T;
     const int chunks = (p.Cin / KC) / p.ksplit;
     const int nkt = S3R_ABLH(p, 2) ? 1 : T * chunks;
+#ifdef S3R_ABLATE   // S3R_ABL=7: [cu key, entry, tables done, first K tile landed, loop end, epilogue issued, stores landed, ticks spent in the
+    unsigned long long tl[7] = {0, 0, 0, 0, 0, 0, 0};      // loop's `s_waitcnt vmcnt(0)` (operands of the NEXT K tile not landed yet)]
+    if (p.debug == 7) tl[0] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const EpRegs epr = load_ep(p, tid, n0, BNW);
     // ---- decode this tile's positions once: input corner (bytes) and output offset (elements)
@@ -496,9 +500,15 @@ __global__ __launch_bounds__(256, NH == 2 ? (KC == 64 ? 2 : 3) : min_waves_h(TM,
 #pragma unroll
                 for (int r = 0; r < M::NACC; ++r) acc[nh][a][b][r] = 0.f;
 
+#ifdef S3R_ABLATE
+    if (p.debug == 7) tl[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef S3R_ABLATE
+    if (p.debug == 7) tl[2] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // fragment byte offsets inside a K tile image: row*ROWB + ((NK*q + lk) ^ swz(row))*16; q toggles the bits above lk's
     int a_off[NPT], b_off[NCT * NH];
@@ -531,15 +541,39 @@ __global__ __launch_bounds__(256, NH == 2 ? (KC == 64 ? 2 : 3) : min_waves_h(TM,
                 for (int ct = 0; ct < NCT * NH; ++ct)
                     acc[ct / NCT][pt][ct % NCT] = mma<SH>(bv[ct], av[pt], acc[ct / NCT][pt][ct % NCT]);
         }
+#ifdef S3R_ABLATE
+        unsigned long long w0 = 0;
+        if (p.debug == 7) w0 = __builtin_amdgcn_s_memrealtime();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef S3R_ABLATE
+        if (p.debug == 7) tl[6] += __builtin_amdgcn_s_memrealtime() - w0;
+#endif
         __syncthreads();
     }
+#ifdef S3R_ABLATE
+    if (p.debug == 7) tl[3] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     store_ep(epr, ep, tid, BNW);
 #pragma unroll
     for (int nh = 0; nh < NH; ++nh)
         epilogue_h<SH, TM, HEAD>(p, acc[nh], yoff, ep + nh * 192, smem + wave * (32 * ST_ROW), wave, li, lk, m0, n0 + nh * HBN,
                                  cls, kz, BM);
+#ifdef S3R_ABLATE
+    if (p.debug == 7 && tid == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 65536) {
+        tl[4] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tl[5] = __builtin_amdgcn_s_memrealtime();
+        const unsigned hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* t = s3r_timeline_h + 8 * (size_t)blockIdx.x;
+        t[0] = ((unsigned long long)(xcc & 15u) << 8) | ((hw >> 8) & 0xffu);
+        for (int i = 0; i < 6; ++i) t[1 + i] = tl[i];
+        t[7] = tl[6];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -345,8 +345,9 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, const int bi
     float* ep_hw = smem + 2 * BM;   // [BM] fused-head weights (0 for padded couts)
     if (tid < BM) {
         const int m = m0 + tid;
-        ep_sc[tid] = (p.scale && m < p.Cout) ? p.scale[m] : 1.f;
-        ep_sf[tid] = (p.shift && m < p.Cout) ? p.shift[m] : 0.f;
+        const int mc = p.shuf_s ? p.dSC.div(m) : m;                // (depth-to-space rows: s^nd taps share their cout's constants)
+        ep_sc[tid] = (p.scale && m < p.Cout) ? p.scale[mc] : 1.f;
+        ep_sf[tid] = (p.shift && m < p.Cout) ? p.shift[mc] : 0.f;
         ep_hw[tid] = (p.head_w && m < p.Cout) ? p.head_w[m] : 0.f;
     }
     __syncthreads();
@@ -424,6 +425,43 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, const int bi
         return;
     }
 #endif
+    if constexpr (!HEAD) {
+        if (p.shuf_s) {
+            // ---- depth-to-space store (ConvTranspose with k == stride as ONE GEMM over cout x taps rows, s3r_general.hip): row
+            // m = cout * s^nd + (rd, rh, rw) of position q lands at (s qd + rd, s qh + rh, s qw + rw) of channel cout.  The rw
+            // rows of a (cout, rd, rh) are consecutive r of ONE lane, the lanes of a wave consecutive qw: a wave's stores of s
+            // consecutive rows fill whole lines (the per-class launches of the residue-class form wrote every s-th dword of a line
+            // per launch: 2 TB/s effective)
+            const int mb = m0 + wm * TM * 32 + 4 * h * TM;
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
+            const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+            const bool sig = p.act == ACT_SIGMOID;
+            const int s = p.shuf_s;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dm = ((r & 3) + 8 * (r >> 2)) * TM + tm;
+                    const int m = mb + dm;
+                    if (m >= p.Cout) continue;
+                    const int co = p.dSC.div(m);
+                    int tap = m - co * (p.shuf_nd == 3 ? s * s * s : s * s);
+                    const int t1 = p.dS1.div(tap);
+                    const int rw = tap - t1 * s;
+                    const int rd = p.shuf_nd == 3 ? p.dS1.div(t1) : 0;
+                    const int rh = t1 - rd * s;
+                    const int ro = (co * p.y_cs + rd * p.y_ds + rh * p.y_hs + rw) * 4;
+                    const float sc = ep_sc[m - m0], sf = ep_sf[m - m0];
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        const float t = fmaf(acc[tm][tn][r], sc, sf);
+                        const float v = sig ? act_fn<ACT_SIGMOID>(t) : fmaxf(t, lo);
+                        if (yok[tn]) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, yoff[tn] * 4 + ro, 0, 0);
+                    }
+                }
+            return;
+        }
+    }
     const bool lane_vec = TN > 1 && vec_ok && yok[TN - 1];
     const int mbase = wm * TM * 32 + 4 * h * TM;
     const int mlimit = p.Cout - (m0 + mbase);                  // rows dm >= mlimit are padding

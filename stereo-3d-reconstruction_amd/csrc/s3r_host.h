@@ -93,6 +93,10 @@ s3r::ConvParams make_params_staged(const s3r_conv_desc* d, const Geo& g);
 struct TClassAxis { int kr, ke, qmin, nq; };
 bool tclass_layer(const s3r_conv_desc* d);
 bool tclass_direct(const s3r_conv_desc* d);
+// ... and a residue-class layer with k == stride, pad 0, out_pad 0 (every class is ONE tap on the same input element): one GEMM over
+// cout x taps rows with a depth-to-space store instead of stride^ndim launches
+bool tshuf_layer(const s3r_conv_desc* d);
+s3r::ConvParams make_params_tshuf(const s3r_conv_desc* d, const Geo& g);
 int want_halo(const s3r_conv_desc* d, Route r);
 TClassAxis tclass_axis(const s3r_conv_desc* d, int r);
 int tclass_halo(const s3r_conv_desc* d);

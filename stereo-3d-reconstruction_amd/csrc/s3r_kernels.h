@@ -102,6 +102,8 @@ struct ConvParams {
     int y_org;            // element offset of output (0,0,0): halo_out per axis
     int y_step;           // output elements between consecutive positions along every axis (0 / 1: dense; s: one residue class of a
                           // general ConvTranspose of stride s, run as a stride-1 convolution — s3r_general.hip; transposed = 1 implies 2)
+    int shuf_s, shuf_nd;  // > 0: the GEMM's M rows are (cout, tap) of a ConvTranspose with k == stride (row m = cout * s^nd + tap): row m of
+    FastDiv dSC, dS1;     // position q goes to output s q + tap of channel cout — a depth-to-space store (dSC: / s^nd, dS1: / s); y_step = s
     unsigned x_bytes;     // size of the input buffer (buffer descriptor range)
     unsigned y_bytes;     // size of the output buffer
     int transposed;       // 0: convolution, 1: ConvTranspose3d(k=4,s=2,p=1) split into 8 parity classes

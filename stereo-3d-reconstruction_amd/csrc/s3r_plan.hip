@@ -99,7 +99,11 @@ int tclass_halo(const s3r_conv_desc* d) {
     }
     return h;
 }
+bool tshuf_layer(const s3r_conv_desc* d) {
+    return tclass_layer(d) && d->k == d->stride && d->stride >= 2 && d->pad == 0 && d->out_pad == 0;
+}
 int64_t tclass_w_elems(const s3r_conv_desc* d) {
+    if (tshuf_layer(d)) return (int64_t)((d->cin + 15) / 16 * 16) * cout_pad(d->cout * (int)ipow(d->stride, d->ndim));      // [CinPad][cout x taps]
     int64_t per_axis = 0;
     for (int r = 0; r < d->stride; ++r) per_axis += tclass_axis(d, r).ke;
     return ipow(per_axis, d->ndim) * ((d->cin + 15) / 16 * 16) * cout_pad(d->cout);      // sum over classes of prod ke = (sum ke)^nd
@@ -632,6 +636,38 @@ s3r::ConvParams make_params_staged(const s3r_conv_desc* d, const Geo& g) {
     p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
     p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
     p.dW = s3r::FastDiv((unsigned)p.Nw);
+    return p;
+}
+
+s3r::ConvParams make_params_tshuf(const s3r_conv_desc* d, const Geo& g) {
+    const bool is3 = d->ndim == 3;
+    StagedGeo sg = staged_geo(d);                 // (k == stride, pad 0: the classes read no halo; staged only to pad the channels)
+    if (tclass_direct(d)) {
+        sg.pe = d->in_halo;
+        sg.sp = d->in_size + 2 * d->in_halo;
+        sg.elems = (int64_t)d->batch * sg.cin_pad * ipow(sg.sp, d->ndim);
+    }
+    const int s = d->stride, sc = (int)ipow(s, d->ndim);
+    s3r::ConvParams p = make_params(d, g);
+    p.Cin = sg.cin_pad;
+    p.Cout = d->cout * sc;                        // GEMM rows: (cout, tap); y_bs / y_cs stay the real output's
+    p.CoutPad = cout_pad(p.Cout);
+    p.transposed = 0;
+    p.x_hs = sg.sp; p.x_ds = is3 ? sg.sp * sg.sp : 0; p.x_cs = (int)ipow(sg.sp, g.nd);
+    p.x_bytes = (unsigned)(sg.elems * 4);
+    p.x_org = sg.pe * (p.x_ds + p.x_hs + 1);
+    p.Nd = is3 ? d->in_size : 1; p.Nh = d->in_size; p.Nw = d->in_size;
+    p.kd = p.kh = p.kw = 1; p.T = 1;
+    p.stride = 1; p.dil = 1;
+    p.y_step = s;
+    p.shuf_s = s; p.shuf_nd = d->ndim;
+    p.dSC = s3r::FastDiv((unsigned)sc);
+    p.dS1 = s3r::FastDiv((unsigned)s);
+    p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
+    p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
+    p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
+    p.dW = s3r::FastDiv((unsigned)p.Nw);
+    p.ksplit = 1;
     return p;
 }
 

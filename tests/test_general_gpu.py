@@ -93,6 +93,11 @@ def test_transposed_layers_run_as_residue_classes(s3r, oracle):
         ([L("a", "deconv3d", 16, 8, 4, 3, 0)], 4, 1),                                  # 3D k4 s3
         ([L("a", "deconv3d", 48, 32, 3, 1, 1)], 7, 2),                                 # stride 1: a flipped convolution, one class
         ([L("a", "deconv2d", 20, 12, 4, 2, 1, False, "elu")], 11, 2),                  # odd channels + ELU + no BN
+        # k == stride, pad 0: ONE GEMM over (cout, tap) rows with a depth-to-space store (no class launches)
+        ([L("a", "deconv2d", 32, 24, 3, 3, 0)], 7, 2),
+        ([L("a", "deconv2d", 16, 40, 4, 4, 0, True, "sigmoid")], 5, 3),
+        ([L("a", "deconv3d", 24, 10, 2, 2, 0, True, "leaky_relu")], 5, 2),              # + odd channels (staged for the channel padding only)
+        ([L("a", "deconv3d", 16, 72, 3, 3, 0, False, "none")], 3, 1),                   # 27 taps x 72 couts = 1944 GEMM rows
     ]
     for i, (layers, n_in, B) in enumerate(cases):
         _check(s3r, oracle, layers, n_in, B, seed=80 + i)
@@ -134,7 +139,7 @@ def test_residue_class_layers_read_their_producers_halo_in_place(s3r, oracle):
     ch._run(torch.randn(2, 16, 12, 12, device="cuda:0"))
     rec = [r for r in s3r.profile_read(32) if r["family"] == "conv_mfma"]
     s3r.profile_enable(0)
-    assert [r["launches"] for r in rec][1:] == [4, 4], rec
+    assert [r["launches"] for r in rec][1:] == [4, 1], rec       # (b: four residue classes; c: k == stride, one depth-to-space GEMM)
 
 
 def test_linear_layers_take_every_activation(s3r, oracle):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-workgroup timeline of one bf16 plane-kernel layer (diagnostic build: `make -C stereo-3d-reconstruction_amd/csrc abl`):
+"""Per-workgroup timeline of one bf16 layer, plane kernel or (r06) per-tap kernel (diagnostic build: `make -C stereo-3d-reconstruction_amd/csrc abl`):
   S3R_LIB=tools/alt/abl.so S3R_ABL=7 python tools/timeline_bf16.py --layer e2 [--tile 22] [--batch 256]
 phases per workgroup: tables (position decode, LDS tables), image (first image DMA issued -> landed), loop, epilogue
 (issue), stores (landed); and how many workgroups of a CU are inside their MFMA loop at a time."""
@@ -51,6 +51,10 @@ stat("K loop", le - im)
 stat("epilogue (issue)", ei - le)
 stat("stores landed", en - ei)
 stat("workgroup lifetime", en - st)
+if (t[:, 7] > 0).any():      # per-tap kernel: ticks wave 0 spent in the loop's `s_waitcnt vmcnt(0)` — the NEXT K tile's operands not landed yet
+    wt = t[:, 7] / 100.0
+    stat("  of the K loop: waiting on DMA", wt)
+    print(f"  share of the K loop spent waiting for the next K tile's operands: {float((wt / np.maximum(le - im, 1e-9)).mean()):.3f}")
 span = en.max()
 grid = np.linspace(0, span, 2000)
 hist = np.zeros(12)
