@@ -244,6 +244,8 @@ int s3r_conv_pack_weights(const s3r_conv_desc* d, const float* w, void* packedv,
                     e = s3r::launch_pack_tclass(w, packed + w_off, d->cin, staged_geo(d).cin_pad, d->cout, cout_pad(d->cout), g.nd, d->k,
                                                 d->stride, rd, rh, rw, s);
                 }
+            } else if (im2col_layer(d)) {      // w[Cout][Cin][k^nd] IS [Cout][cin x taps]: the K rows of the unfolded GEMM
+                e = s3r::launch_pack_general(w, packed, d->cin * (int)ipow(d->k, g.nd), staged_geo(d).cin_pad, d->cout, cout_pad(d->cout), 1, 0, s);
             } else if (staged_layer(d)) {
                 e = s3r::launch_pack_general(w, packed, d->cin, staged_geo(d).cin_pad, d->cout, cout_pad(d->cout), (int)ipow(d->k, g.nd),
                                              d->op == S3R_OP_DECONV, s);
@@ -385,12 +387,46 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                     if (!scratch || scratch_elems < need)
                         return fail(S3R_ERR_WORKSPACE, "a parameter-general layer stages its input in %lld floats of scratch "
                                     "(s3r_conv_scratch_elems), got %lld", (long long)need, (long long)(scratch ? scratch_elems : 0));
-                    s3r::AuxScope aux(s, 4.0 * ((double)g.x_elems + (double)sg.elems));
-                    e = s3r::launch_stage(x, scratch, d->batch, d->cin, sg.cin_pad, g.nd, d->in_size, d->in_halo, sg.sp, sg.pe, sg.step, s);
+                    if (im2col_layer(d)) {
+                        // ---- cin <= 8: unfold (sub-batches of sg.bmax samples) -> a 1 x 1 GEMM per pass [-> activation pass]
+                        Launch Li;
+                        s3r_conv_desc di = *d;
+                        di.ksplit = 1;
+                        const int64_t x_sample = g.x_elems / d->batch, s_sample = sg.elems / (d->batch < sg.bmax ? d->batch : sg.bmax);
+                        for (int b0 = 0; b0 < d->batch; b0 += sg.bmax) {
+                            const int nb = d->batch - b0 < sg.bmax ? d->batch - b0 : sg.bmax;
+                            {
+                                s3r::AuxScope aux(s, 4.0 * ((double)nb * x_sample + (double)nb * s_sample));
+                                e = s3r::launch_stage_im2col(x + (int64_t)b0 * x_sample, scratch, nb, d->cin, sg.cin_pad, g.nd, d->in_size,
+                                                             d->in_halo, sg.sp, d->k, d->stride, d->pad, dil_of(d), s);
+                            }
+                            if (e != hipSuccess) return hip_fail(e, "unfolding launch");
+                            s3r::ConvParams c = q;
+                            c.x = scratch;
+                            c.B = nb; c.Ntotal = nb * c.Nd * c.Nh * c.Nw;
+                            c.x_bytes = (unsigned)(4 * nb * s_sample);
+                            c.y = y + (int64_t)b0 * c.y_bs; c.y_bytes = (unsigned)(4 * (int64_t)nb * c.y_bs);
+                            if ((rc = resolve_launch(&di, &c, &Li))) return rc;
+                            e = s3r::launch_conv_mfma(c, Li.cfg + 16 * Li.vec, s);
+                            if (e != hipSuccess) return hip_fail(e, "conv forward launch (unfolded)");
+                            ps.launches += 1 + s3r::conv_last_launch_count();
+                        }
+                        ps.exec = 2.0 * d->batch * (double)d->cout * (double)g.out_sp * sg.cin_pad;
+                        if (needs_act_pass(d)) {
+                            s3r::AuxScope aux2(s, 8.0 * (double)g.y_elems);
+                            e = s3r::launch_act(y, g.y_elems, d->act, d->act_param, s);
+                            if (e != hipSuccess) return hip_fail(e, "activation launch");
+                            ps.launches += 1;
+                        }
+                        return S3R_OK;
+                    } else {
+                        s3r::AuxScope aux(s, 4.0 * ((double)g.x_elems + (double)sg.elems));
+                        e = s3r::launch_stage(x, scratch, d->batch, d->cin, sg.cin_pad, g.nd, d->in_size, d->in_halo, sg.sp, sg.pe, sg.step, s);
+                        ps.launches += 2;
+                        ps.exec = 2.0 * d->batch * (double)d->cout * (double)g.out_sp * sg.cin_pad * (double)ipow(d->k, g.nd);
+                    }
                     if (e != hipSuccess) return hip_fail(e, "staging launch");
                     q.x = scratch;
-                    ps.launches += 2;
-                    ps.exec = 2.0 * d->batch * (double)d->cout * (double)g.out_sp * sg.cin_pad * (double)ipow(d->k, g.nd);
                 }
                 Launch L;
                 s3r_conv_desc dd = *d;
@@ -428,7 +464,7 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                     if (e != hipSuccess) return hip_fail(e, "conv forward launch");
                     ps.launches += s3r::conv_last_launch_count();
                 }
-                if (d->act > S3R_ACT_SIGMOID) {
+                if (needs_act_pass(d)) {
                     s3r::AuxScope aux(s, 8.0 * (double)g.y_elems);
                     e = s3r::launch_act(y, g.y_elems, d->act, d->act_param, s);
                     if (e != hipSuccess) return hip_fail(e, "activation launch");
@@ -520,7 +556,7 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
             ProfScope ps(s, F_MFMA, d->tag, g.flops, g.bytes);
             e = s3r::launch_conv_mfma(p, L.cfg + 16 * L.vec, s);
             ps.launches = s3r::conv_last_launch_count();
-            if (e == hipSuccess && d->act > S3R_ACT_SIGMOID) {       // (make_params ran the kernel with ACT_NONE; split-K as the descriptor says)
+            if (e == hipSuccess && needs_act_pass(d)) {       // (make_params ran the kernel with ACT_NONE; split-K as the descriptor says)
                 s3r::AuxScope aux(s, 8.0 * (double)g.y_elems);
                 e = s3r::launch_act(y, g.y_elems, d->act, d->act_param, s);
                 ps.launches += 1;

@@ -455,7 +455,7 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, const int bi
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
                         const float t = fmaf(acc[tm][tn][r], sc, sf);
-                        const float v = sig ? act_fn<ACT_SIGMOID>(t) : fmaxf(t, lo);
+                        const float v = sig ? act_fn<ACT_SIGMOID>(t) : fmaxf(t, fmaf(t, p.slope, lo));
                         if (yok[tn]) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, yoff[tn] * 4 + ro, 0, 0);
                     }
                 }
@@ -472,9 +472,11 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, const int bi
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) yvo[tn] = (yoff[tn] + (m0 + mbase) * p.y_cs) * 4;
     const int row_bytes = p.y_cs * 4;
-    auto rows = [&](auto sig_tag) {
-        constexpr bool SIG = decltype(sig_tag)::value;
+    auto rows = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;      // 0: ReLU / identity, 1: sigmoid, 2: LeakyReLU (max(t, slope t), slope in (0, 1])
+        constexpr bool SIG = MODE == 1;
         const float lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+        const float slope = p.slope;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -486,7 +488,7 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, const int bi
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const float t = fmaf(acc[tm][tn][r], sc, sf);
-                    v[tn] = SIG ? act_fn<ACT_SIGMOID>(t) : fmaxf(t, lo);
+                    v[tn] = SIG ? act_fn<ACT_SIGMOID>(t) : MODE == 2 ? fmaxf(t, t * slope) : fmaxf(t, lo);
                 }
                 const int so = dm * row_bytes;
                 if (lane_vec) {                    // dword-aligned (not 16-B aligned) vector store: legal on gfx950
@@ -505,7 +507,9 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, const int bi
                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
     };
-    if (p.act == ACT_SIGMOID) rows(std::true_type{}); else rows(std::false_type{});
+    if (p.act == ACT_SIGMOID) rows(std::integral_constant<int, 1>{});
+    else if (p.act == ACT_RELU && p.slope != 0.f) rows(std::integral_constant<int, 2>{});
+    else rows(std::integral_constant<int, 0>{});
 }
 
 template <int WM, int WN, int TM, int TN, int VEC, bool HEAD = false, int NBUF = 2>
@@ -588,7 +592,7 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(const ConvParams p, in
             int e = b * p.Cout * p.y_cs + p.y_org + (pd * p.y_ds + ph * p.y_hs + pw) * ostep;
             if (p.transposed) e += rd * p.y_ds + rh * p.y_hs + rw;
             float t = fmaf(sum[k], sc, sf);
-            if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
+            if (p.act == ACT_RELU) t = fmaxf(t, fmaf(t, p.slope, 0.f));
             else if (p.act == ACT_SIGMOID) t = 1.f / (1.f + __expf(-t));
             yrow[e] = t;
         }

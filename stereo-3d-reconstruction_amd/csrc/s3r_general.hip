@@ -54,6 +54,47 @@ hipError_t launch_stage(const float* x, float* y, int B, int Cin, int CinPad, in
     return hipGetLastError();
 }
 
+// im2col staging (r06): a convolution with cin <= 8 (an RGB stem that is not this network's: Conv2d 3 -> 64, k7 s2 p3) wastes 13 of
+// every 16 channel rows of the direct kernel's K tiles when its channels are padded to 16 (5.3 x the multiplications).  Unfolded, the
+// layer is a 1 x 1 GEMM over K = cin k^nd rows (147 -> 160: 1.09 x) at the price of a staged tensor k^nd / stride^nd times the input.
+__global__ __launch_bounds__(256) void stage_im2col_kernel(const float* __restrict__ x, float* __restrict__ y, long long total, int Cin, int KPad,
+                                                           int nd, int n, int x_hs, int x_ds, int x_cs, int x_org, int no, int k, int stride,
+                                                           int pad, int dil) {
+    const long long OS = nd == 3 ? (long long)no * no * no : (long long)no * no;
+    const int T = nd == 3 ? k * k * k : k * k;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long r = i;
+        const int ow = (int)(r % no); r /= no;
+        const int oh = (int)(r % no); r /= no;
+        const int od = nd == 3 ? (int)(r % no) : 0;
+        if (nd == 3) r /= no;
+        const int kidx = (int)(r % KPad);
+        const long long b = r / KPad;
+        float v = 0.f;
+        if (kidx < Cin * T) {
+            const int c = kidx / T, tap = kidx - c * T;
+            const int tw = tap % k, th = (tap / k) % k, td = nd == 3 ? tap / (k * k) : 0;
+            const int iw = ow * stride - pad + tw * dil, ih = oh * stride - pad + th * dil, id = nd == 3 ? od * stride - pad + td * dil : 0;
+            if (iw >= 0 && iw < n && ih >= 0 && ih < n && id >= 0 && id < n)
+                v = x[(b * Cin + c) * x_cs + x_org + (long long)id * x_ds + (long long)ih * x_hs + iw];
+        }
+        y[i] = v;
+    }
+    (void)OS;
+}
+
+hipError_t launch_stage_im2col(const float* x, float* y, int B, int Cin, int KPad, int nd, int n, int in_halo, int n_out, int k, int stride,
+                               int pad, int dil, hipStream_t s) {
+    const long long total = (long long)B * KPad * (nd == 3 ? (long long)n_out * n_out * n_out : (long long)n_out * n_out);
+    const int np = n + 2 * in_halo;
+    const int x_hs = np, x_ds = nd == 3 ? np * np : 0, x_cs = nd == 3 ? np * np * np : np * np;
+    const int x_org = in_halo * (x_ds + x_hs + 1);
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(stage_im2col_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, x, y, total, Cin, KPad, nd, n,
+                       x_hs, x_ds, x_cs, x_org, n_out, k, stride, pad, dil);
+    return hipGetLastError();
+}
+
 // wp[(chunk * T + tap) * 16 + c][CoutPad]; conv: w[Cout][Cin][taps]; transposed: w[Cin][Cout][taps] read at the FLIPPED tap
 __global__ void pack_general_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int CinPad, int Cout, int CoutPad, int T,
                                     int flip) {

@@ -85,12 +85,15 @@ int wino_r(const s3r_conv_desc*);
 int out_size(const s3r_conv_desc* d);
 int dil_of(const s3r_conv_desc* d);
 bool staged_layer(const s3r_conv_desc* d);
-struct StagedGeo { int cin_pad, step, pe, sp; int64_t elems; };
+struct StagedGeo { int cin_pad, step, pe, sp; int64_t elems; int bmax; };      // bmax > 0 (im2col): samples staged per pass
 StagedGeo staged_geo(const s3r_conv_desc* d);
 s3r::ConvParams make_params_staged(const s3r_conv_desc* d, const Geo& g);
 // residue classes of a general ConvTranspose with dilation 1 (s3r_general.hip): class r of an axis = the outputs o with
 // (o + pad) % stride == r; kr taps (0: none of that residue), ke >= 1 taps packed, positions q = qmin .. qmin + nq - 1 (nq <= 0: no output)
 struct TClassAxis { int kr, ke, qmin, nq; };
+bool im2col_layer(const s3r_conv_desc* d);      // a staged convolution with cin <= 8: unfolded to a 1 x 1 GEMM over cin k^nd rows
+bool leaky_fused(const s3r_conv_desc* d);
+bool needs_act_pass(const s3r_conv_desc* d);
 bool tclass_layer(const s3r_conv_desc* d);
 bool tclass_direct(const s3r_conv_desc* d);
 // ... and a residue-class layer with k == stride, pad 0, out_pad 0 (every class is ONE tap on the same input element): one GEMM over

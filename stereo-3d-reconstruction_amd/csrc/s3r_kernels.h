@@ -108,6 +108,8 @@ struct ConvParams {
     unsigned y_bytes;     // size of the output buffer
     int transposed;       // 0: convolution, 1: ConvTranspose3d(k=4,s=2,p=1) split into 8 parity classes
     int act;              // 0 none, 1 relu, 2 sigmoid
+    float slope;          // direct kernel + split-K finish: act = relu with slope a in (0, 1] is LeakyReLU(a) = max(t, a t), fused
+                          // (0: plain ReLU, bit for bit the r05 epilogue: the floor is fma(t, slope, lo) = +0)
     int Ntotal;           // B*Nd*Nh*Nw
     int n_begin, n_end;   // position range [n_begin, n_end) this launch covers (a layer may be cut in two launches)
     int n_tiles, m_tiles;
@@ -234,6 +236,10 @@ hipError_t launch_cost_volume_wino(const float* fl, const float* fr, float* V, i
 hipError_t launch_stage(const float* x, float* y, int B, int Cin, int CinPad, int nd, int n, int in_halo, int sp, int pe, int step,
                         hipStream_t s);
 hipError_t launch_pack_general(const float* w, float* wp, int Cin, int CinPad, int Cout, int CoutPad, int T, int flip, hipStream_t s);
+// im2col staging of a convolution with very few input channels (an RGB first layer): y[b][(c, td, th, tw)][od][oh][ow] = x at the tap's
+// input position (0 where it is padding, 0 for the rows that pad Cin k^nd up to KPad) — the layer is then a 1 x 1 GEMM over KPad
+hipError_t launch_stage_im2col(const float* x, float* y, int B, int Cin, int KPad, int nd, int n, int in_halo, int n_out, int k, int stride,
+                               int pad, int dil, hipStream_t s);
 // one residue class of a general ConvTranspose (w[Cin][Cout][k^nd]) as a stride-1 correlation kernel of kd x kh x kw taps: tap j of an
 // axis with residue r and kr taps reads kernel index r + stride * (kr - 1 - j); an axis with NO tap of that residue (kr = 0: stride > k)
 // packs one zero tap (the class's outputs are act(shift))

@@ -108,9 +108,28 @@ int64_t tclass_w_elems(const s3r_conv_desc* d) {
     for (int r = 0; r < d->stride; ++r) per_axis += tclass_axis(d, r).ke;
     return ipow(per_axis, d->ndim) * ((d->cin + 15) / 16 * 16) * cout_pad(d->cout);      // sum over classes of prod ke = (sum ke)^nd
 }
+// (decided from the layer's PER-SAMPLE geometry only: the packed weights have the unfolded layout, and they are packed once for every
+// batch; a batch whose unfolded copy would pass 1 GiB goes through in sub-batches)
+bool im2col_layer(const s3r_conv_desc* d) {
+    if (d->op != S3R_OP_CONV || !staged_layer(d) || d->cin > 8 || d->k > 16 || d->k < 2 || d->in_size > 4096) return false;
+    const int no = out_size(d);
+    if (no <= 0) return false;
+    const double per_sample = ((double)d->cin * (double)ipow(d->k, d->ndim) + 15.0) * (d->ndim == 3 ? (double)no * no * no : (double)no * no);
+    return per_sample * 4 <= 64.0 * (1 << 20);      // (else: channels padded to 16, the halo-padded copy)
+}
 StagedGeo staged_geo(const s3r_conv_desc* d) {
     StagedGeo s;
+    s.bmax = 0;
     s.cin_pad = (d->cin + 15) / 16 * 16;
+    if (im2col_layer(d)) {                        // (B, KPad, n_out, ...): every tap of every channel is a K row
+        s.cin_pad = (d->cin * (int)ipow(d->k, d->ndim) + 15) / 16 * 16;
+        s.step = 1; s.pe = 0;
+        s.sp = out_size(d);
+        const int64_t per_sample = (int64_t)s.cin_pad * ipow(s.sp, d->ndim);
+        s.bmax = (int)(((int64_t)1 << 28) / per_sample);          // 1 GiB of floats per pass (>= 16 samples by im2col_layer's bound)
+        s.elems = (int64_t)(d->batch < s.bmax ? d->batch : s.bmax) * per_sample;
+        return s;
+    }
     if (tclass_layer(d)) {
         s.step = 1;
         s.pe = tclass_halo(d);
@@ -169,7 +188,7 @@ int geometry(const s3r_conv_desc* d, Geo* g) {
     }
     // (a staged layer builds its own halo of any width — pe is not bounded by the caller-halo limit above; what bounds it is the size
     // of the staged copy, checked HERE so that planning and the forward agree: ADVICE r05)
-    if (staged_layer(d)) {
+    if (staged_layer(d) && !im2col_layer(d)) {
         const bool tr = d->op == S3R_OP_DECONV && !tclass_layer(d);      // (in double first: the int64 product of staged_geo may not exist)
         if (d->stride > 64 || d->k > 1024) return fail(S3R_ERR_INVALID, "stride / kernel size out of range");
         const double pe = tclass_layer(d) ? (double)tclass_halo(d) : tr ? (double)dil_of(d) * (d->k - 1) - d->pad : d->pad;
@@ -340,6 +359,13 @@ int wino2_max_edge() {
     static const int e = getenv("S3R_WINO2_MAX_EDGE") ? atoi(getenv("S3R_WINO2_MAX_EDGE")) : 28;
     return e;
 }
+// LeakyReLU with a slope in [0, 1] is max(t, slope t): the direct kernel's epilogue and its split-K finish apply it themselves (r06: a
+// DispNet-style network has it behind every convolution; as a pass of its own it cost every layer a round trip of its output)
+bool leaky_fused(const s3r_conv_desc* d) {
+    return d->dtype == S3R_F32 && d->op != S3R_OP_LINEAR && d->act == S3R_ACT_LEAKY_RELU && d->act_param >= 0.f && d->act_param <= 1.f;
+}
+bool needs_act_pass(const s3r_conv_desc* d) { return d->act > S3R_ACT_SIGMOID && !leaky_fused(d); }
+
 // the algorithm a descriptor resolves to; *form = the forced launch form of the one-axis kernel, or -1
 int resolve_algo(const s3r_conv_desc* d, int* alg, int* form) {
     *alg = ALG_DIRECT;
@@ -609,7 +635,8 @@ s3r::ConvParams make_params(const s3r_conv_desc* d, const Geo& g) {
         p.x_org = (d->in_halo - d->pad) * (p.x_ds + p.x_hs + 1);
     }
     p.dil = dil_of(d);
-    if (p.act > S3R_ACT_SIGMOID) p.act = S3R_ACT_NONE;     // (LeakyReLU / ELU / Tanh: launch_act behind the convolution)
+    if (leaky_fused(d)) { p.act = S3R_ACT_RELU; p.slope = d->act_param; }      // max(t, slope t) in the direct kernel's epilogue
+    else if (p.act > S3R_ACT_SIGMOID) p.act = S3R_ACT_NONE;     // (ELU / Tanh, LeakyReLU with a slope outside [0, 1]: launch_act behind the convolution)
     p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
     p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
     p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
@@ -630,8 +657,13 @@ s3r::ConvParams make_params_staged(const s3r_conv_desc* d, const Geo& g) {
     p.x_org = 0;
     p.x_bytes = (unsigned)(sg.elems * 4);
     p.Nd = is3 ? g.out : 1; p.Nh = g.out; p.Nw = g.out;
-    p.kd = is3 ? d->k : 1; p.kh = d->k; p.kw = d->k; p.T = p.kd * p.kh * p.kw;
-    p.stride = d->op == S3R_OP_DECONV ? 1 : d->stride;
+    if (im2col_layer(d)) {                        // the unfolded tensor: a 1 x 1 GEMM, one position per output
+        p.kd = p.kh = p.kw = 1; p.T = 1;
+        p.stride = 1; p.dil = 1;
+    } else {
+        p.kd = is3 ? d->k : 1; p.kh = d->k; p.kw = d->k; p.T = p.kd * p.kh * p.kw;
+        p.stride = d->op == S3R_OP_DECONV ? 1 : d->stride;
+    }
     p.Ntotal = p.B * p.Nd * p.Nh * p.Nw;
     p.dS = s3r::FastDiv((unsigned)(p.Nd * p.Nh * p.Nw));
     p.dHW = s3r::FastDiv((unsigned)(p.Nh * p.Nw));
@@ -875,6 +907,7 @@ int s3r_conv_packed_elems(const s3r_conv_desc* d, int64_t* elems) {
         case R_LINEAR: *elems = g.w_elems; break;
         case R_MFMA: {
             if (tclass_layer(d)) { *elems = tclass_w_elems(d); break; }
+            if (im2col_layer(d)) { *elems = (int64_t)staged_geo(d).cin_pad * cout_pad(d->cout); break; }
             if (staged_layer(d)) { *elems = ipow(d->k, g.nd) * staged_geo(d).cin_pad * cout_pad(d->cout); break; }
             const int64_t taps = d->op == S3R_OP_DECONV ? 64 : ipow(d->k, g.nd);
             if (d->dtype == S3R_BF16) *elems = (taps * d->cin * cout_pad_h(d->cout) + 1) / 2;   // bf16, in float units

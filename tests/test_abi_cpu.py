@@ -160,7 +160,12 @@ def test_invalid_arguments_are_reported_not_crashed(s3r, lib):
     spec = s3r.arch_spec
     e = C.c_int64(0)
     bad = _desc(s3r, spec.Layer("x", "conv2d", 5, 8, 3, 1, 1), 1, 8)       # cin % 16 != 0: fp32 stages it (ABI 8), bf16 cannot
-    assert lib.s3r_conv_packed_elems(C.byref(bad), C.byref(e)) == 0 and e.value == 9 * 16 * 128
+    # (cin <= 8: staged UNFOLDED — K rows = cin k^2 = 45 -> 48 — whatever the batch: the weights are packed once for every batch)
+    assert lib.s3r_conv_packed_elems(C.byref(bad), C.byref(e)) == 0 and e.value == 48 * 128
+    bad.batch = 100000
+    assert lib.s3r_conv_packed_elems(C.byref(bad), C.byref(e)) == 0 and e.value == 48 * 128
+    assert lib.s3r_conv_scratch_elems(C.byref(bad)) == (2 ** 28 // (48 * 64)) * 48 * 64      # sub-batches of <= 2^28 floats (1 GiB) per pass
+    bad.batch = 1
     bad.dtype = 1
     assert lib.s3r_conv_packed_elems(C.byref(bad), C.byref(e)) == -1
     assert b"cin" in lib.s3r_last_error()

@@ -142,6 +142,36 @@ def test_residue_class_layers_read_their_producers_halo_in_place(s3r, oracle):
     assert [r["launches"] for r in rec][1:] == [4, 1], rec       # (b: four residue classes; c: k == stride, one depth-to-space GEMM)
 
 
+def test_rgb_first_layers_are_unfolded_and_leaky_relu_is_fused(s3r, oracle):
+    """r06, what a DispNet-style front end holds: Conv2d 3 -> 64 k7 s2 p3 + LeakyReLU(0.1).  cin <= 8 layers are staged as im2col — a 1 x 1
+    GEMM over cin k^nd rows (147 -> 160) instead of 16 channel rows per tap of which 13 are zero (5.3 x the multiplications) — and
+    LeakyReLU with a slope in [0, 1] is max(t, slope t) in the direct kernel's epilogue (and its split-K finish), not a pass of its own."""
+    L = s3r.arch_spec.Layer
+    cases = [
+        ([L("a", "conv2d", 3, 64, 7, 2, 3, True, "leaky_relu", 1, 0, 0.1)], 64, 2),
+        ([L("a", "conv2d", 6, 32, 5, 2, 2, False, "leaky_relu", 1, 0, 0.1)], 40, 3),
+        ([L("a", "conv3d", 1, 16, 3, 1, 1)], 12, 2),
+        ([L("a", "conv3d", 2, 24, 4, 2, 1, True, "elu")], 10, 2),
+        ([L("a", "conv2d", 3, 16, 3, 1, 2, True, "relu", 2)], 17, 2),                                  # dilation 2 through the unfolding
+        ([L("a", "conv2d", 32, 48, 3, 2, 1, True, "leaky_relu", 1, 0, 0.2)], 20, 2),                  # fused on a plain direct layer
+        ([L("a", "conv3d", 128, 32, 3, 1, 1, True, "leaky_relu", 1, 0, 1.0)], 6, 2),                  # slope 1: identity; deep K: split-K finish
+        ([L("a", "conv2d", 32, 32, 3, 1, 1, True, "leaky_relu", 1, 0, 0.0)], 8, 2),                   # slope 0: ReLU
+        ([L("a", "conv2d", 16, 16, 3, 1, 1, True, "leaky_relu", 1, 0, 1.5)], 8, 2),                   # slope > 1 is min(t, slope t): the pass
+        ([L("a", "deconv2d", 32, 16, 4, 2, 1, True, "leaky_relu", 1, 0, 0.1)], 9, 2),                 # residue classes + fused LeakyReLU
+        ([L("a", "deconv2d", 16, 16, 2, 2, 0, True, "leaky_relu", 1, 0, 0.1)], 9, 2),                 # depth-to-space store + fused LeakyReLU
+    ]
+    for i, (layers, n_in, B) in enumerate(cases):
+        _check(s3r, oracle, layers, n_in, B, seed=120 + i)
+    ratio, rec = _exec_ratio(s3r, L("a", "conv2d", 3, 64, 7, 2, 3, True, "leaky_relu", 1, 0, 0.1), 224, 8)
+    assert ratio <= 160 / 147 + 1e-6, ratio
+    assert sum(r["launches"] for r in rec) == 2, rec                   # the unfolding pass + ONE GEMM launch: no activation pass
+    with s3r.debug_overrides(ksplit={"a": 2}):
+        _check(s3r, oracle, [L("a", "conv3d", 64, 32, 3, 2, 1, True, "leaky_relu", 1, 0, 0.3)], 9, 2, seed=140)      # split-K finish applies it
+    # a batch whose unfolded copy passes 1 GiB goes through in sub-batches (here 16 + 4 samples of 64 MB each): same values, and a
+    # sample's bits do not depend on the pass it went through (_check compares the last sample alone with it inside the batch)
+    _check(s3r, oracle, [L("a", "conv2d", 8, 16, 7, 1, 3, True, "leaky_relu", 1, 0, 0.1)], 200, 20, seed=141)
+
+
 def test_linear_layers_take_every_activation(s3r, oracle):
     """a linear layer with LeakyReLU / ELU / Tanh ran with NO activation (the LINEAR branch of geometry() returned before
     the range check and the linear epilogue knows none / ReLU / sigmoid only).  They are a pass behind the layer now."""

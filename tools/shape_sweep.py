@@ -28,7 +28,8 @@ import s3r  # noqa: E402
 
 PEAK_TF, PEAK_TB = 157.3, 6.3
 PAIRS = [(16, 16), (24, 24), (32, 32), (48, 48), (64, 64), (96, 96), (128, 128), (256, 256), (512, 512),
-         (32, 64), (64, 128), (128, 256), (256, 512), (64, 32), (256, 128), (24, 48), (48, 96)]
+         (32, 64), (64, 128), (128, 256), (256, 512), (64, 32), (256, 128), (24, 48), (48, 96),
+         (1, 16), (3, 32), (3, 64), (6, 64)]      # first layers (grey / RGB / a stacked stereo pair): cin <= 8 is staged unfolded (im2col)
 
 
 def shapes(ops, quick):
@@ -45,7 +46,7 @@ def shapes(ops, quick):
                 for k, s, p, opad in geo:
                     if quick and (cin, cout) not in ((32, 32), (64, 128), (48, 48), (256, 256)):
                         continue
-                    if k > n + 2 * p:
+                    if k > n + 2 * p or (cin <= 8 and (op.startswith("deconv") or k == 1 or n < 28)):
                         continue
                     yield L("s", op, cin, cout, k, s, p, True, "relu", 1, opad), n, nd
 
