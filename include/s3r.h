@@ -27,10 +27,10 @@
  *   - return value: S3R_OK (0) or a negative s3r_status; s3r_last_error() gives a message for the
  *     calling thread; nothing throws across the ABI;
  *   - every tensor of one call must be < 2^31 elements and < 4 GiB (32-bit buffer offsets);
- *   - size queries (s3r_conv_scratch_elems, s3r_chain_workspace_elems, ...) and the forward they size must be made with the SAME
- *     current HIP device: launch forms (bit-identical among themselves) are planned against that device's compute-unit count and
- *     have different scratch footprints.  A mismatch is S3R_ERR_WORKSPACE from the forward, never a wrong result.  A process with no
- *     device (host-only planning) plans for an unpartitioned MI355X (256 CUs).
+ *   - size queries (s3r_conv_scratch_elems, s3r_chain_workspace_elems, ...) do not depend on the device they are asked on: launch
+ *     forms of one algorithm (bit-identical among themselves) are planned against the current device's compute-unit count and have
+ *     different scratch footprints, so whenever the LIBRARY picks the form the query is sized for the largest one (r06).  A process
+ *     with no device (host-only planning) plans launches for an unpartitioned MI355X (256 CUs).
  */
 #ifndef S3R_H
 #define S3R_H
@@ -151,10 +151,13 @@ typedef struct s3r_conv_desc {
     int32_t algo;      /* s3r_algo (ABI 7): AUTO = the library's geometry-only policy */
     /* ABI 8 — parameter-general layers (fp32 path).  The shapes this build's network has keep their tuned kernels; any other
      * (k, stride, pad, dilation) convolution with cin % 16 == 0 runs the direct kernel; everything else listed here goes through
-     * the direct kernel behind a staging pass: cin % 16 != 0 (channels zero-padded), ConvTranspose2d / 3d with any k / stride / pad /
-     * output padding (dilation 1: one stride-1 convolution launch per output residue class over the halo-padded copy; dilation > 1:
-     * the input zero-stuffed at the stride, the kernel flipped), and the activations below (a pass of their own behind the layer).  0 / 0 / 0.f are NOT the neutral values of `dilation`:
-     * a zero-initialised ABI-7 descriptor means dilation 1 and is read so. */
+     * the direct kernel too: cin % 16 != 0 behind a staged copy (channels zero-padded to 16; cin <= 8: unfolded so that every tap
+     * of every channel is a K row, in sub-batches of <= 1 GiB), ConvTranspose2d / 3d with any k / stride / pad / output padding
+     * (dilation 1: one stride-1 launch per output residue class, reading a halo of ceil(k / stride) — the producer's, when in_halo
+     * provides it and cin % 16 == 0, else a halo-padded copy's; k == stride, pad 0: one GEMM with a depth-to-space store;
+     * dilation > 1: the input zero-stuffed at the stride, the kernel flipped), LeakyReLU with a slope in [0, 1] inside the direct
+     * kernel's epilogue, ELU / Tanh / other slopes as a pass of their own behind the layer.  0 / 0 / 0.f are NOT the neutral
+     * values of `dilation`: a zero-initialised ABI-7 descriptor means dilation 1 and is read so. */
     int32_t dilation;  /* >= 1 (0 is read as 1) */
     int32_t out_pad;   /* ConvTranspose output_padding (< max(stride, dilation)) */
     float act_param;   /* S3R_ACT_LEAKY_RELU: negative slope; S3R_ACT_ELU: alpha (S3R_OP_LINEAR descriptors take the three too: a pass behind

@@ -322,7 +322,9 @@ Dwino3Need dwino3_need(const s3r_conv_desc* d, int form) {
     n.diff = (3 * (int64_t)d->batch * d->cin * ipow(d->in_size + 2, 3) + 255) / 256 * 256;
     const int ntotal = d->batch * (int)ipow(d->in_size / 2, 3);
     n.split = s3r::dwino3_split(d->cout, ntotal, form);
-    n.total = n.diff + (n.split ? (s3r::dwino3_slab_elems(d->cout, ntotal) + 255) / 256 * 256 : 0);
+    // (sized for the class-parallel form whenever the LIBRARY picks the launch form: that pick counts workgroups against the current
+    // device's compute units, and a size query must not depend on the device it is asked on — ADVICE r05)
+    n.total = n.diff + ((n.split || form < 0) ? (s3r::dwino3_slab_elems(d->cout, ntotal) + 255) / 256 * 256 : 0);
     return n;
 }
 int64_t dwino3_w_offset(const s3r_conv_desc* d) {
@@ -500,7 +502,8 @@ WinoNeed wino_need(const s3r_conv_desc* d, int form, bool head) {
     if (d->op == S3R_OP_DECONV) {
         w.v = dwino_d_elems(d);
         const int nt = (int)wino_positions(d, d->batch);
-        w.slab = s3r::wino_slab_elems(kind, d->cout, nt, s3r::wino_plan(kind, d->cout, wino_kcls(d), nt, head, form));
+        // (form < 0, the library's pick: sized for the class-parallel form, the largest — the pick depends on the device's CU count)
+        w.slab = s3r::wino_slab_elems(kind, d->cout, nt, s3r::wino_plan(kind, d->cout, wino_kcls(d), nt, head, form < 0 ? 1 : form));
     } else {
         const int bmax = wino_bmax(d);
         if (bmax <= 0) return w;
@@ -509,7 +512,7 @@ WinoNeed wino_need(const s3r_conv_desc* d, int form, bool head) {
             const int nb = d->batch - b0 < bmax ? d->batch - b0 : bmax;
             if (b0 > 0 && nb == bmax) continue;
             const int nt = (int)wino_positions(d, nb);
-            const int64_t sl = s3r::wino_slab_elems(kind, d->cout, nt, s3r::wino_plan(kind, d->cout, wino_kcls(d), nt, false, form));
+            const int64_t sl = s3r::wino_slab_elems(kind, d->cout, nt, s3r::wino_plan(kind, d->cout, wino_kcls(d), nt, false, form < 0 ? 1 : form));
             if (sl > w.slab) w.slab = sl;
         }
     }
@@ -542,7 +545,8 @@ WinoNeed wino2_need(const s3r_conv_desc* d, int form) {
         const int nb = d->batch - b0 < g2.bmax ? d->batch - b0 : g2.bmax;
         if (b0 > 0 && nb == g2.bmax) continue;
         const int nt = (int)(g2.pos_sample * nb);
-        const int64_t sl = s3r::wino2_slab_elems(g2.ax, d->cout, nt, wino2_form_of(d, nt, form));
+        // (form < 0: sized for the class-parallel form — 36 / 25 class slabs against the semi-fused form's 24)
+        const int64_t sl = s3r::wino2_slab_elems(g2.ax, d->cout, nt, form < 0 ? 0 : wino2_form_of(d, nt, form));
         if (sl > w.slab) w.slab = sl;
     }
     w.total = w.v + w.slab;

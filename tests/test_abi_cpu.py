@@ -476,3 +476,22 @@ def test_release_path_reads_no_kernel_policy_from_the_environment(s3r, monkeypat
     assert dec._tile_ksplit_of(v2) == (1, 0) and s3r.debug_overrides.active() == {}
     with pytest.raises(TypeError):
         s3r.debug_overrides(tile={"v2": "2"})
+
+
+def test_scratch_queries_do_not_depend_on_the_launch_form_the_device_would_pick(s3r, lib):
+    """launch forms (bit-identical among themselves) are planned against the current device's compute-unit count and have
+    different scratch footprints; a size query made on another device — or on none — than the forward's would then disagree with it.
+    Whenever the LIBRARY picks the form the query is sized for the largest one, so it covers every form a device may pick."""
+    L = s3r._lib
+    dec = {l.name: (l, n) for l, n, _ in s3r.arch_spec.stage_table("decoder")}
+    enc = {l.name: (l, n) for l, n, _ in s3r.arch_spec.stage_table("encoder")}
+    for name, table, forms in (("e2", enc, (0, 1, 2)), ("e4", enc, (0, 1, 2)), ("v1", dec, (3, 4, 5)), ("e6", enc, (3, 4, 5)), ("v5", dec, (3, 4, 5)),
+                               ("d2", dec, (0, 1, 2)), ("d3", dec, (6, 7, 8))):
+        layer, n = table[name]
+        for batch in (1, 2, 8, 32, 64):
+            auto = lib.s3r_conv_scratch_elems(C.byref(L.make_desc(layer, batch, n, in_halo=1, algo=L.ALGO_AUTO)))
+            assert auto > 0, (name, batch, lib.s3r_last_error())
+            for tile in forms:
+                forced = lib.s3r_conv_scratch_elems(C.byref(L.make_desc(layer, batch, n, in_halo=1, algo=L.ALGO_WINOGRAD, tile=tile)))
+                if forced >= 0:            # (a form the layer does not have at this batch is refused, not sized)
+                    assert auto >= forced, (name, batch, tile, auto, forced)
