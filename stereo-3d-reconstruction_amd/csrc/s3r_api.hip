@@ -443,19 +443,38 @@ int conv_forward_impl(const s3r_conv_desc* d, const void* xv, const void* x2v, i
                     ps.launches += s3r::conv_last_launch_count();
                     ps.exec = 2.0 * (double)c.Ntotal * c.Cin * (double)c.Cout;
                 } else if (tclass_layer(d)) {
-                    // ---- ConvTranspose, dilation 1: one stride-1 convolution launch per residue class of the output
+                    // ---- ConvTranspose, dilation 1: the residue classes of the output, each a stride-1 convolution — ONE launch over a
+                    // class table (up to 27 classes), one launch per class beyond that
                     double macs_all = 0.0;
                     dd.tile = -1;
-                    for (int cls = 0; cls < (int)ipow(d->stride, g.nd); ++cls) {
+                    const int ncls = (int)ipow(d->stride, g.nd);
+                    s3r::TClsTable tab;
+                    tab.n = 0;
+                    s3r::ConvParams base;
+                    int64_t w_first = 0;
+                    for (int cls = 0; cls < ncls; ++cls) {
                         const int rw = cls % d->stride, rh = (cls / d->stride) % d->stride, rd = g.nd == 3 ? cls / (d->stride * d->stride) : 0;
                         s3r::ConvParams c; int64_t w_off; double macs;
                         if (!make_params_tclass(d, g, rd, rh, rw, &c, &w_off, &macs)) continue;
                         c.x = in_place ? x : scratch; c.w = packed_w + w_off; c.scale = scale; c.shift = shift; c.y = y;
+                        macs_all += macs;
+                        if (ncls <= s3r::kTClsMax) {
+                            if (tab.n == 0) { base = c; w_first = w_off; }
+                            s3r::TClsEntry& t = tab.e[tab.n++];
+                            t.Nd = c.Nd; t.Nh = c.Nh; t.Nw = c.Nw; t.kd = c.kd; t.kh = c.kh; t.kw = c.kw; t.T = c.T;
+                            t.x_org = c.x_org; t.y_org = c.y_org; t.Ntotal = c.Ntotal; t.wg_begin = 0; t.w_off = (int)(w_off - w_first);
+                            t.dS = c.dS; t.dHW = c.dHW; t.dW = c.dW;
+                            continue;
+                        }
                         if ((rc = resolve_launch(&dd, &c, &L))) return rc;
                         e = s3r::launch_conv_mfma(c, L.cfg + 16 * L.vec, s);
                         if (e != hipSuccess) return hip_fail(e, "conv forward launch (transposed class)");
                         ps.launches += s3r::conv_last_launch_count();
-                        macs_all += macs;
+                    }
+                    if (tab.n > 0) {
+                        e = s3r::launch_conv_tcls(base, tab, s);
+                        if (e != hipSuccess) return hip_fail(e, "conv forward launch (transposed classes)");
+                        ps.launches += 1;
                     }
                     ps.exec = 2.0 * macs_all;
                 } else {

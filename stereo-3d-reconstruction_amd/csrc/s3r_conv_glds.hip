@@ -534,6 +534,55 @@ __global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_dual_kernel(
                                                   smem);
 }
 
+// The residue classes of a general ConvTranspose in ONE launch (r06): class c owns workgroups [wg_begin_c, wg_begin_{c+1}) and runs the
+// same body on a parameter block patched with its own grid, taps, origins and weight slab (all wave-uniform: SGPRs).  As one launch
+// per class a k4 s2 2D layer was four grids of under a round each, every one paying its own ramp and tail; same K order per output,
+// so nothing changes bitwise.
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256, min_waves(TM, TN)) void conv_glds_tcls_kernel(const ConvParams p, const TClsTable tab) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int c = 0;
+    for (int i = 1; i < tab.n; ++i)
+        if ((int)blockIdx.x >= tab.e[i].wg_begin) c = i;
+    const TClsEntry e = tab.e[c];
+    const int wg_end = c + 1 < tab.n ? tab.e[c + 1].wg_begin : (int)gridDim.x;
+    ConvParams q = p;
+    q.Nd = e.Nd; q.Nh = e.Nh; q.Nw = e.Nw;
+    q.kd = e.kd; q.kh = e.kh; q.kw = e.kw; q.T = e.T;
+    q.x_org = e.x_org; q.y_org = e.y_org;
+    q.Ntotal = e.Ntotal;
+    q.dS = e.dS; q.dHW = e.dHW; q.dW = e.dW;
+    q.w = p.w + e.w_off;
+    conv_glds_body<WM, WN, TM, TN, 1, false, 2>(q, (int)blockIdx.x - e.wg_begin, wg_end - e.wg_begin, 0, e.Ntotal, 0, smem);
+}
+
+template <int WM, int WN, int TM, int TN>
+static hipError_t launch_tcls_cfg(const ConvParams& base, TClsTable& tab, hipStream_t stream) {
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    const int m_tiles = (base.Cout + BM - 1) / BM;
+    int wgs = 0;
+    for (int i = 0; i < tab.n; ++i) {
+        tab.e[i].wg_begin = wgs;
+        wgs += m_tiles * ((tab.e[i].Ntotal + BN - 1) / BN);
+    }
+    const size_t lds = (size_t)2 * GBK * (BM + BN) * sizeof(float);
+    if (lds > 48 * 1024) {
+        static LdsAttr lds_attr;
+        const hipError_t attr = lds_attr.ensure(reinterpret_cast<const void*>(&conv_glds_tcls_kernel<WM, WN, TM, TN>), (int)lds);
+        if (attr != hipSuccess) return attr;
+    }
+    hipLaunchKernelGGL((conv_glds_tcls_kernel<WM, WN, TM, TN>), dim3(wgs), dim3(256), lds, stream, base, tab);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_tcls(const ConvParams& base, TClsTable tab, hipStream_t stream) {
+    if (tab.n < 1 || tab.n > kTClsMax || base.Cin % GBK != 0 || base.ksplit != 1 || base.transposed || base.head_w) return hipErrorInvalidValue;
+    long w128 = 0;                               // workgroups of the 64 x 128 tile
+    for (int i = 0; i < tab.n; ++i) w128 += (long)((base.Cout + 63) / 64) * ((tab.e[i].Ntotal + 127) / 128);
+    if (w128 >= 1024) return launch_tcls_cfg<1, 4, 2, 1>(base, tab, stream);      // cfg 7
+    return launch_tcls_cfg<2, 2, 1, 1>(base, tab, stream);                       // cfg 3: 64 x 64
+}
+
 // ------------------------------------------------------------------------------------------------
 // split-K finish: y = act(scale * sum_kz slab[cls][kz][m][n] + shift), summed in kz order (deterministic),
 // scattered to the (halo-padded) output position of n.  One thread per 4 consecutive n of one cout.

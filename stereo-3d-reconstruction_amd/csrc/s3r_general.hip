@@ -3,7 +3,7 @@
 //
 //   stage_kernel         x (B, Cin, n [+ 2 halo] ...) -> staged (B, CinPad, U + 2 pe, ...), zero everywhere else: channels padded to a
 //                        multiple of 16, the zero padding pe materialised as a halo.
-//   ConvTranspose(k, s, p, op), dilation 1 (r06): s^ndim RESIDUE CLASSES, each a stride-1 convolution launch of the direct kernel over
+//   ConvTranspose(k, s, p, op), dilation 1 (r06): s^ndim RESIDUE CLASSES (ONE launch over a class table), each a stride-1 convolution of the direct kernel over
 //                        the halo-padded (NOT stuffed) input: output o = s q + r - p of class r takes the taps t = r, r + s, ... < k from
 //                        inputs q, q - 1, ...; the class kernel is that tap subset in correlation order (pack_tclass_kernel), its
 //                        positions are the q with 0 <= o < n_out, its outputs go out s elements apart (ConvParams::y_step).  Executes

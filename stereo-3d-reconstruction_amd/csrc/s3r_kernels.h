@@ -134,6 +134,16 @@ struct ConvParams {
     int xd_mode;
 };
 
+// The residue classes of a general ConvTranspose (s3r_general.hip) as ONE launch of the direct kernel: workgroup ranges of a class
+// table, each entry overriding what differs between the classes — position grid, taps, input / output origin, weight slab
+struct TClsEntry {
+    int Nd, Nh, Nw, kd, kh, kw, T, x_org, y_org, Ntotal, wg_begin, w_off;
+    FastDiv dS, dHW, dW;
+};
+constexpr int kTClsMax = 27;                 // stride 3 in 3D; more classes (stride 4 in 3D: 64) run one launch per class
+struct TClsTable { int n; TClsEntry e[kTClsMax]; };
+hipError_t launch_conv_tcls(const ConvParams& base, TClsTable tab, hipStream_t stream);     // fills wg_begin; base.w = the first slab
+
 // Launch form of a Winograd layer (s3r_conv_wino.hip): serial (one workgroup walks all classes of its tile), class-parallel (one
 // workgroup per (tile, class), class sums to slabs, a finish kernel transforms them — bit-identical to the serial form), or dual
 // (positions [0, n_cut) serial and [n_cut, N) class-parallel in one launch).
