@@ -124,6 +124,11 @@ def test_residue_class_layers_read_their_producers_halo_in_place(s3r, oracle):
         ([L("a", "conv2d", 16, 32, 3, 1, 1), L("b", "deconv2d", 32, 16, 4, 2, 1), L("c", "deconv2d", 16, 8, 2, 2, 0, True, "none")], 12, 2),
         ([L("a", "conv3d", 16, 32, 3, 1, 1), L("b", "deconv3d", 32, 16, 2, 2, 0), L("c", "deconv3d", 16, 16, 3, 2, 1, True, "tanh", 1, 1)], 6, 2),
         ([L("a", "deconv2d", 32, 32, 5, 3, 1), L("b", "deconv2d", 32, 16, 3, 1, 1)], 5, 1),
+        # producers that run Winograd forms (finish kernels that build padded planes) writing the WIDER halos such consumers read
+        ([L("a", "conv2d", 32, 32, 3, 1, 1), L("b", "deconv2d", 32, 16, 7, 2, 0)], 8, 2),             # two-axis 2D producer, halo 3
+        ([L("a", "conv3d", 32, 32, 3, 1, 1), L("b", "deconv3d", 32, 16, 7, 2, 0, True, "tanh")], 8, 1), # two-axis 3D producer, halo 3
+        ([L("a", "conv2d", 32, 64, 3, 1, 1), L("b", "deconv2d", 64, 16, 4, 2, 1)], 40, 2),            # one-axis F(4,3) producer (edge 40), halo 1
+        ([L("a", "deconv3d", 32, 32, 4, 2, 1), L("b", "deconv2d", 32, 16, 4, 2, 1)][:1] + [L("c", "deconv3d", 32, 16, 5, 2, 2, True, "relu", 1, 1)], 4, 2),  # tuned transposed producer, halo 1
     ]
     for i, (layers, n_in, B) in enumerate(chains):
         _check(s3r, oracle, layers, n_in, B, seed=90 + i)
