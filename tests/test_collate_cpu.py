@@ -128,3 +128,23 @@ def test_bench_and_runner_start_their_own_ranks(monkeypatch):
             mod.main()
         assert not calls
         monkeypatch.delenv("WORLD_SIZE")
+
+
+def test_bench_override_flag_parses_into_the_debug_context(s3r, monkeypatch):
+    """`bench.py --override tile.v2=2 ksplit.v4=2 algo.e6=1` -> s3r.debug_overrides kwargs; a run under it (or under a kernel A/B
+    environment switch) is listed in the line's `kernel_env_overrides`, i.e. marked as not the plain configuration."""
+    import bench
+    kw = bench.parse_overrides(["tile.v2=2", "ksplit.v4=2", "algo.e6=1"])
+    assert kw == {"tile": {"v2": 2}, "ksplit": {"v4": 2}, "algo": {"e6": 1}}
+    with pytest.raises(SystemExit):
+        bench.parse_overrides(["tiles.v2=2"])
+    with pytest.raises(SystemExit):
+        bench.parse_overrides(["tile.v2=two"])
+    for k in list(os.environ):
+        if k.startswith("S3R_"):
+            monkeypatch.delenv(k)
+    assert bench.kernel_env_overrides(s3r) == []
+    monkeypatch.setenv("S3R_WINO", "0")
+    with s3r.debug_overrides(**kw):
+        assert bench.kernel_env_overrides(s3r) == ["S3R_WINO", "algo.e6=1", "ksplit.v4=2", "tile.v2=2"]
+    assert bench.kernel_env_overrides(s3r) == ["S3R_WINO"]
