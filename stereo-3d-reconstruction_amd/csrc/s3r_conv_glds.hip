@@ -752,9 +752,10 @@ int conv_pick_tile(const ConvParams& p) {
     if (const Tuned* t = find_tuned(p))
         if (wgs(t->tile) >= 512) return t->tile;      // tuned at batch 32; tiny batches use the rules
     // (r06 shape sweep: a 32 x 256 tile over a few thousand positions is a few dozen workgroups — conv2d 64 -> 32, k7 s2 over 16^2 at
-    // B = 256 ran 64 workgroups at 0.10 of its roof; below two rounds of the chip the 64 x 64 tile's 4x the workgroups win although
-    // half of its cout rows are padding.  Tiles never change a bit: the K order is fixed)
-    if (p.Cout <= 32) return wgs(2) >= 512 ? 2 : 3;
+    // B = 256 ran 64 workgroups at 0.10 of its roof; below half a round of the chip the 64 x 64 tile's 4x the workgroups win although
+    // half of its cout rows are padding.  Not earlier: e8 of this network (196 workgroups at B = 32, HBM-bound) measured 22 us with the
+    // 32 x 256 tile and 25 us with 64 x 64.  Tiles never change a bit: the K order is fixed)
+    if (p.Cout <= 32) return wgs(2) >= 128 ? 2 : 3;
     if (p.Cout <= 64) return wgs(1) >= 2000 ? 1 : (wgs(7) >= 2000 ? 7 : 3);
     if (wgs(2) >= 1500) return 2;
     return wgs(7) >= 1500 ? 7 : 3;
